@@ -1,0 +1,129 @@
+"""ctypes binding of libdqnzoo_hip.so (the C ABI declared in include/dqnzoo_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or does
+not export a symbol, importing/using it raises immediately (task rule: "the
+product path must fail loudly when the HIP extension is missing").
+"""
+
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libdqnzoo_hip.so')
+
+DZ_OK = 0
+DZ_ERR_INVALID_ARG = -1
+DZ_ERR_HIP = -2
+DZ_ERR_UNSUPPORTED = -3
+
+ST_BAD_VALUE = 1
+ST_BAD_TARGET = 2
+ST_BAD_INDEX = 4
+ST_ZERO_ROOT = 8
+ST_NONFINITE_WEIGHT = 16
+
+MAX_FIELDS = 8
+
+c_vp = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f64 = ctypes.c_double
+c_f32 = ctypes.c_float
+
+
+class FieldDesc(ctypes.Structure):
+  _fields_ = [('src', c_vp), ('dst', c_vp), ('row_bytes', c_i64)]
+
+
+class PrioSampleArgs(ctypes.Structure):
+  _fields_ = [
+      ('node', c_vp), ('cap_pow2', c_i64), ('capacity', c_i64),
+      ('size', c_i64), ('t', c_i64), ('pos', c_vp), ('u_target', c_vp),
+      ('u_mix', c_vp), ('usp', c_f64), ('one_minus_usp', c_f64),
+      ('usp_times_up', c_f64), ('uniform_prob', c_f64), ('beta', c_f64),
+      ('normalize', c_int), ('compute_weights', c_int),
+      ('assume_nonzero_root', c_int),
+  ]
+
+
+# name -> (restype, argtypes).  tests/test_abi.py checks this table against
+# the prototypes in include/dqnzoo_hip.h and against the built library.
+SIGNATURES = {
+    'dz_version': (ctypes.c_char_p, []),
+    'dz_last_hip_error': (c_int, []),
+    'dz_built_arch': (ctypes.c_char_p, []),
+    'dz_replay_gather': (c_int, [ctypes.POINTER(FieldDesc), c_int, c_vp, c_int,
+                                 c_i64, c_vp]),
+    'dz_uniform_pos_to_id': (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp,
+                                     c_vp]),
+    'dz_sumtree_set': (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_vp,
+                               c_vp]),
+    'dz_sumtree_get': (c_int, [c_vp, c_i64, c_i64, c_vp, c_int, c_vp, c_vp,
+                               c_vp]),
+    'dz_sumtree_rebuild': (c_int, [c_vp, c_i64, c_i64, c_vp]),
+    'dz_sumtree_query': (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_vp]),
+    'dz_prioritized_sample': (c_int, [ctypes.POINTER(PrioSampleArgs), c_int,
+                                      c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                      c_vp]),
+    'dz_prioritized_update': (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp,
+                                      c_vp, c_int, c_f64, c_int, c_vp, c_vp,
+                                      c_vp]),
+    'dz_prioritized_add': (c_int, [c_vp, c_i64, c_i64, c_i64, c_int, c_f64,
+                                   c_vp, c_f64, c_vp, c_vp]),
+}
+
+
+class HipLibraryError(RuntimeError):
+  pass
+
+
+_lib = None
+
+
+def load():
+  """Loads the library once; raises HipLibraryError if it is unusable."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise HipLibraryError(
+        'libdqnzoo_hip.so is not built (%s). Run `python -m dqn_zoo_amd.build` '
+        '(hipcc, --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+  try:
+    lib = ctypes.CDLL(LIB_PATH)
+  except OSError as e:
+    raise HipLibraryError('cannot load %s: %s' % (LIB_PATH, e)) from e
+  for name, (res, args) in SIGNATURES.items():
+    try:
+      fn = getattr(lib, name)
+    except AttributeError as e:
+      raise HipLibraryError('%s does not export %s' % (LIB_PATH, name)) from e
+    fn.restype = res
+    fn.argtypes = args
+  _lib = lib
+  return lib
+
+
+def check(code, what):
+  """Maps a DZ_ERR_* return code to a Python exception."""
+  if code == DZ_OK:
+    return
+  if code == DZ_ERR_INVALID_ARG:
+    raise ValueError('%s: invalid argument' % what)
+  if code == DZ_ERR_HIP:
+    raise HipLibraryError('%s: HIP error %d' % (what, load().dz_last_hip_error()))
+  if code == DZ_ERR_UNSUPPORTED:
+    raise NotImplementedError('%s: unsupported configuration' % what)
+  raise HipLibraryError('%s: unknown error code %d' % (what, code))
+
+
+def ptr(t):
+  """Device pointer of a torch tensor (or 0 for None)."""
+  if t is None:
+    return None
+  return t.data_ptr()
+
+
+def current_stream_ptr():
+  import torch
+  return torch.cuda.current_stream().cuda_stream

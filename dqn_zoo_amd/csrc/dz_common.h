@@ -1,0 +1,35 @@
+// Shared host-side helpers for libdqnzoo_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dqnzoo_hip.h"
+
+extern int g_dz_last_hip_error;
+
+#define DZ_HIP_CHECK(expr)                         \
+  do {                                             \
+    hipError_t _e = (expr);                        \
+    if (_e != hipSuccess) {                        \
+      g_dz_last_hip_error = (int)_e;               \
+      return DZ_ERR_HIP;                           \
+    }                                              \
+  } while (0)
+
+#define DZ_LAUNCH_CHECK() DZ_HIP_CHECK(hipGetLastError())
+
+#define DZ_REQUIRE(cond)                  \
+  do {                                    \
+    if (!(cond)) return DZ_ERR_INVALID_ARG; \
+  } while (0)
+
+static inline hipStream_t dz_s(dz_stream_t s) { return (hipStream_t)s; }
+
+static inline bool dz_is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// Euclidean modulo for possibly negative a (b > 0).
+__host__ __device__ static inline int64_t dz_mod(int64_t a, int64_t b) {
+  int64_t r = a % b;
+  return r < 0 ? r + b : r;
+}

@@ -1,0 +1,425 @@
+// Sum-tree kernels (float64 implicit heap in HBM) and the fused prioritized
+// sample / update / add built on them.
+//
+// Bit-exactness contract (tests/test_replay_gpu.py): every internal node is
+// exactly fl(left + right) in IEEE float64, the descent compares and subtracts
+// in float64, and products/sums that NumPy evaluates as separate operations
+// are kept separate here -- this file MUST be compiled with -ffp-contract=off.
+//
+// Roofline: dependent-load latency (log2(cap) levels), not bandwidth: a batch of
+// 32 touches 32*20*2*8 B = 10 KiB when sampling and 15 KiB when updating
+// (SURVEY.md 8d).  All batch-sized kernels run as ONE workgroup so that the
+// level-by-level recompute can use workgroup barriers.
+#include "dz_common.h"
+
+namespace {
+
+constexpr int kMaxBatch = 1024;
+
+__device__ __forceinline__ bool finite_nonneg(double v) {
+  return (v >= 0.0) && (v < __builtin_inf());  // false for NaN, -x, +inf
+}
+
+__device__ __forceinline__ void raise(uint32_t* status, uint32_t bit) {
+  if (status) atomicOr(status, bit);
+}
+
+// Shared body of SumTree.set for one workgroup.  `leaf[i]` are tree indices in
+// [0, cap), `val[i]` the new leaf values; n <= blockDim.x.
+// ref: replay.py:283-290.  After all leaves are assigned (last duplicate wins),
+// the sequential per-index root walks of the reference leave every touched node
+// equal to fl(left+right) of its final children; recomputing the touched nodes
+// level by level gives the identical final array.
+__device__ void set_leaves_and_ancestors(double* node, int64_t cap, int64_t my_leaf,
+                                         double my_val, bool active,
+                                         const int64_t* s_leaf, int n) {
+  const int i = threadIdx.x;
+  if (active) {
+    bool last = true;
+    for (int j = i + 1; j < n; ++j) last &= (s_leaf[j] != my_leaf);
+    if (last) node[cap + my_leaf] = my_val;
+  }
+  __syncthreads();
+  int64_t p = (cap + my_leaf) >> 1;
+  for (int64_t level = cap >> 1; level >= 1; level >>= 1) {
+    if (active) node[p] = node[2 * p] + node[2 * p + 1];
+    p >>= 1;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kMaxBatch) void sumtree_set_kernel(
+    double* node, int64_t cap, int64_t size, const int64_t* __restrict__ idx,
+    const double* __restrict__ val, int n, uint32_t* status) {
+  __shared__ int64_t s_leaf[kMaxBatch];
+  const int i = threadIdx.x;
+  const bool active = i < n;
+  int64_t leaf = active ? idx[i] : 0;
+  const double v = active ? val[i] : 0.0;
+  const bool bad_v = active && !finite_nonneg(v);
+  if (leaf < 0) leaf += size;  // NumPy negative indexing on the values view.
+  const bool bad_i = active && (leaf < 0 || leaf >= size);
+  if (active) s_leaf[i] = leaf;
+  const int any_bad_v = __syncthreads_or(bad_v);
+  const int any_bad_i = __syncthreads_or(bad_i);
+  if (any_bad_v || any_bad_i) {  // the reference raises before writing anything
+    if (i == 0) raise(status, (any_bad_v ? DZ_ST_BAD_VALUE : 0u) |
+                                  (any_bad_i ? DZ_ST_BAD_INDEX : 0u));
+    return;
+  }
+  set_leaves_and_ancestors(node, cap, leaf, v, active, s_leaf, n);
+}
+
+__global__ void sumtree_get_kernel(const double* __restrict__ node, int64_t cap,
+                                   int64_t size, const int64_t* __restrict__ idx,
+                                   int n, double* __restrict__ out,
+                                   uint32_t* status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t k = idx[i];
+  if (k < 0 || k >= size) {
+    raise(status, DZ_ST_BAD_INDEX);
+    out[i] = __builtin_nan("");
+    return;
+  }
+  out[i] = node[cap + k];
+}
+
+// Zero the tail leaves [size, cap) and node[0].
+__global__ void sumtree_zero_tail_kernel(double* node, int64_t cap, int64_t size) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) node[0] = 0.0;
+  const int64_t k = size + i;
+  if (k < cap) node[cap + k] = 0.0;
+}
+
+// One launch per level: node[i] = node[2i] + node[2i+1] for i in [first, 2*first).
+__global__ void sumtree_level_kernel(double* node, int64_t first) {
+  const int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * first) node[i] = node[2 * i] + node[2 * i + 1];
+}
+
+// ref: replay.py:406-426.
+__device__ __forceinline__ int64_t descend(const double* __restrict__ node,
+                                           int64_t cap, double target) {
+  int64_t i = 1;
+  while (i < cap) {
+    const double left = node[2 * i];
+    if (target < left) {
+      i = 2 * i;
+    } else {
+      target -= left;
+      i = 2 * i + 1;
+    }
+  }
+  return i - cap;
+}
+
+__global__ void sumtree_query_kernel(const double* __restrict__ node, int64_t cap,
+                                     const double* __restrict__ targets, int n,
+                                     int64_t* __restrict__ out, uint32_t* status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double t = targets[i];
+  const double root = node[1];
+  if (!(0.0 <= t && t < root)) {
+    raise(status, DZ_ST_BAD_TARGET);
+    out[i] = -1;
+    return;
+  }
+  out[i] = descend(node, cap, t);
+}
+
+// id -> tree index and back for the fixed-capacity distribution
+// (ref: replay.py:457,499,533: the free stack is popped from its END, and an
+// evicted index is pushed and popped straight back).
+__device__ __forceinline__ int64_t tree_index_of_id(int64_t id, int64_t N) {
+  return N - 1 - dz_mod(id, N);
+}
+// The live id whose slot is N-1-ti; live ids are [t-size, t).
+__device__ __forceinline__ int64_t id_of_tree_index(int64_t ti, int64_t N,
+                                                    int64_t t, int64_t size) {
+  const int64_t slot = N - 1 - ti;
+  const int64_t base = t - size;
+  return base + dz_mod(slot - base, N);
+}
+// ref: replay.py:52-82 applied to _active_indices (positions hold tree indices
+// of the ids of the uniform swap-remove list).
+__device__ __forceinline__ int64_t id_at_position(int64_t j, int64_t N, int64_t t) {
+  if (t <= N || N == 1) return (N == 1) ? t - 1 : j;
+  if (j == N - 1) return t - 1;
+  const int64_t base = t - N;
+  return base + dz_mod(j - base, N - 1);
+}
+
+__global__ __launch_bounds__(kMaxBatch) void prioritized_sample_kernel(
+    dz_prio_sample_args_t a, int n, int64_t* __restrict__ ids_out,
+    int64_t* __restrict__ tree_idx_out, double* __restrict__ probs_out,
+    double* __restrict__ weights_out, float* __restrict__ weights32_out,
+    uint32_t* status) {
+  __shared__ double s_red[kMaxBatch / 64];
+  __shared__ double s_max;
+  const int i = threadIdx.x;
+  const bool active = i < n;
+  const double* __restrict__ node = a.node;
+  const int64_t N = a.capacity, cap = a.cap_pow2;
+  const double root = node[1];
+  const bool zero_root = (root == 0.0);
+  if (zero_root && a.assume_nonzero_root && i == 0) raise(status, DZ_ST_ZERO_ROOT);
+
+  double w = 0.0;
+  if (active) {
+    // uniform candidate: replay.py:551-554
+    const int64_t uni_ti = tree_index_of_id(id_at_position(a.pos[i], N, a.t), N);
+    // prioritized candidate: replay.py:556-560
+    int64_t pri_ti = uni_ti;
+    if (!zero_root) {
+      const double target = a.u_target[i] * root;
+      if (!(0.0 <= target && target < root)) {
+        raise(status, DZ_ST_BAD_TARGET);
+      } else {
+        pri_ti = descend(node, cap, target);
+      }
+    }
+    // mix: replay.py:562-567
+    const int64_t ti = (a.u_mix[i] < a.usp) ? uni_ti : pri_ti;
+    // probabilities: replay.py:569-577 (separate mul, mul, add: no FMA)
+    const double leaf = node[cap + ti];
+    const double pp = zero_root ? a.uniform_prob : leaf / root;
+    const double m1 = a.one_minus_usp * pp;
+    const double prob = m1 + a.usp_times_up;
+    if (ids_out) ids_out[i] = id_of_tree_index(ti, N, a.t, a.size);
+    if (tree_idx_out) tree_idx_out[i] = ti;
+    if (probs_out) probs_out[i] = prob;
+    if (a.compute_weights) {
+      // replay.py:238: (uniform_probability / probabilities) ** exponent
+      const double ratio = a.uniform_prob / prob;
+      if (a.beta == 1.0) w = ratio;            // NumPy scalar fast path
+      else if (a.beta == 0.5) w = sqrt(ratio); //   "
+      else w = pow(ratio, a.beta);
+    }
+  }
+  if (!a.compute_weights) return;
+
+  if (a.normalize) {  // replay.py:239-240: weights /= max(weights)
+    double m = active ? w : -__builtin_inf();
+    // NaN-propagating max like np.max.
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double o = __shfl_xor(m, off);
+      m = (m != m || o != o) ? __builtin_nan("") : (o > m ? o : m);
+    }
+    if ((i & 63) == 0) s_red[i >> 6] = m;
+    __syncthreads();
+    if (i == 0) {
+      double mm = s_red[0];
+      for (int k = 1; k < (int)((blockDim.x + 63) / 64); ++k) {
+        const double o = s_red[k];
+        mm = (mm != mm || o != o) ? __builtin_nan("") : (o > mm ? o : mm);
+      }
+      s_max = mm;
+    }
+    __syncthreads();
+    w = w / s_max;
+  }
+  if (active) {
+    if (!(w - w == 0.0)) raise(status, DZ_ST_NONFINITE_WEIGHT);  // replay.py:241
+    if (weights_out) weights_out[i] = w;
+    if (weights32_out) weights32_out[i] = (float)w;  // the jit-boundary cast
+  }
+}
+
+// power_zero_safe in the dtype NumPy would use (replay.py:203-208).
+__device__ __forceinline__ double leaf_from_priority_f64(double p, double e) {
+  if (p == 0.0) return 0.0;
+  if (e == 0.5) return sqrt(p);
+  if (e == 1.0) return p;
+  if (e == 2.0) return p * p;
+  if (e == 0.0) return 1.0;
+  return pow(p, e);
+}
+__device__ __forceinline__ double leaf_from_priority_f32(float p, double e) {
+  if (p == 0.0f) return 0.0;
+  if (e == 0.5) return (double)sqrtf(p);
+  if (e == 1.0) return (double)p;
+  if (e == 2.0) return (double)(p * p);
+  if (e == 0.0) return 1.0;
+  return (double)powf(p, (float)e);
+}
+
+__global__ __launch_bounds__(kMaxBatch) void prioritized_update_kernel(
+    double* node, int64_t cap, int64_t N, int64_t size, int64_t t,
+    const int64_t* __restrict__ ids, const void* __restrict__ prio, int is_f32,
+    double exponent, int n, double* max_seen, uint32_t* status) {
+  __shared__ int64_t s_leaf[kMaxBatch];
+  __shared__ double s_red[kMaxBatch / 64];
+  const int i = threadIdx.x;
+  const bool active = i < n;
+  int64_t leaf = 0;
+  double v = 0.0, p64 = 0.0;
+  bool bad_id = false;
+  if (active) {
+    const int64_t id = ids[i];
+    bad_id = (id < t - size) || (id >= t);  // replay.py:541-543
+    leaf = tree_index_of_id(id, N);
+    if (is_f32) {
+      const float p = ((const float*)prio)[i];
+      p64 = (double)p;
+      v = leaf_from_priority_f32(p, exponent);
+    } else {
+      p64 = ((const double*)prio)[i];
+      v = leaf_from_priority_f64(p64, exponent);
+    }
+    s_leaf[i] = leaf;
+  }
+  const bool bad_v = active && !finite_nonneg(v);
+  const int any_bad_i = __syncthreads_or(bad_id);
+  const int any_bad_v = __syncthreads_or(bad_v);
+  if (any_bad_i || any_bad_v) {
+    if (i == 0) raise(status, (any_bad_v ? DZ_ST_BAD_VALUE : 0u) |
+                                  (any_bad_i ? DZ_ST_BAD_INDEX : 0u));
+    return;
+  }
+  if (max_seen) {  // rainbow/agent.py:196-197
+    double m = active ? p64 : -__builtin_inf();
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double o = __shfl_xor(m, off);
+      m = o > m ? o : m;
+    }
+    if ((i & 63) == 0) s_red[i >> 6] = m;
+    __syncthreads();
+    if (i == 0) {
+      double mm = *max_seen;
+      for (int k = 0; k < (int)((blockDim.x + 63) / 64); ++k)
+        mm = s_red[k] > mm ? s_red[k] : mm;
+      *max_seen = mm;
+    }
+  }
+  set_leaves_and_ancestors(node, cap, leaf, v, active, s_leaf, n);
+}
+
+__global__ __launch_bounds__(kMaxBatch) void prioritized_add_kernel(
+    double* node, int64_t cap, int64_t N, int64_t t, int n, double priority_h,
+    const double* priority_d, double exponent, uint32_t* status) {
+  __shared__ int64_t s_leaf[kMaxBatch];
+  const int i = threadIdx.x;
+  const bool active = i < n;
+  const double p = priority_d ? *priority_d : priority_h;
+  const double v = leaf_from_priority_f64(p, exponent);
+  const int64_t leaf = tree_index_of_id(t + (active ? i : 0), N);
+  if (active) s_leaf[i] = leaf;
+  if (!finite_nonneg(v)) {  // uniform across the block
+    if (i == 0) raise(status, DZ_ST_BAD_VALUE);
+    return;
+  }
+  __syncthreads();
+  set_leaves_and_ancestors(node, cap, leaf, v, active, s_leaf, n);
+}
+
+inline int round_up_64(int n) { return (n + 63) / 64 * 64; }
+
+}  // namespace
+
+extern "C" int dz_sumtree_set(double* node, int64_t cap_pow2, int64_t size,
+                              const int64_t* idx, const double* val, int n,
+                              uint32_t* status, dz_stream_t stream) {
+  DZ_REQUIRE(node && idx && val && dz_is_pow2(cap_pow2) && size >= 0 &&
+             size <= cap_pow2);
+  DZ_REQUIRE(n >= 0 && n <= kMaxBatch);
+  if (n == 0) return DZ_OK;
+  hipLaunchKernelGGL(sumtree_set_kernel, dim3(1), dim3(round_up_64(n)), 0,
+                     dz_s(stream), node, cap_pow2, size, idx, val, n, status);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
+extern "C" int dz_sumtree_get(const double* node, int64_t cap_pow2, int64_t size,
+                              const int64_t* idx, int n, double* out,
+                              uint32_t* status, dz_stream_t stream) {
+  DZ_REQUIRE(node && idx && out && dz_is_pow2(cap_pow2) && n >= 0);
+  if (n == 0) return DZ_OK;
+  hipLaunchKernelGGL(sumtree_get_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     dz_s(stream), node, cap_pow2, size, idx, n, out, status);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
+extern "C" int dz_sumtree_rebuild(double* node, int64_t cap_pow2, int64_t size,
+                                  dz_stream_t stream) {
+  DZ_REQUIRE(node && dz_is_pow2(cap_pow2) && size >= 0 && size <= cap_pow2);
+  const int64_t tail = cap_pow2 - size;
+  const int64_t zt = tail > 0 ? tail : 1;
+  hipLaunchKernelGGL(sumtree_zero_tail_kernel, dim3((unsigned)((zt + 255) / 256)),
+                     dim3(256), 0, dz_s(stream), node, cap_pow2, size);
+  DZ_LAUNCH_CHECK();
+  for (int64_t first = cap_pow2 >> 1; first >= 1; first >>= 1) {
+    hipLaunchKernelGGL(sumtree_level_kernel,
+                       dim3((unsigned)((first + 255) / 256)), dim3(256), 0,
+                       dz_s(stream), node, first);
+    DZ_LAUNCH_CHECK();
+  }
+  return DZ_OK;
+}
+
+extern "C" int dz_sumtree_query(const double* node, int64_t cap_pow2,
+                                const double* targets, int n, int64_t* out,
+                                uint32_t* status, dz_stream_t stream) {
+  DZ_REQUIRE(node && targets && out && dz_is_pow2(cap_pow2) && n >= 0);
+  if (n == 0) return DZ_OK;
+  hipLaunchKernelGGL(sumtree_query_kernel, dim3((n + 63) / 64), dim3(64), 0,
+                     dz_s(stream), node, cap_pow2, targets, n, out, status);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
+extern "C" int dz_prioritized_sample(const dz_prio_sample_args_t* args, int batch,
+                                     int64_t* ids_out, int64_t* tree_idx_out,
+                                     double* probs_out, double* weights_out,
+                                     float* weights32_out, uint32_t* status,
+                                     dz_stream_t stream) {
+  DZ_REQUIRE(args && ids_out && batch > 0 && batch <= kMaxBatch);
+  DZ_REQUIRE(args->node && dz_is_pow2(args->cap_pow2) && args->capacity > 0 &&
+             args->capacity <= args->cap_pow2);
+  DZ_REQUIRE(args->size > 0 && args->size <= args->capacity &&
+             args->t >= args->size);
+  DZ_REQUIRE(args->pos && args->u_target && args->u_mix);
+  hipLaunchKernelGGL(prioritized_sample_kernel, dim3(1),
+                     dim3(round_up_64(batch)), 0, dz_s(stream), *args, batch,
+                     ids_out, tree_idx_out, probs_out, weights_out,
+                     weights32_out, status);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
+extern "C" int dz_prioritized_update(double* node, int64_t cap_pow2,
+                                     int64_t capacity, int64_t size, int64_t t,
+                                     const int64_t* ids, const void* priorities,
+                                     int prio_is_f32, double exponent, int n,
+                                     double* max_seen, uint32_t* status,
+                                     dz_stream_t stream) {
+  DZ_REQUIRE(node && ids && priorities && dz_is_pow2(cap_pow2));
+  DZ_REQUIRE(capacity > 0 && capacity <= cap_pow2 && size >= 0 &&
+             size <= capacity && t >= size);
+  DZ_REQUIRE(n >= 0 && n <= kMaxBatch && exponent >= 0.0);
+  if (n == 0) return DZ_OK;
+  hipLaunchKernelGGL(prioritized_update_kernel, dim3(1), dim3(round_up_64(n)), 0,
+                     dz_s(stream), node, cap_pow2, capacity, size, t, ids,
+                     priorities, prio_is_f32, exponent, n, max_seen, status);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
+extern "C" int dz_prioritized_add(double* node, int64_t cap_pow2,
+                                  int64_t capacity, int64_t t, int n,
+                                  double priority_h, const double* priority_d,
+                                  double exponent, uint32_t* status,
+                                  dz_stream_t stream) {
+  DZ_REQUIRE(node && dz_is_pow2(cap_pow2) && capacity > 0 &&
+             capacity <= cap_pow2 && t >= 0);
+  DZ_REQUIRE(n >= 0 && n <= kMaxBatch && n <= capacity && exponent >= 0.0);
+  if (n == 0) return DZ_OK;
+  hipLaunchKernelGGL(prioritized_add_kernel, dim3(1), dim3(round_up_64(n)), 0,
+                     dz_s(stream), node, cap_pow2, capacity, t, n, priority_h,
+                     priority_d, exponent, status);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}

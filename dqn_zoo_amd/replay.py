@@ -1,0 +1,838 @@
+"""HBM-resident experience replay with the surface of dqn_zoo's `replay.py`.
+
+Drop-in classes (same names, constructor arguments, methods, return types and
+error behaviour as the reference) whose storage, sampling and priority
+bookkeeping live on one MI355X and run as hand-written HIP kernels behind the
+C ABI of `include/dqnzoo_hip.h`:
+
+  TransitionReplay             ref: dqn_zoo/replay.py:120-200
+  PrioritizedTransitionReplay  ref: dqn_zoo/replay.py:654-768
+  SumTree                      ref: dqn_zoo/replay.py:246-426
+  Transition, importance_sampling_weights, TransitionAccumulator,
+  NStepTransitionAccumulator   ref: replay.py:36-41, 211-243, 771-892
+
+Design (DESIGN.md has the long form):
+  * storage is one `[capacity, *field_shape]` device array per field of the
+    replay structure; slot(id) = id mod capacity, so eviction of the oldest
+    item is an overwrite and no id<->slot tables exist;
+  * the reference's swap-remove position lists and free-index stack have
+    closed forms under its only usage pattern, evaluated on the
+    device: tree_index(id) = capacity-1-(id mod capacity);
+  * randomness stays the injected `np.random.RandomState`: the host draws in
+    the reference's exact order and uploads the raw draws, so ids are bit-exact
+    for a fixed seed;
+  * two call styles: the reference's (`sample()` -> NumPy, synchronous, exact
+    float64 importance weights computed with NumPy on the 32 probabilities) and
+    a pipelined one for the on-device learner (`sample_device()`, nothing
+    leaves HBM, no host sync).
+
+There is no CPU fallback: without libdqnzoo_hip.so and a GPU these classes
+raise at construction.
+"""
+
+import collections
+import ctypes
+import typing
+from typing import Any, Callable, Generic, Iterable, Mapping, Optional, Sequence, Tuple, TypeVar
+
+import numpy as np
+import torch
+
+from dqn_zoo_amd import _lib
+
+ReplayStructure = TypeVar('ReplayStructure', bound=Tuple[Any, ...])
+
+
+class Transition(typing.NamedTuple):
+  s_tm1: Optional[np.ndarray]
+  a_tm1: Optional[int]
+  r_t: Optional[float]
+  discount_t: Optional[float]
+  s_t: Optional[np.ndarray]
+
+
+def _require_gpu(device):
+  if not torch.cuda.is_available():
+    raise _lib.HipLibraryError(
+        'dqn_zoo_amd.replay needs an AMD GPU (torch.cuda.is_available() is '
+        'False); there is no CPU fallback.')
+  return torch.device('cuda', torch.cuda.current_device()) if device is None \
+      else torch.device(device)
+
+
+def _next_pow2(n):
+  c = 1
+  while c < n:
+    c *= 2
+  return c
+
+
+def _raise_status(bits):
+  """Maps sticky device status bits to the reference's exceptions."""
+  if bits & _lib.ST_BAD_VALUE:
+    raise ValueError('value must be finite and positive.')
+  if bits & _lib.ST_BAD_TARGET:
+    raise ValueError('Require 0 <= target < total sum.')
+  if bits & _lib.ST_BAD_INDEX:
+    raise IndexError('index out of range')
+  if bits & _lib.ST_NONFINITE_WEIGHT:
+    raise ValueError('Weights are not finite.')
+  if bits & _lib.ST_ZERO_ROOT:
+    raise RuntimeError('pipelined sampling met an all-zero sum tree')
+
+
+class _Status:
+  """Sticky device status word shared by the kernels of one object."""
+
+  def __init__(self, device):
+    self.word = torch.zeros(1, dtype=torch.int32, device=device)
+
+  def check(self):
+    bits = int(self.word.item())  # synchronises
+    if bits:
+      self.word.zero_()
+      _raise_status(bits)
+
+
+# --------------------------------------------------------------------------- #
+#  Host-side closed forms (mirrors of the device code; also used by ids()).
+# --------------------------------------------------------------------------- #
+def position_to_id(pos, t, capacity):
+  """ids held at `pos` of the reference's swap-remove list (replay.py:52-82)."""
+  pos = np.asarray(pos, dtype=np.int64)
+  if t <= capacity:
+    return pos.copy()
+  if capacity == 1:
+    return np.full_like(pos, t - 1)
+  base = t - capacity
+  out = base + np.mod(pos - base, capacity - 1)
+  return np.where(pos == capacity - 1, t - 1, out)
+
+
+def tree_index_of_id(ids, capacity):
+  """Sum-tree index of an id (free stack popped from the end, replay.py:499)."""
+  return capacity - 1 - np.mod(np.asarray(ids, dtype=np.int64), capacity)
+
+
+# --------------------------------------------------------------------------- #
+#  Device ring store
+# --------------------------------------------------------------------------- #
+class _FieldRing:
+  """One `[capacity, *shape]` device array per structure field."""
+
+  def __init__(self, capacity, structure, device):
+    self.capacity = capacity
+    self.structure = structure
+    self.device = device
+    self.fields = None      # list[torch.Tensor]
+    self.np_dtypes = None
+    self.shapes = None
+
+  def allocate_like(self, item):
+    fields, dts, shapes = [], [], []
+    for x in item:
+      a = np.asarray(x)
+      dts.append(a.dtype)
+      shapes.append(a.shape)
+      tdt = torch.from_numpy(np.zeros(1, a.dtype)).dtype
+      fields.append(torch.empty((self.capacity,) + a.shape, dtype=tdt,
+                                device=self.device))
+    self.fields, self.np_dtypes, self.shapes = fields, dts, shapes
+
+  def allocate(self, shapes, np_dtypes):
+    self.allocate_like([np.zeros(s, d) for s, d in zip(shapes, np_dtypes)])
+
+  def write(self, slot, item):
+    if self.fields is None:
+      self.allocate_like(item)
+    for f, x, dt, shp in zip(self.fields, item, self.np_dtypes, self.shapes):
+      a = np.asarray(x, dtype=dt)
+      if a.shape != shp:
+        raise ValueError('replay item field has shape %s, expected %s' %
+                         (a.shape, shp))
+      if a.ndim == 0:
+        f[slot] = a.item()
+      else:
+        f[slot].copy_(torch.from_numpy(np.ascontiguousarray(a)))
+
+  def read(self, slot):
+    return type(self.structure)(*[
+        (f[slot].cpu().numpy() if f.dim() > 1 else f[slot].cpu().numpy()[()])
+        for f in self.fields])
+
+  def gather(self, ids_dev, batch, stream):
+    """dst[b] = field[ids[b] mod capacity] for all fields, one launch."""
+    outs = [torch.empty((batch,) + tuple(f.shape[1:]), dtype=f.dtype,
+                        device=self.device) for f in self.fields]
+    n = len(self.fields)
+    arr = (_lib.FieldDesc * n)()
+    for i, (f, o) in enumerate(zip(self.fields, outs)):
+      arr[i].src = f.data_ptr()
+      arr[i].dst = o.data_ptr()
+      arr[i].row_bytes = f[0].numel() * f.element_size()
+    _lib.check(_lib.load().dz_replay_gather(arr, n, ids_dev.data_ptr(), batch,
+                                            self.capacity, stream),
+               'dz_replay_gather')
+    return outs
+
+
+class _ReplayBase(Generic[ReplayStructure]):
+
+  def __init__(self, capacity, structure, random_state, encoder, decoder,
+               device):
+    if capacity <= 0:
+      raise ValueError('capacity must be positive')
+    _lib.load()
+    self._device = _require_gpu(device)
+    self._capacity = int(capacity)
+    self._structure = structure
+    self._random_state = random_state
+    # encoder/decoder (snappy state compression in the reference,
+    # rainbow/run_atari.py:190-206) are accepted for signature compatibility;
+    # an HBM-resident store keeps raw rows, so they are not applied.
+    self._encoder = encoder
+    self._decoder = decoder
+    self._ring = _FieldRing(self._capacity, structure, self._device)
+    self._t = 0      # items ever added == id of the next item.
+    self._size = 0
+    self._status = _Status(self._device)
+
+  # -- shared surface --------------------------------------------------------
+  @property
+  def size(self) -> int:
+    return self._size
+
+  @property
+  def capacity(self) -> int:
+    return self._capacity
+
+  def ids(self) -> Iterable[int]:
+    """IDs of stored items, oldest first (ref: replay.py:165-167)."""
+    return range(self._t - self._size, self._t)
+
+  def get(self, ids: Sequence[int]) -> Iterable[ReplayStructure]:
+    """Retrieves items by id as host values (ref: replay.py:152-155)."""
+    for i in ids:
+      i = int(i)
+      if not self._t - self._size <= i < self._t:
+        raise KeyError(i)
+      yield self._ring.read(i % self._capacity)
+
+  def _stream(self):
+    return torch.cuda.current_stream(self._device).cuda_stream
+
+  def _store(self, item):
+    self._ring.write(self._t % self._capacity, item)
+    self._t += 1
+    self._size = min(self._size + 1, self._capacity)
+
+  def _to_host(self, tensors):
+    return type(self._structure)(*[x.cpu().numpy() for x in tensors])
+
+  def bulk_fill(self, fields: Sequence[torch.Tensor]) -> int:
+    """Appends `n` items given as device tensors `[n, *shape]` per field
+    (synthetic-benchmark fill; equivalent to n add() calls on the storage)."""
+    n = int(fields[0].shape[0])
+    if self._ring.fields is None:
+      self._ring.allocate([tuple(f.shape[1:]) for f in fields],
+                          [np.dtype(str(f.dtype).replace('torch.', ''))
+                           for f in fields])
+    if n > self._capacity:
+      raise ValueError('bulk_fill of more than capacity items')
+    start = self._t % self._capacity
+    first = min(n, self._capacity - start)
+    for dst, src in zip(self._ring.fields, fields):
+      dst[start:start + first].copy_(src[:first])
+      if first < n:
+        dst[:n - first].copy_(src[first:])
+    self._t += n
+    self._size = min(self._size + n, self._capacity)
+    return n
+
+
+class TransitionReplay(_ReplayBase):
+  """Uniform replay with FIFO eviction (ref: dqn_zoo/replay.py:120-200)."""
+
+  def __init__(
+      self,
+      capacity: int,
+      structure: ReplayStructure,
+      random_state: np.random.RandomState,
+      encoder: Optional[Callable[[ReplayStructure], Any]] = None,
+      decoder: Optional[Callable[[Any], ReplayStructure]] = None,
+      device=None,
+  ):
+    super().__init__(capacity, structure, random_state, encoder, decoder,
+                     device)
+
+  def add(self, item: ReplayStructure) -> None:
+    """Adds a single item, evicting the oldest when full (replay.py:141-150)."""
+    self._store(item)
+
+  def sample_ids_device(self, size: int) -> torch.Tensor:
+    """Draws `size` ids exactly as the reference (replay.py:76-82)."""
+    if self._size == 0:
+      raise ValueError('low >= high')  # what randint(0) raises in NumPy.
+    pos = self._random_state.randint(self._size, size=size)
+    pos_d = torch.from_numpy(pos.astype(np.int64)).to(self._device,
+                                                      non_blocking=True)
+    ids_d = torch.empty(size, dtype=torch.int64, device=self._device)
+    _lib.check(_lib.load().dz_uniform_pos_to_id(
+        pos_d.data_ptr(), size, self._t, self._size, self._capacity,
+        ids_d.data_ptr(), self._stream()), 'dz_uniform_pos_to_id')
+    return ids_d
+
+  def sample_device(self, size: int):
+    """Pipelined sample: (structure of device tensors, ids tensor)."""
+    ids_d = self.sample_ids_device(size)
+    outs = self._ring.gather(ids_d, size, self._stream())
+    return type(self._structure)(*outs), ids_d
+
+  def sample(self, size: int) -> ReplayStructure:
+    """Samples a batch uniformly with replacement (replay.py:157-163)."""
+    outs, _ = self.sample_device(size)
+    return self._to_host(outs)
+
+  def get_state(self) -> Mapping[str, Any]:
+    return {
+        't': self._t,
+        'size': self._size,
+        'fields': None if self._ring.fields is None else
+                  [f.cpu().numpy() for f in self._ring.fields],
+    }
+
+  def set_state(self, state: Mapping[str, Any]) -> None:
+    self._t = state['t']
+    self._size = state['size']
+    if state['fields'] is not None:
+      self._ring.allocate([f.shape[1:] for f in state['fields']],
+                          [f.dtype for f in state['fields']])
+      for dst, src in zip(self._ring.fields, state['fields']):
+        dst.copy_(torch.from_numpy(src))
+
+  def check_valid(self) -> Tuple[bool, str]:
+    if self._t < self._size:
+      return False, 't should be >= storage size.'
+    if not 0 <= self._size <= self._capacity:
+      return False, 'size should be within [0, capacity].'
+    return True, ''
+
+
+def _power(base, exponent) -> np.ndarray:
+  """`base ** exponent` except 0 ** 0 == 0 (ref: replay.py:203-208)."""
+  base = np.asarray(base)
+  return np.where(base == 0.0, 0.0, base**exponent)
+
+
+def importance_sampling_weights(
+    probabilities: np.ndarray,
+    uniform_probability: float,
+    exponent: float,
+    normalize: bool,
+) -> np.ndarray:
+  """Importance-sampling weights from probabilities (ref: replay.py:211-243)."""
+  if not 0.0 <= exponent <= 1.0:
+    raise ValueError('Require 0 <= exponent <= 1.')
+  if not 0.0 <= uniform_probability <= 1.0:
+    raise ValueError('Expected 0 <= uniform_probability <= 1.')
+  weights = (uniform_probability / probabilities) ** exponent
+  if normalize:
+    weights /= np.max(weights)
+  if not np.isfinite(weights).all():
+    raise ValueError('Weights are not finite: %s.' % weights)
+  return weights
+
+
+class SumTree:
+  """Device-resident float64 sum tree (ref: dqn_zoo/replay.py:246-426).
+
+  Same surface as the reference class; storage is a `float64[2*capacity]`
+  implicit heap in HBM and set/get/query run as HIP kernels.  Host arguments
+  are uploaded, results downloaded (this class is the synchronous, test-facing
+  view of the kernels the prioritized replay uses in place).
+  """
+
+  def __init__(self, device=None):
+    _lib.load()
+    self._device = _require_gpu(device)
+    self._size = 0
+    self._first_leaf = 0
+    self._storage = torch.zeros(0, dtype=torch.float64, device=self._device)
+    self._status = _Status(self._device)
+
+  def _stream(self):
+    return torch.cuda.current_stream(self._device).cuda_stream
+
+  def _dev(self, a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))
+                            ).to(self._device)
+
+  def resize(self, size: int) -> None:
+    self._initialize(size, None)
+
+  def get(self, indices: Sequence[int]) -> np.ndarray:
+    indices = np.asarray(indices)
+    if not ((0 <= indices) & (indices < self.size)).all():
+      raise IndexError('index out of range, expect 0 <= index < %s' % self.size)
+    flat = indices.reshape(-1)
+    if flat.size == 0:
+      return np.zeros(indices.shape, np.float64)
+    idx_d = self._dev(flat, np.int64)
+    out = torch.empty(flat.size, dtype=torch.float64, device=self._device)
+    _lib.check(_lib.load().dz_sumtree_get(
+        self._storage.data_ptr(), self._first_leaf, self._size,
+        idx_d.data_ptr(), flat.size, out.data_ptr(),
+        self._status.word.data_ptr(), self._stream()), 'dz_sumtree_get')
+    return out.cpu().numpy().reshape(indices.shape)
+
+  def set(self, indices: Sequence[int], values: Sequence[float]) -> None:
+    values = np.asarray(values)
+    if not np.isfinite(values).all() or (values < 0.0).any():
+      raise ValueError('value must be finite and positive.')
+    indices = np.asarray(indices, dtype=np.int64).reshape(-1)
+    values = np.broadcast_to(values.astype(np.float64), indices.shape)
+    if indices.size == 0:
+      return
+    if ((indices < -self._size) | (indices >= self._size)).any():
+      raise IndexError('index out of range')
+    for lo in range(0, indices.size, 1024):  # kernel handles <= 1024 per call
+      idx_d = self._dev(indices[lo:lo + 1024], np.int64)
+      val_d = self._dev(values[lo:lo + 1024], np.float64)
+      _lib.check(_lib.load().dz_sumtree_set(
+          self._storage.data_ptr(), self._first_leaf, self._size,
+          idx_d.data_ptr(), val_d.data_ptr(), idx_d.numel(),
+          self._status.word.data_ptr(), self._stream()), 'dz_sumtree_set')
+
+  def set_all(self, values: Sequence[float]) -> None:
+    values = np.asarray(values)
+    if not np.isfinite(values).all() or (values < 0.0).any():
+      raise ValueError('Values must be finite positive numbers.')
+    self._initialize(len(values), values)
+
+  def query(self, targets: Sequence[float]) -> Sequence[int]:
+    targets = np.asarray(targets, dtype=np.float64).reshape(-1)
+    if targets.size == 0:
+      return []
+    t_d = self._dev(targets, np.float64)
+    out = torch.empty(targets.size, dtype=torch.int64, device=self._device)
+    _lib.check(_lib.load().dz_sumtree_query(
+        self._storage.data_ptr(), self._first_leaf, t_d.data_ptr(),
+        targets.size, out.data_ptr(), self._status.word.data_ptr(),
+        self._stream()), 'dz_sumtree_query')
+    self._status.check()
+    return [int(i) for i in out.cpu().numpy()]
+
+  def root(self) -> float:
+    if self._size == 0:
+      return np.nan
+    return float(self._storage[1].item())
+
+  @property
+  def values(self) -> np.ndarray:
+    return self._storage[self._first_leaf:self._first_leaf + self._size
+                         ].cpu().numpy()
+
+  @property
+  def size(self) -> int:
+    return self._size
+
+  @property
+  def capacity(self) -> int:
+    return self._first_leaf
+
+  def get_state(self) -> Mapping[str, Any]:
+    return {'size': self._size, 'storage': self._storage.cpu().numpy(),
+            'first_leaf': self._first_leaf}
+
+  def set_state(self, state: Mapping[str, Any]) -> None:
+    self._size = state['size']
+    self._storage = torch.from_numpy(np.array(state['storage'],
+                                              dtype=np.float64)).to(self._device)
+    self._first_leaf = state['first_leaf']
+
+  def check_valid(self) -> Tuple[bool, str]:
+    if self._storage.numel() != 2 * self._first_leaf:
+      return False, 'first_leaf should be half the size of storage.'
+    if not 0 <= self.size <= self.capacity:
+      return False, 'Require 0 <= self.size <= self.capacity.'
+    s = self._storage.cpu().numpy()
+    n = self._first_leaf
+    if n > 1:
+      inner = np.arange(1, n)
+      bad = np.nonzero(s[inner] != s[2 * inner] + s[2 * inner + 1])[0]
+      if bad.size:
+        return False, ('Non-leaf node %d should be sum of child nodes.' %
+                       inner[bad[0]])
+    return True, ''
+
+  def _initialize(self, size, values):
+    assert size >= 0
+    assert values is None or len(values) == size
+    if size < self._size:
+      new_values = self.values[:size] if values is None else values
+      self._size = size
+      self._set_values(new_values)
+    elif size <= self.capacity:
+      self._size = size
+      if values is not None:
+        self._set_values(values)
+    else:
+      new_values = self.values if values is None else values
+      cap = _next_pow2(size)
+      self._storage = torch.zeros(2 * cap, dtype=torch.float64,
+                                  device=self._device)
+      self._first_leaf = cap
+      self._size = size
+      self._set_values(new_values)
+
+  def _set_values(self, values):
+    values = np.asarray(values, dtype=np.float64)
+    n = len(values)
+    assert n <= self.capacity
+    if self.capacity == 0:
+      return
+    if n:
+      self._storage[self._first_leaf:self._first_leaf + n] = self._dev(
+          values, np.float64)
+    _lib.check(_lib.load().dz_sumtree_rebuild(
+        self._storage.data_ptr(), self._first_leaf, n, self._stream()),
+               'dz_sumtree_rebuild')
+
+
+class DeviceSample(typing.NamedTuple):
+  """Result of `PrioritizedTransitionReplay.sample_device` (all in HBM)."""
+  transitions: Any
+  ids: torch.Tensor          # int64[B]
+  probabilities: torch.Tensor  # float64[B]
+  weights: torch.Tensor      # float64[B]  (device pow)
+  weights32: torch.Tensor    # float32[B]  (what the learner consumes)
+
+
+class PrioritizedTransitionReplay(_ReplayBase):
+  """Proportional prioritized replay (ref: dqn_zoo/replay.py:654-768)."""
+
+  def __init__(
+      self,
+      capacity: int,
+      structure: ReplayStructure,
+      priority_exponent: float,
+      importance_sampling_exponent: Callable[[int], float],
+      uniform_sample_probability: float,
+      normalize_weights: bool,
+      random_state: np.random.RandomState,
+      encoder: Optional[Callable[[ReplayStructure], Any]] = None,
+      decoder: Optional[Callable[[Any], ReplayStructure]] = None,
+      device=None,
+  ):
+    # Same argument checks as PrioritizedDistribution (replay.py:440-448).
+    if priority_exponent < 0.0:
+      raise ValueError('Require priority_exponent >= 0.')
+    if not 0.0 <= uniform_sample_probability <= 1.0:
+      raise ValueError('Require 0 <= uniform_sample_probability <= 1.')
+    super().__init__(capacity, structure, random_state, encoder, decoder,
+                     device)
+    self._priority_exponent = float(priority_exponent)
+    self._usp = float(uniform_sample_probability)
+    self._importance_sampling_exponent = importance_sampling_exponent
+    self._normalize_weights = bool(normalize_weights)
+    self._cap_pow2 = _next_pow2(self._capacity)
+    # float64[2*cap_pow2]: 16 MiB at capacity 1e6 (replay.py:382-385).
+    self._tree = torch.zeros(2 * self._cap_pow2, dtype=torch.float64,
+                             device=self._device)
+    # Running max of priorities, kept on the device for the pipelined learner
+    # (ref: rainbow/agent.py:79,196-197 keep it in the agent).
+    self.max_seen_priority_device = torch.ones(1, dtype=torch.float64,
+                                               device=self._device)
+
+  # -- adds ------------------------------------------------------------------
+  def add(self, item: ReplayStructure, priority: float) -> None:
+    """Adds one item with a host-side priority (ref: replay.py:690-699)."""
+    leaf = _power(np.asarray([priority], dtype=np.float64),
+                  self._priority_exponent)
+    if not np.isfinite(leaf).all() or (leaf < 0.0).any():
+      raise ValueError('value must be finite and positive.')
+    ti = int(tree_index_of_id(self._t, self._capacity))
+    self._store(item)
+    self._tree_set_host(np.array([ti], np.int64), leaf)
+
+  def add_with_device_priority(self, item, priority_d=None) -> None:
+    """add() whose priority is a device scalar (default: the running max);
+    no host sync.  Tree-side equivalent of replay.py:690-699."""
+    p = self.max_seen_priority_device if priority_d is None else priority_d
+    t = self._t
+    self._store(item)
+    _lib.check(_lib.load().dz_prioritized_add(
+        self._tree.data_ptr(), self._cap_pow2, self._capacity, t, 1, 0.0,
+        p.data_ptr(), self._priority_exponent, self._status.word.data_ptr(),
+        self._stream()), 'dz_prioritized_add')
+
+  def bulk_fill(self, fields, priority: float = 1.0) -> int:
+    t0 = self._t
+    n = super().bulk_fill(fields)
+    lib = _lib.load()
+    for lo in range(0, n, 1024):
+      m = min(1024, n - lo)
+      _lib.check(lib.dz_prioritized_add(
+          self._tree.data_ptr(), self._cap_pow2, self._capacity, t0 + lo, m,
+          float(priority), None, self._priority_exponent,
+          self._status.word.data_ptr(), self._stream()), 'dz_prioritized_add')
+    return n
+
+  def _tree_set_host(self, tree_idx, leaf_values):
+    idx_d = torch.from_numpy(np.ascontiguousarray(tree_idx, dtype=np.int64)
+                             ).to(self._device)
+    val_d = torch.from_numpy(np.ascontiguousarray(leaf_values,
+                                                  dtype=np.float64)
+                             ).to(self._device)
+    _lib.check(_lib.load().dz_sumtree_set(
+        self._tree.data_ptr(), self._cap_pow2, self._capacity,
+        idx_d.data_ptr(), val_d.data_ptr(), idx_d.numel(),
+        self._status.word.data_ptr(), self._stream()), 'dz_sumtree_set')
+
+  # -- sampling --------------------------------------------------------------
+  def _draw(self, size, zero_root):
+    """Host RNG draws in the reference's order (replay.py:551-566)."""
+    rs = self._random_state
+    pos = rs.randint(self._size, size=size).astype(np.int64)
+    if zero_root:
+      u_target = np.zeros(size, np.float64)  # the reference skips this draw.
+    else:
+      u_target = rs.uniform(size=size)
+    u_mix = rs.uniform(size=size)
+    # one upload: [pos int64 | u_target f64 bits | u_mix f64 bits]
+    packed = np.empty(3 * size, np.int64)
+    packed[:size] = pos
+    packed[size:2 * size] = u_target.view(np.int64)
+    packed[2 * size:] = u_mix.view(np.int64)
+    return torch.from_numpy(packed).to(self._device, non_blocking=True)
+
+  def _launch_sample(self, size, draws_d, compute_weights, pipelined):
+    dev = self._device
+    ids = torch.empty(size, dtype=torch.int64, device=dev)
+    probs = torch.empty(size, dtype=torch.float64, device=dev)
+    w64 = torch.empty(size, dtype=torch.float64, device=dev)
+    w32 = torch.empty(size, dtype=torch.float32, device=dev)
+    a = _lib.PrioSampleArgs()
+    a.node = self._tree.data_ptr()
+    a.cap_pow2 = self._cap_pow2
+    a.capacity = self._capacity
+    a.size = self._size
+    a.t = self._t
+    base = draws_d.data_ptr()
+    a.pos = base
+    a.u_target = base + 8 * size
+    a.u_mix = base + 16 * size
+    up = 1.0 / self._size
+    a.usp = self._usp
+    a.one_minus_usp = 1.0 - self._usp
+    a.usp_times_up = self._usp * up
+    a.uniform_prob = up
+    a.beta = float(self.importance_sampling_exponent)
+    a.normalize = int(self._normalize_weights)
+    a.compute_weights = int(compute_weights)
+    a.assume_nonzero_root = int(pipelined)
+    _lib.check(_lib.load().dz_prioritized_sample(
+        ctypes.byref(a), size, ids.data_ptr(), None, probs.data_ptr(),
+        w64.data_ptr(), w32.data_ptr(), self._status.word.data_ptr(),
+        self._stream()), 'dz_prioritized_sample')
+    return ids, probs, w64, w32
+
+  def sample_device(self, size: int) -> DeviceSample:
+    """Pipelined sample for the on-device learner: no host synchronisation.
+
+    ids and probabilities are bit-identical to the reference; weights use the
+    device pow (equal to NumPy's after the float32 cast the learner applies,
+    see DESIGN.md).  Assumes root() != 0, which holds whenever priorities come
+    from max_seen_priority >= 1 (rainbow/agent.py:79,149); a zero root raises
+    through the sticky status word at the next `check_status()`.
+    """
+    if self._size == 0:
+      raise RuntimeError('No IDs to sample.')
+    beta = float(self.importance_sampling_exponent)
+    if not 0.0 <= beta <= 1.0:
+      raise ValueError('Require 0 <= exponent <= 1.')
+    draws = self._draw(size, zero_root=False)
+    ids, probs, w64, w32 = self._launch_sample(size, draws, True, True)
+    outs = self._ring.gather(ids, size, self._stream())
+    return DeviceSample(type(self._structure)(*outs), ids, probs, w64, w32)
+
+  def sample(self, size: int) -> Tuple[ReplayStructure, np.ndarray, np.ndarray]:
+    """Samples a batch of transitions (ref: replay.py:706-723).
+
+    Synchronous and bit-exact: ids/probabilities from the device, importance
+    weights from NumPy on the host (`importance_sampling_weights`)."""
+    if self._size == 0:
+      raise RuntimeError('No IDs to sample.')
+    root = float(self._tree[1].item())
+    draws = self._draw(size, zero_root=(root == 0.0))
+    ids_d, probs_d, _, _ = self._launch_sample(size, draws, False, False)
+    outs = self._ring.gather(ids_d, size, self._stream())
+    probs = probs_d.cpu().numpy()
+    self._status.check()
+    weights = importance_sampling_weights(
+        probs, uniform_probability=1.0 / self._size,
+        exponent=self.importance_sampling_exponent,
+        normalize=self._normalize_weights)
+    return self._to_host(outs), ids_d.cpu().numpy(), weights
+
+  # -- priorities ------------------------------------------------------------
+  def update_priorities(self, ids, priorities) -> None:
+    """Updates ids with given priorities (ref: replay.py:725-730, 536-545).
+
+    Host arrays: leaf values are computed with NumPy exactly as the reference
+    does (dtype rules included) and only the tree update runs on the device.
+    Device tensors: everything runs on the device (`dz_prioritized_update`),
+    which also folds max(priorities) into `max_seen_priority_device`.
+    """
+    if isinstance(priorities, torch.Tensor) or isinstance(ids, torch.Tensor):
+      ids_d = ids if isinstance(ids, torch.Tensor) else torch.from_numpy(
+          np.asarray(ids, dtype=np.int64)).to(self._device)
+      p_d = priorities if isinstance(priorities, torch.Tensor) else (
+          torch.from_numpy(np.asarray(priorities)).to(self._device))
+      if p_d.dtype not in (torch.float32, torch.float64):
+        raise TypeError('priorities must be float32 or float64')
+      _lib.check(_lib.load().dz_prioritized_update(
+          self._tree.data_ptr(), self._cap_pow2, self._capacity, self._size,
+          self._t, ids_d.data_ptr(), p_d.data_ptr(),
+          int(p_d.dtype == torch.float32), self._priority_exponent,
+          ids_d.numel(), self.max_seen_priority_device.data_ptr(),
+          self._status.word.data_ptr(), self._stream()),
+                 'dz_prioritized_update')
+      return
+    priorities = np.asarray(priorities)
+    ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+    for i in ids:
+      if not self._t - self._size <= i < self._t:
+        raise IndexError('ID %d does not exist.' % i)
+    leaf = _power(priorities, self._priority_exponent)
+    if not np.isfinite(leaf).all() or (leaf < 0.0).any():
+      raise ValueError('value must be finite and positive.')
+    leaf = np.broadcast_to(np.asarray(leaf, dtype=np.float64), ids.shape)
+    self._tree_set_host(tree_index_of_id(ids, self._capacity), leaf)
+
+  def check_status(self) -> None:
+    """Synchronises and raises if any pipelined kernel flagged an error."""
+    self._status.check()
+
+  @property
+  def importance_sampling_exponent(self):
+    """Importance sampling exponent at current step (replay.py:742-745)."""
+    return self._importance_sampling_exponent(self._t)
+
+  @property
+  def tree_storage(self) -> torch.Tensor:
+    """The float64[2*cap_pow2] heap array in HBM (root at [1])."""
+    return self._tree
+
+  def get_state(self) -> Mapping[str, Any]:
+    return {
+        't': self._t,
+        'size': self._size,
+        'fields': None if self._ring.fields is None else
+                  [f.cpu().numpy() for f in self._ring.fields],
+        'sum_tree_storage': self._tree.cpu().numpy(),
+        'max_seen_priority': float(self.max_seen_priority_device.item()),
+    }
+
+  def set_state(self, state: Mapping[str, Any]) -> None:
+    self._t = state['t']
+    self._size = state['size']
+    if state['fields'] is not None:
+      self._ring.allocate([f.shape[1:] for f in state['fields']],
+                          [f.dtype for f in state['fields']])
+      for dst, src in zip(self._ring.fields, state['fields']):
+        dst.copy_(torch.from_numpy(src))
+    self._tree.copy_(torch.from_numpy(state['sum_tree_storage']))
+    self.max_seen_priority_device.fill_(state['max_seen_priority'])
+
+  def check_valid(self) -> Tuple[bool, str]:
+    if self._t < self._size:
+      return False, 't should be >= storage size.'
+    s = self._tree.cpu().numpy()
+    n = self._cap_pow2
+    if n > 1:
+      inner = np.arange(1, n)
+      bad = np.nonzero(s[inner] != s[2 * inner] + s[2 * inner + 1])[0]
+      if bad.size:
+        return False, ('Non-leaf node %d should be sum of child nodes.' %
+                       inner[bad[0]])
+    live = tree_index_of_id(np.arange(self._t - self._size, self._t),
+                            self._capacity)
+    dead = np.ones(n, bool)
+    dead[live] = False
+    if (s[n:][dead] != 0.0).any():
+      return False, 'Inactive tree indices should have zero priority.'
+    return True, ''
+
+
+# --------------------------------------------------------------------------- #
+#  Transition accumulators: host-side feeders (stay on host).
+# --------------------------------------------------------------------------- #
+class TransitionAccumulator:
+  """Accumulates timesteps into 1-step transitions (ref: replay.py:771-805)."""
+
+  def __init__(self):
+    self.reset()
+
+  def step(self, timestep_t, a_t) -> Iterable[Transition]:
+    if timestep_t.first():
+      self.reset()
+    prev, prev_a = self._timestep_tm1, self._a_tm1
+    if prev is None and not timestep_t.first():
+      raise ValueError('Expected FIRST timestep, got %s.' % str(timestep_t))
+    self._timestep_tm1, self._a_tm1 = timestep_t, a_t
+    if prev is None:
+      return
+    yield Transition(s_tm1=prev.observation, a_tm1=prev_a,
+                     r_t=timestep_t.reward, discount_t=timestep_t.discount,
+                     s_t=timestep_t.observation)
+
+  def reset(self) -> None:
+    self._timestep_tm1 = None
+    self._a_tm1 = None
+
+
+def _fold_n_step(window):
+  """One n-step transition from n consecutive 1-step ones (replay.py:808-823)."""
+  reward, discount = 0.0, 1.0
+  for tr in window:
+    reward += discount * tr.r_t
+    discount *= tr.discount_t
+  return Transition(s_tm1=window[0].s_tm1, a_tm1=window[0].a_tm1, r_t=reward,
+                    discount_t=discount, s_t=window[-1].s_t)
+
+
+class NStepTransitionAccumulator:
+  """Accumulates timesteps into n-step transitions (ref: replay.py:826-892).
+
+  FIRST: nothing.  MID: once n 1-step transitions are buffered, one n-step
+  transition per step.  LAST: every suffix of the buffer, longest first.
+  """
+
+  def __init__(self, n):
+    self._window = collections.deque(maxlen=n)
+    self.reset()
+
+  def step(self, timestep_t, a_t) -> Iterable[Transition]:
+    if timestep_t.first():
+      self.reset()
+    prev, prev_a = self._timestep_tm1, self._a_tm1
+    if prev is None and not timestep_t.first():
+      raise ValueError('Expected FIRST timestep, got %s.' % str(timestep_t))
+    self._timestep_tm1, self._a_tm1 = timestep_t, a_t
+    if prev is None:
+      return
+    self._window.append(Transition(
+        s_tm1=prev.observation, a_tm1=prev_a, r_t=timestep_t.reward,
+        discount_t=timestep_t.discount, s_t=timestep_t.observation))
+    if timestep_t.last():
+      while self._window:
+        yield _fold_n_step(self._window)
+        self._window.popleft()
+    elif len(self._window) == self._window.maxlen:
+      yield _fold_n_step(self._window)
+
+  def reset(self) -> None:
+    self._window.clear()
+    self._timestep_tm1 = None
+    self._a_tm1 = None

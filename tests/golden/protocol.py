@@ -63,14 +63,22 @@ def priority_stream(seed):
   return draw
 
 
-def drive_prioritized(replay, capacity, fill, batch, steps, seed, on_sample):
-  """Runs the protocol.  `on_sample(k, ids, weights)` is called per step."""
+def drive_prioritized(replay, capacity, fill, batch, steps, seed, on_sample,
+                      bulk_fill=None):
+  """Runs the protocol.  `on_sample(k, ids, weights)` is called per step.
+
+  `bulk_fill(replay, n)`, if given, must be equivalent to the n initial
+  `add(Item(a=i, b=-i), 1.0)` calls (used for the 1M-item device fill)."""
   draw = priority_stream(seed)
   max_seen = 1.0
   t = 0  # number of adds so far == id of the next item (replay.py:696).
-  for _ in range(fill):
-    replay.add(Item(a=t, b=-t), 1.0)
-    t += 1
+  if bulk_fill is not None:
+    bulk_fill(replay, fill)
+    t = fill
+  else:
+    for _ in range(fill):
+      replay.add(Item(a=t, b=-t), 1.0)
+      t += 1
   for k in range(steps):
     _, ids, weights = replay.sample(batch)
     on_sample(k, np.asarray(ids), np.asarray(weights))
@@ -82,11 +90,16 @@ def drive_prioritized(replay, capacity, fill, batch, steps, seed, on_sample):
       t += 1
 
 
-def drive_uniform(replay, capacity, fill, batch, steps, seed, on_sample):
+def drive_uniform(replay, capacity, fill, batch, steps, seed, on_sample,
+                  bulk_fill=None):
   t = 0  # Item.a carries the item's id, so sampled ids can be read back.
-  for _ in range(fill):
-    replay.add(Item(a=t, b=-t))
-    t += 1
+  if bulk_fill is not None:
+    bulk_fill(replay, fill)
+    t = fill
+  else:
+    for _ in range(fill):
+      replay.add(Item(a=t, b=-t))
+      t += 1
   for k in range(steps):
     s = replay.sample(batch)
     on_sample(k, s)
