@@ -89,6 +89,10 @@ def load():
     raise HipLibraryError(
         'libdqnzoo_hip.so is not built (%s). Run `python -m dqn_zoo_amd.build` '
         '(hipcc, --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+  # PyTorch-ROCm bundles its own libamdhip64.so; it must be mapped BEFORE this
+  # library so that both resolve to ONE HIP runtime instance (streams and
+  # device pointers are shared between them).
+  import torch  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
   try:
     lib = ctypes.CDLL(LIB_PATH)
   except OSError as e:
@@ -100,8 +104,22 @@ def load():
       raise HipLibraryError('%s does not export %s' % (LIB_PATH, name)) from e
     fn.restype = res
     fn.argtypes = args
+  _check_single_hip_runtime()
   _lib = lib
   return lib
+
+
+def _check_single_hip_runtime():
+  try:
+    with open('/proc/self/maps') as f:
+      paths = {line.split()[-1] for line in f if 'libamdhip64' in line}
+  except OSError:
+    return
+  real = {os.path.realpath(p) for p in paths}
+  if len(real) > 1:
+    raise HipLibraryError(
+        'two HIP runtimes are mapped in this process (%s): import torch before '
+        'loading libdqnzoo_hip.so' % sorted(real))
 
 
 def check(code, what):
