@@ -46,12 +46,55 @@ class PrioSampleArgs(ctypes.Structure):
   ]
 
 
+c_i32 = ctypes.c_int32
+
+
+class RainbowLayout(ctypes.Structure):
+  _fields_ = (
+      [('num_actions', c_i32), ('num_atoms', c_i32), ('batch', c_i32),
+       ('groups', c_i32), ('param_count', c_i64), ('param_count_ref', c_i64),
+       ('conv_w', c_i64 * 3), ('conv_b', c_i64 * 3)] +
+      [(n, c_i64) for n in (
+          'fc1_mu_w', 'fc1_mu_b', 'fc1_sig_w', 'fc1_sig_b', 'adv2_mu_w',
+          'adv2_sig_w', 'val2_mu_w', 'val2_sig_w', 'fc2_sig_b', 'noise_stride',
+          'n_adv1_in', 'n_val1_in', 'n_fc1_out', 'n_adv2_in', 'n_val2_in',
+          'n_fc2_out', 'ws_count', 'ws_act1', 'ws_act2', 'ws_feat',
+          'ws_fc1_part', 'ws_h1', 'ws_fc2_part', 'ws_fc2_out', 'ws_dout2',
+          'ws_dh1', 'ws_dfeat_part', 'ws_dfeat', 'ws_dact2', 'ws_dact1',
+          'ws_wgrad_part', 'ws_norm_part', 'ws_scalars', 'ws_q_sel',
+          'ws_target_probs')])
+
+
+class RainbowArgs(ctypes.Structure):
+  _fields_ = [
+      ('num_actions', c_i32), ('num_atoms', c_i32), ('batch', c_i32),
+      ('online', c_vp), ('target', c_vp), ('grad', c_vp), ('adam_m', c_vp),
+      ('adam_v', c_vp), ('adam_count', c_vp), ('s_tm1', c_vp), ('s_t', c_vp),
+      ('a_tm1', c_vp), ('r_t', c_vp), ('discount_t', c_vp), ('weights', c_vp),
+      ('support', c_vp), ('noise', c_vp), ('ws', c_vp), ('losses', c_vp),
+      ('priorities', c_vp), ('lr', c_f32), ('b1', c_f32), ('b2', c_f32),
+      ('eps', c_f32), ('max_norm', c_f32),
+  ]
+
+
+SC_GNORM, SC_LOSS, SC_BC1, SC_BC2, SC_CLIP = 0, 1, 2, 3, 4
+PHASE_FORWARD, PHASE_BACKWARD, PHASE_OPTIMIZER, PHASE_ALL = 1, 2, 4, 7
+
+STRUCT_IDS = {0: FieldDesc, 1: PrioSampleArgs, 2: RainbowLayout, 3: RainbowArgs}
+
 # name -> (restype, argtypes).  tests/test_abi.py checks this table against
 # the prototypes in include/dqnzoo_hip.h and against the built library.
 SIGNATURES = {
     'dz_version': (ctypes.c_char_p, []),
     'dz_last_hip_error': (c_int, []),
     'dz_built_arch': (ctypes.c_char_p, []),
+    'dz_struct_size': (c_int, [c_int]),
+    'dz_rainbow_layout': (c_int, [c_int, c_int, c_int,
+                                  ctypes.POINTER(RainbowLayout)]),
+    'dz_rainbow_learn': (c_int, [ctypes.POINTER(RainbowArgs), c_int, c_vp]),
+    'dz_noise_fill': (c_int, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64,
+                              c_vp]),
+    'dz_param_copy': (c_int, [c_vp, c_vp, c_i64, c_vp]),
     'dz_replay_gather': (c_int, [ctypes.POINTER(FieldDesc), c_int, c_vp, c_int,
                                  c_i64, c_vp]),
     'dz_uniform_pos_to_id': (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp,
@@ -104,6 +147,11 @@ def load():
       raise HipLibraryError('%s does not export %s' % (LIB_PATH, name)) from e
     fn.restype = res
     fn.argtypes = args
+  for which, cls in STRUCT_IDS.items():
+    if lib.dz_struct_size(which) != ctypes.sizeof(cls):
+      raise HipLibraryError(
+          'ABI mismatch: struct %s is %d bytes in the library, %d in _lib.py' %
+          (cls.__name__, lib.dz_struct_size(which), ctypes.sizeof(cls)))
   _check_single_hip_runtime()
   _lib = lib
   return lib

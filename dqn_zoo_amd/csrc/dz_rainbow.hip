@@ -1,0 +1,597 @@
+// Rainbow learner step on one MI355X (ref: rainbow/agent.py:85-121).
+//
+// Launch sequence (all on the caller's stream, no host synchronisation):
+//   forward : conv1 conv2 conv3 (3 applies batched as groups) -> fc1 (noisy,
+//             adv1|val1 fused, split-K) -> epilogue -> fc2 (noisy adv2, val2)
+//             -> epilogue -> head/loss (dueling + softmax + double-Q selector +
+//             Cramer projection + cross-entropy + dlogits + priorities)
+//   backward: fc2 wgrad/dgrad, fc1 wgrad/dgrad, conv3 wgrad/dgrad, conv2
+//             wgrad/dgrad, conv1 wgrad, bias column sums
+//   update  : sum of squares -> global norm/clip scale -> Adam
+// Roofline notes per kernel are in DESIGN.md.
+#include "dz_qnet_ops.h"
+
+namespace {
+
+constexpr int kFlat = 3136;   // 7*7*64 torso features
+constexpr int kHid = 512;
+constexpr int kG = 3;         // applies: online(s_tm1), online(s_t), target(s_t)
+constexpr int kS_fc1 = 7;     // grid split-K factors
+constexpr int kS_fc2 = 4;
+constexpr int kS_dfeat = 8;
+constexpr int kS_cw1 = 100, kS_cw2 = 27, kS_cw3 = 14;
+constexpr int kNormBlocks = 512;
+
+inline int64_t align4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+
+// conv geometries (networks.py:194-198)
+//                      U8  H   W   C  KS S  OH  OW  CO
+using Conv1Fwd = ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 4, 1, 1>;
+using Conv2Fwd = ConvFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 1, 2, 2>;
+using Conv3Fwd = ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 2, 2>;
+using Conv1Wg = ConvWgradOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 2, 1, 2>;
+using Conv2Wg = ConvWgradOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 2, 2, 1>;
+using Conv3Wg = ConvWgradOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 2, 2, 1>;
+using Conv2Dg = ConvDgradOp<20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4>;
+using Conv3Dg = ConvDgradOp<9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4>;
+using FcFwd = FcFwdOp<1, 2, 2>;
+using FcDg = FcDgradOp<1, 2, 2>;
+using FcWg = FcWgradOp<2, 2, 1>;
+
+// ---- small kernels ----------------------------------------------------------
+
+// out[r][c] = act( sum_s part[s][r][c] + b_mu[c] + b_sig[c]*eps_out[g][c] )
+__global__ void fc_epilogue_kernel(const float* __restrict__ part, int S, int rows,
+                                   int cols, int ld, int rows_per_group,
+                                   const float* p0, const float* p1, const float* p2,
+                                   long b_mu, long b_sig, const float* n0,
+                                   const float* n1, const float* n2, int eps_out,
+                                   int relu, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (c >= cols) return;
+  const int g = r / rows_per_group;
+  const float* prm = g == 0 ? p0 : (g == 1 ? p1 : p2);
+  const float* nz = g == 0 ? n0 : (g == 1 ? n1 : n2);
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += part[((long)s * rows + r) * ld + c];
+  if (b_mu >= 0) v += prm[b_mu + c];
+  if (b_sig >= 0) v += prm[b_sig + c] * nz[eps_out + c];
+  if (relu) v = v > 0.f ? v : 0.f;
+  out[(long)r * ld + c] = v;
+}
+
+// out[i] = (mask? mask[i] > 0 : 1) * sum_s part[s][i]
+__global__ void reduce_parts_kernel(const float* part, int S, long n,
+                                    const float* __restrict__ mask, float* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += part[(long)s * n + i];
+  if (mask && !(mask[i] > 0.f)) v = 0.f;
+  out[i] = v;
+}
+
+// Column sums of row-major matrices: out[c] = scale[c]? * sum_r m[r][c].
+struct ColsumJob {
+  const float* m; int rows; int cols; int ld; float* out; const float* scale;
+  float* out_scaled;
+};
+struct ColsumJobs { ColsumJob j[6]; int n; };
+__global__ __launch_bounds__(256) void colsum_kernel(ColsumJobs jobs) {
+  __shared__ float red[4][64];
+  const ColsumJob jb = jobs.j[blockIdx.y];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  if (blockIdx.x * 64 >= jb.cols) return;
+  float v = 0.f;
+  if (c < jb.cols)
+    for (int r = w; r < jb.rows; r += 4) v += jb.m[(long)r * jb.ld + c];
+  red[w][threadIdx.x & 63] = v;
+  __syncthreads();
+  if (w == 0 && c < jb.cols) {
+    const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                    red[3][threadIdx.x];
+    if (jb.out) jb.out[c] = s;
+    if (jb.out_scaled) jb.out_scaled[c] = s * jb.scale[c];
+  }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// One wave per sample; lane k owns atom k (K <= 64).
+// ref: networks.py:254-258 (dueling, softmax, expectation),
+//      rainbow/agent.py:97-109 + rlax.categorical_double_q_learning,
+//      rainbow/agent.py:194 (priorities).
+__global__ __launch_bounds__(64) void rainbow_head_loss_kernel(
+    const float* __restrict__ fc2_out, int ld, int B, int A, int K,
+    const int64_t* __restrict__ a_tm1, const double* __restrict__ r_t,
+    const double* __restrict__ d_t, const float* __restrict__ weights,
+    const float* __restrict__ support, float* __restrict__ dout2,
+    float* __restrict__ losses, float* __restrict__ priorities,
+    float* __restrict__ q_sel_out, float* __restrict__ target_out) {
+  __shared__ float s_p[64];
+  __shared__ float s_z[64];
+  const int b = blockIdx.x, k = threadIdx.x;
+  const bool on = k < K;
+  const int NA = A * K;
+  const float z = on ? support[k] : 0.f;
+  const float invA = 1.0f / (float)A;
+
+  // ---- group 1: q_values of online(s_t) -> argmax (double-Q selector) ----
+  const float* o1 = fc2_out + (long)(1 * B + b) * ld;
+  float mean_adv = 0.f;
+  for (int a = 0; a < A; ++a) mean_adv += on ? o1[a * K + k] : 0.f;
+  mean_adv /= (float)A;
+  const float v1 = on ? o1[NA + k] : 0.f;
+  float best_q = -__builtin_inff();
+  int a_star = 0;
+  for (int a = 0; a < A; ++a) {
+    const float lg = on ? (v1 + o1[a * K + k] - mean_adv) : -__builtin_inff();
+    const float mx = wave_max(lg);
+    const float e = on ? expf(lg - mx) : 0.f;
+    const float sm = wave_sum(e);
+    const float q = wave_sum((e / sm) * z);
+    if (k == 0 && q_sel_out) q_sel_out[b * A + a] = q;
+    if (q > best_q) { best_q = q; a_star = a; }  // first maximum, as jnp.argmax
+  }
+  // ---- group 2: target distribution of the selected action ----
+  const float* o2 = fc2_out + (long)(2 * B + b) * ld;
+  float mean2 = 0.f;
+  for (int a = 0; a < A; ++a) mean2 += on ? o2[a * K + k] : 0.f;
+  mean2 /= (float)A;
+  const float lg2 = on ? (o2[NA + k] + o2[a_star * K + k] - mean2) : -__builtin_inff();
+  const float mx2 = wave_max(lg2);
+  const float e2 = on ? expf(lg2 - mx2) : 0.f;
+  const float p_t = e2 / wave_sum(e2);
+  // ---- Cramer projection of (r + g z, p_t) onto the support ----
+  const float r = (float)r_t[b], g = (float)d_t[b];  // f64 -> f32 at the jit boundary
+  const float vmin = support[0], vmax = support[K - 1];
+  float zp = r + g * z;
+  zp = fminf(fmaxf(zp, vmin), vmax);
+  s_p[k] = on ? p_t : 0.f;
+  s_z[k] = zp;
+  __syncthreads();
+  float m = 0.f;
+  if (on) {
+    const float zq = z;
+    const float dpos = (k + 1 < K ? support[k + 1] : support[0]) - zq;
+    const float dneg = zq - (k > 0 ? support[k - 1] : support[K - 1]);
+    const float rpos = dpos > 0.f ? 1.0f / dpos : 0.f;
+    const float rneg = dneg > 0.f ? 1.0f / dneg : 0.f;
+    for (int j = 0; j < K; ++j) {
+      const float delta = s_z[j] - zq;
+      const float dh = delta >= 0.f ? delta * rpos : -(delta * rneg);
+      const float c = fminf(fmaxf(1.0f - dh, 0.f), 1.f);
+      m += c * s_p[j];
+    }
+  }
+  if (target_out && on) target_out[b * K + k] = m;
+  // ---- group 0: cross-entropy with log_softmax(logits_tm1[a_tm1]) ----
+  const int a0 = (int)a_tm1[b];
+  const float* o0 = fc2_out + (long)(0 * B + b) * ld;
+  float mean0 = 0.f;
+  for (int a = 0; a < A; ++a) mean0 += on ? o0[a * K + k] : 0.f;
+  mean0 /= (float)A;
+  const float lg0 = on ? (o0[NA + k] + o0[a0 * K + k] - mean0) : -__builtin_inff();
+  const float mx0 = wave_max(lg0);
+  const float sh = lg0 - mx0;
+  const float e0 = on ? expf(sh) : 0.f;
+  const float se0 = wave_sum(e0);
+  const float lsm = sh - logf(se0);
+  const float loss = -wave_sum(on ? m * lsm : 0.f);
+  const float msum = wave_sum(m);
+  // d loss / d logits_tm1[a0][k], scaled by w/B (loss = mean(losses*w))
+  const float gk = on ? ((e0 / se0) * msum - m) * (weights[b] / (float)B) : 0.f;
+  if (on) {
+    float* d = dout2 + (long)b * ld;
+    for (int a = 0; a < A; ++a)  // dadv[a][k] = G[a][k] - mean_a G[.][k]
+      d[a * K + k] = (a == a0 ? gk : 0.f) - gk * invA;
+    d[NA + k] = gk;              // dval[k] = sum_a G[a][k]
+  }
+  if (k == 0) {
+    losses[b] = loss;
+    priorities[b] = fminf(fmaxf(fabsf(loss), 0.f), 100.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
+                                                    long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = ((const float4*)g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// One block: global norm, clip decision, Adam bias corrections, mean loss.
+__global__ __launch_bounds__(256) void opt_scalars_kernel(
+    const float* __restrict__ part, int nparts, int32_t* count, float b1, float b2,
+    float max_norm, const float* __restrict__ losses, const float* __restrict__ weights,
+    int B, float* __restrict__ sc) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float gn = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const int c = *count + 1;  // optax: count_inc = count + 1
+    *count = c;
+    sc[DZ_SC_GNORM] = gn;
+    sc[DZ_SC_BC1] = 1.0f - powf(b1, (float)c);
+    sc[DZ_SC_BC2] = 1.0f - powf(b2, (float)c);
+    sc[DZ_SC_CLIP] = (max_norm > 0.f && !(gn < max_norm)) ? 0.f : 1.f;
+    float l = 0.f;
+    for (int i = 0; i < B; ++i) l += losses[i] * weights[i];
+    sc[DZ_SC_LOSS] = l / (float)B;
+  }
+}
+
+// optax.clip_by_global_norm then optax.adam, then apply_updates.
+__global__ __launch_bounds__(256) void adam_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+    float* __restrict__ v, long n4, const float* __restrict__ sc, float lr, float b1,
+    float b2, float eps, float max_norm) {
+  const float gn = sc[DZ_SC_GNORM], bc1 = sc[DZ_SC_BC1], bc2 = sc[DZ_SC_BC2];
+  const bool pass = sc[DZ_SC_CLIP] != 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 gv = ((const float4*)g)[i];
+    float4 mv = ((float4*)m)[i], vv = ((float4*)v)[i], pv = ((float4*)p)[i];
+    float* G = (float*)&gv; float* M = (float*)&mv; float* V = (float*)&vv;
+    float* P = (float*)&pv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = pass ? G[j] : (G[j] / gn) * max_norm;
+      M[j] = (1.0f - b1) * gj + b1 * M[j];
+      V[j] = (1.0f - b2) * (gj * gj) + b2 * V[j];
+      const float upd = (M[j] / bc1) / (sqrtf(V[j] / bc2) + eps);
+      P[j] = P[j] + (-lr) * upd;
+    }
+    ((float4*)m)[i] = mv; ((float4*)v)[i] = vv; ((float4*)p)[i] = pv;
+  }
+}
+
+__global__ void copy_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                            long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long)gridDim.x * blockDim.x)
+    ((float4*)dst)[i] = ((const float4*)src)[i];
+}
+
+// Counter-based generator (splitmix64 finaliser on (seed, counter+i)), two
+// 24-bit uniforms -> standard normal via inverse CDF restricted to [-2,2].
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ void noise_fill_kernel(float* __restrict__ out, long n, uint64_t seed,
+                                  uint64_t counter) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t h = mix64(mix64(seed) ^ mix64(counter + (uint64_t)i));
+  // jax.random.truncated_normal: sqrt2 * erfinv(U(erf(lo/sqrt2), erf(hi/sqrt2)))
+  const float u01 = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+  const float e = 0.9544997361036416f;  // erf(2/sqrt(2))
+  const float u = (2.0f * u01 - 1.0f) * e;
+  float x = 1.4142135623730951f * erfinvf(u);
+  x = fminf(fmaxf(x, -2.0f), 2.0f);
+  const float s = sqrtf(fabsf(x));
+  out[i] = x < 0.f ? -s : (x > 0.f ? s : 0.f);  // sign(x) * sqrt|x| (networks.py:144)
+}
+
+}  // namespace
+
+// ---- layout -----------------------------------------------------------------
+extern "C" int dz_rainbow_layout(int A, int K, int B, dz_rainbow_layout_t* L) {
+  DZ_REQUIRE(L && A > 0 && K > 0 && K <= 64 && B > 0 && B <= 1024);
+  const int NA = A * K, NAK = NA + K;
+  L->num_actions = A; L->num_atoms = K; L->batch = B; L->groups = kG;
+  int64_t o = 0;
+  const int64_t cw[3] = {256 * 32, 512 * 64, 576 * 64};
+  const int64_t cb[3] = {32, 64, 64};
+  for (int i = 0; i < 3; ++i) {
+    L->conv_w[i] = o; o = align4(o + cw[i]);
+    L->conv_b[i] = o; o = align4(o + cb[i]);
+  }
+  L->fc1_mu_w = o; o = align4(o + (int64_t)kFlat * 1024);
+  L->fc1_mu_b = o; o = align4(o + 1024);
+  L->fc1_sig_w = o; o = align4(o + (int64_t)kFlat * 1024);
+  L->fc1_sig_b = o; o = align4(o + 1024);
+  L->adv2_mu_w = o; o = align4(o + (int64_t)kHid * NA);
+  L->adv2_sig_w = o; o = align4(o + (int64_t)kHid * NA);
+  L->val2_mu_w = o; o = align4(o + (int64_t)kHid * K);
+  L->val2_sig_w = o; o = align4(o + (int64_t)kHid * K);
+  L->fc2_sig_b = o; o = align4(o + NAK);
+  L->param_count = o;
+  L->param_count_ref = 77984 + 2 * ((int64_t)kFlat * 512 * 2 + 1024) +
+                       ((int64_t)kHid * NA * 2 + NA) + ((int64_t)kHid * K * 2 + K);
+  // noise block of one apply
+  L->n_adv1_in = 0; L->n_val1_in = kFlat; L->n_fc1_out = 2 * kFlat;
+  L->n_adv2_in = 2 * kFlat + 1024; L->n_val2_in = L->n_adv2_in + kHid;
+  L->n_fc2_out = L->n_val2_in + kHid;
+  L->noise_stride = align4(L->n_fc2_out + NAK);
+  // workspace
+  const int64_t GB = (int64_t)kG * B;
+  const int64_t ld2 = align4(NAK);
+  int64_t w = 0;
+  auto take = [&](int64_t n) { int64_t r = w; w = align4(w + n); return r; };
+  L->ws_act1 = take(GB * 400 * 32);
+  L->ws_act2 = take(GB * 81 * 64);
+  L->ws_feat = take(GB * kFlat);
+  L->ws_fc1_part = take((int64_t)kS_fc1 * GB * 1024);
+  L->ws_h1 = take(GB * 1024);
+  L->ws_fc2_part = take((int64_t)kS_fc2 * GB * ld2);
+  L->ws_fc2_out = take(GB * ld2);
+  L->ws_dout2 = take((int64_t)B * ld2);
+  L->ws_dh1 = take((int64_t)B * 1024);
+  L->ws_dfeat_part = take((int64_t)kS_dfeat * B * kFlat);
+  L->ws_dfeat = take((int64_t)B * kFlat);
+  L->ws_dact2 = take((int64_t)B * 81 * 64);
+  L->ws_dact1 = take((int64_t)B * 400 * 32);
+  int64_t wp = (int64_t)kS_cw1 * 256 * 32;
+  if ((int64_t)kS_cw2 * 512 * 64 > wp) wp = (int64_t)kS_cw2 * 512 * 64;
+  if ((int64_t)kS_cw3 * 576 * 64 > wp) wp = (int64_t)kS_cw3 * 576 * 64;
+  L->ws_wgrad_part = take(wp);
+  L->ws_norm_part = take(kNormBlocks);
+  L->ws_scalars = take(16);
+  L->ws_q_sel = take((int64_t)B * A);
+  L->ws_target_probs = take((int64_t)B * K);
+  L->ws_count = w;
+  return DZ_OK;
+}
+
+// ---- the step ---------------------------------------------------------------
+extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
+                                dz_stream_t stream) {
+  DZ_REQUIRE(a && a->online && a->target && a->ws && a->noise && a->support);
+  DZ_REQUIRE(a->s_tm1 && a->s_t && a->a_tm1 && a->r_t && a->discount_t && a->weights);
+  DZ_REQUIRE(a->losses && a->priorities);
+  dz_rainbow_layout_t L;
+  int rc = dz_rainbow_layout(a->num_actions, a->num_atoms, a->batch, &L);
+  if (rc != DZ_OK) return rc;
+  hipStream_t s = dz_s(stream);
+  const int B = a->batch, A = a->num_actions, K = a->num_atoms;
+  const int NA = A * K, NAK = NA + K, ld2 = (int)align4(NAK);
+  float* ws = a->ws;
+  const float* prm[kG] = {a->online, a->online, a->target};
+  const float* nz[kG] = {a->noise, a->noise + L.noise_stride,
+                         a->noise + 2 * L.noise_stride};
+
+  FcHead fc1h[2], fc2h[2];
+  for (int h = 0; h < 2; ++h) {
+    fc1h[h].w_mu = L.fc1_mu_w + 512 * h; fc1h[h].w_sig = L.fc1_sig_w + 512 * h;
+    fc1h[h].ldw = 1024; fc1h[h].N = 512; fc1h[h].K = kFlat; fc1h[h].x_off = 0;
+    fc1h[h].eps_in = (int)(h == 0 ? L.n_adv1_in : L.n_val1_in);
+    fc1h[h].eps_out = (int)L.n_fc1_out + 512 * h; fc1h[h].out_off = 512 * h;
+  }
+  fc2h[0].w_mu = L.adv2_mu_w; fc2h[0].w_sig = L.adv2_sig_w; fc2h[0].ldw = NA;
+  fc2h[0].N = NA; fc2h[0].K = kHid; fc2h[0].x_off = 0;
+  fc2h[0].eps_in = (int)L.n_adv2_in; fc2h[0].eps_out = (int)L.n_fc2_out;
+  fc2h[0].out_off = 0;
+  fc2h[1].w_mu = L.val2_mu_w; fc2h[1].w_sig = L.val2_sig_w; fc2h[1].ldw = K;
+  fc2h[1].N = K; fc2h[1].K = kHid; fc2h[1].x_off = 512;
+  fc2h[1].eps_in = (int)L.n_val2_in; fc2h[1].eps_out = (int)L.n_fc2_out + NA;
+  fc2h[1].out_off = NA;
+
+  if (phases & DZ_PHASE_FORWARD) {
+    {  // conv1: uint8 states -> act1, u8->f32 /255 fused into the A-tile load
+      ConvFwdParams p;
+      p.in[0] = a->s_tm1; p.in[1] = a->s_t; p.in[2] = a->s_t;
+      for (int g = 0; g < kG; ++g) {
+        p.in_img_base[g] = 0; p.w[g] = prm[g] + L.conv_w[0]; p.bias[g] = prm[g] + L.conv_b[0];
+      }
+      p.out = ws + L.ws_act1; p.B = B; p.G = kG;
+      rc = dz_launch_gemm<Conv1Fwd>(p, dim3(1, kG * Conv1Fwd::tiles_per_group(B)), s);
+      if (rc) return rc;
+    }
+    {  // conv2
+      ConvFwdParams p;
+      for (int g = 0; g < kG; ++g) {
+        p.in[g] = ws + L.ws_act1; p.in_img_base[g] = g * B; p.w[g] = prm[g] + L.conv_w[1]; p.bias[g] = prm[g] + L.conv_b[1];
+      }
+      p.out = ws + L.ws_act2; p.B = B; p.G = kG;
+      rc = dz_launch_gemm<Conv2Fwd>(p, dim3(1, kG * Conv2Fwd::tiles_per_group(B)), s);
+      if (rc) return rc;
+    }
+    {  // conv3 (+ flatten: NHWC rows are already (h,w,c) order)
+      ConvFwdParams p;
+      for (int g = 0; g < kG; ++g) {
+        p.in[g] = ws + L.ws_act2; p.in_img_base[g] = g * B; p.w[g] = prm[g] + L.conv_w[2]; p.bias[g] = prm[g] + L.conv_b[2];
+      }
+      p.out = ws + L.ws_feat; p.B = B; p.G = kG;
+      rc = dz_launch_gemm<Conv3Fwd>(p, dim3(1, kG * Conv3Fwd::tiles_per_group(B)), s);
+      if (rc) return rc;
+    }
+    {  // fc1: noisy adv1 | val1, split-K partials
+      FcFwdParams p;
+      p.x = ws + L.ws_feat; p.ldx = kFlat; p.M = B; p.G = kG; p.NH = 2; p.S = kS_fc1;
+      p.noisy = 1;
+      for (int g = 0; g < kG; ++g) { p.params[g] = prm[g]; p.noise[g] = nz[g]; }
+      p.head[0] = fc1h[0]; p.head[1] = fc1h[1];
+      p.part = ws + L.ws_fc1_part; p.ldo = 1024;
+      rc = dz_launch_gemm<FcFwd>(p, dim3(512 / FcFwd::BN, (B + 31) / 32, kG * 2 * kS_fc1), s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(fc_epilogue_kernel, dim3(4, kG * B), dim3(256), 0, s,
+                         ws + L.ws_fc1_part, kS_fc1, kG * B, 1024, 1024, B,
+                         prm[0], prm[1], prm[2], (long)L.fc1_mu_b, (long)L.fc1_sig_b,
+                         nz[0], nz[1], nz[2], (int)L.n_fc1_out, 1, ws + L.ws_h1);
+      DZ_LAUNCH_CHECK();
+    }
+    {  // fc2: noisy adv2 (no mu bias) and val2 (no mu bias)
+      FcFwdParams p;
+      p.x = ws + L.ws_h1; p.ldx = 1024; p.M = B; p.G = kG; p.NH = 2; p.S = kS_fc2;
+      p.noisy = 1;
+      for (int g = 0; g < kG; ++g) { p.params[g] = prm[g]; p.noise[g] = nz[g]; }
+      p.head[0] = fc2h[0]; p.head[1] = fc2h[1];
+      p.part = ws + L.ws_fc2_part; p.ldo = ld2;
+      rc = dz_launch_gemm<FcFwd>(p, dim3((NA + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32,
+                                        kG * 2 * kS_fc2), s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(fc_epilogue_kernel, dim3((NAK + 255) / 256, kG * B), dim3(256),
+                         0, s, ws + L.ws_fc2_part, kS_fc2, kG * B, NAK, ld2, B,
+                         prm[0], prm[1], prm[2], (long)-1, (long)L.fc2_sig_b, nz[0],
+                         nz[1], nz[2], (int)L.n_fc2_out, 0, ws + L.ws_fc2_out);
+      DZ_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(rainbow_head_loss_kernel, dim3(B), dim3(64), 0, s,
+                       ws + L.ws_fc2_out, ld2, B, A, K, a->a_tm1, a->r_t, a->discount_t,
+                       a->weights, a->support, ws + L.ws_dout2, a->losses, a->priorities,
+                       ws + L.ws_q_sel, ws + L.ws_target_probs);
+    DZ_LAUNCH_CHECK();
+  }
+
+  if (phases & DZ_PHASE_BACKWARD) {
+    DZ_REQUIRE(a->grad);
+    float* grad = a->grad;
+    {  // fc2 weight gradients (mu and sigma) from h1 (group 0) and dout2
+      FcWgradParams p;
+      p.x = ws + L.ws_h1; p.ldx = 1024; p.dy = ws + L.ws_dout2; p.ldy = ld2; p.M = B;
+      p.NH = 2; p.noisy = 1; p.noise = nz[0]; p.head[0] = fc2h[0]; p.head[1] = fc2h[1];
+      p.grad = grad;
+      rc = dz_launch_gemm<FcWg>(p, dim3((NA + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 2), s);
+      if (rc) return rc;
+    }
+    {  // fc2 input gradient -> dh1, masked by relu(h1)
+      for (int h = 0; h < 2; ++h) {
+        FcDgradParams p;
+        p.dy = ws + L.ws_dout2; p.ldy = ld2; p.M = B; p.NH = 1; p.S = 1; p.noisy = 1;
+        p.params = a->online; p.noise = nz[0]; p.head[0] = fc2h[h];
+        p.part = ws + L.ws_dh1; p.ldo = 1024; p.K = kHid; p.x_off = 512 * h;
+        rc = dz_launch_gemm<FcDg>(p, dim3(kHid / FcDg::BN, (B + 31) / 32, 1), s);
+        if (rc) return rc;
+      }
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * 1024 + 255) / 256), dim3(256), 0,
+                         s, ws + L.ws_dh1, 1, (long)B * 1024, ws + L.ws_h1,
+                         ws + L.ws_dh1);
+      DZ_LAUNCH_CHECK();
+    }
+    {  // fc1 weight gradients
+      FcWgradParams p;
+      p.x = ws + L.ws_feat; p.ldx = kFlat; p.dy = ws + L.ws_dh1; p.ldy = 1024; p.M = B;
+      p.NH = 2; p.noisy = 1; p.noise = nz[0]; p.head[0] = fc1h[0]; p.head[1] = fc1h[1];
+      p.grad = grad;
+      rc = dz_launch_gemm<FcWg>(p, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
+      if (rc) return rc;
+    }
+    {  // fc1 input gradient (adv1 + val1 paths) -> dfeat, masked by relu(conv3)
+      FcDgradParams p;
+      p.dy = ws + L.ws_dh1; p.ldy = 1024; p.M = B; p.NH = 2; p.S = kS_dfeat; p.noisy = 1;
+      p.params = a->online; p.noise = nz[0]; p.head[0] = fc1h[0]; p.head[1] = fc1h[1];
+      p.part = ws + L.ws_dfeat_part; p.ldo = kFlat; p.K = kFlat; p.x_off = 0;
+      rc = dz_launch_gemm<FcDg>(p, dim3(kFlat / FcDg::BN, (B + 31) / 32, kS_dfeat), s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 255) / 256), dim3(256), 0,
+                         s, ws + L.ws_dfeat_part, kS_dfeat, (long)B * kFlat,
+                         ws + L.ws_feat, ws + L.ws_dfeat);
+      DZ_LAUNCH_CHECK();
+    }
+    {  // conv3: weight gradient, then input gradient (masked by relu(conv2))
+      ConvWgradParams p;
+      p.in = ws + L.ws_act2; p.dy = ws + L.ws_dfeat; p.part = ws + L.ws_wgrad_part;
+      p.B = B; p.S = kS_cw3;
+      rc = dz_launch_gemm<Conv3Wg>(p, dim3(64 / Conv3Wg::BN, 576 / Conv3Wg::BM, kS_cw3), s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((576 * 64 + 255) / 256), dim3(256), 0,
+                         s, ws + L.ws_wgrad_part, kS_cw3, (long)576 * 64,
+                         (const float*)nullptr, grad + L.conv_w[2]);
+      DZ_LAUNCH_CHECK();
+      ConvDgradParams d;
+      d.dy = ws + L.ws_dfeat; d.w = a->online + L.conv_w[2]; d.act = ws + L.ws_act2;
+      d.dx = ws + L.ws_dact2; d.B = B;
+      rc = dz_launch_gemm<Conv3Dg>(d, dim3(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1), s);
+      if (rc) return rc;
+    }
+    {  // conv2
+      ConvWgradParams p;
+      p.in = ws + L.ws_act1; p.dy = ws + L.ws_dact2; p.part = ws + L.ws_wgrad_part;
+      p.B = B; p.S = kS_cw2;
+      rc = dz_launch_gemm<Conv2Wg>(p, dim3(64 / Conv2Wg::BN, 512 / Conv2Wg::BM, kS_cw2), s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((512 * 64 + 255) / 256), dim3(256), 0,
+                         s, ws + L.ws_wgrad_part, kS_cw2, (long)512 * 64,
+                         (const float*)nullptr, grad + L.conv_w[1]);
+      DZ_LAUNCH_CHECK();
+      ConvDgradParams d;
+      d.dy = ws + L.ws_dact2; d.w = a->online + L.conv_w[1]; d.act = ws + L.ws_act1;
+      d.dx = ws + L.ws_dact1; d.B = B;
+      rc = dz_launch_gemm<Conv2Dg>(d, dim3(32 / Conv2Dg::BN, Conv2Dg::tiles(B), 4), s);
+      if (rc) return rc;
+    }
+    {  // conv1 weight gradient straight from the uint8 states
+      ConvWgradParams p;
+      p.in = a->s_tm1; p.dy = ws + L.ws_dact1; p.part = ws + L.ws_wgrad_part;
+      p.B = B; p.S = kS_cw1;
+      rc = dz_launch_gemm<Conv1Wg>(p, dim3(32 / Conv1Wg::BN, 256 / Conv1Wg::BM, kS_cw1), s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((256 * 32 + 255) / 256), dim3(256), 0,
+                         s, ws + L.ws_wgrad_part, kS_cw1, (long)256 * 32,
+                         (const float*)nullptr, grad + L.conv_w[0]);
+      DZ_LAUNCH_CHECK();
+    }
+    {  // bias gradients = column sums of the layer output gradients
+      ColsumJobs J;
+      J.n = 5;
+      J.j[0] = {ws + L.ws_dact1, B * 400, 32, 32, grad + L.conv_b[0], nullptr, nullptr};
+      J.j[1] = {ws + L.ws_dact2, B * 81, 64, 64, grad + L.conv_b[1], nullptr, nullptr};
+      J.j[2] = {ws + L.ws_dfeat, B * 49, 64, 64, grad + L.conv_b[2], nullptr, nullptr};
+      J.j[3] = {ws + L.ws_dh1, B, 1024, 1024, grad + L.fc1_mu_b, nz[0] + L.n_fc1_out,
+                grad + L.fc1_sig_b};
+      J.j[4] = {ws + L.ws_dout2, B, NAK, ld2, nullptr, nz[0] + L.n_fc2_out,
+                grad + L.fc2_sig_b};
+      hipLaunchKernelGGL(colsum_kernel, dim3(16, J.n), dim3(256), 0, s, J);
+      DZ_LAUNCH_CHECK();
+    }
+  }
+
+  if (phases & DZ_PHASE_OPTIMIZER) {
+    DZ_REQUIRE(a->grad && a->adam_m && a->adam_v && a->adam_count);
+    float* sc = ws + L.ws_scalars;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
+                       (long)L.param_count, ws + L.ws_norm_part);
+    DZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(opt_scalars_kernel, dim3(1), dim3(256), 0, s,
+                       ws + L.ws_norm_part, kNormBlocks, a->adam_count, a->b1, a->b2,
+                       a->max_norm, a->losses, a->weights, B, sc);
+    DZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
+                       a->adam_m, a->adam_v, (long)(L.param_count >> 2), sc, a->lr,
+                       a->b1, a->b2, a->eps, a->max_norm);
+    DZ_LAUNCH_CHECK();
+  }
+  return DZ_OK;
+}
+
+extern "C" int dz_noise_fill(float* noise, int64_t count, uint64_t seed,
+                             uint64_t counter, dz_stream_t stream) {
+  DZ_REQUIRE(noise && count > 0);
+  hipLaunchKernelGGL(noise_fill_kernel, dim3((unsigned)((count + 255) / 256)),
+                     dim3(256), 0, dz_s(stream), noise, (long)count, seed, counter);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
+extern "C" int dz_param_copy(float* dst, const float* src, int64_t count,
+                             dz_stream_t stream) {
+  DZ_REQUIRE(dst && src && count > 0 && (count & 3) == 0);
+  hipLaunchKernelGGL(copy_kernel, dim3(1024), dim3(256), 0, dz_s(stream), dst, src,
+                     (long)(count >> 2));
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}

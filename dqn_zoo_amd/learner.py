@@ -1,0 +1,145 @@
+"""On-device Rainbow learner: the reference's jitted `update`
+(ref: rainbow/agent.py:85-123) as one C-ABI call that enqueues every kernel of
+the step (3 network applies, categorical double-Q loss, backward,
+clip_by_global_norm + Adam) on the current HIP stream.
+
+All state (online/target parameters, Adam moments, step count, workspace,
+noise) lives in PyTorch-ROCm tensors owned by this object and is handed to the
+library as raw device pointers; nothing is copied to the host unless asked.
+"""
+
+import ctypes
+import typing
+
+import numpy as np
+import torch
+
+from dqn_zoo_amd import _lib
+from dqn_zoo_amd import networks
+
+
+class AdamConfig(typing.NamedTuple):
+  """optax.chain(clip_by_global_norm(max_norm), adam(lr, eps=eps))
+  (ref: rainbow/run_atari.py:77-81, 229-235).  max_norm <= 0 disables the clip."""
+  learning_rate: float = 0.00025 / 4
+  eps: float = 0.005 / 32
+  b1: float = 0.9
+  b2: float = 0.999
+  max_global_grad_norm: float = 10.0
+
+
+class RainbowLearner:
+
+  def __init__(self, network: networks.RainbowNetwork, optimizer: AdamConfig,
+               batch_size: int, seed: int = 1, device=None, params=None):
+    self._lib = _lib.load()
+    if not torch.cuda.is_available():
+      raise _lib.HipLibraryError('RainbowLearner needs an AMD GPU; no CPU fallback')
+    self.device = torch.device('cuda', torch.cuda.current_device()) \
+        if device is None else torch.device(device)
+    self.network = network
+    self.opt = optimizer
+    self.batch_size = int(batch_size)
+    self.layout = network.layout(self.batch_size)
+    L = self.layout
+    if params is None:
+      params = network.init(np.random.RandomState(seed))
+    f32 = dict(dtype=torch.float32, device=self.device)
+    self.online = torch.from_numpy(L.pack(params)).to(self.device)
+    self.target = self.online.clone()  # rainbow/agent.py:72
+    self.grad = torch.zeros(L.param_count, **f32)
+    self.adam_m = torch.zeros(L.param_count, **f32)
+    self.adam_v = torch.zeros(L.param_count, **f32)
+    self.adam_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+    self.ws = torch.zeros(L.ws_count, **f32)
+    self.noise = torch.zeros(3 * L.noise_stride, **f32)
+    self.losses = torch.zeros(self.batch_size, **f32)
+    self.priorities = torch.zeros(self.batch_size, **f32)
+    self.support = torch.from_numpy(network.support).to(self.device)
+    self._noise_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    self._noise_counter = 0
+
+  # -- state ------------------------------------------------------------------
+  def get_params(self, which='online') -> dict:
+    t = self.online if which == 'online' else self.target
+    return self.layout.unpack(t.cpu().numpy())
+
+  def set_params(self, params: dict, which='online') -> None:
+    t = self.online if which == 'online' else self.target
+    t.copy_(torch.from_numpy(self.layout.pack(params)))
+
+  def sync_target(self) -> None:
+    """target <- online (ref: rainbow/agent.py:157-158)."""
+    _lib.check(self._lib.dz_param_copy(
+        self.target.data_ptr(), self.online.data_ptr(), self.layout.param_count,
+        torch.cuda.current_stream(self.device).cuda_stream), 'dz_param_copy')
+
+  def set_noise(self, noises: typing.Sequence[dict]) -> None:
+    """Explicit noise for the 3 applies (parity runs)."""
+    blocks = [self.layout.pack_noise(n) for n in noises]
+    self.noise.copy_(torch.from_numpy(np.concatenate(blocks)))
+
+  def resample_noise(self) -> None:
+    """Fresh factorised noise for the 3 applies, generated on the device."""
+    n = self.noise.numel()
+    _lib.check(self._lib.dz_noise_fill(
+        self.noise.data_ptr(), n, self._noise_seed, self._noise_counter,
+        torch.cuda.current_stream(self.device).cuda_stream), 'dz_noise_fill')
+    self._noise_counter += n
+
+  def scalars(self) -> dict:
+    """Synchronises and returns the step's scalars (gnorm, loss, ...)."""
+    off = int(self.layout.c.ws_scalars)
+    sc = self.ws[off:off + 8].cpu().numpy()
+    return dict(gnorm=float(sc[_lib.SC_GNORM]), loss=float(sc[_lib.SC_LOSS]),
+                bc1=float(sc[_lib.SC_BC1]), bc2=float(sc[_lib.SC_BC2]),
+                unclipped=bool(sc[_lib.SC_CLIP] != 0))
+
+  def ws_view(self, name: str, count: int) -> torch.Tensor:
+    off = int(getattr(self.layout.c, 'ws_' + name))
+    return self.ws[off:off + count]
+
+  # -- the step -----------------------------------------------------------------
+  def step(self, s_tm1, a_tm1, r_t, discount_t, s_t, weights,
+           phases: int = _lib.PHASE_ALL, resample_noise: bool = True) -> None:
+    """Enqueues one learner step.  Inputs are device tensors exactly as
+    `PrioritizedTransitionReplay.sample_device` returns them: uint8 states
+    [B,84,84,4], int64 actions, float64 rewards/discounts, float32 weights.
+    Results: `self.losses`, `self.priorities` (device), updated parameters."""
+    b = self.batch_size
+    assert s_tm1.dtype == torch.uint8 and s_t.dtype == torch.uint8
+    assert s_tm1.is_contiguous() and s_t.is_contiguous()
+    assert tuple(s_tm1.shape) == (b, 84, 84, 4) and tuple(s_t.shape) == (b, 84, 84, 4)
+    assert a_tm1.dtype == torch.int64 and r_t.dtype == torch.float64
+    assert discount_t.dtype == torch.float64 and weights.dtype == torch.float32
+    if resample_noise:
+      self.resample_noise()
+    a = _lib.RainbowArgs()
+    a.num_actions = self.network.num_actions
+    a.num_atoms = self.network.num_atoms
+    a.batch = b
+    a.online = self.online.data_ptr()
+    a.target = self.target.data_ptr()
+    a.grad = self.grad.data_ptr()
+    a.adam_m = self.adam_m.data_ptr()
+    a.adam_v = self.adam_v.data_ptr()
+    a.adam_count = self.adam_count.data_ptr()
+    a.s_tm1 = s_tm1.data_ptr()
+    a.s_t = s_t.data_ptr()
+    a.a_tm1 = a_tm1.data_ptr()
+    a.r_t = r_t.data_ptr()
+    a.discount_t = discount_t.data_ptr()
+    a.weights = weights.data_ptr()
+    a.support = self.support.data_ptr()
+    a.noise = self.noise.data_ptr()
+    a.ws = self.ws.data_ptr()
+    a.losses = self.losses.data_ptr()
+    a.priorities = self.priorities.data_ptr()
+    a.lr = self.opt.learning_rate
+    a.b1 = self.opt.b1
+    a.b2 = self.opt.b2
+    a.eps = self.opt.eps
+    a.max_norm = self.opt.max_global_grad_norm
+    _lib.check(self._lib.dz_rainbow_learn(
+        ctypes.byref(a), phases,
+        torch.cuda.current_stream(self.device).cuda_stream), 'dz_rainbow_learn')

@@ -50,6 +50,10 @@ const char* dz_version(void);
 int dz_last_hip_error(void);
 /* Name of the gfx target the device code was built for ("gfx950"). */
 const char* dz_built_arch(void);
+/* sizeof() of the ABI structs as the library was compiled, so that a binding
+ * can verify its mirror: 0 dz_field_t, 1 dz_prio_sample_args_t,
+ * 2 dz_rainbow_layout_t, 3 dz_rainbow_args_t.  -1 for an unknown id.        */
+int dz_struct_size(int which);
 
 /* ------------------------------------------------------------------------- *
  *  Replay storage: HBM-resident field arrays, one row per transition slot.
@@ -173,6 +177,95 @@ int dz_prioritized_add(double* node, int64_t cap_pow2, int64_t capacity,
                        int64_t t, int n, double priority_h,
                        const double* priority_d, double exponent,
                        uint32_t* status, dz_stream_t stream);
+
+
+/* ------------------------------------------------------------------------- *
+ *  Rainbow learner step: 3 network applies + categorical double-Q loss +
+ *  backward + clip_by_global_norm + Adam, all enqueued on one stream.
+ *  ref: rainbow/agent.py:85-121 (loss_fn, update), networks.py:224-261
+ *  (rainbow_atari_network), rainbow/run_atari.py:229-235 (optimizer chain).
+ * ------------------------------------------------------------------------- */
+
+/* Offsets (in floats) of every tensor inside the flat parameter buffer, of
+ * every noise vector inside one apply's noise block, and of every intermediate
+ * inside the workspace.  Single source of truth for Python and for tests that
+ * inspect intermediates.  All weight matrices are row-major [in][out] (the
+ * reference's own layout, networks_test.py:44,53).                         */
+typedef struct {
+  int32_t num_actions, num_atoms, batch, groups;
+  int64_t param_count;      /* floats in a parameter buffer (16-byte padded)  */
+  int64_t param_count_ref;  /* the reference's count (6 868 485 for A=6)      */
+  /* parameters */
+  int64_t conv_w[3], conv_b[3];         /* [kh*kw*cin][cout], [cout]          */
+  int64_t fc1_mu_w, fc1_mu_b;           /* [3136][1024] = [adv1 | val1], [1024] */
+  int64_t fc1_sig_w, fc1_sig_b;
+  int64_t adv2_mu_w, adv2_sig_w;        /* [512][A*K]                         */
+  int64_t val2_mu_w, val2_sig_w;        /* [512][K]                           */
+  int64_t fc2_sig_b;                    /* [A*K + K] = [adv2 | val2]          */
+  /* one apply's noise block */
+  int64_t noise_stride;
+  int64_t n_adv1_in, n_val1_in, n_fc1_out, n_adv2_in, n_val2_in, n_fc2_out;
+  /* workspace (floats) */
+  int64_t ws_count;
+  int64_t ws_act1, ws_act2, ws_feat, ws_fc1_part, ws_h1, ws_fc2_part, ws_fc2_out;
+  int64_t ws_dout2, ws_dh1, ws_dfeat_part, ws_dfeat, ws_dact2, ws_dact1;
+  int64_t ws_wgrad_part, ws_norm_part, ws_scalars, ws_q_sel, ws_target_probs;
+} dz_rainbow_layout_t;
+
+int dz_rainbow_layout(int num_actions, int num_atoms, int batch,
+                      dz_rainbow_layout_t* out);
+
+/* ws_scalars[]: */
+#define DZ_SC_GNORM 0     /* global gradient norm before clipping             */
+#define DZ_SC_LOSS 1      /* mean(losses * weights)                           */
+#define DZ_SC_BC1 2       /* 1 - b1^count                                     */
+#define DZ_SC_BC2 3       /* 1 - b2^count                                     */
+#define DZ_SC_CLIP 4      /* 1 if gnorm < max_norm else 0                     */
+
+typedef struct {
+  int32_t num_actions, num_atoms, batch;
+  /* parameter-shaped buffers (dz_rainbow_layout.param_count floats each) */
+  float* online;
+  const float* target;
+  float* grad;
+  float* adam_m;
+  float* adam_v;
+  int32_t* adam_count;       /* device int32, incremented by the step         */
+  /* the sampled batch, as PrioritizedTransitionReplay hands it over           */
+  const uint8_t* s_tm1;      /* [B][84][84][4]                                */
+  const uint8_t* s_t;
+  const int64_t* a_tm1;      /* int64 -> int32 like the jit boundary          */
+  const double* r_t;         /* float64 -> float32 like the jit boundary      */
+  const double* discount_t;
+  const float* weights;      /* importance weights (float32)                  */
+  const float* support;      /* [K] atoms, passed as data                     */
+  /* noise: 3 applies x noise_stride, order online(s_tm1), online(s_t),
+   * target(s_t) (rainbow/agent.py:87-96)                                      */
+  const float* noise;
+  float* ws;                 /* workspace, ws_count floats                    */
+  float* losses;             /* [B] per-sample cross-entropy (aux output)     */
+  float* priorities;         /* [B] clip(|loss|,0,100) (rainbow/agent.py:194) */
+  /* optimizer: optax.chain(clip_by_global_norm(max_norm), adam(lr, eps))     */
+  float lr, b1, b2, eps, max_norm;
+} dz_rainbow_args_t;
+
+#define DZ_PHASE_FORWARD 1   /* 3 applies + loss (+ dlogits)                  */
+#define DZ_PHASE_BACKWARD 2  /* gradients into args->grad                     */
+#define DZ_PHASE_OPTIMIZER 4 /* global norm + clip + Adam into args->online   */
+#define DZ_PHASE_ALL 7
+
+int dz_rainbow_learn(const dz_rainbow_args_t* args, int phases, dz_stream_t stream);
+
+/* Fills n noise blocks with f(x)=sign(x)sqrt|x|, x ~ truncated normal on
+ * [-2,2] (ref: networks.py:142-144), from a counter-based generator keyed by
+ * (seed, counter).  Distribution-equivalent to the reference, not bit-equal
+ * to JAX's threefry stream.                                     */
+int dz_noise_fill(float* noise, int64_t count, uint64_t seed, uint64_t counter,
+                  dz_stream_t stream);
+
+/* dst = src for a parameter buffer (target network sync,
+ * ref: rainbow/agent.py:157-158).                                           */
+int dz_param_copy(float* dst, const float* src, int64_t count, dz_stream_t stream);
 
 #ifdef __cplusplus
 }

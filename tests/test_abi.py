@@ -61,6 +61,18 @@ def test_struct_layouts_match_header(lib):
   # sizes computed from the C declarations (LP64): 3x8 and the sample args.
   assert ctypes.sizeof(_lib.FieldDesc) == 24
   assert ctypes.sizeof(_lib.PrioSampleArgs) == 8 * 8 + 5 * 8 + 3 * 4 + 4
+  for which, cls in _lib.STRUCT_IDS.items():
+    assert lib.dz_struct_size(which) == ctypes.sizeof(cls), cls.__name__
+  assert lib.dz_struct_size(99) == -1
+
+
+def test_rainbow_layout_matches_reference_counts(lib):
+  L = _lib.RainbowLayout()
+  assert lib.dz_rainbow_layout(6, 51, 32, ctypes.byref(L)) == 0
+  assert L.param_count_ref == 6868485
+  assert L.param_count >= L.param_count_ref and L.param_count % 4 == 0
+  assert L.noise_stride >= 2 * 3136 + 1024 + 1024 + 6 * 51 + 51
+  assert lib.dz_rainbow_layout(6, 65, 32, ctypes.byref(L)) == _lib.DZ_ERR_INVALID_ARG
 
 
 def test_code_object_is_gfx950_only():

@@ -1,0 +1,206 @@
+"""GPU parity of the Rainbow learner step (through dz_rainbow_learn) against the
+NumPy oracle: per-layer forward, selector/target distributions, per-sample
+losses (<= 1e-5 relative, the BASELINE.json tolerance), every gradient tensor,
+global norm, and the clip+Adam update.  Noise is injected into both sides."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qnet_oracle as qo
+
+pytestmark = pytest.mark.gpu
+
+K = 51
+SUPPORT = np.linspace(-10.0, 10.0, K).astype(np.float32)
+
+
+def _problem(A, B, seed, sigma_scale=3.0):
+  rs = np.random.RandomState(seed)
+  online = qo.init_params('rainbow', A, rs)
+  target = qo.init_params('rainbow', A, rs)
+  for p in (online, target):
+    for k in p:
+      if 'sigma' in k:
+        p[k] = (p[k] * sigma_scale).astype(np.float32)
+  s_tm1 = rs.randint(0, 256, (B, 84, 84, 4)).astype(np.uint8)
+  s_t = rs.randint(0, 256, (B, 84, 84, 4)).astype(np.uint8)
+  a = rs.randint(A, size=B).astype(np.int64)
+  r = rs.choice([-1.0, 0.0, 1.0], size=B) * rs.uniform(0.5, 1.5, size=B)
+  d = rs.choice([0.0, 0.99 ** 3], size=B)
+  w = rs.uniform(0.1, 1.0, size=B).astype(np.float32)
+  noises = [qo.sample_noise(rs, A) for _ in range(3)]
+  return online, target, (s_tm1, a, r, d, s_t), w, noises
+
+
+def _learner(A, B, online, target, noises, max_norm=10.0):
+  from dqn_zoo_amd import learner as learner_lib
+  from dqn_zoo_amd import networks
+  net = networks.RainbowNetwork(A, SUPPORT)
+  ln = learner_lib.RainbowLearner(
+      net, learner_lib.AdamConfig(max_global_grad_norm=max_norm), B,
+      params=online)
+  ln.set_params(target, 'target')
+  ln.set_noise(noises)
+  return ln
+
+
+def _dev_batch(batch, w):
+  s_tm1, a, r, d, s_t = batch
+  return (torch.from_numpy(s_tm1).cuda(), torch.from_numpy(a).cuda(),
+          torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda(),
+          torch.from_numpy(s_t).cuda(), torch.from_numpy(w).cuda())
+
+
+def _rel(a, b):
+  return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize('A,B,seed', [(6, 32, 0), (18, 32, 1), (3, 10, 2)])
+def test_forward_loss_backward_vs_oracle(A, B, seed):
+  online, target, batch, w, noises = _problem(A, B, seed)
+  ln = _learner(A, B, online, target, noises)
+  from dqn_zoo_amd import _lib
+  ln.step(*_dev_batch(batch, w), phases=_lib.PHASE_FORWARD | _lib.PHASE_BACKWARD,
+          resample_noise=False)
+  torch.cuda.synchronize()
+  L = ln.layout
+  s_tm1, a, r, d, s_t = batch
+
+  # ---- per-layer forward, all three applies ----
+  applies = [(online, s_tm1, noises[0]), (online, s_t, noises[1]),
+             (target, s_t, noises[2])]
+  act1 = ln.ws_view('act1', 3 * B * 400 * 32).cpu().numpy().reshape(3, B, 20, 20, 32)
+  act2 = ln.ws_view('act2', 3 * B * 81 * 64).cpu().numpy().reshape(3, B, 9, 9, 64)
+  feat = ln.ws_view('feat', 3 * B * 3136).cpu().numpy().reshape(3, B, 3136)
+  h1 = ln.ws_view('h1', 3 * B * 1024).cpu().numpy().reshape(3, B, 1024)
+  out2 = ln.ws_view('fc2_out', 3 * B * L.ld2).cpu().numpy().reshape(3, B, L.ld2)
+  for g, (p, x, nz) in enumerate(applies):
+    logits, q, cache = qo.rainbow_fwd(p, x, nz, SUPPORT, A)
+    tc = cache['torso']
+    assert _rel(act1[g], np.maximum(tc['conv1'][2], 0)) < 2e-6
+    assert _rel(act2[g], np.maximum(tc['conv2'][2], 0)) < 3e-6
+    assert _rel(feat[g], cache['feat']) < 5e-6
+    assert _rel(h1[g][:, :512], cache['ha']) < 1e-5
+    assert _rel(h1[g][:, 512:], cache['hv']) < 1e-5
+    adv = out2[g][:, :A * K].reshape(B, A, K)
+    val = out2[g][:, A * K:A * K + K].reshape(B, 1, K)
+    glogits = val + adv - adv.mean(axis=1, keepdims=True)
+    assert _rel(glogits, logits) < 2e-5
+    if g == 1:
+      q_sel = ln.ws_view('q_sel', B * A).cpu().numpy().reshape(B, A)
+      np.testing.assert_allclose(q_sel, q, rtol=2e-4, atol=2e-5)
+
+  # ---- losses, targets, gradients ----
+  loss, losses, grads, aux = qo.rainbow_loss_and_grads(
+      online, target, batch, w, noises, SUPPORT, A)
+  _, _, tgt = qo.categorical_double_q_losses(
+      SUPPORT, aux['logits_tm1'], a, np.asarray(r, np.float32),
+      np.asarray(d, np.float32), aux['logits_target'], aux['q_t'])
+  tp = ln.ws_view('target_probs', B * K).cpu().numpy().reshape(B, K)
+  np.testing.assert_allclose(tp, tgt, rtol=1e-4, atol=2e-7)
+  np.testing.assert_allclose(ln.losses.cpu().numpy(), losses, rtol=1e-5)
+  np.testing.assert_allclose(ln.priorities.cpu().numpy(),
+                             np.clip(np.abs(losses), 0, 100), rtol=1e-5)
+  dout2 = ln.ws_view('dout2', B * L.ld2).cpu().numpy().reshape(B, L.ld2)
+  dl = aux['dlogits']
+  assert _rel(dout2[:, A * K:A * K + K], dl.sum(axis=1)) < 2e-5
+  g_dev = L.unpack(ln.grad.cpu().numpy())
+  assert set(g_dev) == set(grads)
+  # float64 evaluation of the same step = ground truth for the gradients.  A
+  # device tensor passes if it is within 1e-4 of it (relative to the tensor's
+  # max-abs) or at least as accurate as the float32 oracle itself (long
+  # cancelling sums such as conv1/b = sum over 12800 pixels are
+  # summation-order limited in float32 on either side).
+  f64 = lambda t: {k: v.astype(np.float64) for k, v in t.items()}
+  _, _, g64, _ = qo.rainbow_loss_and_grads(
+      f64(online), f64(target), batch, w, [f64(n) for n in noises],
+      SUPPORT.astype(np.float64), A, np.float64)
+  for k in sorted(grads):
+    scale = np.abs(g64[k]).max()
+    e_dev = np.abs(g_dev[k] - g64[k]).max() / scale
+    e_orc = np.abs(grads[k] - g64[k]).max() / scale
+    assert e_dev < max(1e-4, 4 * e_orc), (k, e_dev, e_orc)
+
+
+@pytest.mark.parametrize('max_norm', [10.0, 1e-3, 0.0])
+def test_clip_and_adam_vs_oracle(max_norm):
+  A, B = 6, 32
+  online, target, batch, w, noises = _problem(A, B, 5)
+  ln = _learner(A, B, online, target, noises, max_norm=max_norm)
+  dev = _dev_batch(batch, w)
+  p = {k: v.copy() for k, v in online.items()}
+  st = qo.adam_init(p)
+  for it in range(3):
+    ln.step(*dev, resample_noise=False)
+    torch.cuda.synchronize()
+    # oracle optimizer fed with the DEVICE gradients: isolates clip+Adam
+    g_dev = ln.layout.unpack(ln.grad.cpu().numpy())
+    if max_norm > 0:
+      clipped, gn = qo.clip_by_global_norm(g_dev, max_norm)
+    else:
+      clipped, gn = g_dev, qo.global_norm(g_dev)
+    p, st = qo.adam_update(p, clipped, st, ln.opt.learning_rate, ln.opt.eps)
+    sc = ln.scalars()
+    np.testing.assert_allclose(sc['gnorm'], gn, rtol=2e-5)
+    assert sc['unclipped'] == (max_norm <= 0 or gn < max_norm)
+    assert int(ln.adam_count.item()) == it + 1
+    np.testing.assert_allclose(sc['bc1'], 1 - 0.9 ** (it + 1), rtol=1e-5)
+    p_dev = ln.get_params()
+    m_dev = ln.layout.unpack(ln.adam_m.cpu().numpy())
+    v_dev = ln.layout.unpack(ln.adam_v.cpu().numpy())
+    for k in p:
+      np.testing.assert_allclose(m_dev[k], st['mu'][k], rtol=1e-5, atol=1e-12)
+      np.testing.assert_allclose(v_dev[k], st['nu'][k], rtol=1e-5, atol=1e-20)
+      assert np.abs(p_dev[k] - p[k]).max() <= 2e-3 * ln.opt.learning_rate + 1e-9, k
+    # keep the oracle's parameters locked to the device's for the next step
+    p = p_dev
+    st = dict(count=st['count'], mu=m_dev, nu=v_dev)
+
+
+def test_full_step_vs_oracle_update():
+  """End-to-end: oracle rainbow_update vs device step, same inputs."""
+  A, B = 6, 32
+  online, target, batch, w, noises = _problem(A, B, 9)
+  ln = _learner(A, B, online, target, noises)
+  ln.step(*_dev_batch(batch, w), resample_noise=False)
+  torch.cuda.synchronize()
+  newp, st, out = qo.rainbow_update(online, target, qo.adam_init(online), batch,
+                                    w, noises, SUPPORT, A)
+  sc = ln.scalars()
+  np.testing.assert_allclose(sc['loss'], out['loss'], rtol=1e-5)
+  np.testing.assert_allclose(sc['gnorm'], out['gnorm'], rtol=1e-4)
+  np.testing.assert_allclose(ln.losses.cpu().numpy(), out['losses'], rtol=1e-5)
+  p_dev = ln.get_params()
+  lr = ln.opt.learning_rate
+  for k in newp:
+    diff = np.abs(p_dev[k] - newp[k])
+    # Adam's first step moves every weight by ~lr*g/(|g|+eps); entries whose
+    # gradient is ~eps are ill-conditioned, so bound the bulk tightly and the
+    # tail by the step size itself.
+    assert np.percentile(diff, 99) <= 0.02 * lr, k
+    assert diff.max() <= 1.01 * lr, k
+  # target untouched, then synced
+  t_dev = ln.get_params('target')
+  for k in target:
+    np.testing.assert_array_equal(t_dev[k], target[k])
+  ln.sync_target()
+  t_dev = ln.get_params('target')
+  for k in target:
+    np.testing.assert_array_equal(t_dev[k], p_dev[k])
+
+
+def test_device_noise_distribution():
+  A, B = 6, 32
+  online, target, batch, w, noises = _problem(A, B, 3)
+  ln = _learner(A, B, online, target, noises)
+  ln.resample_noise()
+  x = ln.noise.cpu().numpy()
+  ln.resample_noise()
+  y = ln.noise.cpu().numpy()
+  assert not np.array_equal(x, y)
+  # f(n) = sign(n) sqrt|n|, n ~ N(0,1) truncated to [-2,2]
+  assert np.abs(x).max() <= np.sqrt(2.0) + 1e-6
+  n = np.sign(x) * x * x
+  assert abs(n.mean()) < 0.02 and abs(n.std() - 0.8796) < 0.02
+  assert abs((np.abs(n) < 1).mean() - 0.6827 / 0.9545) < 0.01
