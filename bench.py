@@ -1,0 +1,316 @@
+"""Headline benchmark: Rainbow gradient-steps/sec on MI355X (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 2000 --warmup 200
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic transitions:
+  PrioritizedTransitionReplay.sample (sum-tree descent, IS weights, 2x32 state
+  gather from the 1M-transition HBM store) -> Rainbow update (3 noisy dueling
+  C51 network applies, categorical double-Q loss, backward, global-norm clip,
+  Adam) -> priority write-back into the sum tree
+(ref: rainbow/agent.py:181-198).  Inputs are resident in HBM before the timed
+region.  N > 1 runs N independent replicas (one process per GPU, different
+seeds; SURVEY.md 8e "replicas only") and all-reduces episode-style statistics
+once over RCCL; `value` is the whole-job steps/s.
+
+Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (HIP
+event timing of the dominant kernel against its algorithmic bytes/flops) and
+`cpu_baseline` (the CPU oracle port timed on the host cores, N=1 only).
+"""
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+NUM_ACTIONS = 6            # Pong
+NUM_ATOMS = 51
+VMAX = 10.0
+N_STEP_DISCOUNT = 0.99 ** 3
+PEAK_HBM = 8.0e12          # B/s   (MI355X_MICROARCH.md, spec)
+PEAK_F32_MFMA = 157.3e12   # FLOP/s (MI355X_MICROARCH.md, f32-in MFMA = vector peak)
+
+
+def parse_args():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=2000)
+  ap.add_argument('--warmup', type=int, default=200)
+  ap.add_argument('--capacity', type=int, default=1000000)
+  ap.add_argument('--batch', type=int, default=32)
+  ap.add_argument('--seed', type=int, default=1)
+  ap.add_argument('--cpu-seconds', type=float, default=15.0,
+                  help='CPU-baseline time budget (0 disables)')
+  ap.add_argument('--prof-steps', type=int, default=100)
+  return ap.parse_args()
+
+
+def build_workload(args, device, seed):
+  from dqn_zoo_amd import learner as learner_lib
+  from dqn_zoo_amd import networks
+  from dqn_zoo_amd import parts
+  from dqn_zoo_amd import replay as replay_lib
+
+  cap, b = args.capacity, args.batch
+  rs = np.random.RandomState(seed)
+  # IS exponent schedule of rainbow/run_atari.py:180-188
+  beta = parts.LinearSchedule(begin_t=int(0.02 * cap), end_t=200 * 250000,
+                              begin_value=0.4, end_value=1.0)
+  replay = replay_lib.PrioritizedTransitionReplay(
+      capacity=cap,
+      structure=replay_lib.Transition(None, None, None, None, None),
+      priority_exponent=0.5, importance_sampling_exponent=beta,
+      uniform_sample_probability=1e-3, normalize_weights=True,
+      random_state=rs, device=device)
+  # synthetic transitions: pool of 256 seeded random frames
+  g = torch.Generator(device=device)
+  g.manual_seed(seed)
+  pool = torch.randint(0, 256, (256, 84, 84, 4), dtype=torch.uint8,
+                       device=device, generator=g)
+  chunk = 4096
+  done = 0
+  while done < cap:
+    n = min(chunk, cap - done)
+    i1 = torch.randint(0, 256, (n,), device=device, generator=g)
+    i2 = torch.randint(0, 256, (n,), device=device, generator=g)
+    a = torch.randint(0, NUM_ACTIONS, (n,), device=device, generator=g)
+    r = (torch.randint(0, 3, (n,), device=device, generator=g) - 1).double()
+    d = torch.randint(0, 2, (n,), device=device, generator=g).double() * \
+        N_STEP_DISCOUNT
+    replay.bulk_fill([pool[i1], a, r, d, pool[i2]], priority=1.0)
+    done += n
+  support = np.linspace(-VMAX, VMAX, NUM_ATOMS).astype(np.float32)
+  net = networks.RainbowNetwork(NUM_ACTIONS, support, 0.1)
+  learner = learner_lib.RainbowLearner(net, learner_lib.AdamConfig(), b,
+                                       seed=seed, device=device)
+  torch.cuda.synchronize(device)
+  return replay, learner, pool
+
+
+def make_step(replay, learner, batch):
+
+  def step():
+    s = replay.sample_device(batch)
+    t = s.transitions
+    learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32)
+    replay.update_priorities(s.ids, learner.priorities)
+
+  return step
+
+
+# ---- algorithmic work per kernel (SURVEY.md 8d figures, per launch) ----------
+def kernel_work(b, a=NUM_ACTIONS, k=NUM_ATOMS):
+  """name -> (flops, bytes) of ONE launch at batch b."""
+  na = a * k
+  p_ref = 77984 + 2 * (3136 * 512 * 2 + 1024) + (512 * na * 2 + na) + \
+      (512 * k * 2 + k)
+  g = 3
+  f = lambda m, n, kk: 2.0 * m * n * kk
+  w = {}
+  w['conv1_fwd'] = (f(g * b * 400, 32, 256), g * b * 28224 + g * b * 400 * 32 * 4)
+  w['conv2_fwd'] = (f(g * b * 81, 64, 512), g * b * (12800 + 5184) * 4)
+  w['conv3_fwd'] = (f(g * b * 49, 64, 576), g * b * (5184 + 3136) * 4)
+  # noisy layers in the reference's two-GEMM form; weights of each parameter set
+  # (online, target) streamed once
+  w['fc1_fwd'] = (2 * f(g * b, 1024, 3136), 2 * 2 * 3136 * 1024 * 4)
+  w['fc2_fwd'] = (2 * f(g * b, na + k, 512), 2 * 2 * 512 * (na + k) * 4)
+  w['fc1_wgrad'] = (f(3136, 1024, b), 2 * 3136 * 1024 * 4)
+  w['fc1_dgrad'] = (2 * f(b, 3136, 1024), 2 * 3136 * 1024 * 4)
+  w['fc2_wgrad'] = (f(512, na + k, b), 2 * 512 * (na + k) * 4)
+  w['fc2_dgrad'] = (2 * f(b, 1024, (na + k) / 2.0), 2 * 512 * (na + k) * 4)
+  w['conv3_wgrad'] = (f(576, 64, b * 49), b * (5184 + 3136) * 4)
+  w['conv3_dgrad'] = (f(b * 81, 64, 576), b * (3136 + 5184) * 4)
+  w['conv2_wgrad'] = (f(512, 64, b * 81), b * (12800 + 5184) * 4)
+  w['conv2_dgrad'] = (f(b * 400, 32, 256), b * (5184 + 12800) * 4)
+  w['conv1_wgrad'] = (f(256, 32, b * 400), b * 28224 + b * 12800 * 4)
+  w['adam'] = (0.0, 7.0 * p_ref * 4)           # read g,p,m,v; write p,m,v
+  w['grad_sumsq'] = (0.0, 1.0 * p_ref * 4)
+  return w
+
+
+def measure_roofline(step, prof_steps, batch):
+  """Per-kernel average durations from HIP events recorded on the launch
+  stream (dz_prof_*), then the roofline fraction of the dominant kernel."""
+  from dqn_zoo_amd import _lib
+  lib = _lib.load()
+  lib.dz_prof_enable(1)
+  ms = (ctypes.c_float * 96)()
+  names = ctypes.create_string_buffer(96 * 32)
+  acc = {}
+  for _ in range(prof_steps):
+    step()
+    torch.cuda.synchronize()
+    n = lib.dz_prof_read(96, ctypes.addressof(ms), ctypes.addressof(names))
+    for i in range(n):
+      nm = names.raw[32 * i:32 * i + 32].split(b'\0')[0].decode()
+      acc.setdefault(nm, []).append(ms[i] * 1e-3)
+  lib.dz_prof_enable(0)
+  avg = {k: float(np.mean(v)) for k, v in acc.items()}
+  work = kernel_work(batch)
+  dom = max(avg, key=avg.get)
+  out = {'kernel': dom, 'avg_us': round(avg[dom] * 1e6, 2), 'traffic': None}
+  if dom in work:
+    flops, nbytes = work[dom]
+    t_m, t_h = flops / PEAK_F32_MFMA, nbytes / PEAK_HBM
+    if t_m > t_h:
+      out.update(bound='mfma', achieved=flops / avg[dom] / 1e12,
+                 peak=PEAK_F32_MFMA / 1e12, unit='TFLOP/s')
+    else:
+      out.update(bound='hbm', achieved=nbytes / avg[dom] / 1e9,
+                 peak=PEAK_HBM / 1e9, unit='GB/s')
+    out['frac'] = out['achieved'] / out['peak']
+    out['achieved'] = round(out['achieved'], 3)
+    out['frac'] = round(out['frac'], 4)
+  table = {}
+  for k2, v in sorted(avg.items(), key=lambda kv: -kv[1]):
+    e = {'us': round(v * 1e6, 2)}
+    if k2 in work:
+      fl, nb = work[k2]
+      e['tflops'] = round(fl / v / 1e12, 2)
+      e['gbps'] = round(nb / v / 1e9, 1)
+    table[k2] = e
+  out['per_kernel'] = table
+  out['learn_kernels_us'] = round(sum(avg.values()) * 1e6, 1)
+  return out
+
+
+def cpu_baseline(args, seed, budget_s):
+  """The CPU oracle port of the same step (reference replay algorithms in
+  Python + torch-CPU update on all host cores), on a bounded sample."""
+  from oracle import qnet_oracle as qo
+  from oracle import qnet_torch_cpu
+  from oracle import replay_oracle as ro
+  from dqn_zoo_amd import parts
+  from dqn_zoo_amd import replay as replay_lib
+
+  cap, b = args.capacity, args.batch
+  rs = np.random.RandomState(seed)
+  beta = parts.LinearSchedule(begin_t=int(0.02 * cap), end_t=200 * 250000,
+                              begin_value=0.4, end_value=1.0)
+  T = replay_lib.Transition
+  rep = ro.PrioritizedReplayOracle(cap, T(None, None, None, None, None), 0.5,
+                                   beta, 1e-3, True, rs)
+  frs = np.random.RandomState(seed + 7)
+  pool = frs.randint(0, 256, (256, 84, 84, 4)).astype(np.uint8)
+  i1 = frs.randint(0, 256, cap)
+  i2 = frs.randint(0, 256, cap)
+  acts = frs.randint(0, NUM_ACTIONS, cap)
+  rew = frs.randint(0, 3, cap) - 1.0
+  dis = frs.randint(0, 2, cap) * N_STEP_DISCOUNT
+  rep.bulk_fill(cap, lambda i: T(pool[i1[i]], int(acts[i]), float(rew[i]),
+                                 float(dis[i]), pool[i2[i]]), 1.0)
+  support = np.linspace(-VMAX, VMAX, NUM_ATOMS).astype(np.float32)
+  prs = np.random.RandomState(seed)
+  params = qo.init_params('rainbow', NUM_ACTIONS, prs)
+  port = qnet_torch_cpu.RainbowTorchCpu(params, params, support, NUM_ACTIONS)
+  torch.set_num_threads(os.cpu_count())
+  nrs = np.random.RandomState(seed + 3)
+
+  def one():
+    tr, ids, w = rep.sample(b)
+    noises = [qo.sample_noise(nrs, NUM_ACTIONS) for _ in range(3)]
+    out = port.update((tr.s_tm1, tr.a_tm1, tr.r_t, tr.discount_t, tr.s_t), w,
+                      noises)
+    rep.update_priorities(ids, out['priorities'])
+
+  for _ in range(3):
+    one()
+  n, t0 = 0, time.perf_counter()
+  while time.perf_counter() - t0 < budget_s:
+    one()
+    n += 1
+  dt = time.perf_counter() - t0
+  return {'value': round(n / dt, 2), 'unit': 'steps/s',
+          'cores': int(torch.get_num_threads()), 'kind': 'port',
+          'sample': '%d Rainbow steps (oracle replay sample + torch-CPU update '
+                    '+ priority write-back), capacity %d, batch %d, %.1f s' %
+                    (n, cap, b, dt)}
+
+
+def main():
+  args = parse_args()
+  rank = int(os.environ.get('RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist  # RCCL (backend "nccl" on ROCm)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=device)
+
+  replay, learner, _ = build_workload(args, device, args.seed + 1000 * rank)
+  step = make_step(replay, learner, args.batch)
+
+  for _ in range(args.warmup):
+    step()
+  torch.cuda.synchronize()
+  if dist is not None:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step()
+  # statistics boundary: one RCCL all-reduce of packed sums over xGMI
+  # (keys of EpisodeTracker/StepRateTracker, parts.py:239-284)
+  from dqn_zoo_amd import distributed as dz_dist
+  stats = dz_dist.ReplicaStats(device)
+  stats.add(grad_steps=args.steps, loss_sum=learner.losses.double().sum())
+  totals = stats.all_reduce()
+  torch.cuda.synchronize()
+  if dist is not None:
+    dist.barrier()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  if dist is not None:
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+  replay.check_status()
+  assert int(totals['grad_steps']) == world * args.steps
+
+  if rank == 0:
+    value = world * args.steps / dt
+    out = {
+        'metric': 'gradient-steps/sec (Rainbow, batch %d)' % args.batch,
+        'value': round(value, 2), 'unit': 'steps/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(1e3 * dt / args.steps, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'replay_samples_per_sec': round(value * args.batch, 1),
+        'config': {
+            'workload': 'rainbow learner step: prioritized sum-tree sample + '
+                        'gather + 3x noisy dueling C51 apply + double-Q loss + '
+                        'backward + clip/Adam + priority write-back',
+            'replay_capacity': args.capacity, 'global_batch': args.batch * world,
+            'state': '84x84x4 uint8', 'num_actions': NUM_ACTIONS,
+            'num_atoms': NUM_ATOMS, 'parallelism': 'replicas x%d' % world},
+    }
+    out['roofline'] = measure_roofline(step, args.prof_steps, args.batch)
+    if world == 1 and args.cpu_seconds > 0:
+      out['cpu_baseline'] = cpu_baseline(args, args.seed, args.cpu_seconds)
+      out['speedup_vs_cpu_baseline'] = round(
+          value / out['cpu_baseline']['value'], 1)
+    print(json.dumps(out), flush=True)
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -16,3 +16,46 @@ extern "C" int dz_struct_size(int which) {
     default: return -1;
   }
 }
+
+// ---- event profiler ----------------------------------------------------------
+#include <string.h>
+bool g_dz_prof_on = false;
+namespace {
+constexpr int kMaxMarks = 96;
+hipEvent_t g_ev[kMaxMarks + 1];
+const char* g_names[kMaxMarks];
+int g_nmarks = 0;
+bool g_ev_created = false;
+}  // namespace
+
+void dz_prof_begin(hipStream_t s) {
+  g_nmarks = 0;
+  (void)hipEventRecord(g_ev[0], s);
+}
+void dz_prof_mark(hipStream_t s, const char* name) {
+  if (g_nmarks >= kMaxMarks) return;
+  g_names[g_nmarks] = name;
+  (void)hipEventRecord(g_ev[g_nmarks + 1], s);
+  ++g_nmarks;
+}
+extern "C" int dz_prof_enable(int on) {
+  if (on && !g_ev_created) {
+    for (int i = 0; i <= kMaxMarks; ++i) DZ_HIP_CHECK(hipEventCreate(&g_ev[i]));
+    g_ev_created = true;
+  }
+  g_dz_prof_on = on != 0;
+  g_nmarks = 0;
+  return DZ_OK;
+}
+extern "C" int dz_prof_read(int max_marks, float* ms_out, char* names_out) {
+  DZ_REQUIRE(ms_out && names_out && max_marks > 0);
+  const int n = g_nmarks < max_marks ? g_nmarks : max_marks;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    DZ_HIP_CHECK(hipEventElapsedTime(&ms, g_ev[i], g_ev[i + 1]));
+    ms_out[i] = ms;
+    strncpy(names_out + 32 * i, g_names[i], 31);
+    names_out[32 * i + 31] = 0;
+  }
+  return n;
+}

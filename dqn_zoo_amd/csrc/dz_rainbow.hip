@@ -390,6 +390,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   fc2h[1].eps_in = (int)L.n_val2_in; fc2h[1].eps_out = (int)L.n_fc2_out + NA;
   fc2h[1].out_off = NA;
 
+  if (g_dz_prof_on) dz_prof_begin(s);
   if (phases & DZ_PHASE_FORWARD) {
     {  // conv1: uint8 states -> act1, u8->f32 /255 fused into the A-tile load
       ConvFwdParams p;
@@ -400,6 +401,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       p.out = ws + L.ws_act1; p.B = B; p.G = kG;
       rc = dz_launch_gemm<Conv1Fwd>(p, dim3(1, kG * Conv1Fwd::tiles_per_group(B)), s);
       if (rc) return rc;
+      DZ_PROF(s, "conv1_fwd");
     }
     {  // conv2
       ConvFwdParams p;
@@ -409,6 +411,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       p.out = ws + L.ws_act2; p.B = B; p.G = kG;
       rc = dz_launch_gemm<Conv2Fwd>(p, dim3(1, kG * Conv2Fwd::tiles_per_group(B)), s);
       if (rc) return rc;
+      DZ_PROF(s, "conv2_fwd");
     }
     {  // conv3 (+ flatten: NHWC rows are already (h,w,c) order)
       ConvFwdParams p;
@@ -418,6 +421,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       p.out = ws + L.ws_feat; p.B = B; p.G = kG;
       rc = dz_launch_gemm<Conv3Fwd>(p, dim3(1, kG * Conv3Fwd::tiles_per_group(B)), s);
       if (rc) return rc;
+      DZ_PROF(s, "conv3_fwd");
     }
     {  // fc1: noisy adv1 | val1, split-K partials
       FcFwdParams p;
@@ -428,11 +432,13 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       p.part = ws + L.ws_fc1_part; p.ldo = 1024;
       rc = dz_launch_gemm<FcFwd>(p, dim3(512 / FcFwd::BN, (B + 31) / 32, kG * 2 * kS_fc1), s);
       if (rc) return rc;
+      DZ_PROF(s, "fc1_fwd");
       hipLaunchKernelGGL(fc_epilogue_kernel, dim3(4, kG * B), dim3(256), 0, s,
                          ws + L.ws_fc1_part, kS_fc1, kG * B, 1024, 1024, B,
                          prm[0], prm[1], prm[2], (long)L.fc1_mu_b, (long)L.fc1_sig_b,
                          nz[0], nz[1], nz[2], (int)L.n_fc1_out, 1, ws + L.ws_h1);
       DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "fc1_epilogue");
     }
     {  // fc2: noisy adv2 (no mu bias) and val2 (no mu bias)
       FcFwdParams p;
@@ -444,17 +450,20 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       rc = dz_launch_gemm<FcFwd>(p, dim3((NA + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32,
                                         kG * 2 * kS_fc2), s);
       if (rc) return rc;
+      DZ_PROF(s, "fc2_fwd");
       hipLaunchKernelGGL(fc_epilogue_kernel, dim3((NAK + 255) / 256, kG * B), dim3(256),
                          0, s, ws + L.ws_fc2_part, kS_fc2, kG * B, NAK, ld2, B,
                          prm[0], prm[1], prm[2], (long)-1, (long)L.fc2_sig_b, nz[0],
                          nz[1], nz[2], (int)L.n_fc2_out, 0, ws + L.ws_fc2_out);
       DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "fc2_epilogue");
     }
     hipLaunchKernelGGL(rainbow_head_loss_kernel, dim3(B), dim3(64), 0, s,
                        ws + L.ws_fc2_out, ld2, B, A, K, a->a_tm1, a->r_t, a->discount_t,
                        a->weights, a->support, ws + L.ws_dout2, a->losses, a->priorities,
                        ws + L.ws_q_sel, ws + L.ws_target_probs);
     DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "head_loss");
   }
 
   if (phases & DZ_PHASE_BACKWARD) {
@@ -467,6 +476,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       p.grad = grad;
       rc = dz_launch_gemm<FcWg>(p, dim3((NA + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 2), s);
       if (rc) return rc;
+      DZ_PROF(s, "fc2_wgrad");
     }
     {  // fc2 input gradient -> dh1, masked by relu(h1)
       for (int h = 0; h < 2; ++h) {
@@ -481,6 +491,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
                          s, ws + L.ws_dh1, 1, (long)B * 1024, ws + L.ws_h1,
                          ws + L.ws_dh1);
       DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "fc2_dgrad");
     }
     {  // fc1 weight gradients
       FcWgradParams p;
@@ -489,6 +500,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       p.grad = grad;
       rc = dz_launch_gemm<FcWg>(p, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
       if (rc) return rc;
+      DZ_PROF(s, "fc1_wgrad");
     }
     {  // fc1 input gradient (adv1 + val1 paths) -> dfeat, masked by relu(conv3)
       FcDgradParams p;
@@ -497,10 +509,12 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       p.part = ws + L.ws_dfeat_part; p.ldo = kFlat; p.K = kFlat; p.x_off = 0;
       rc = dz_launch_gemm<FcDg>(p, dim3(kFlat / FcDg::BN, (B + 31) / 32, kS_dfeat), s);
       if (rc) return rc;
+      DZ_PROF(s, "fc1_dgrad");
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 255) / 256), dim3(256), 0,
                          s, ws + L.ws_dfeat_part, kS_dfeat, (long)B * kFlat,
                          ws + L.ws_feat, ws + L.ws_dfeat);
       DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "fc1_dgrad_reduce");
     }
     {  // conv3: weight gradient, then input gradient (masked by relu(conv2))
       ConvWgradParams p;
@@ -508,15 +522,18 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       p.B = B; p.S = kS_cw3;
       rc = dz_launch_gemm<Conv3Wg>(p, dim3(64 / Conv3Wg::BN, 576 / Conv3Wg::BM, kS_cw3), s);
       if (rc) return rc;
+      DZ_PROF(s, "conv3_wgrad");
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((576 * 64 + 255) / 256), dim3(256), 0,
                          s, ws + L.ws_wgrad_part, kS_cw3, (long)576 * 64,
                          (const float*)nullptr, grad + L.conv_w[2]);
       DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "conv3_wgrad_reduce");
       ConvDgradParams d;
       d.dy = ws + L.ws_dfeat; d.w = a->online + L.conv_w[2]; d.act = ws + L.ws_act2;
       d.dx = ws + L.ws_dact2; d.B = B;
       rc = dz_launch_gemm<Conv3Dg>(d, dim3(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1), s);
       if (rc) return rc;
+      DZ_PROF(s, "conv3_dgrad");
     }
     {  // conv2
       ConvWgradParams p;
@@ -524,15 +541,18 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       p.B = B; p.S = kS_cw2;
       rc = dz_launch_gemm<Conv2Wg>(p, dim3(64 / Conv2Wg::BN, 512 / Conv2Wg::BM, kS_cw2), s);
       if (rc) return rc;
+      DZ_PROF(s, "conv2_wgrad");
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((512 * 64 + 255) / 256), dim3(256), 0,
                          s, ws + L.ws_wgrad_part, kS_cw2, (long)512 * 64,
                          (const float*)nullptr, grad + L.conv_w[1]);
       DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "conv2_wgrad_reduce");
       ConvDgradParams d;
       d.dy = ws + L.ws_dact2; d.w = a->online + L.conv_w[1]; d.act = ws + L.ws_act1;
       d.dx = ws + L.ws_dact1; d.B = B;
       rc = dz_launch_gemm<Conv2Dg>(d, dim3(32 / Conv2Dg::BN, Conv2Dg::tiles(B), 4), s);
       if (rc) return rc;
+      DZ_PROF(s, "conv2_dgrad");
     }
     {  // conv1 weight gradient straight from the uint8 states
       ConvWgradParams p;
@@ -540,10 +560,12 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       p.B = B; p.S = kS_cw1;
       rc = dz_launch_gemm<Conv1Wg>(p, dim3(32 / Conv1Wg::BN, 256 / Conv1Wg::BM, kS_cw1), s);
       if (rc) return rc;
+      DZ_PROF(s, "conv1_wgrad");
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((256 * 32 + 255) / 256), dim3(256), 0,
                          s, ws + L.ws_wgrad_part, kS_cw1, (long)256 * 32,
                          (const float*)nullptr, grad + L.conv_w[0]);
       DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "conv1_wgrad_reduce");
     }
     {  // bias gradients = column sums of the layer output gradients
       ColsumJobs J;
@@ -557,6 +579,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
                 grad + L.fc2_sig_b};
       hipLaunchKernelGGL(colsum_kernel, dim3(16, J.n), dim3(256), 0, s, J);
       DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "bias_colsum");
     }
   }
 
@@ -566,14 +589,17 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
                        (long)L.param_count, ws + L.ws_norm_part);
     DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "grad_sumsq");
     hipLaunchKernelGGL(opt_scalars_kernel, dim3(1), dim3(256), 0, s,
                        ws + L.ws_norm_part, kNormBlocks, a->adam_count, a->b1, a->b2,
                        a->max_norm, a->losses, a->weights, B, sc);
     DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "opt_scalars");
     hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
                        a->adam_m, a->adam_v, (long)(L.param_count >> 2), sc, a->lr,
                        a->b1, a->b2, a->eps, a->max_norm);
     DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "adam");
   }
   return DZ_OK;
 }

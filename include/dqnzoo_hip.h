@@ -263,6 +263,15 @@ int dz_rainbow_learn(const dz_rainbow_args_t* args, int phases, dz_stream_t stre
 int dz_noise_fill(float* noise, int64_t count, uint64_t seed, uint64_t counter,
                   dz_stream_t stream);
 
+/* Optional per-kernel timing: when enabled, dz_rainbow_learn records a HIP
+ * event on the launch stream before its first kernel and after every kernel.
+ * dz_prof_read (call after synchronising the stream) returns the number of
+ * marks of the LAST learn call and writes, per mark, the elapsed milliseconds
+ * since the previous event and a NUL-terminated name of at most 31 chars
+ * (names_out: max_marks * 32 bytes).  Used by bench.py for `roofline`.       */
+int dz_prof_enable(int on);
+int dz_prof_read(int max_marks, float* ms_out, char* names_out);
+
 /* dst = src for a parameter buffer (target network sync,
  * ref: rainbow/agent.py:157-158).                                           */
 int dz_param_copy(float* dst, const float* src, int64_t count, dz_stream_t stream);

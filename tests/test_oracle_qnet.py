@@ -301,3 +301,22 @@ def test_rainbow_update_f32_runs_and_priorities():
   _, l64, _, _ = qo.rainbow_loss_and_grads(o64, t64, batch, w, n64, SUPPORT, A,
                                            np.float64)
   np.testing.assert_allclose(out['losses'], l64, rtol=1e-5)
+
+
+def test_torch_cpu_port_matches_oracle():
+  """The cpu_baseline port (oracle/qnet_torch_cpu.py) evaluates the oracle's
+  arithmetic: same losses (1e-5), same gradient norm, same Adam step."""
+  from oracle import qnet_torch_cpu
+  online, target, batch, w, noises = _setup(np.float32, b=8, seed=11)
+  sup = SUPPORT.astype(np.float32)
+  port = qnet_torch_cpu.RainbowTorchCpu(online, target, sup, A)
+  out_t = port.update(batch, w, noises)
+  newp, st, out = qo.rainbow_update(online, target, qo.adam_init(online), batch,
+                                    w, noises, sup, A)
+  np.testing.assert_allclose(out_t['losses'], out['losses'], rtol=1e-5)
+  np.testing.assert_allclose(out_t['gnorm'], out['gnorm'], rtol=1e-4)
+  np.testing.assert_allclose(out_t['priorities'], out['priorities'], rtol=1e-5)
+  lr = 0.00025 / 4
+  for k in newp:
+    diff = np.abs(port.p[k].detach().numpy() - newp[k])
+    assert np.percentile(diff, 99) <= 0.02 * lr and diff.max() <= 1.01 * lr, k

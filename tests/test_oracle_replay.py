@@ -223,3 +223,25 @@ def test_sumtree_random_ops_vs_live_reference(seed):
   np.testing.assert_array_equal(protocol.f64_bits(ta.values),
                                 protocol.f64_bits(tb.leaves()))
   assert ta.root() == tb.root()
+
+
+def test_oracle_bulk_fill_equals_sequential_adds():
+  for cap, n in ((8, 8), (8, 5), (37, 37), (64, 20)):
+    mk = lambda: ro.PrioritizedReplayOracle(
+        cap, protocol.Item(None, None), 0.5, protocol.beta_schedule(cap), 1e-3,
+        True, np.random.RandomState(3))
+    a, b = mk(), mk()
+    for i in range(n):
+      a.add(protocol.Item(i, -i), 2.0)
+    b.bulk_fill(n, lambda i: protocol.Item(i, -i), 2.0)
+    np.testing.assert_array_equal(a.dist.tree.node, b.dist.tree.node)
+    assert a.dist.free == b.dist.free and a.dist.active == b.dist.active
+    assert a.dist.where == b.dist.where and a.dist.index_of == b.dist.index_of
+    assert a.dist.id_of == b.dist.id_of and a.store.items == b.store.items
+    for _ in range(5):
+      ia, _, wa = a.sample_ids(4)
+      ib, _, wb = b.sample_ids(4)
+      np.testing.assert_array_equal(ia, ib)
+      a.add(protocol.Item(0, 0), 1.5)
+      b.add(protocol.Item(0, 0), 1.5)
+    np.testing.assert_array_equal(a.dist.tree.node, b.dist.tree.node)
