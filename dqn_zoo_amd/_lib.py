@@ -52,7 +52,8 @@ c_i32 = ctypes.c_int32
 class RainbowLayout(ctypes.Structure):
   _fields_ = (
       [('num_actions', c_i32), ('num_atoms', c_i32), ('batch', c_i32),
-       ('groups', c_i32), ('param_count', c_i64), ('param_count_ref', c_i64),
+       ('groups', c_i32), ('adv2_ld', c_i32), ('val2_ld', c_i32), ('fc1_ld', c_i32), ('pad0_', c_i32),
+       ('param_count', c_i64), ('param_count_ref', c_i64),
        ('conv_w', c_i64 * 3), ('conv_b', c_i64 * 3)] +
       [(n, c_i64) for n in (
           'fc1_mu_w', 'fc1_mu_b', 'fc1_sig_w', 'fc1_sig_b', 'adv2_mu_w',
@@ -62,7 +63,7 @@ class RainbowLayout(ctypes.Structure):
           'ws_fc1_part', 'ws_h1', 'ws_fc2_part', 'ws_fc2_out', 'ws_dout2',
           'ws_dh1', 'ws_dfeat_part', 'ws_dfeat', 'ws_dact2', 'ws_dact1',
           'ws_wgrad_part', 'ws_norm_part', 'ws_scalars', 'ws_q_sel',
-          'ws_target_probs')])
+          'ws_target_probs', 'ws_colsum_part')])
 
 
 class RainbowArgs(ctypes.Structure):
@@ -95,6 +96,7 @@ SIGNATURES = {
     'dz_noise_fill': (c_int, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64,
                               c_vp]),
     'dz_param_copy': (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    'dz_set_tuning': (c_int, [c_int, c_int]),
     'dz_prof_enable': (c_int, [c_int]),
     'dz_prof_read': (c_int, [c_int, c_vp, c_vp]),
     'dz_replay_gather': (c_int, [ctypes.POINTER(FieldDesc), c_int, c_vp, c_int,

@@ -12,8 +12,11 @@
 //     latency is also 64 cycles, so one chain per wave already runs the matrix
 //     pipe at its issue rate; MI355X_MICROARCH.md "Per-instruction cycle
 //     constants");
-//   * a stage = BK = 16*WK reduction indices.  Global loads for stage s+1 are
-//     issued into registers before the MFMAs of stage s (register-staged
+//   * a stage = BK = 16*WK*KT reduction indices (every wave consumes KT chunks
+//     of 16 per stage: 8*KT MFMAs between barriers, and 16*WK*KT rows of both
+//     operands in flight per workgroup, which is what hides HBM latency at the
+//     1-2 workgroups/CU these small problems give).  Global loads for stage s+1
+//     are issued into registers before the MFMAs of stage s (register-staged
 //     pipeline, cdna_hip_programming.md T14), written to LDS after the barrier;
 //   * LDS tiles come in two layouts chosen per operand so that global loads are
 //     16-byte and contiguous in whichever dimension memory is contiguous:
@@ -66,13 +69,13 @@ __device__ __forceinline__ float4 dz_load4_masked(const float* __restrict__ p,
   return v;
 }
 
-template <int ROWS, int WK, int LAYOUT>
+template <int ROWS, int CPS, int LAYOUT>
 struct DzLdsTile {
   static constexpr int LD = (LAYOUT == DZ_KC) ? 20 : ROWS;
   static constexpr int CHUNK = (LAYOUT == DZ_KC) ? ROWS * 20 : 16 * ROWS;
-  static constexpr int ELEMS = WK * CHUNK;
+  static constexpr int ELEMS = CPS * CHUNK;
   // number of float4 "load slots" per stage and per thread
-  static constexpr int SLOTS = ROWS * 16 * WK / 4;
+  static constexpr int SLOTS = ROWS * 16 * CPS / 4;
   static constexpr int PER_THREAD = (SLOTS + 255) / 256;
 };
 
@@ -87,11 +90,12 @@ struct DzLdsTile {
 //   void  store(p, t, wm, wn, lane, acc)
 template <class Op>
 __global__ __launch_bounds__(256) void dz_mfma_gemm(typename Op::Params p) {
-  constexpr int WM = Op::WM, WN = Op::WN, WK = Op::WK;
+  constexpr int WM = Op::WM, WN = Op::WN, WK = Op::WK, KT = Op::KT;
+  constexpr int CPS = WK * KT;  // 16-deep chunks per stage
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
   constexpr int BM = 32 * WM, BN = 32 * WN;
-  using AT = DzLdsTile<BM, WK, Op::A_LAYOUT>;
-  using BT = DzLdsTile<BN, WK, Op::B_LAYOUT>;
+  using AT = DzLdsTile<BM, CPS, Op::A_LAYOUT>;
+  using BT = DzLdsTile<BN, CPS, Op::B_LAYOUT>;
   constexpr int RED_ELEMS = (WK > 1) ? (WK - 1) * WM * WN * 16 * 64 : 0;
   constexpr int TILE_ELEMS = AT::ELEMS + BT::ELEMS;
   constexpr int SMEM = TILE_ELEMS > RED_ELEMS ? TILE_ELEMS : RED_ELEMS;
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void dz_mfma_gemm(typename Op::Params p) {
   const int l31 = lane & 31;
 
   constexpr int A_ROW16 = (Op::A_LAYOUT == DZ_KC && Op::A_MAP == DZ_MAP_ROW16);
-  constexpr int NA = A_ROW16 ? ((BM * WK + 255) / 256) * 4 : AT::PER_THREAD;
+  constexpr int NA = A_ROW16 ? ((BM * CPS + 255) / 256) * 4 : AT::PER_THREAD;
   constexpr int NB = BT::PER_THREAD;
   float4 ra[NA];
   float4 rb[NB];
@@ -123,14 +127,14 @@ __global__ __launch_bounds__(256) void dz_mfma_gemm(typename Op::Params p) {
       for (int j = 0; j < NA / 4; ++j) {
         const int idx = tid + j * 256;
         float4 v[4] = {dz_f4zero(), dz_f4zero(), dz_f4zero(), dz_f4zero()};
-        if (idx < BM * WK) Op::load_a16(p, t, st, idx % WK, idx / WK, v);
+        if (idx < BM * CPS) Op::load_a16(p, t, st, idx % CPS, idx / CPS, v);
         ra[4 * j] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3];
       }
     } else if constexpr (Op::A_LAYOUT == DZ_KC) {
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         const int idx = tid + j * 256;
-        const int row = idx / (4 * WK), rem = idx % (4 * WK);
+        const int row = idx / (4 * CPS), rem = idx % (4 * CPS);
         ra[j] = (idx < AT::SLOTS) ? Op::load_a(p, t, st, rem >> 2, row, rem & 3)
                                   : dz_f4zero();
       }
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void dz_mfma_gemm(typename Op::Params p) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int idx = tid + j * 256;
-        const int row = idx / (4 * WK), rem = idx % (4 * WK);
+        const int row = idx / (4 * CPS), rem = idx % (4 * CPS);
         rb[j] = (idx < BT::SLOTS) ? Op::load_b(p, t, st, rem >> 2, row, rem & 3)
                                   : dz_f4zero();
       }
@@ -167,8 +171,8 @@ __global__ __launch_bounds__(256) void dz_mfma_gemm(typename Op::Params p) {
 #pragma unroll
       for (int j = 0; j < NA / 4; ++j) {
         const int idx = tid + j * 256;
-        if (idx < BM * WK) {
-          float* dst = As + (idx % WK) * AT::CHUNK + (idx / WK) * 20;
+        if (idx < BM * CPS) {
+          float* dst = As + (idx % CPS) * AT::CHUNK + (idx / CPS) * 20;
 #pragma unroll
           for (int q = 0; q < 4; ++q) *(float4*)(dst + 4 * q) = ra[4 * j + q];
         }
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void dz_mfma_gemm(typename Op::Params p) {
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         const int idx = tid + j * 256;
-        const int row = idx / (4 * WK), rem = idx % (4 * WK);
+        const int row = idx / (4 * CPS), rem = idx % (4 * CPS);
         if (idx < AT::SLOTS)
           *(float4*)(As + (rem >> 2) * AT::CHUNK + row * 20 + 4 * (rem & 3)) = ra[j];
       }
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void dz_mfma_gemm(typename Op::Params p) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int idx = tid + j * 256;
-        const int row = idx / (4 * WK), rem = idx % (4 * WK);
+        const int row = idx / (4 * CPS), rem = idx % (4 * CPS);
         if (idx < BT::SLOTS)
           *(float4*)(Bs + (rem >> 2) * BT::CHUNK + row * 20 + 4 * (rem & 3)) = rb[j];
       }
@@ -220,30 +224,34 @@ __global__ __launch_bounds__(256) void dz_mfma_gemm(typename Op::Params p) {
     __syncthreads();
     if (st + 1 < t.st_end) load_stage(st + 1);  // in flight under the MFMAs
 
-    float fa[8], fb[8];
-    if constexpr (Op::A_LAYOUT == DZ_KC) {
-      const float* src = As + wk * AT::CHUNK + (wm * 32 + l31) * 20 + half * 8;
-      const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
-      fa[0] = v0.x; fa[1] = v0.y; fa[2] = v0.z; fa[3] = v0.w;
-      fa[4] = v1.x; fa[5] = v1.y; fa[6] = v1.z; fa[7] = v1.w;
-    } else {
-      const float* src = As + wk * AT::CHUNK + (half * 8) * BM + wm * 32 + l31;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) fa[s] = src[s * BM];
+    for (int kt = 0; kt < KT; ++kt) {
+      const int ch = wk * KT + kt;  // this wave's chunk of the stage
+      float fa[8], fb[8];
+      if constexpr (Op::A_LAYOUT == DZ_KC) {
+        const float* src = As + ch * AT::CHUNK + (wm * 32 + l31) * 20 + half * 8;
+        const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
+        fa[0] = v0.x; fa[1] = v0.y; fa[2] = v0.z; fa[3] = v0.w;
+        fa[4] = v1.x; fa[5] = v1.y; fa[6] = v1.z; fa[7] = v1.w;
+      } else {
+        const float* src = As + ch * AT::CHUNK + (half * 8) * BM + wm * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) fa[s] = src[s * BM];
+      }
+      if constexpr (Op::B_LAYOUT == DZ_KC) {
+        const float* src = Bs + ch * BT::CHUNK + (wn * 32 + l31) * 20 + half * 8;
+        const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
+        fb[0] = v0.x; fb[1] = v0.y; fb[2] = v0.z; fb[3] = v0.w;
+        fb[4] = v1.x; fb[5] = v1.y; fb[6] = v1.z; fb[7] = v1.w;
+      } else {
+        const float* src = Bs + ch * BT::CHUNK + (half * 8) * BN + wn * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) fb[s] = src[s * BN];
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
     }
-    if constexpr (Op::B_LAYOUT == DZ_KC) {
-      const float* src = Bs + wk * BT::CHUNK + (wn * 32 + l31) * 20 + half * 8;
-      const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
-      fb[0] = v0.x; fb[1] = v0.y; fb[2] = v0.z; fb[3] = v0.w;
-      fb[4] = v1.x; fb[5] = v1.y; fb[6] = v1.z; fb[7] = v1.w;
-    } else {
-      const float* src = Bs + wk * BT::CHUNK + (half * 8) * BN + wn * 32 + l31;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) fb[s] = src[s * BN];
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
   }
 
   if constexpr (WK > 1) {

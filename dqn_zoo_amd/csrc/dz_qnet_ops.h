@@ -2,12 +2,36 @@
 // linear layers of the DQN-family networks (ref: dqn_zoo/networks.py:82-221),
 // forward and backward.  Activations are NHWC, conv weights HWIO flattened to
 // [kh*kw*cin][cout], linear weights [in][out] -- the reference's own layouts
-// (networks_test.py:44,53), so weights are always a row-major [K][N] matrix.
+// (networks_test.py:44,53), so weights are always a row-major [K][ld] matrix.
+//
+// LOADER RULE: every load_a/load_b is BRANCH-FREE.  Out-of-range rows, taps or
+// reduction indices are handled by clamping the address into the buffer and
+// zeroing the value with a select afterwards.  A conditional load makes hipcc
+// wrap it in an exec-mask branch with its own `s_waitcnt vmcnt(0)`, which
+// serialises the 8-12 loads of a stage into 8-12 dependent memory round trips
+// (measured: 385 s_and_saveexec / 40 vmcnt waits in the fc1 kernel, 65 us
+// instead of ~15 us).  All operand rows are 16-byte aligned by construction
+// (leading dimensions are multiples of 4 floats), so loads are always float4.
 #pragma once
 
 #include "dz_gemm.h"
 
 #define DZ_MAX_GROUPS 3
+
+__device__ __forceinline__ float4 dz_ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ float4 dz_sel4(bool ok, float4 v) {
+  return dz_f4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+// keep v[j] iff i+j < n
+__device__ __forceinline__ float4 dz_mask4(float4 v, int i, int n) {
+  return dz_f4(i < n ? v.x : 0.f, i + 1 < n ? v.y : 0.f, i + 2 < n ? v.z : 0.f,
+               i + 3 < n ? v.w : 0.f);
+}
+__device__ __forceinline__ float4 dz_u8x4_to_unit(unsigned w) {
+  // networks.py:193: x.astype(float32) / 255.0 (a true division).
+  return dz_f4((float)(w & 0xff) / 255.0f, (float)((w >> 8) & 0xff) / 255.0f,
+               (float)((w >> 16) & 0xff) / 255.0f, (float)(w >> 24) / 255.0f);
+}
 
 // --------------------------------------------------------------------------- //
 //  Convolution forward: out[img,oh,ow,:] = relu(sum_k patch(img,oh,ow,k) W[k,:] + b)
@@ -24,15 +48,16 @@ struct ConvFwdParams {
 };
 
 template <int IN_U8, int H, int W, int C, int KS, int S, int OH, int OW, int CO,
-          int WM_, int WN_, int WK_>
+          int WM_, int WN_, int WK_, int KT_ = 1>
 struct ConvFwdOp {
-  static constexpr int WM = WM_, WN = WN_, WK = WK_;
+  static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_RC;
   static constexpr int A_MAP = IN_U8 ? DZ_MAP_ROW16 : DZ_MAP_QUAD;
-  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * WK;
+  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   static constexpr int K = KS * KS * C;
   static_assert(K % BK == 0, "K must be a multiple of the stage depth");
   static_assert(IN_U8 ? (KS * C == 32) : (C % 16 == 0), "chunk must not straddle taps");
+  static_assert(CO % BN == 0, "column tiles are full");
   typedef ConvFwdParams Params;
 
   static int tiles_per_group(int B) { return (B * OH * OW + BM - 1) / BM; }
@@ -46,44 +71,43 @@ struct ConvFwdOp {
     t.st_end = K / BK;
     return t.z < p.G;
   }
-  // pixel index (within group) -> element offset of input pixel (oh*S, ow*S, 0)
+  // pixel index (within group, clamped) -> element offset of input pixel
+  // (oh*S, ow*S, 0); returns whether the row is real.
   __device__ static bool pixel_base(const Params& p, const DzTile& t, int row,
                                     long& off) {
+    const int rows = p.B * OH * OW;
     const int ml = t.m0 + row;
-    if (ml >= p.B * OH * OW) return false;
-    const int img = ml / (OH * OW), pix = ml % (OH * OW);
+    const int mc = min(ml, rows - 1);
+    const int img = mc / (OH * OW), pix = mc % (OH * OW);
     const int oh = pix / OW, ow = pix % OW;
     off = (((long)(p.in_img_base[t.z] + img) * H + oh * S) * W + ow * S) * C;
-    return true;
+    return ml < rows;
   }
   __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
                                   int row, int q) {
     long off;
-    if (!pixel_base(p, t, row, off)) return dz_f4zero();
+    const bool ok = pixel_base(p, t, row, off);
     const int k0 = st * BK + c * 16 + 4 * q;
     const int tap = k0 / C, ci = k0 % C;
     const int kh = tap / KS, kw = tap % KS;
-    return *(const float4*)((const float*)p.in[t.z] + off + ((long)kh * W + kw) * C + ci);
+    return dz_sel4(ok, dz_ld4((const float*)p.in[t.z] + off + ((long)kh * W + kw) * C + ci));
   }
   __device__ static void load_a16(const Params& p, const DzTile& t, int st, int c,
                                   int row, float4 (&v)[4]) {
     long off;
-    if (!pixel_base(p, t, row, off)) return;
+    const bool ok = pixel_base(p, t, row, off);
     const int k0 = st * BK + c * 16;  // KS*C == 32 bytes per kernel row
     const int kh = k0 / 32, o = k0 % 32;
     const uint4 raw = *(const uint4*)((const uint8_t*)p.in[t.z] + off + (long)kh * W * C + o);
-    const unsigned wds[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // networks.py:193: x.astype(float32) / 255.0 (a true division).
-      v[i] = dz_f4((float)(wds[i] & 0xff) / 255.0f, (float)((wds[i] >> 8) & 0xff) / 255.0f,
-                   (float)((wds[i] >> 16) & 0xff) / 255.0f, (float)(wds[i] >> 24) / 255.0f);
-    }
+    v[0] = dz_sel4(ok, dz_u8x4_to_unit(raw.x));
+    v[1] = dz_sel4(ok, dz_u8x4_to_unit(raw.y));
+    v[2] = dz_sel4(ok, dz_u8x4_to_unit(raw.z));
+    v[3] = dz_sel4(ok, dz_u8x4_to_unit(raw.w));
   }
   __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
                                   int kk, int rq) {
     const int k = st * BK + c * 16 + kk;
-    return *(const float4*)(p.w[t.z] + (long)k * CO + t.n0 + 4 * rq);
+    return dz_ld4(p.w[t.z] + (long)k * CO + t.n0 + 4 * rq);
   }
   __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
@@ -107,6 +131,9 @@ struct ConvFwdOp {
 //  Noisy form (networks.py:168-176):
 //     y = x Wmu + bmu + ((x . eps_in) Wsig + bsig) . eps_out
 //  is evaluated as ONE contraction of depth 2K: [x | x.eps_in] [Wmu ; Wsig.eps_out].
+//  Weight rows have pitch ldw (multiple of 4, >= N): columns in [N, ldw) are zero
+//  padding; a tile may read columns beyond N (clamped to the pitch), whose
+//  products land in output columns that are never stored.
 // --------------------------------------------------------------------------- //
 struct FcHead {
   long w_mu;     // offset of [K][ldw] matrix in the parameter buffer
@@ -117,7 +144,7 @@ struct FcHead {
   int x_off;     // column offset of this head's input in x
   int eps_in;    // offsets into the group's noise block (noisy only)
   int eps_out;
-  int out_off;   // column offset in the output row
+  int out_off;   // column offset in the output row (multiple of 4)
 };
 
 struct FcFwdParams {
@@ -135,11 +162,11 @@ struct FcFwdParams {
   int ldo;
 };
 
-template <int WM_, int WN_, int WK_>
+template <int WM_, int WN_, int WK_, int KT_ = 1>
 struct FcFwdOp {
-  static constexpr int WM = WM_, WN = WN_, WK = WK_;
+  static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_RC, A_MAP = DZ_MAP_QUAD;
-  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * WK;
+  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   typedef FcFwdParams Params;
 
   __device__ static bool tile(const Params& p, DzTile& t) {
@@ -151,7 +178,7 @@ struct FcFwdOp {
     t.m0 = blockIdx.y * BM;
     t.n0 = blockIdx.x * BN;
     const int chunks = (hd.K / 16) * (p.noisy ? 2 : 1);
-    const int stages = (chunks + WK - 1) / WK;
+    const int stages = (chunks + CPS - 1) / CPS;
     const int per = (stages + p.S - 1) / p.S;
     t.st_begin = split * per;
     t.st_end = min(stages, t.st_begin + per);
@@ -160,31 +187,30 @@ struct FcFwdOp {
   __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
                                   int row, int q) {
     const FcHead& hd = p.head[t.z2 & 0xff];
-    const int kc = hd.K / 16;
-    int gc = st * WK + c;
+    const int kc = hd.K / 16, total = kc * (p.noisy ? 2 : 1);
+    const int gc = st * CPS + c;
     const int m = t.m0 + row;
-    if (m >= p.M || gc >= kc * (p.noisy ? 2 : 1)) return dz_f4zero();
-    const bool sig = gc >= kc;
-    if (sig) gc -= kc;
-    const int k = gc * 16 + 4 * q;
-    float4 v = *(const float4*)(p.x + (long)(t.z * p.M + m) * p.ldx + hd.x_off + k);
-    if (sig) v = dz_mul4(v, *(const float4*)(p.noise[t.z] + hd.eps_in + k));
-    return v;
+    const bool ok = (m < p.M) & (gc < total);
+    const int gcc = min(gc, total - 1);
+    const bool sig = gcc >= kc;
+    const int k = (gcc - (sig ? kc : 0)) * 16 + 4 * q;
+    const float4 v = dz_ld4(p.x + (long)(t.z * p.M + min(m, p.M - 1)) * p.ldx + hd.x_off + k);
+    const float4 e = dz_ld4(p.noise[t.z] + hd.eps_in + k);  // L2-resident, tiny
+    return dz_sel4(ok, sig ? dz_mul4(v, e) : v);
   }
   __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
                                   int kk, int rq) {
     const FcHead& hd = p.head[t.z2 & 0xff];
-    const int kc = hd.K / 16;
-    int gc = st * WK + c;
-    if (gc >= kc * (p.noisy ? 2 : 1)) return dz_f4zero();
-    const bool sig = gc >= kc;
-    if (sig) gc -= kc;
-    const int k = gc * 16 + kk;
-    const int n = t.n0 + 4 * rq;
-    const float* wrow = p.params[t.z] + (sig ? hd.w_sig : hd.w_mu) + (long)k * hd.ldw;
-    float4 v = dz_load4_masked(wrow, n, hd.N);
-    if (sig) v = dz_mul4(v, dz_load4_masked(p.noise[t.z] + hd.eps_out, n, hd.N));
-    return v;
+    const int kc = hd.K / 16, total = kc * (p.noisy ? 2 : 1);
+    const int gc = st * CPS + c;
+    const bool ok = gc < total;
+    const int gcc = min(gc, total - 1);
+    const bool sig = gcc >= kc;
+    const int k = (gcc - (sig ? kc : 0)) * 16 + kk;
+    const int n = min(t.n0 + 4 * rq, hd.ldw - 4);
+    const float4 v = dz_ld4(p.params[t.z] + (sig ? hd.w_sig : hd.w_mu) + (long)k * hd.ldw + n);
+    const float4 e = dz_ld4(p.noise[t.z] + hd.eps_out + n);
+    return dz_sel4(ok, sig ? dz_mul4(v, e) : v);
   }
   __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
@@ -205,11 +231,12 @@ struct FcFwdOp {
 // dX[m][x_off+k] = sum_n dY[m][n] Wmu[k][n] + eps_in[k] sum_n dY[m][n] eps_out[n] Wsig[k][n]
 // accumulated over every head that reads the same input columns (fc1: adv1 and
 // val1 both read the torso features).  Reduction index = (head, mu|sigma, n).
+// dY values with n >= N are zeroed, so weight columns beyond N never matter.
 struct FcDgradParams {
   const float* dy;  // [M][ldy]
   int ldy;
   int M;
-  int NH;           // heads summed into the same output columns
+  int NH;           // heads summed into the same output columns (1 or 2)
   int S;
   int noisy;
   const float* params;
@@ -221,33 +248,41 @@ struct FcDgradParams {
   int x_off;        // output column offset
 };
 
-template <int WM_, int WN_, int WK_>
+template <int WM_, int WN_, int WK_, int KT_ = 1>
 struct FcDgradOp {
-  static constexpr int WM = WM_, WN = WN_, WK = WK_;
+  static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_KC, A_MAP = DZ_MAP_QUAD;
-  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * WK;
+  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   typedef FcDgradParams Params;
 
-  __device__ static int chunks_per_part(const FcHead& hd) { return (hd.N + 15) / 16; }
-  // global chunk -> (head, sigma?, n0)
-  __device__ static bool locate(const Params& p, int gc, int& h, bool& sig, int& n0) {
-    for (h = 0; h < p.NH; ++h) {
-      const int cp = chunks_per_part(p.head[h]);
-      const int tot = cp * (p.noisy ? 2 : 1);
-      if (gc < tot) {
-        sig = gc >= cp;
-        n0 = (sig ? gc - cp : gc) * 16;
-        return true;
-      }
-      gc -= tot;
-    }
-    return false;
+  struct Loc { int N, ldw, eps_in, eps_out, out_off, n0; long w; bool sig, ok; };
+
+  __device__ static int chunks_of(const Params& p, int h) {
+    return ((p.head[h].N + 15) / 16) * (p.noisy ? 2 : 1);
+  }
+  // global chunk -> (head, mu|sigma, first n), arithmetic only (NH <= 2).
+  __device__ static Loc locate(const Params& p, int gc) {
+    const int tot0 = chunks_of(p, 0);
+    const int tot1 = p.NH > 1 ? chunks_of(p, 1) : 0;
+    Loc L;
+    L.ok = gc < tot0 + tot1;
+    gc = min(gc, tot0 + tot1 - 1);
+    const bool h1 = gc >= tot0;
+    const FcHead& a = p.head[0];
+    const FcHead& b = p.head[p.NH > 1 ? 1 : 0];
+    L.N = h1 ? b.N : a.N; L.ldw = h1 ? b.ldw : a.ldw;
+    L.eps_in = h1 ? b.eps_in : a.eps_in; L.eps_out = h1 ? b.eps_out : a.eps_out;
+    L.out_off = h1 ? b.out_off : a.out_off;
+    const int gl = gc - (h1 ? tot0 : 0);
+    const int cp = (L.N + 15) / 16;
+    L.sig = gl >= cp;
+    L.n0 = (gl - (L.sig ? cp : 0)) * 16;
+    L.w = L.sig ? (h1 ? b.w_sig : a.w_sig) : (h1 ? b.w_mu : a.w_mu);
+    return L;
   }
   __device__ static bool tile(const Params& p, DzTile& t) {
-    int chunks = 0;
-    for (int h = 0; h < p.NH; ++h)
-      chunks += chunks_per_part(p.head[h]) * (p.noisy ? 2 : 1);
-    const int stages = (chunks + WK - 1) / WK;
+    const int chunks = chunks_of(p, 0) + (p.NH > 1 ? chunks_of(p, 1) : 0);
+    const int stages = (chunks + CPS - 1) / CPS;
     const int per = (stages + p.S - 1) / p.S;
     t.z = blockIdx.z;  // split
     t.m0 = blockIdx.y * BM;
@@ -258,27 +293,24 @@ struct FcDgradOp {
   }
   __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
                                   int row, int q) {
-    int h, n0; bool sig;
+    const Loc L = locate(p, st * CPS + c);
     const int m = t.m0 + row;
-    if (m >= p.M || !locate(p, st * WK + c, h, sig, n0)) return dz_f4zero();
-    const FcHead& hd = p.head[h];
-    const int n = n0 + 4 * q;
-    float4 v = dz_load4_masked(p.dy + (long)m * p.ldy + hd.out_off, n, hd.N);
-    if (sig) v = dz_mul4(v, dz_load4_masked(p.noise + hd.eps_out, n, hd.N));
-    return v;
+    const int n = L.n0 + 4 * q;
+    const int nc = min(n, L.ldw - 4);  // dY columns share the weights' padded pitch
+    float4 v = dz_ld4(p.dy + (long)min(m, p.M - 1) * p.ldy + L.out_off + nc);
+    const float4 e = dz_ld4(p.noise + L.eps_out + nc);
+    v = L.sig ? dz_mul4(v, e) : v;
+    return dz_mask4(dz_sel4(L.ok & (m < p.M), v), n, L.N);
   }
   // B tile row = output column k; 4 consecutive reduction indices n.
   __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
                                   int row, int q) {
-    int h, n0; bool sig;
-    const int k = t.n0 + row;
-    if (k >= p.K || !locate(p, st * WK + c, h, sig, n0)) return dz_f4zero();
-    const FcHead& hd = p.head[h];
-    const int n = n0 + 4 * q;
-    float4 v = dz_load4_masked(p.params + (sig ? hd.w_sig : hd.w_mu) + (long)k * hd.ldw,
-                               n, hd.N);
-    if (sig) v = dz_scale4(v, p.noise[hd.eps_in + k]);
-    return v;
+    const Loc L = locate(p, st * CPS + c);
+    const int k = min(t.n0 + row, p.K - 1);
+    const int nc = min(L.n0 + 4 * q, L.ldw - 4);
+    const float4 v = dz_ld4(p.params + L.w + (long)k * L.ldw + nc);
+    const float e = p.noise[L.eps_in + k];
+    return L.sig ? dz_scale4(v, e) : v;
   }
   __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
@@ -307,11 +339,11 @@ struct FcWgradParams {
   float* grad;      // gradient buffer with the parameter layout
 };
 
-template <int WM_, int WN_, int WK_>
+template <int WM_, int WN_, int WK_, int KT_ = 1>
 struct FcWgradOp {
-  static constexpr int WM = WM_, WN = WN_, WK = WK_;
+  static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int A_LAYOUT = DZ_RC, B_LAYOUT = DZ_RC, A_MAP = DZ_MAP_QUAD;
-  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * WK;
+  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   typedef FcWgradParams Params;
 
   __device__ static bool tile(const Params& p, DzTile& t) {
@@ -327,16 +359,15 @@ struct FcWgradOp {
                                   int kk, int rq) {
     const FcHead& hd = p.head[t.z];
     const int m = st * BK + c * 16 + kk;
-    const int k = t.m0 + 4 * rq;
-    if (m >= p.M || k >= hd.K) return dz_f4zero();
-    return *(const float4*)(p.x + (long)m * p.ldx + hd.x_off + k);
+    const int k = min(t.m0 + 4 * rq, hd.K - 4);
+    return dz_sel4(m < p.M, dz_ld4(p.x + (long)min(m, p.M - 1) * p.ldx + hd.x_off + k));
   }
   __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
                                   int kk, int rq) {
     const FcHead& hd = p.head[t.z];
     const int m = st * BK + c * 16 + kk;
-    if (m >= p.M) return dz_f4zero();
-    return dz_load4_masked(p.dy + (long)m * p.ldy + hd.out_off, t.n0 + 4 * rq, hd.N);
+    const int n = min(t.n0 + 4 * rq, hd.ldw - 4);
+    return dz_sel4(m < p.M, dz_ld4(p.dy + (long)min(m, p.M - 1) * p.ldy + hd.out_off + n));
   }
   __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
@@ -357,24 +388,31 @@ struct FcWgradOp {
 };
 
 // --------------------------------------------------------------------------- //
-//  Convolution weight gradient: dW[k][co] = sum_pixels patch(pixel,k) dY[pixel][co]
-//  rows = k (contiguous inside a kernel row), reduction = output pixels (split).
+//  Convolution weight AND bias gradient:
+//     dW[k][co] = sum_pixels patch(pixel,k) dY[pixel][co],   db[co] = sum_pixels dY
+//  rows = k (contiguous inside a kernel row) plus ONE extra row k == K whose
+//  "patch" value is 1, so the bias gradient falls out of the same MFMAs;
+//  reduction = output pixels (grid split).  part layout [S][KROWS][CO] with
+//  rows [0,K) the weights and row K the bias -- the same order as the parameter
+//  buffer (conv_b directly follows conv_w), so one reduction pass writes both.
 // --------------------------------------------------------------------------- //
 struct ConvWgradParams {
   const void* in;   // layer input, u8 or f32 [B][H][W][C]
   const float* dy;  // [B*OH*OW][CO]
-  float* part;      // [S][K][CO]
+  float* part;      // [S][KROWS][CO]
   int B;
   int S;
 };
 
 template <int IN_U8, int H, int W, int C, int KS, int S, int OH, int OW, int CO,
-          int WM_, int WN_, int WK_>
+          int WM_, int WN_, int WK_, int KT_ = 1>
 struct ConvWgradOp {
-  static constexpr int WM = WM_, WN = WN_, WK = WK_;
+  static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int A_LAYOUT = DZ_RC, B_LAYOUT = DZ_RC, A_MAP = DZ_MAP_QUAD;
-  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * WK;
+  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   static constexpr int K = KS * KS * C;
+  static constexpr int KROWS = K + 1;                  // + the bias row
+  static constexpr int MT = (KROWS + BM - 1) / BM;     // row tiles
   static_assert(K % BM == 0 && CO % BN == 0 && C % 4 == 0, "tile shape");
   typedef ConvWgradParams Params;
 
@@ -390,35 +428,37 @@ struct ConvWgradOp {
   }
   __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
                                   int kk, int rq) {
+    const int rows = p.B * OH * OW;
     const int ml = st * BK + c * 16 + kk;
-    if (ml >= p.B * OH * OW) return dz_f4zero();
-    const int img = ml / (OH * OW), pix = ml % (OH * OW);
+    const int mc = min(ml, rows - 1);
+    const int img = mc / (OH * OW), pix = mc % (OH * OW);
     const int oh = pix / OW, ow = pix % OW;
     const int k = t.m0 + 4 * rq;
-    const int tap = k / C, ci = k % C;
+    const int kc = min(k, K - 4);
+    const int tap = kc / C, ci = kc % C;
     const int kh = tap / KS, kw = tap % KS;
     const long off = (((long)img * H + oh * S + kh) * W + ow * S + kw) * C + ci;
-    if (IN_U8) {
-      const unsigned wd = *(const unsigned*)((const uint8_t*)p.in + off);
-      return dz_f4((float)(wd & 0xff) / 255.0f, (float)((wd >> 8) & 0xff) / 255.0f,
-                   (float)((wd >> 16) & 0xff) / 255.0f, (float)(wd >> 24) / 255.0f);
-    }
-    return *(const float4*)((const float*)p.in + off);
+    float4 v;
+    if (IN_U8) v = dz_u8x4_to_unit(*(const unsigned*)((const uint8_t*)p.in + off));
+    else v = dz_ld4((const float*)p.in + off);
+    // rows >= K: the bias row (value 1 at k == K) then zero padding
+    v = k < K ? v : dz_f4(k == K ? 1.f : 0.f, 0.f, 0.f, 0.f);
+    return dz_sel4(ml < rows, v);
   }
   __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
                                   int kk, int rq) {
+    const int rows = p.B * OH * OW;
     const int ml = st * BK + c * 16 + kk;
-    if (ml >= p.B * OH * OW) return dz_f4zero();
-    return *(const float4*)(p.dy + (long)ml * CO + t.n0 + 4 * rq);
+    return dz_sel4(ml < rows, dz_ld4(p.dy + (long)min(ml, rows - 1) * CO + t.n0 + 4 * rq));
   }
   __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
     const int col = t.n0 + wn * 32 + (lane & 31);
-    float* base = p.part + (long)t.z * K * CO + col;
+    float* base = p.part + (long)t.z * KROWS * CO + col;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = t.m0 + wm * 32 + dz_acc_row(r, lane);
-      base[(long)k * CO] = acc[r];
+      if (k < KROWS) base[(long)k * CO] = acc[r];
     }
   }
 };
@@ -439,16 +479,16 @@ struct ConvDgradParams {
 };
 
 template <int H, int W, int C, int KS, int S, int OH, int OW, int CO,
-          int WM_, int WN_, int WK_>
+          int WM_, int WN_, int WK_, int KT_ = 1>
 struct ConvDgradOp {
-  static constexpr int WM = WM_, WN = WN_, WK = WK_;
+  static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_KC, A_MAP = DZ_MAP_QUAD;
-  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * WK;
+  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   static constexpr int TS = (KS + S - 1) / S;   // taps per dimension per class
   static constexpr int HP = (H + S - 1) / S, WP = (W + S - 1) / S;  // class grid
   static constexpr int RED = TS * TS * CO;
   static_assert(CO % 16 == 0 && RED % BK == 0 && C % BN == 0, "tile shape");
-  static_assert(H % S == 0 && W % S == 0, "every parity class has the same size");
+  static_assert(H % S == 0 && W % S == 0 && KS % S == 0, "uniform parity classes");
   typedef ConvDgradParams Params;
 
   static int tiles(int B) { return (B * HP * WP + BM - 1) / BM; }
@@ -463,25 +503,26 @@ struct ConvDgradOp {
   }
   __device__ static bool pixel(const Params& p, const DzTile& t, int row, int& img,
                                int& h, int& w) {
+    const int rows = p.B * HP * WP;
     const int ml = t.m0 + row;
-    if (ml >= p.B * HP * WP) return false;
-    img = ml / (HP * WP);
-    const int pix = ml % (HP * WP);
+    const int mc = min(ml, rows - 1);
+    img = mc / (HP * WP);
+    const int pix = mc % (HP * WP);
     h = (pix / WP) * S + t.z / S;
     w = (pix % WP) * S + t.z % S;
-    return true;
+    return ml < rows;
   }
   __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
                                   int row, int q) {
     int img, h, w;
-    if (!pixel(p, t, row, img, h, w)) return dz_f4zero();
+    bool ok = pixel(p, t, row, img, h, w);
     const int r0 = st * BK + c * 16 + 4 * q;
     const int tap = r0 / CO, co = r0 % CO;
-    const int kh = (t.z / S) + (tap / TS) * S, kw = (t.z % S) + (tap % TS) * S;
-    const int oh = (h - kh) / S, ow = (w - kw) / S;  // exact by construction
-    if (kh >= KS || kw >= KS || h < kh || w < kw || oh >= OH || ow >= OW)
-      return dz_f4zero();
-    return *(const float4*)(p.dy + (((long)img * OH + oh) * OW + ow) * CO + co);
+    const int kh = (t.z / S) + (tap / TS) * S, kw = (t.z % S) + (tap % TS) * S;  // < KS
+    const int oh = (h - kh) / S, ow = (w - kw) / S;  // exact when h >= kh, w >= kw
+    ok = ok & (h >= kh) & (w >= kw) & (oh < OH) & (ow < OW);
+    const int ohc = min(max(oh, 0), OH - 1), owc = min(max(ow, 0), OW - 1);
+    return dz_sel4(ok, dz_ld4(p.dy + (((long)img * OH + ohc) * OW + owc) * CO + co));
   }
   __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
                                   int row, int q) {
@@ -489,8 +530,7 @@ struct ConvDgradOp {
     const int r0 = st * BK + c * 16 + 4 * q;
     const int tap = r0 / CO, co = r0 % CO;
     const int kh = (t.z / S) + (tap / TS) * S, kw = (t.z % S) + (tap % TS) * S;
-    if (kh >= KS || kw >= KS) return dz_f4zero();
-    return *(const float4*)(p.w + ((long)(kh * KS + kw) * C + ci) * CO + co);
+    return dz_ld4(p.w + ((long)(kh * KS + kw) * C + ci) * CO + co);
   }
   __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
                                int lane, const f32x16& acc) {

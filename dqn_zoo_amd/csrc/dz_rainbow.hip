@@ -18,25 +18,33 @@ constexpr int kHid = 512;
 constexpr int kG = 3;         // applies: online(s_tm1), online(s_t), target(s_t)
 constexpr int kS_fc1 = 7;     // grid split-K factors
 constexpr int kS_fc2 = 4;
+constexpr int kS_dh1 = 5;
 constexpr int kS_dfeat = 8;
-constexpr int kS_cw1 = 100, kS_cw2 = 27, kS_cw3 = 14;
+constexpr int kS_cw1 = 50, kS_cw2 = 27, kS_cw3 = 14;
 constexpr int kNormBlocks = 512;
 
 inline int64_t align4(int64_t v) { return (v + 3) & ~(int64_t)3; }
 
+// Run-time tuning knobs (dz_set_tuning): kernel variant and split factors, used
+// by tools/tune.py to sweep configurations in ONE GPU session.
+constexpr int kMaxSplitFc1 = 16;
+int g_fc1_variant = 0;
+int g_fc1_splits = 7;
+
 // conv geometries (networks.py:194-198)
 //                      U8  H   W   C  KS S  OH  OW  CO
-using Conv1Fwd = ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 4, 1, 1>;
-using Conv2Fwd = ConvFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 1, 2, 2>;
-using Conv3Fwd = ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 2, 2>;
-using Conv1Wg = ConvWgradOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 2, 1, 2>;
-using Conv2Wg = ConvWgradOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 2, 2, 1>;
-using Conv3Wg = ConvWgradOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 2, 2, 1>;
-using Conv2Dg = ConvDgradOp<20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4>;
-using Conv3Dg = ConvDgradOp<9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4>;
-using FcFwd = FcFwdOp<1, 2, 2>;
-using FcDg = FcDgradOp<1, 2, 2>;
-using FcWg = FcWgradOp<2, 2, 1>;
+//                                                       WM WN WK KT
+using Conv1Fwd = ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 4, 1, 1, 4>;
+using Conv2Fwd = ConvFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 1, 2, 2, 4>;
+using Conv3Fwd = ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 2, 2, 3>;
+using Conv1Wg = ConvWgradOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 2, 1, 2, 2>;
+using Conv2Wg = ConvWgradOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 2, 2, 1, 2>;
+using Conv3Wg = ConvWgradOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 2, 2, 1, 2>;
+using Conv2Dg = ConvDgradOp<20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4, 1>;
+using Conv3Dg = ConvDgradOp<9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4, 3>;
+using FcFwd = FcFwdOp<1, 2, 2, 4>;
+using FcDg = FcDgradOp<1, 2, 2, 4>;
+using FcWg = FcWgradOp<2, 2, 1, 2>;
 
 // ---- small kernels ----------------------------------------------------------
 
@@ -61,37 +69,50 @@ __global__ void fc_epilogue_kernel(const float* __restrict__ part, int S, int ro
   out[(long)r * ld + c] = v;
 }
 
-// out[i] = (mask? mask[i] > 0 : 1) * sum_s part[s][i]
-__global__ void reduce_parts_kernel(const float* part, int S, long n,
-                                    const float* __restrict__ mask, float* out) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// out[i] = (mask? mask[i] > 0 : 1) * sum_s part[s][i].  64 outputs per block;
+// the 4 waves stride over the S partial slabs and combine through LDS, so the
+// dependent-add chain is S/4 long and every load is a coalesced 256-byte row.
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* part, int S,
+                                                           long n, const float* mask,
+                                                           float* out) {
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + l;
   float v = 0.f;
-  for (int s = 0; s < S; ++s) v += part[(long)s * n + i];
-  if (mask && !(mask[i] > 0.f)) v = 0.f;
-  out[i] = v;
+  if (i < n)
+    for (int s = w; s < S; s += 4) v += part[(long)s * n + i];
+  red[w][l] = v;
+  __syncthreads();
+  if (w == 0 && i < n) {
+    v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    if (mask && !(mask[i] > 0.f)) v = 0.f;
+    out[i] = v;
+  }
 }
 
-// Column sums of row-major matrices: out[c] = scale[c]? * sum_r m[r][c].
+// Column sums of the (short) linear-layer output gradients: out[c] = sum_r m[r][c],
+// out_scaled[c] = out[c] * scale[c] (the sigma-bias gradient).  Convolution
+// bias gradients come out of the wgrad GEMM (ConvWgradOp's extra row).
 struct ColsumJob {
   const float* m; int rows; int cols; int ld; float* out; const float* scale;
   float* out_scaled;
 };
-struct ColsumJobs { ColsumJob j[6]; int n; };
+struct ColsumJobs { ColsumJob j[4]; int n; };
 __global__ __launch_bounds__(256) void colsum_kernel(ColsumJobs jobs) {
   __shared__ float red[4][64];
   const ColsumJob jb = jobs.j[blockIdx.y];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int w = threadIdx.x >> 6;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l;
   if (blockIdx.x * 64 >= jb.cols) return;
   float v = 0.f;
-  if (c < jb.cols)
+  if (c < jb.cols) {
+#pragma unroll 4
     for (int r = w; r < jb.rows; r += 4) v += jb.m[(long)r * jb.ld + c];
-  red[w][threadIdx.x & 63] = v;
+  }
+  red[w][l] = v;
   __syncthreads();
   if (w == 0 && c < jb.cols) {
-    const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
-                    red[3][threadIdx.x];
+    const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
     if (jb.out) jb.out[c] = s;
     if (jb.out_scaled) jb.out_scaled[c] = s * jb.scale[c];
   }
@@ -111,7 +132,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 //      rainbow/agent.py:97-109 + rlax.categorical_double_q_learning,
 //      rainbow/agent.py:194 (priorities).
 __global__ __launch_bounds__(64) void rainbow_head_loss_kernel(
-    const float* __restrict__ fc2_out, int ld, int B, int A, int K,
+    const float* __restrict__ fc2_out, int ld, int val_off, int B, int A, int K,
     const int64_t* __restrict__ a_tm1, const double* __restrict__ r_t,
     const double* __restrict__ d_t, const float* __restrict__ weights,
     const float* __restrict__ support, float* __restrict__ dout2,
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(64) void rainbow_head_loss_kernel(
   __shared__ float s_z[64];
   const int b = blockIdx.x, k = threadIdx.x;
   const bool on = k < K;
-  const int NA = A * K;
+  const int NA = val_off;  // value-head columns start at the padded offset
   const float z = on ? support[k] : 0.f;
   const float invA = 1.0f / (float)A;
 
@@ -301,7 +322,7 @@ __global__ void noise_fill_kernel(float* __restrict__ out, long n, uint64_t seed
 // ---- layout -----------------------------------------------------------------
 extern "C" int dz_rainbow_layout(int A, int K, int B, dz_rainbow_layout_t* L) {
   DZ_REQUIRE(L && A > 0 && K > 0 && K <= 64 && B > 0 && B <= 1024);
-  const int NA = A * K, NAK = NA + K;
+  const int NA = A * K;
   L->num_actions = A; L->num_atoms = K; L->batch = B; L->groups = kG;
   int64_t o = 0;
   const int64_t cw[3] = {256 * 32, 512 * 64, 576 * 64};
@@ -310,15 +331,21 @@ extern "C" int dz_rainbow_layout(int A, int K, int B, dz_rainbow_layout_t* L) {
     L->conv_w[i] = o; o = align4(o + cw[i]);
     L->conv_b[i] = o; o = align4(o + cb[i]);
   }
-  L->fc1_mu_w = o; o = align4(o + (int64_t)kFlat * 1024);
+  // fc1 rows are padded by 32 floats: a 4096-byte row pitch maps every row of a
+  // column tile to the same HBM channel group (measured 3x slower streaming)
+  L->fc1_ld = 1024 + 32;
+  L->fc1_mu_w = o; o = align4(o + (int64_t)kFlat * L->fc1_ld);
   L->fc1_mu_b = o; o = align4(o + 1024);
-  L->fc1_sig_w = o; o = align4(o + (int64_t)kFlat * 1024);
+  L->fc1_sig_w = o; o = align4(o + (int64_t)kFlat * L->fc1_ld);
   L->fc1_sig_b = o; o = align4(o + 1024);
-  L->adv2_mu_w = o; o = align4(o + (int64_t)kHid * NA);
-  L->adv2_sig_w = o; o = align4(o + (int64_t)kHid * NA);
-  L->val2_mu_w = o; o = align4(o + (int64_t)kHid * K);
-  L->val2_sig_w = o; o = align4(o + (int64_t)kHid * K);
-  L->fc2_sig_b = o; o = align4(o + NAK);
+  // fc2 matrices use a leading dimension padded to 4 floats so that every row
+  // is 16-byte aligned (pad columns are zero and receive zero gradients)
+  L->adv2_ld = (int32_t)align4(NA); L->val2_ld = (int32_t)align4(K);
+  L->adv2_mu_w = o; o = align4(o + (int64_t)kHid * L->adv2_ld);
+  L->adv2_sig_w = o; o = align4(o + (int64_t)kHid * L->adv2_ld);
+  L->val2_mu_w = o; o = align4(o + (int64_t)kHid * L->val2_ld);
+  L->val2_sig_w = o; o = align4(o + (int64_t)kHid * L->val2_ld);
+  L->fc2_sig_b = o; o = align4(o + L->adv2_ld + L->val2_ld);
   L->param_count = o;
   L->param_count_ref = 77984 + 2 * ((int64_t)kFlat * 512 * 2 + 1024) +
                        ((int64_t)kHid * NA * 2 + NA) + ((int64_t)kHid * K * 2 + K);
@@ -326,16 +353,16 @@ extern "C" int dz_rainbow_layout(int A, int K, int B, dz_rainbow_layout_t* L) {
   L->n_adv1_in = 0; L->n_val1_in = kFlat; L->n_fc1_out = 2 * kFlat;
   L->n_adv2_in = 2 * kFlat + 1024; L->n_val2_in = L->n_adv2_in + kHid;
   L->n_fc2_out = L->n_val2_in + kHid;
-  L->noise_stride = align4(L->n_fc2_out + NAK);
+  L->noise_stride = align4(L->n_fc2_out + L->adv2_ld + L->val2_ld);
   // workspace
   const int64_t GB = (int64_t)kG * B;
-  const int64_t ld2 = align4(NAK);
+  const int64_t ld2 = L->adv2_ld + L->val2_ld;  // padded fc2 column space
   int64_t w = 0;
   auto take = [&](int64_t n) { int64_t r = w; w = align4(w + n); return r; };
   L->ws_act1 = take(GB * 400 * 32);
   L->ws_act2 = take(GB * 81 * 64);
   L->ws_feat = take(GB * kFlat);
-  L->ws_fc1_part = take((int64_t)kS_fc1 * GB * 1024);
+  L->ws_fc1_part = take((int64_t)kMaxSplitFc1 * GB * 1024);
   L->ws_h1 = take(GB * 1024);
   L->ws_fc2_part = take((int64_t)kS_fc2 * GB * ld2);
   L->ws_fc2_out = take(GB * ld2);
@@ -345,11 +372,12 @@ extern "C" int dz_rainbow_layout(int A, int K, int B, dz_rainbow_layout_t* L) {
   L->ws_dfeat = take((int64_t)B * kFlat);
   L->ws_dact2 = take((int64_t)B * 81 * 64);
   L->ws_dact1 = take((int64_t)B * 400 * 32);
-  int64_t wp = (int64_t)kS_cw1 * 256 * 32;
-  if ((int64_t)kS_cw2 * 512 * 64 > wp) wp = (int64_t)kS_cw2 * 512 * 64;
-  if ((int64_t)kS_cw3 * 576 * 64 > wp) wp = (int64_t)kS_cw3 * 576 * 64;
+  int64_t wp = (int64_t)kS_cw1 * Conv1Wg::KROWS * 32;
+  if ((int64_t)kS_cw2 * Conv2Wg::KROWS * 64 > wp) wp = (int64_t)kS_cw2 * Conv2Wg::KROWS * 64;
+  if ((int64_t)kS_cw3 * Conv3Wg::KROWS * 64 > wp) wp = (int64_t)kS_cw3 * Conv3Wg::KROWS * 64;
   L->ws_wgrad_part = take(wp);
   L->ws_norm_part = take(kNormBlocks);
+  L->ws_colsum_part = take(4);
   L->ws_scalars = take(16);
   L->ws_q_sel = take((int64_t)B * A);
   L->ws_target_probs = take((int64_t)B * K);
@@ -368,7 +396,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   if (rc != DZ_OK) return rc;
   hipStream_t s = dz_s(stream);
   const int B = a->batch, A = a->num_actions, K = a->num_atoms;
-  const int NA = A * K, NAK = NA + K, ld2 = (int)align4(NAK);
+  const int NA = A * K, NAp = L.adv2_ld, ld2 = L.adv2_ld + L.val2_ld;
   float* ws = a->ws;
   const float* prm[kG] = {a->online, a->online, a->target};
   const float* nz[kG] = {a->noise, a->noise + L.noise_stride,
@@ -377,18 +405,18 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   FcHead fc1h[2], fc2h[2];
   for (int h = 0; h < 2; ++h) {
     fc1h[h].w_mu = L.fc1_mu_w + 512 * h; fc1h[h].w_sig = L.fc1_sig_w + 512 * h;
-    fc1h[h].ldw = 1024; fc1h[h].N = 512; fc1h[h].K = kFlat; fc1h[h].x_off = 0;
+    fc1h[h].ldw = L.fc1_ld; fc1h[h].N = 512; fc1h[h].K = kFlat; fc1h[h].x_off = 0;
     fc1h[h].eps_in = (int)(h == 0 ? L.n_adv1_in : L.n_val1_in);
     fc1h[h].eps_out = (int)L.n_fc1_out + 512 * h; fc1h[h].out_off = 512 * h;
   }
-  fc2h[0].w_mu = L.adv2_mu_w; fc2h[0].w_sig = L.adv2_sig_w; fc2h[0].ldw = NA;
+  fc2h[0].w_mu = L.adv2_mu_w; fc2h[0].w_sig = L.adv2_sig_w; fc2h[0].ldw = L.adv2_ld;
   fc2h[0].N = NA; fc2h[0].K = kHid; fc2h[0].x_off = 0;
   fc2h[0].eps_in = (int)L.n_adv2_in; fc2h[0].eps_out = (int)L.n_fc2_out;
   fc2h[0].out_off = 0;
-  fc2h[1].w_mu = L.val2_mu_w; fc2h[1].w_sig = L.val2_sig_w; fc2h[1].ldw = K;
+  fc2h[1].w_mu = L.val2_mu_w; fc2h[1].w_sig = L.val2_sig_w; fc2h[1].ldw = L.val2_ld;
   fc2h[1].N = K; fc2h[1].K = kHid; fc2h[1].x_off = 512;
-  fc2h[1].eps_in = (int)L.n_val2_in; fc2h[1].eps_out = (int)L.n_fc2_out + NA;
-  fc2h[1].out_off = NA;
+  fc2h[1].eps_in = (int)L.n_val2_in; fc2h[1].eps_out = (int)L.n_fc2_out + NAp;
+  fc2h[1].out_off = NAp;
 
   if (g_dz_prof_on) dz_prof_begin(s);
   if (phases & DZ_PHASE_FORWARD) {
@@ -430,11 +458,23 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       for (int g = 0; g < kG; ++g) { p.params[g] = prm[g]; p.noise[g] = nz[g]; }
       p.head[0] = fc1h[0]; p.head[1] = fc1h[1];
       p.part = ws + L.ws_fc1_part; p.ldo = 1024;
-      rc = dz_launch_gemm<FcFwd>(p, dim3(512 / FcFwd::BN, (B + 31) / 32, kG * 2 * kS_fc1), s);
+      p.S = g_fc1_splits;
+      const dim3 gz(1, (B + 31) / 32, kG * 2 * g_fc1_splits);
+      switch (g_fc1_variant) {
+        default:
+        case 0: rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4>>(p, dim3(8, gz.y, gz.z), s); break;
+        case 1: rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 2>>(p, dim3(8, gz.y, gz.z), s); break;
+        case 2: rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 1>>(p, dim3(8, gz.y, gz.z), s); break;
+        case 3: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 4>>(p, dim3(4, gz.y, gz.z), s); break;
+        case 4: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 2>>(p, dim3(4, gz.y, gz.z), s); break;
+        case 5: rc = dz_launch_gemm<FcFwdOp<1, 1, 4, 2>>(p, dim3(16, gz.y, gz.z), s); break;
+        case 6: rc = dz_launch_gemm<FcFwdOp<1, 1, 4, 1>>(p, dim3(16, gz.y, gz.z), s); break;
+        case 7: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 1>>(p, dim3(4, gz.y, gz.z), s); break;
+      }
       if (rc) return rc;
       DZ_PROF(s, "fc1_fwd");
       hipLaunchKernelGGL(fc_epilogue_kernel, dim3(4, kG * B), dim3(256), 0, s,
-                         ws + L.ws_fc1_part, kS_fc1, kG * B, 1024, 1024, B,
+                         ws + L.ws_fc1_part, g_fc1_splits, kG * B, 1024, 1024, B,
                          prm[0], prm[1], prm[2], (long)L.fc1_mu_b, (long)L.fc1_sig_b,
                          nz[0], nz[1], nz[2], (int)L.n_fc1_out, 1, ws + L.ws_h1);
       DZ_LAUNCH_CHECK();
@@ -451,15 +491,15 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
                                         kG * 2 * kS_fc2), s);
       if (rc) return rc;
       DZ_PROF(s, "fc2_fwd");
-      hipLaunchKernelGGL(fc_epilogue_kernel, dim3((NAK + 255) / 256, kG * B), dim3(256),
-                         0, s, ws + L.ws_fc2_part, kS_fc2, kG * B, NAK, ld2, B,
+      hipLaunchKernelGGL(fc_epilogue_kernel, dim3((ld2 + 255) / 256, kG * B), dim3(256),
+                         0, s, ws + L.ws_fc2_part, kS_fc2, kG * B, ld2, ld2, B,
                          prm[0], prm[1], prm[2], (long)-1, (long)L.fc2_sig_b, nz[0],
                          nz[1], nz[2], (int)L.n_fc2_out, 0, ws + L.ws_fc2_out);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "fc2_epilogue");
     }
     hipLaunchKernelGGL(rainbow_head_loss_kernel, dim3(B), dim3(64), 0, s,
-                       ws + L.ws_fc2_out, ld2, B, A, K, a->a_tm1, a->r_t, a->discount_t,
+                       ws + L.ws_fc2_out, ld2, NAp, B, A, K, a->a_tm1, a->r_t, a->discount_t,
                        a->weights, a->support, ws + L.ws_dout2, a->losses, a->priorities,
                        ws + L.ws_q_sel, ws + L.ws_target_probs);
     DZ_LAUNCH_CHECK();
@@ -481,14 +521,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     {  // fc2 input gradient -> dh1, masked by relu(h1)
       for (int h = 0; h < 2; ++h) {
         FcDgradParams p;
-        p.dy = ws + L.ws_dout2; p.ldy = ld2; p.M = B; p.NH = 1; p.S = 1; p.noisy = 1;
+        p.dy = ws + L.ws_dout2; p.ldy = ld2; p.M = B; p.NH = 1; p.S = kS_dh1; p.noisy = 1;
         p.params = a->online; p.noise = nz[0]; p.head[0] = fc2h[h];
-        p.part = ws + L.ws_dh1; p.ldo = 1024; p.K = kHid; p.x_off = 512 * h;
-        rc = dz_launch_gemm<FcDg>(p, dim3(kHid / FcDg::BN, (B + 31) / 32, 1), s);
+        p.part = ws + L.ws_dfeat_part; p.ldo = 1024; p.K = kHid; p.x_off = 512 * h;
+        rc = dz_launch_gemm<FcDg>(p, dim3(kHid / FcDg::BN, (B + 31) / 32, kS_dh1), s);
         if (rc) return rc;
       }
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * 1024 + 255) / 256), dim3(256), 0,
-                         s, ws + L.ws_dh1, 1, (long)B * 1024, ws + L.ws_h1,
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * 1024 + 63) / 64), dim3(256), 0,
+                         s, ws + L.ws_dfeat_part, kS_dh1, (long)B * 1024, ws + L.ws_h1,
                          ws + L.ws_dh1);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "fc2_dgrad");
@@ -510,7 +550,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       rc = dz_launch_gemm<FcDg>(p, dim3(kFlat / FcDg::BN, (B + 31) / 32, kS_dfeat), s);
       if (rc) return rc;
       DZ_PROF(s, "fc1_dgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 255) / 256), dim3(256), 0,
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0,
                          s, ws + L.ws_dfeat_part, kS_dfeat, (long)B * kFlat,
                          ws + L.ws_feat, ws + L.ws_dfeat);
       DZ_LAUNCH_CHECK();
@@ -520,11 +560,11 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       ConvWgradParams p;
       p.in = ws + L.ws_act2; p.dy = ws + L.ws_dfeat; p.part = ws + L.ws_wgrad_part;
       p.B = B; p.S = kS_cw3;
-      rc = dz_launch_gemm<Conv3Wg>(p, dim3(64 / Conv3Wg::BN, 576 / Conv3Wg::BM, kS_cw3), s);
+      rc = dz_launch_gemm<Conv3Wg>(p, dim3(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), s);
       if (rc) return rc;
       DZ_PROF(s, "conv3_wgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((576 * 64 + 255) / 256), dim3(256), 0,
-                         s, ws + L.ws_wgrad_part, kS_cw3, (long)576 * 64,
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((577 * 64 + 63) / 64), dim3(256), 0,
+                         s, ws + L.ws_wgrad_part, kS_cw3, (long)577 * 64,
                          (const float*)nullptr, grad + L.conv_w[2]);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "conv3_wgrad_reduce");
@@ -539,11 +579,11 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       ConvWgradParams p;
       p.in = ws + L.ws_act1; p.dy = ws + L.ws_dact2; p.part = ws + L.ws_wgrad_part;
       p.B = B; p.S = kS_cw2;
-      rc = dz_launch_gemm<Conv2Wg>(p, dim3(64 / Conv2Wg::BN, 512 / Conv2Wg::BM, kS_cw2), s);
+      rc = dz_launch_gemm<Conv2Wg>(p, dim3(64 / Conv2Wg::BN, Conv2Wg::MT, kS_cw2), s);
       if (rc) return rc;
       DZ_PROF(s, "conv2_wgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((512 * 64 + 255) / 256), dim3(256), 0,
-                         s, ws + L.ws_wgrad_part, kS_cw2, (long)512 * 64,
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((513 * 64 + 63) / 64), dim3(256), 0,
+                         s, ws + L.ws_wgrad_part, kS_cw2, (long)513 * 64,
                          (const float*)nullptr, grad + L.conv_w[1]);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "conv2_wgrad_reduce");
@@ -558,24 +598,21 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       ConvWgradParams p;
       p.in = a->s_tm1; p.dy = ws + L.ws_dact1; p.part = ws + L.ws_wgrad_part;
       p.B = B; p.S = kS_cw1;
-      rc = dz_launch_gemm<Conv1Wg>(p, dim3(32 / Conv1Wg::BN, 256 / Conv1Wg::BM, kS_cw1), s);
+      rc = dz_launch_gemm<Conv1Wg>(p, dim3(32 / Conv1Wg::BN, Conv1Wg::MT, kS_cw1), s);
       if (rc) return rc;
       DZ_PROF(s, "conv1_wgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((256 * 32 + 255) / 256), dim3(256), 0,
-                         s, ws + L.ws_wgrad_part, kS_cw1, (long)256 * 32,
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((257 * 32 + 63) / 64), dim3(256), 0,
+                         s, ws + L.ws_wgrad_part, kS_cw1, (long)257 * 32,
                          (const float*)nullptr, grad + L.conv_w[0]);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "conv1_wgrad_reduce");
     }
-    {  // bias gradients = column sums of the layer output gradients
+    {  // linear-layer bias gradients = column sums of the output gradients
       ColsumJobs J;
-      J.n = 5;
-      J.j[0] = {ws + L.ws_dact1, B * 400, 32, 32, grad + L.conv_b[0], nullptr, nullptr};
-      J.j[1] = {ws + L.ws_dact2, B * 81, 64, 64, grad + L.conv_b[1], nullptr, nullptr};
-      J.j[2] = {ws + L.ws_dfeat, B * 49, 64, 64, grad + L.conv_b[2], nullptr, nullptr};
-      J.j[3] = {ws + L.ws_dh1, B, 1024, 1024, grad + L.fc1_mu_b, nz[0] + L.n_fc1_out,
+      J.n = 2;
+      J.j[0] = {ws + L.ws_dh1, B, 1024, 1024, grad + L.fc1_mu_b, nz[0] + L.n_fc1_out,
                 grad + L.fc1_sig_b};
-      J.j[4] = {ws + L.ws_dout2, B, NAK, ld2, nullptr, nz[0] + L.n_fc2_out,
+      J.j[1] = {ws + L.ws_dout2, B, ld2, ld2, nullptr, nz[0] + L.n_fc2_out,
                 grad + L.fc2_sig_b};
       hipLaunchKernelGGL(colsum_kernel, dim3(16, J.n), dim3(256), 0, s, J);
       DZ_LAUNCH_CHECK();
@@ -602,6 +639,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       DZ_PROF(s, "adam");
   }
   return DZ_OK;
+}
+
+extern "C" int dz_set_tuning(int key, int value) {
+  switch (key) {
+    case 0: g_fc1_variant = value; return DZ_OK;
+    case 1: DZ_REQUIRE(value >= 1 && value <= kMaxSplitFc1); g_fc1_splits = value; return DZ_OK;
+    default: return DZ_ERR_INVALID_ARG;
+  }
 }
 
 extern "C" int dz_noise_fill(float* noise, int64_t count, uint64_t seed,

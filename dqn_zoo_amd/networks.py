@@ -83,8 +83,10 @@ class RainbowParamLayout:
                'dz_rainbow_layout')
     self.num_actions, self.num_atoms, self.batch = num_actions, num_atoms, batch_size
     self.na = num_actions * num_atoms
-    self.nak = self.na + num_atoms
-    self.ld2 = (self.nak + 3) // 4 * 4
+    # fc2 "column space": advantage logits at [0, A*K), value logits at
+    # [val_off, val_off+K); both blocks padded to 4 floats (pads stay zero).
+    self.val_off = int(self.c.adv2_ld)
+    self.ld2 = int(self.c.adv2_ld) + int(self.c.val2_ld)
 
   @property
   def param_count(self):
@@ -110,16 +112,18 @@ class RainbowParamLayout:
       v['conv%d/b' % (i + 1)] = flat[c.conv_b[i]:c.conv_b[i] + shp[3]]
     for part, wo, bo in (('mu', c.fc1_mu_w, c.fc1_mu_b),
                          ('sigma', c.fc1_sig_w, c.fc1_sig_b)):
-      w = flat[wo:wo + FLAT * 1024].reshape(FLAT, 1024)
+      l1 = int(c.fc1_ld)  # padded row pitch
+      w = flat[wo:wo + FLAT * l1].reshape(FLAT, l1)
       b = flat[bo:bo + 1024]
-      v['adv1/%s/w' % part], v['val1/%s/w' % part] = w[:, :512], w[:, 512:]
+      v['adv1/%s/w' % part], v['val1/%s/w' % part] = w[:, :512], w[:, 512:1024]
       v['adv1/%s/b' % part], v['val1/%s/b' % part] = b[:512], b[512:]
-    v['adv2/mu/w'] = flat[c.adv2_mu_w:c.adv2_mu_w + HIDDEN * na].reshape(HIDDEN, na)
-    v['adv2/sigma/w'] = flat[c.adv2_sig_w:c.adv2_sig_w + HIDDEN * na].reshape(HIDDEN, na)
-    v['val2/mu/w'] = flat[c.val2_mu_w:c.val2_mu_w + HIDDEN * k].reshape(HIDDEN, k)
-    v['val2/sigma/w'] = flat[c.val2_sig_w:c.val2_sig_w + HIDDEN * k].reshape(HIDDEN, k)
+    la, lv = int(c.adv2_ld), int(c.val2_ld)  # padded leading dimensions
+    v['adv2/mu/w'] = flat[c.adv2_mu_w:c.adv2_mu_w + HIDDEN * la].reshape(HIDDEN, la)[:, :na]
+    v['adv2/sigma/w'] = flat[c.adv2_sig_w:c.adv2_sig_w + HIDDEN * la].reshape(HIDDEN, la)[:, :na]
+    v['val2/mu/w'] = flat[c.val2_mu_w:c.val2_mu_w + HIDDEN * lv].reshape(HIDDEN, lv)[:, :k]
+    v['val2/sigma/w'] = flat[c.val2_sig_w:c.val2_sig_w + HIDDEN * lv].reshape(HIDDEN, lv)[:, :k]
     v['adv2/sigma/b'] = flat[c.fc2_sig_b:c.fc2_sig_b + na]
-    v['val2/sigma/b'] = flat[c.fc2_sig_b + na:c.fc2_sig_b + na + k]
+    v['val2/sigma/b'] = flat[c.fc2_sig_b + la:c.fc2_sig_b + la + k]
     return v
 
   def pack(self, params: dict) -> np.ndarray:
@@ -148,7 +152,8 @@ class RainbowParamLayout:
     out[c.n_adv2_in:c.n_adv2_in + HIDDEN] = noise['adv2/in']
     out[c.n_val2_in:c.n_val2_in + HIDDEN] = noise['val2/in']
     out[c.n_fc2_out:c.n_fc2_out + self.na] = noise['adv2/out']
-    out[c.n_fc2_out + self.na:c.n_fc2_out + self.nak] = noise['val2/out']
+    vo = c.n_fc2_out + self.val_off
+    out[vo:vo + self.num_atoms] = noise['val2/out']
     return out
 
   def unpack_noise(self, block: np.ndarray) -> dict:
@@ -161,5 +166,6 @@ class RainbowParamLayout:
         'adv2/in': block[c.n_adv2_in:c.n_adv2_in + HIDDEN].copy(),
         'val2/in': block[c.n_val2_in:c.n_val2_in + HIDDEN].copy(),
         'adv2/out': block[c.n_fc2_out:c.n_fc2_out + self.na].copy(),
-        'val2/out': block[c.n_fc2_out + self.na:c.n_fc2_out + self.nak].copy(),
+        'val2/out': block[c.n_fc2_out + self.val_off:
+                          c.n_fc2_out + self.val_off + self.num_atoms].copy(),
     }

@@ -193,14 +193,16 @@ int dz_prioritized_add(double* node, int64_t cap_pow2, int64_t capacity,
  * reference's own layout, networks_test.py:44,53).                         */
 typedef struct {
   int32_t num_actions, num_atoms, batch, groups;
+  int32_t adv2_ld, val2_ld; /* leading dimensions (floats) of the fc2 matrices */
+  int32_t fc1_ld, pad0_;    /* leading dimension of the fused fc1 matrices     */
   int64_t param_count;      /* floats in a parameter buffer (16-byte padded)  */
   int64_t param_count_ref;  /* the reference's count (6 868 485 for A=6)      */
   /* parameters */
   int64_t conv_w[3], conv_b[3];         /* [kh*kw*cin][cout], [cout]          */
-  int64_t fc1_mu_w, fc1_mu_b;           /* [3136][1024] = [adv1 | val1], [1024] */
+  int64_t fc1_mu_w, fc1_mu_b;           /* [3136][fc1_ld], cols [adv1 512 | val1 512]; [1024] */
   int64_t fc1_sig_w, fc1_sig_b;
-  int64_t adv2_mu_w, adv2_sig_w;        /* [512][A*K]                         */
-  int64_t val2_mu_w, val2_sig_w;        /* [512][K]                           */
+  int64_t adv2_mu_w, adv2_sig_w;        /* [512][adv2_ld], first A*K columns  */
+  int64_t val2_mu_w, val2_sig_w;        /* [512][val2_ld], first K columns    */
   int64_t fc2_sig_b;                    /* [A*K + K] = [adv2 | val2]          */
   /* one apply's noise block */
   int64_t noise_stride;
@@ -210,6 +212,7 @@ typedef struct {
   int64_t ws_act1, ws_act2, ws_feat, ws_fc1_part, ws_h1, ws_fc2_part, ws_fc2_out;
   int64_t ws_dout2, ws_dh1, ws_dfeat_part, ws_dfeat, ws_dact2, ws_dact1;
   int64_t ws_wgrad_part, ws_norm_part, ws_scalars, ws_q_sel, ws_target_probs;
+  int64_t ws_colsum_part;
 } dz_rainbow_layout_t;
 
 int dz_rainbow_layout(int num_actions, int num_atoms, int batch,
@@ -271,6 +274,10 @@ int dz_noise_fill(float* noise, int64_t count, uint64_t seed, uint64_t counter,
  * (names_out: max_marks * 32 bytes).  Used by bench.py for `roofline`.       */
 int dz_prof_enable(int on);
 int dz_prof_read(int max_marks, float* ms_out, char* names_out);
+
+/* Tuning knobs for tools/tune.py (kernel variant / split-K sweeps in one GPU
+ * session): key 0 = fc1 forward variant, 1 = fc1 forward split-K factor.     */
+int dz_set_tuning(int key, int value);
 
 /* dst = src for a parameter buffer (target network sync,
  * ref: rainbow/agent.py:157-158).                                           */

@@ -92,5 +92,5 @@ class RainbowTorchCpu:
         upd = (self.m[k] / bc1) / (torch.sqrt(self.v[k] / bc2) + self.eps)
         prm.add_(upd, alpha=-self.lr)
     ld = losses.detach()
-    return dict(loss=float(loss), losses=ld.numpy(), gnorm=float(gnorm),
+    return dict(loss=float(loss.detach()), losses=ld.numpy(), gnorm=float(gnorm),
                 priorities=torch.clamp(ld.abs(), 0, 100).numpy())

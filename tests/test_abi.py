@@ -72,6 +72,8 @@ def test_rainbow_layout_matches_reference_counts(lib):
   assert L.param_count_ref == 6868485
   assert L.param_count >= L.param_count_ref and L.param_count % 4 == 0
   assert L.noise_stride >= 2 * 3136 + 1024 + 1024 + 6 * 51 + 51
+  assert L.adv2_ld % 4 == 0 and L.val2_ld % 4 == 0 and L.fc1_ld % 4 == 0
+  assert L.conv_b[0] == L.conv_w[0] + 256 * 32   # bias follows weights (wgrad reduce)
   assert lib.dz_rainbow_layout(6, 65, 32, ctypes.byref(L)) == _lib.DZ_ERR_INVALID_ARG
 
 

@@ -84,7 +84,7 @@ def test_forward_loss_backward_vs_oracle(A, B, seed):
     assert _rel(h1[g][:, :512], cache['ha']) < 1e-5
     assert _rel(h1[g][:, 512:], cache['hv']) < 1e-5
     adv = out2[g][:, :A * K].reshape(B, A, K)
-    val = out2[g][:, A * K:A * K + K].reshape(B, 1, K)
+    val = out2[g][:, L.val_off:L.val_off + K].reshape(B, 1, K)
     glogits = val + adv - adv.mean(axis=1, keepdims=True)
     assert _rel(glogits, logits) < 2e-5
     if g == 1:
@@ -104,7 +104,7 @@ def test_forward_loss_backward_vs_oracle(A, B, seed):
                              np.clip(np.abs(losses), 0, 100), rtol=1e-5)
   dout2 = ln.ws_view('dout2', B * L.ld2).cpu().numpy().reshape(B, L.ld2)
   dl = aux['dlogits']
-  assert _rel(dout2[:, A * K:A * K + K], dl.sum(axis=1)) < 2e-5
+  assert _rel(dout2[:, L.val_off:L.val_off + K], dl.sum(axis=1)) < 2e-5
   g_dev = L.unpack(ln.grad.cpu().numpy())
   assert set(g_dev) == set(grads)
   # float64 evaluation of the same step = ground truth for the gradients.  A
