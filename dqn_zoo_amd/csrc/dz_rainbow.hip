@@ -9,7 +9,7 @@
 //             wgrad/dgrad, conv1 wgrad, bias column sums
 //   update  : sum of squares -> global norm/clip scale -> Adam
 // Roofline notes per kernel are in DESIGN.md.
-#include "dz_qnet_ops.h"
+#include "dz_fc_stream.h"
 
 namespace {
 
@@ -27,9 +27,11 @@ inline int64_t align4(int64_t v) { return (v + 3) & ~(int64_t)3; }
 
 // Run-time tuning knobs (dz_set_tuning): kernel variant and split factors, used
 // by tools/tune.py to sweep configurations in ONE GPU session.
-constexpr int kMaxSplitFc1 = 16;
-int g_fc1_variant = 0;
-int g_fc1_splits = 7;
+constexpr int kMaxSplitFc1 = 32;
+int g_fc1_variant = 9;   // 8/9 = weight-streaming kernels (dz_fc_stream.h)
+int g_fc1_splits = 32;
+int g_fc1_dgrad_stream = 0;  // measured: tile-GEMM 26 us vs streaming 35 us
+int g_fc1_blocked_experiment = 0;
 
 // conv geometries (networks.py:194-198)
 //                      U8  H   W   C  KS S  OH  OW  CO
@@ -49,20 +51,26 @@ using FcWg = FcWgradOp<2, 2, 1, 2>;
 // ---- small kernels ----------------------------------------------------------
 
 // out[r][c] = act( sum_s part[s][r][c] + b_mu[c] + b_sig[c]*eps_out[g][c] )
-__global__ void fc_epilogue_kernel(const float* __restrict__ part, int S, int rows,
-                                   int cols, int ld, int rows_per_group,
-                                   const float* p0, const float* p1, const float* p2,
-                                   long b_mu, long b_sig, const float* n0,
-                                   const float* n1, const float* n2, int eps_out,
-                                   int relu, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// block = 64 columns x 4 waves striding over the split slabs (LDS combine).
+__global__ __launch_bounds__(256) void fc_epilogue_kernel(
+    const float* __restrict__ part, int S, int rows, int cols, int ld,
+    int rows_per_group, const float* p0, const float* p1, const float* p2, long b_mu,
+    long b_sig, const float* n0, const float* n1, const float* n2, int eps_out, int relu,
+    float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l;
   const int r = blockIdx.y;
-  if (c >= cols) return;
+  float v = 0.f;
+  if (c < cols)
+    for (int s = w; s < S; s += 4) v += part[((long)s * rows + r) * ld + c];
+  red[w][l] = v;
+  __syncthreads();
+  if (w != 0 || c >= cols) return;
+  v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
   const int g = r / rows_per_group;
   const float* prm = g == 0 ? p0 : (g == 1 ? p1 : p2);
   const float* nz = g == 0 ? n0 : (g == 1 ? n1 : n2);
-  float v = 0.f;
-  for (int s = 0; s < S; ++s) v += part[((long)s * rows + r) * ld + c];
   if (b_mu >= 0) v += prm[b_mu + c];
   if (b_sig >= 0) v += prm[b_sig + c] * nz[eps_out + c];
   if (relu) v = v > 0.f ? v : 0.f;
@@ -470,10 +478,42 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         case 5: rc = dz_launch_gemm<FcFwdOp<1, 1, 4, 2>>(p, dim3(16, gz.y, gz.z), s); break;
         case 6: rc = dz_launch_gemm<FcFwdOp<1, 1, 4, 1>>(p, dim3(16, gz.y, gz.z), s); break;
         case 7: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 1>>(p, dim3(4, gz.y, gz.z), s); break;
+        case 8: {
+          DZ_REQUIRE(B <= 32);
+          FcStreamFwdParams q;
+          q.x = p.x; q.ldx = p.ldx; q.M = B; q.G = kG; q.NH = 2; q.S = g_fc1_splits;
+          q.noisy = 1;
+          for (int g = 0; g < kG; ++g) { q.params[g] = prm[g]; q.noise[g] = nz[g]; }
+          q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
+          q.part = p.part; q.ldo = p.ldo;
+          hipLaunchKernelGGL(dz_fc_stream_fwd, dim3(8, kG * g_fc1_splits), dim3(256), 0,
+                             s, q);
+          DZ_LAUNCH_CHECK();
+          rc = DZ_OK;
+          break;
+        }
+        case 9: {
+          DZ_REQUIRE(B <= 32);
+          FcStreamFwd2Params q;
+          q.x = p.x; q.ldx = p.ldx; q.M = B; q.G = kG; q.NH = 2; q.S = g_fc1_splits;
+          q.noisy = 1;
+          for (int g = 0; g < kG; ++g) { q.params[g] = prm[g]; q.noise[g] = nz[g]; }
+          q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
+          q.part = p.part; q.ldo = p.ldo;
+          const int rtotal = 2 * kFlat;
+          q.rows_per_split = ((rtotal + g_fc1_splits - 1) / g_fc1_splits + 3) & ~3;
+          DZ_REQUIRE(q.rows_per_split <= DZ_FC2_MAX_ROWS);
+          q.blocked = g_fc1_blocked_experiment;
+          hipLaunchKernelGGL(dz_fc_stream_fwd2, dim3(8, kG * g_fc1_splits), dim3(256),
+                             (size_t)q.rows_per_split * 32 * sizeof(float), s, q);
+          DZ_LAUNCH_CHECK();
+          rc = DZ_OK;
+          break;
+        }
       }
       if (rc) return rc;
       DZ_PROF(s, "fc1_fwd");
-      hipLaunchKernelGGL(fc_epilogue_kernel, dim3(4, kG * B), dim3(256), 0, s,
+      hipLaunchKernelGGL(fc_epilogue_kernel, dim3(16, kG * B), dim3(256), 0, s,
                          ws + L.ws_fc1_part, g_fc1_splits, kG * B, 1024, 1024, B,
                          prm[0], prm[1], prm[2], (long)L.fc1_mu_b, (long)L.fc1_sig_b,
                          nz[0], nz[1], nz[2], (int)L.n_fc1_out, 1, ws + L.ws_h1);
@@ -491,7 +531,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
                                         kG * 2 * kS_fc2), s);
       if (rc) return rc;
       DZ_PROF(s, "fc2_fwd");
-      hipLaunchKernelGGL(fc_epilogue_kernel, dim3((ld2 + 255) / 256, kG * B), dim3(256),
+      hipLaunchKernelGGL(fc_epilogue_kernel, dim3((ld2 + 63) / 64, kG * B), dim3(256),
                          0, s, ws + L.ws_fc2_part, kS_fc2, kG * B, ld2, ld2, B,
                          prm[0], prm[1], prm[2], (long)-1, (long)L.fc2_sig_b, nz[0],
                          nz[1], nz[2], (int)L.n_fc2_out, 0, ws + L.ws_fc2_out);
@@ -542,7 +582,17 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       if (rc) return rc;
       DZ_PROF(s, "fc1_wgrad");
     }
-    {  // fc1 input gradient (adv1 + val1 paths) -> dfeat, masked by relu(conv3)
+    if (g_fc1_dgrad_stream && B <= 32) {
+      // fc1 input gradient, weight-streaming form: writes dfeat directly
+      FcStreamDgradParams q;
+      q.dy = ws + L.ws_dh1; q.ldy = 1024; q.M = B; q.NH = 2; q.noisy = 1;
+      q.params = a->online; q.noise = nz[0]; q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
+      q.act = ws + L.ws_feat; q.dx = ws + L.ws_dfeat; q.ldo = kFlat; q.K = kFlat;
+      hipLaunchKernelGGL(dz_fc_stream_dgrad, dim3(kFlat / 32), dim3(256), 0, s, q);
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "fc1_dgrad");
+    } else {
+      // fc1 input gradient (adv1 + val1 paths) -> dfeat, masked by relu(conv3)
       FcDgradParams p;
       p.dy = ws + L.ws_dh1; p.ldy = 1024; p.M = B; p.NH = 2; p.S = kS_dfeat; p.noisy = 1;
       p.params = a->online; p.noise = nz[0]; p.head[0] = fc1h[0]; p.head[1] = fc1h[1];
@@ -645,6 +695,8 @@ extern "C" int dz_set_tuning(int key, int value) {
   switch (key) {
     case 0: g_fc1_variant = value; return DZ_OK;
     case 1: DZ_REQUIRE(value >= 1 && value <= kMaxSplitFc1); g_fc1_splits = value; return DZ_OK;
+    case 2: g_fc1_dgrad_stream = value; return DZ_OK;
+    case 3: g_fc1_blocked_experiment = value; return DZ_OK;
     default: return DZ_ERR_INVALID_ARG;
   }
 }

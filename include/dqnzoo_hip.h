@@ -276,7 +276,8 @@ int dz_prof_enable(int on);
 int dz_prof_read(int max_marks, float* ms_out, char* names_out);
 
 /* Tuning knobs for tools/tune.py (kernel variant / split-K sweeps in one GPU
- * session): key 0 = fc1 forward variant, 1 = fc1 forward split-K factor.     */
+ * session): key 0 = fc1 forward variant (8 = weight-streaming kernel),
+ * 1 = fc1 forward split-K factor, 2 = fc1 dgrad streaming kernel on/off.     */
 int dz_set_tuning(int key, int value);
 
 /* dst = src for a parameter buffer (target network sync,

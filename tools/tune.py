@@ -44,8 +44,19 @@ def main():
   lib = _lib.load()
   names = {0: '<1,2,2,KT4>', 1: '<1,2,2,KT2>', 2: '<1,2,2,KT1>', 3: '<1,4,1,KT4>',
            4: '<1,4,1,KT2>', 5: '<1,1,4,KT2>', 6: '<1,1,4,KT1>', 7: '<1,4,1,KT1>'}
-  for var in range(8):
-    for splits in (2, 4, 7, 14):
+  names[8] = 'stream'; names[9] = 'stream2'
+  for dg in (0, 1):
+    lib.dz_set_tuning(2, dg)
+    lib.dz_set_tuning(0, 8); lib.dz_set_tuning(1, 8)
+    t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
+    print('fc1_dgrad stream=%d: %.2f us (+reduce %.2f)  fc1_wgrad %.2f adam %.2f' % (
+        dg, t['fc1_dgrad'], t.get('fc1_dgrad_reduce', 0.0), t['fc1_wgrad'], t['adam']))
+  lib.dz_set_tuning(3, 1); lib.dz_set_tuning(0, 9); lib.dz_set_tuning(1, 32)
+  t = timings(ln, dev, steps=20, phases=_lib.PHASE_FORWARD)
+  print('fc1 stream2 BLOCKED-ADDRESS experiment S=32: fc1_fwd %.2f us' % t['fc1_fwd'])
+  lib.dz_set_tuning(3, 0)
+  for var in (9, 8):
+    for splits in ((32,) if var == 9 else (8,)):
       lib.dz_set_tuning(0, var)
       lib.dz_set_tuning(1, splits)
       t = timings(ln, dev, steps=20, phases=_lib.PHASE_FORWARD)
