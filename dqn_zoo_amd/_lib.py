@@ -93,6 +93,8 @@ SIGNATURES = {
     'dz_rainbow_layout': (c_int, [c_int, c_int, c_int,
                                   ctypes.POINTER(RainbowLayout)]),
     'dz_rainbow_learn': (c_int, [ctypes.POINTER(RainbowArgs), c_int, c_vp]),
+    'dz_rainbow_apply': (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
+                                 c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dz_noise_fill': (c_int, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64,
                               c_vp]),
     'dz_param_copy': (c_int, [c_vp, c_vp, c_i64, c_vp]),

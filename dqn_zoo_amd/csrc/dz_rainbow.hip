@@ -325,7 +325,187 @@ __global__ void noise_fill_kernel(float* __restrict__ out, long n, uint64_t seed
   out[i] = x < 0.f ? -s : (x > 0.f ? s : 0.f);  // sign(x) * sqrt|x| (networks.py:144)
 }
 
+// q_values[b][a] = sum_k softmax(v + adv_a - mean_a adv)[k] * support[k]
+// (ref: networks.py:254-258); also the greedy action and its value
+// (ref: rainbow/agent.py:125-131, first maximum).
+__global__ __launch_bounds__(64) void rainbow_q_values_kernel(
+    const float* __restrict__ fc2_out, int ld, int val_off, int A, int K,
+    const float* __restrict__ support, float* __restrict__ q_out,
+    int32_t* __restrict__ greedy_out, float* __restrict__ vmax_out) {
+  const int b = blockIdx.x, k = threadIdx.x;
+  const bool on = k < K;
+  const float z = on ? support[k] : 0.f;
+  const float* o = fc2_out + (long)b * ld;
+  float mean_adv = 0.f;
+  for (int a = 0; a < A; ++a) mean_adv += on ? o[a * K + k] : 0.f;
+  mean_adv /= (float)A;
+  const float v = on ? o[val_off + k] : 0.f;
+  float best = -__builtin_inff();
+  int arg = 0;
+  for (int a = 0; a < A; ++a) {
+    const float lg = on ? (v + o[a * K + k] - mean_adv) : -__builtin_inff();
+    const float mx = wave_max(lg);
+    const float e = on ? expf(lg - mx) : 0.f;
+    const float sm = wave_sum(e);
+    const float q = wave_sum((e / sm) * z);
+    if (k == 0) q_out[b * A + a] = q;
+    if (q > best) { best = q; arg = a; }
+  }
+  if (k == 0) {
+    if (greedy_out) greedy_out[b] = arg;
+    if (vmax_out) vmax_out[b] = best;
+  }
+}
+
 }  // namespace
+
+
+// The network apply for G groups (ref: networks.py:224-253): conv torso, fused
+// noisy fc1 (adv1|val1), noisy fc2 (adv2, val2) into ws_fc2_out rows [G*B].
+struct FwdHeads { FcHead fc1h[2]; FcHead fc2h[2]; };
+static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int G, int B,
+                           const float* const* prm, const float* const* nz,
+                           const uint8_t* const* in, float* ws, hipStream_t s) {
+  int rc = DZ_OK;
+  const int NA = L.num_actions * L.num_atoms;
+  const int ld2 = L.adv2_ld + L.val2_ld;
+  const FcHead* fc1h = H.fc1h;
+  const FcHead* fc2h = H.fc2h;
+  (void)NA;
+    {  // conv1: uint8 states -> act1, u8->f32 /255 fused into the A-tile load
+    ConvFwdParams p;
+    for (int g = 0; g < G; ++g) p.in[g] = in[g];
+    for (int g = 0; g < G; ++g) {
+      p.in_img_base[g] = 0; p.w[g] = prm[g] + L.conv_w[0]; p.bias[g] = prm[g] + L.conv_b[0];
+    }
+    p.out = ws + L.ws_act1; p.B = B; p.G = G;
+    rc = dz_launch_gemm<Conv1Fwd>(p, dim3(1, G * Conv1Fwd::tiles_per_group(B)), s);
+    if (rc) return rc;
+    DZ_PROF(s, "conv1_fwd");
+  }
+  {  // conv2
+    ConvFwdParams p;
+    for (int g = 0; g < G; ++g) {
+      p.in[g] = ws + L.ws_act1; p.in_img_base[g] = g * B; p.w[g] = prm[g] + L.conv_w[1]; p.bias[g] = prm[g] + L.conv_b[1];
+    }
+    p.out = ws + L.ws_act2; p.B = B; p.G = G;
+    rc = dz_launch_gemm<Conv2Fwd>(p, dim3(1, G * Conv2Fwd::tiles_per_group(B)), s);
+    if (rc) return rc;
+    DZ_PROF(s, "conv2_fwd");
+  }
+  {  // conv3 (+ flatten: NHWC rows are already (h,w,c) order)
+    ConvFwdParams p;
+    for (int g = 0; g < G; ++g) {
+      p.in[g] = ws + L.ws_act2; p.in_img_base[g] = g * B; p.w[g] = prm[g] + L.conv_w[2]; p.bias[g] = prm[g] + L.conv_b[2];
+    }
+    p.out = ws + L.ws_feat; p.B = B; p.G = G;
+    rc = dz_launch_gemm<Conv3Fwd>(p, dim3(1, G * Conv3Fwd::tiles_per_group(B)), s);
+    if (rc) return rc;
+    DZ_PROF(s, "conv3_fwd");
+  }
+  {  // fc1: noisy adv1 | val1, split-K partials
+    FcFwdParams p;
+    p.x = ws + L.ws_feat; p.ldx = kFlat; p.M = B; p.G = G; p.NH = 2; p.S = kS_fc1;
+    p.noisy = 1;
+    for (int g = 0; g < G; ++g) { p.params[g] = prm[g]; p.noise[g] = nz[g]; }
+    p.head[0] = fc1h[0]; p.head[1] = fc1h[1];
+    p.part = ws + L.ws_fc1_part; p.ldo = 1024;
+    p.S = g_fc1_splits;
+    const dim3 gz(1, (B + 31) / 32, G * 2 * g_fc1_splits);
+    switch (g_fc1_variant) {
+      default:
+      case 0: rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4>>(p, dim3(8, gz.y, gz.z), s); break;
+      case 1: rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 2>>(p, dim3(8, gz.y, gz.z), s); break;
+      case 2: rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 1>>(p, dim3(8, gz.y, gz.z), s); break;
+      case 3: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 4>>(p, dim3(4, gz.y, gz.z), s); break;
+      case 4: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 2>>(p, dim3(4, gz.y, gz.z), s); break;
+      case 5: rc = dz_launch_gemm<FcFwdOp<1, 1, 4, 2>>(p, dim3(16, gz.y, gz.z), s); break;
+      case 6: rc = dz_launch_gemm<FcFwdOp<1, 1, 4, 1>>(p, dim3(16, gz.y, gz.z), s); break;
+      case 7: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 1>>(p, dim3(4, gz.y, gz.z), s); break;
+      case 8: {
+        DZ_REQUIRE(B <= 32);
+        FcStreamFwdParams q;
+        q.x = p.x; q.ldx = p.ldx; q.M = B; q.G = G; q.NH = 2; q.S = g_fc1_splits;
+        q.noisy = 1;
+        for (int g = 0; g < G; ++g) { q.params[g] = prm[g]; q.noise[g] = nz[g]; }
+        q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
+        q.part = p.part; q.ldo = p.ldo;
+        hipLaunchKernelGGL(dz_fc_stream_fwd, dim3(8, G * g_fc1_splits), dim3(256), 0,
+                           s, q);
+        DZ_LAUNCH_CHECK();
+        rc = DZ_OK;
+        break;
+      }
+      case 9: {
+        DZ_REQUIRE(B <= 32);
+        FcStreamFwd2Params q;
+        q.x = p.x; q.ldx = p.ldx; q.M = B; q.G = G; q.NH = 2; q.S = g_fc1_splits;
+        q.noisy = 1;
+        for (int g = 0; g < G; ++g) { q.params[g] = prm[g]; q.noise[g] = nz[g]; }
+        q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
+        q.part = p.part; q.ldo = p.ldo;
+        const int rtotal = 2 * kFlat;
+        q.rows_per_split = ((rtotal + g_fc1_splits - 1) / g_fc1_splits + 3) & ~3;
+        DZ_REQUIRE(q.rows_per_split <= DZ_FC2_MAX_ROWS);
+        q.blocked = g_fc1_blocked_experiment;
+        hipLaunchKernelGGL(dz_fc_stream_fwd2, dim3(8, G * g_fc1_splits), dim3(256),
+                           (size_t)q.rows_per_split * 32 * sizeof(float), s, q);
+        DZ_LAUNCH_CHECK();
+        rc = DZ_OK;
+        break;
+      }
+    }
+    if (rc) return rc;
+    DZ_PROF(s, "fc1_fwd");
+    hipLaunchKernelGGL(fc_epilogue_kernel, dim3(16, G * B), dim3(256), 0, s,
+                       ws + L.ws_fc1_part, g_fc1_splits, G * B, 1024, 1024, B,
+                       prm[0], prm[1], prm[2], (long)L.fc1_mu_b, (long)L.fc1_sig_b,
+                       nz[0], nz[1], nz[2], (int)L.n_fc1_out, 1, ws + L.ws_h1);
+    DZ_LAUNCH_CHECK();
+    DZ_PROF(s, "fc1_epilogue");
+  }
+  {  // fc2: noisy adv2 (no mu bias) and val2 (no mu bias)
+    FcFwdParams p;
+    p.x = ws + L.ws_h1; p.ldx = 1024; p.M = B; p.G = G; p.NH = 2; p.S = kS_fc2;
+    p.noisy = 1;
+    for (int g = 0; g < G; ++g) { p.params[g] = prm[g]; p.noise[g] = nz[g]; }
+    p.head[0] = fc2h[0]; p.head[1] = fc2h[1];
+    p.part = ws + L.ws_fc2_part; p.ldo = ld2;
+    rc = dz_launch_gemm<FcFwd>(p, dim3((NA + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32,
+                                      G * 2 * kS_fc2), s);
+    if (rc) return rc;
+    DZ_PROF(s, "fc2_fwd");
+    hipLaunchKernelGGL(fc_epilogue_kernel, dim3((ld2 + 63) / 64, G * B), dim3(256),
+                       0, s, ws + L.ws_fc2_part, kS_fc2, G * B, ld2, ld2, B,
+                       prm[0], prm[1], prm[2], (long)-1, (long)L.fc2_sig_b, nz[0],
+                       nz[1], nz[2], (int)L.n_fc2_out, 0, ws + L.ws_fc2_out);
+    DZ_LAUNCH_CHECK();
+    DZ_PROF(s, "fc2_epilogue");
+  }
+  return rc;
+}
+
+static void make_heads(const dz_rainbow_layout_t& L, FwdHeads& H) {
+  const int A = L.num_actions, K = L.num_atoms;
+  const int NA = A * K, NAp = L.adv2_ld;
+  FcHead* fc1h = H.fc1h;
+  FcHead* fc2h = H.fc2h;
+  for (int h = 0; h < 2; ++h) {
+    fc1h[h].w_mu = L.fc1_mu_w + 512 * h; fc1h[h].w_sig = L.fc1_sig_w + 512 * h;
+    fc1h[h].ldw = L.fc1_ld; fc1h[h].N = 512; fc1h[h].K = kFlat; fc1h[h].x_off = 0;
+    fc1h[h].eps_in = (int)(h == 0 ? L.n_adv1_in : L.n_val1_in);
+    fc1h[h].eps_out = (int)L.n_fc1_out + 512 * h; fc1h[h].out_off = 512 * h;
+  }
+  fc2h[0].w_mu = L.adv2_mu_w; fc2h[0].w_sig = L.adv2_sig_w; fc2h[0].ldw = L.adv2_ld;
+  fc2h[0].N = NA; fc2h[0].K = kHid; fc2h[0].x_off = 0;
+  fc2h[0].eps_in = (int)L.n_adv2_in; fc2h[0].eps_out = (int)L.n_fc2_out;
+  fc2h[0].out_off = 0;
+  fc2h[1].w_mu = L.val2_mu_w; fc2h[1].w_sig = L.val2_sig_w; fc2h[1].ldw = L.val2_ld;
+  fc2h[1].N = K; fc2h[1].K = kHid; fc2h[1].x_off = 512;
+  fc2h[1].eps_in = (int)L.n_val2_in; fc2h[1].eps_out = (int)L.n_fc2_out + NAp;
+  fc2h[1].out_off = NAp;
+
+}
 
 // ---- layout -----------------------------------------------------------------
 extern "C" int dz_rainbow_layout(int A, int K, int B, dz_rainbow_layout_t* L) {
@@ -410,133 +590,17 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   const float* nz[kG] = {a->noise, a->noise + L.noise_stride,
                          a->noise + 2 * L.noise_stride};
 
-  FcHead fc1h[2], fc2h[2];
-  for (int h = 0; h < 2; ++h) {
-    fc1h[h].w_mu = L.fc1_mu_w + 512 * h; fc1h[h].w_sig = L.fc1_sig_w + 512 * h;
-    fc1h[h].ldw = L.fc1_ld; fc1h[h].N = 512; fc1h[h].K = kFlat; fc1h[h].x_off = 0;
-    fc1h[h].eps_in = (int)(h == 0 ? L.n_adv1_in : L.n_val1_in);
-    fc1h[h].eps_out = (int)L.n_fc1_out + 512 * h; fc1h[h].out_off = 512 * h;
-  }
-  fc2h[0].w_mu = L.adv2_mu_w; fc2h[0].w_sig = L.adv2_sig_w; fc2h[0].ldw = L.adv2_ld;
-  fc2h[0].N = NA; fc2h[0].K = kHid; fc2h[0].x_off = 0;
-  fc2h[0].eps_in = (int)L.n_adv2_in; fc2h[0].eps_out = (int)L.n_fc2_out;
-  fc2h[0].out_off = 0;
-  fc2h[1].w_mu = L.val2_mu_w; fc2h[1].w_sig = L.val2_sig_w; fc2h[1].ldw = L.val2_ld;
-  fc2h[1].N = K; fc2h[1].K = kHid; fc2h[1].x_off = 512;
-  fc2h[1].eps_in = (int)L.n_val2_in; fc2h[1].eps_out = (int)L.n_fc2_out + NAp;
-  fc2h[1].out_off = NAp;
+  FwdHeads H;
+  make_heads(L, H);
+  const FcHead* fc1h = H.fc1h;
+  const FcHead* fc2h = H.fc2h;
 
   if (g_dz_prof_on) dz_prof_begin(s);
   if (phases & DZ_PHASE_FORWARD) {
-    {  // conv1: uint8 states -> act1, u8->f32 /255 fused into the A-tile load
-      ConvFwdParams p;
-      p.in[0] = a->s_tm1; p.in[1] = a->s_t; p.in[2] = a->s_t;
-      for (int g = 0; g < kG; ++g) {
-        p.in_img_base[g] = 0; p.w[g] = prm[g] + L.conv_w[0]; p.bias[g] = prm[g] + L.conv_b[0];
-      }
-      p.out = ws + L.ws_act1; p.B = B; p.G = kG;
-      rc = dz_launch_gemm<Conv1Fwd>(p, dim3(1, kG * Conv1Fwd::tiles_per_group(B)), s);
+    {
+      const uint8_t* in[kG] = {a->s_tm1, a->s_t, a->s_t};
+      rc = rainbow_forward(L, H, kG, B, prm, nz, in, ws, s);
       if (rc) return rc;
-      DZ_PROF(s, "conv1_fwd");
-    }
-    {  // conv2
-      ConvFwdParams p;
-      for (int g = 0; g < kG; ++g) {
-        p.in[g] = ws + L.ws_act1; p.in_img_base[g] = g * B; p.w[g] = prm[g] + L.conv_w[1]; p.bias[g] = prm[g] + L.conv_b[1];
-      }
-      p.out = ws + L.ws_act2; p.B = B; p.G = kG;
-      rc = dz_launch_gemm<Conv2Fwd>(p, dim3(1, kG * Conv2Fwd::tiles_per_group(B)), s);
-      if (rc) return rc;
-      DZ_PROF(s, "conv2_fwd");
-    }
-    {  // conv3 (+ flatten: NHWC rows are already (h,w,c) order)
-      ConvFwdParams p;
-      for (int g = 0; g < kG; ++g) {
-        p.in[g] = ws + L.ws_act2; p.in_img_base[g] = g * B; p.w[g] = prm[g] + L.conv_w[2]; p.bias[g] = prm[g] + L.conv_b[2];
-      }
-      p.out = ws + L.ws_feat; p.B = B; p.G = kG;
-      rc = dz_launch_gemm<Conv3Fwd>(p, dim3(1, kG * Conv3Fwd::tiles_per_group(B)), s);
-      if (rc) return rc;
-      DZ_PROF(s, "conv3_fwd");
-    }
-    {  // fc1: noisy adv1 | val1, split-K partials
-      FcFwdParams p;
-      p.x = ws + L.ws_feat; p.ldx = kFlat; p.M = B; p.G = kG; p.NH = 2; p.S = kS_fc1;
-      p.noisy = 1;
-      for (int g = 0; g < kG; ++g) { p.params[g] = prm[g]; p.noise[g] = nz[g]; }
-      p.head[0] = fc1h[0]; p.head[1] = fc1h[1];
-      p.part = ws + L.ws_fc1_part; p.ldo = 1024;
-      p.S = g_fc1_splits;
-      const dim3 gz(1, (B + 31) / 32, kG * 2 * g_fc1_splits);
-      switch (g_fc1_variant) {
-        default:
-        case 0: rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4>>(p, dim3(8, gz.y, gz.z), s); break;
-        case 1: rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 2>>(p, dim3(8, gz.y, gz.z), s); break;
-        case 2: rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 1>>(p, dim3(8, gz.y, gz.z), s); break;
-        case 3: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 4>>(p, dim3(4, gz.y, gz.z), s); break;
-        case 4: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 2>>(p, dim3(4, gz.y, gz.z), s); break;
-        case 5: rc = dz_launch_gemm<FcFwdOp<1, 1, 4, 2>>(p, dim3(16, gz.y, gz.z), s); break;
-        case 6: rc = dz_launch_gemm<FcFwdOp<1, 1, 4, 1>>(p, dim3(16, gz.y, gz.z), s); break;
-        case 7: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 1>>(p, dim3(4, gz.y, gz.z), s); break;
-        case 8: {
-          DZ_REQUIRE(B <= 32);
-          FcStreamFwdParams q;
-          q.x = p.x; q.ldx = p.ldx; q.M = B; q.G = kG; q.NH = 2; q.S = g_fc1_splits;
-          q.noisy = 1;
-          for (int g = 0; g < kG; ++g) { q.params[g] = prm[g]; q.noise[g] = nz[g]; }
-          q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
-          q.part = p.part; q.ldo = p.ldo;
-          hipLaunchKernelGGL(dz_fc_stream_fwd, dim3(8, kG * g_fc1_splits), dim3(256), 0,
-                             s, q);
-          DZ_LAUNCH_CHECK();
-          rc = DZ_OK;
-          break;
-        }
-        case 9: {
-          DZ_REQUIRE(B <= 32);
-          FcStreamFwd2Params q;
-          q.x = p.x; q.ldx = p.ldx; q.M = B; q.G = kG; q.NH = 2; q.S = g_fc1_splits;
-          q.noisy = 1;
-          for (int g = 0; g < kG; ++g) { q.params[g] = prm[g]; q.noise[g] = nz[g]; }
-          q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
-          q.part = p.part; q.ldo = p.ldo;
-          const int rtotal = 2 * kFlat;
-          q.rows_per_split = ((rtotal + g_fc1_splits - 1) / g_fc1_splits + 3) & ~3;
-          DZ_REQUIRE(q.rows_per_split <= DZ_FC2_MAX_ROWS);
-          q.blocked = g_fc1_blocked_experiment;
-          hipLaunchKernelGGL(dz_fc_stream_fwd2, dim3(8, kG * g_fc1_splits), dim3(256),
-                             (size_t)q.rows_per_split * 32 * sizeof(float), s, q);
-          DZ_LAUNCH_CHECK();
-          rc = DZ_OK;
-          break;
-        }
-      }
-      if (rc) return rc;
-      DZ_PROF(s, "fc1_fwd");
-      hipLaunchKernelGGL(fc_epilogue_kernel, dim3(16, kG * B), dim3(256), 0, s,
-                         ws + L.ws_fc1_part, g_fc1_splits, kG * B, 1024, 1024, B,
-                         prm[0], prm[1], prm[2], (long)L.fc1_mu_b, (long)L.fc1_sig_b,
-                         nz[0], nz[1], nz[2], (int)L.n_fc1_out, 1, ws + L.ws_h1);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "fc1_epilogue");
-    }
-    {  // fc2: noisy adv2 (no mu bias) and val2 (no mu bias)
-      FcFwdParams p;
-      p.x = ws + L.ws_h1; p.ldx = 1024; p.M = B; p.G = kG; p.NH = 2; p.S = kS_fc2;
-      p.noisy = 1;
-      for (int g = 0; g < kG; ++g) { p.params[g] = prm[g]; p.noise[g] = nz[g]; }
-      p.head[0] = fc2h[0]; p.head[1] = fc2h[1];
-      p.part = ws + L.ws_fc2_part; p.ldo = ld2;
-      rc = dz_launch_gemm<FcFwd>(p, dim3((NA + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32,
-                                        kG * 2 * kS_fc2), s);
-      if (rc) return rc;
-      DZ_PROF(s, "fc2_fwd");
-      hipLaunchKernelGGL(fc_epilogue_kernel, dim3((ld2 + 63) / 64, kG * B), dim3(256),
-                         0, s, ws + L.ws_fc2_part, kS_fc2, kG * B, ld2, ld2, B,
-                         prm[0], prm[1], prm[2], (long)-1, (long)L.fc2_sig_b, nz[0],
-                         nz[1], nz[2], (int)L.n_fc2_out, 0, ws + L.ws_fc2_out);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "fc2_epilogue");
     }
     hipLaunchKernelGGL(rainbow_head_loss_kernel, dim3(B), dim3(64), 0, s,
                        ws + L.ws_fc2_out, ld2, NAp, B, A, K, a->a_tm1, a->r_t, a->discount_t,
@@ -688,6 +752,33 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     DZ_LAUNCH_CHECK();
       DZ_PROF(s, "adam");
   }
+  return DZ_OK;
+}
+
+extern "C" int dz_rainbow_apply(int num_actions, int num_atoms, int batch,
+                                const float* params, const uint8_t* states,
+                                const float* noise, const float* support, float* ws,
+                                float* q_values_out, int32_t* greedy_out,
+                                float* vmax_out, dz_stream_t stream) {
+  DZ_REQUIRE(params && states && noise && support && ws && q_values_out);
+  dz_rainbow_layout_t L;
+  int rc = dz_rainbow_layout(num_actions, num_atoms, batch, &L);
+  if (rc != DZ_OK) return rc;
+  hipStream_t s = dz_s(stream);
+  FwdHeads H;
+  make_heads(L, H);
+  const float* prm[kG] = {params, params, params};
+  const float* nz[kG] = {noise, noise, noise};
+  const uint8_t* in[kG] = {states, states, states};
+  const bool prof = g_dz_prof_on;
+  g_dz_prof_on = false;  // marks belong to dz_rainbow_learn
+  rc = rainbow_forward(L, H, 1, batch, prm, nz, in, ws, s);
+  g_dz_prof_on = prof;
+  if (rc) return rc;
+  hipLaunchKernelGGL(rainbow_q_values_kernel, dim3(batch), dim3(64), 0, s,
+                     ws + L.ws_fc2_out, L.adv2_ld + L.val2_ld, L.adv2_ld, num_actions,
+                     num_atoms, support, q_values_out, greedy_out, vmax_out);
+  DZ_LAUNCH_CHECK();
   return DZ_OK;
 }
 

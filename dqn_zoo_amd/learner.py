@@ -58,6 +58,11 @@ class RainbowLearner:
     self.support = torch.from_numpy(network.support).to(self.device)
     self._noise_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     self._noise_counter = 0
+    # inference (acting) side: own workspace + one noise block, so that an
+    # apply never aliases the buffers of an enqueued learner step.
+    self._act_batch = 0
+    self._act_ws = None
+    self._act_noise = torch.zeros(L.noise_stride, **f32)
 
   # -- state ------------------------------------------------------------------
   def get_params(self, which='online') -> dict:
@@ -86,6 +91,49 @@ class RainbowLearner:
         self.noise.data_ptr(), n, self._noise_seed, self._noise_counter,
         torch.cuda.current_stream(self.device).cuda_stream), 'dz_noise_fill')
     self._noise_counter += n
+
+  def apply(self, states: torch.Tensor, which: str = 'online', noise=None,
+            resample_noise: bool = True):
+    """One network apply on uint8 states [B,84,84,4] (device tensor).
+    Returns device tensors (q_values [B,A] f32, greedy action [B] i32,
+    max_a q [B] f32).  ref: rainbow/agent.py:125-131 (select_action)."""
+    assert states.dtype == torch.uint8 and states.is_contiguous()
+    b = int(states.shape[0])
+    assert tuple(states.shape[1:]) == (84, 84, 4)
+    if self._act_batch != b:
+      self._act_ws = torch.zeros(self.network.layout(b).ws_count,
+                                 dtype=torch.float32, device=self.device)
+      self._act_batch = b
+    stream = torch.cuda.current_stream(self.device).cuda_stream
+    if noise is not None:
+      self._act_noise.copy_(torch.from_numpy(self.layout.pack_noise(noise)))
+    elif resample_noise:
+      n = self._act_noise.numel()
+      _lib.check(self._lib.dz_noise_fill(
+          self._act_noise.data_ptr(), n, self._noise_seed ^ 0xA5A5A5A5,
+          self._noise_counter, stream), 'dz_noise_fill')
+      self._noise_counter += n
+    a = self.network.num_actions
+    q = torch.empty((b, a), dtype=torch.float32, device=self.device)
+    greedy = torch.empty(b, dtype=torch.int32, device=self.device)
+    vmax = torch.empty(b, dtype=torch.float32, device=self.device)
+    params = self.online if which == 'online' else self.target
+    _lib.check(self._lib.dz_rainbow_apply(
+        a, self.network.num_atoms, b, params.data_ptr(), states.data_ptr(),
+        self._act_noise.data_ptr(), self.support.data_ptr(),
+        self._act_ws.data_ptr(), q.data_ptr(), greedy.data_ptr(),
+        vmax.data_ptr(), stream), 'dz_rainbow_apply')
+    return q, greedy, vmax
+
+  def get_opt_state(self) -> dict:
+    return dict(count=int(self.adam_count.item()),
+                mu=self.layout.unpack(self.adam_m.cpu().numpy()),
+                nu=self.layout.unpack(self.adam_v.cpu().numpy()))
+
+  def set_opt_state(self, state: dict) -> None:
+    self.adam_count.fill_(int(state['count']))
+    self.adam_m.copy_(torch.from_numpy(self.layout.pack(state['mu'])))
+    self.adam_v.copy_(torch.from_numpy(self.layout.pack(state['nu'])))
 
   def scalars(self) -> dict:
     """Synchronises and returns the step's scalars (gnorm, loss, ...)."""

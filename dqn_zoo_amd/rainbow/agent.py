@@ -1,0 +1,170 @@
+"""Rainbow agent with the surface of `dqn_zoo/rainbow/agent.py`, learning on one
+MI355X: prioritized replay in HBM, the whole update enqueued as HIP kernels.
+
+Drop-in notes: the constructor keeps the reference's keyword
+names; `network` is a `networks.RainbowNetwork` descriptor instead of an
+`hk.Transformed`, `optimizer` a `learner.AdamConfig` instead of an
+`optax.GradientTransformation`, `rng_key` an integer seed, and `replay` a
+`dqn_zoo_amd.replay.PrioritizedTransitionReplay`.  Methods, properties,
+statistics keys, learning gates and error behaviour follow
+ref: rainbow/agent.py:41-245 line by line (cited below).
+
+Difference that matters for speed: `_learn()` never synchronises with the
+host -- sampled ids, importance weights, losses, priorities and the running
+max priority all stay on the device (the reference does two host<->device
+round trips per learner step, rainbow/agent.py:184-198).
+"""
+
+from typing import Any, Mapping
+
+import numpy as np
+import torch
+
+from dqn_zoo_amd import learner as learner_lib
+from dqn_zoo_amd import networks
+from dqn_zoo_amd import parts
+from dqn_zoo_amd import processors
+from dqn_zoo_amd import replay as replay_lib
+
+
+class Rainbow(parts.Agent):
+  """Rainbow agent (ref: rainbow/agent.py:41)."""
+
+  def __init__(
+      self,
+      preprocessor: processors.Processor,
+      sample_network_input: np.ndarray,
+      network: networks.RainbowNetwork,
+      support: np.ndarray,
+      optimizer: learner_lib.AdamConfig,
+      transition_accumulator: Any,
+      replay: replay_lib.PrioritizedTransitionReplay,
+      batch_size: int,
+      min_replay_capacity_fraction: float,
+      learn_period: int,
+      target_network_update_period: int,
+      rng_key: int,
+  ):
+    if tuple(np.shape(sample_network_input)) != (84, 84, 4):
+      raise ValueError('sample_network_input must have shape (84, 84, 4)')
+    if not np.array_equal(np.asarray(support, np.float32), network.support):
+      raise ValueError('support differs from the network descriptor\'s')
+    self._preprocessor = preprocessor
+    self._replay = replay
+    self._transition_accumulator = transition_accumulator
+    self._batch_size = batch_size
+    self._min_replay_capacity = min_replay_capacity_fraction * replay.capacity
+    self._learn_period = learn_period
+    self._target_network_update_period = target_network_update_period
+
+    # parameters, target copy and optimizer state live in the learner
+    # (ref: rainbow/agent.py:67-73).
+    self._learner = learner_lib.RainbowLearner(
+        network, optimizer, batch_size, seed=int(rng_key),
+        device=replay._device)  # pylint: disable=protected-access
+    self._device = self._learner.device
+
+    self._action = None
+    self._frame_t = -1
+    self._statistics = {'state_value': np.nan}
+    self._obs_device = torch.empty((1, 84, 84, 4), dtype=torch.uint8,
+                                   device=self._device)
+
+  # -- acting / stepping -------------------------------------------------------
+  def step(self, timestep) -> parts.Action:
+    """Selects action given timestep and potentially learns
+    (ref: rainbow/agent.py:135-160)."""
+    self._frame_t += 1
+    timestep = self._preprocessor(timestep)
+
+    if timestep is None:  # repeat action
+      if self._action is None:
+        raise RuntimeError('Cannot repeat if action has never been selected.')
+      action = self._action
+    else:
+      action = self._action = self._act(timestep)
+      for transition in self._transition_accumulator.step(timestep, action):
+        # priority = running max priority, kept on the device (agent.py:149)
+        self._replay.add_with_device_priority(transition)
+
+    if self._replay.size < self._min_replay_capacity:
+      return action
+
+    if self._frame_t % self._learn_period == 0:
+      self._learn()
+
+    if self._frame_t % self._target_network_update_period == 0:
+      self._learner.sync_target()
+
+    return action
+
+  def reset(self) -> None:
+    """Resets episodic state (ref: rainbow/agent.py:162-169)."""
+    self._transition_accumulator.reset()
+    processors.reset(self._preprocessor)
+    self._action = None
+
+  def _act(self, timestep) -> parts.Action:
+    """Greedy action w.r.t. a freshly-noised online network
+    (ref: rainbow/agent.py:171-179)."""
+    obs = np.ascontiguousarray(timestep.observation, dtype=np.uint8)
+    self._obs_device[0].copy_(torch.from_numpy(obs))
+    _, greedy, vmax = self._learner.apply(self._obs_device)
+    a_t = int(greedy.item())           # the one device->host sync per decision
+    self._statistics['state_value'] = float(vmax.item())
+    return parts.Action(a_t)
+
+  def _learn(self) -> None:
+    """Samples a batch and learns from it, entirely on the device
+    (ref: rainbow/agent.py:181-198)."""
+    s = self._replay.sample_device(self._batch_size)
+    t = s.transitions
+    self._learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32)
+    # priorities = clip(|losses|, 0, 100) were written by the loss kernel; the
+    # update kernel also folds their max into the running max priority.
+    self._replay.update_priorities(s.ids, self._learner.priorities)
+
+  # -- properties ----------------------------------------------------------------
+  @property
+  def online_params(self) -> Mapping[str, np.ndarray]:
+    """Current Q-network parameters as Haiku-shaped host arrays."""
+    return self._learner.get_params('online')
+
+  @property
+  def statistics(self) -> Mapping[str, float]:
+    return self._statistics
+
+  @property
+  def importance_sampling_exponent(self) -> float:
+    return self._replay.importance_sampling_exponent
+
+  @property
+  def max_seen_priority(self) -> float:
+    return float(self._replay.max_seen_priority_device.item())
+
+  @property
+  def learner(self) -> learner_lib.RainbowLearner:
+    return self._learner
+
+  # -- (de)serialisation (ref: rainbow/agent.py:224-245) ---------------------------
+  def get_state(self) -> Mapping[str, Any]:
+    ln = self._learner
+    return {
+        'rng_key': (ln._noise_seed, ln._noise_counter),  # pylint: disable=protected-access
+        'frame_t': self._frame_t,
+        'opt_state': ln.get_opt_state(),
+        'online_params': ln.get_params('online'),
+        'target_params': ln.get_params('target'),
+        'replay': self._replay.get_state(),
+        'max_seen_priority': self.max_seen_priority,
+    }
+
+  def set_state(self, state: Mapping[str, Any]) -> None:
+    ln = self._learner
+    ln._noise_seed, ln._noise_counter = state['rng_key']  # pylint: disable=protected-access
+    self._frame_t = state['frame_t']
+    ln.set_opt_state(state['opt_state'])
+    ln.set_params(state['online_params'], 'online')
+    ln.set_params(state['target_params'], 'target')
+    self._replay.set_state(state['replay'])
+    self._replay.max_seen_priority_device.fill_(state['max_seen_priority'])

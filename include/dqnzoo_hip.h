@@ -259,6 +259,17 @@ typedef struct {
 
 int dz_rainbow_learn(const dz_rainbow_args_t* args, int phases, dz_stream_t stream);
 
+/* One network apply (inference): q_values_out[b][a] for `batch` uint8 states
+ * with ONE noise block, plus optionally the greedy action (first maximum) and
+ * max_a q per state.  Uses the same kernels and workspace layout as the learner
+ * (the workspace must hold dz_rainbow_layout(.., batch).ws_count floats and must
+ * not be the one a concurrently enqueued learn step uses).
+ * ref: rainbow/agent.py:125-131 (select_action), networks.py:224-261.       */
+int dz_rainbow_apply(int num_actions, int num_atoms, int batch, const float* params,
+                     const uint8_t* states, const float* noise, const float* support,
+                     float* ws, float* q_values_out, int32_t* greedy_out,
+                     float* vmax_out, dz_stream_t stream);
+
 /* Fills n noise blocks with f(x)=sign(x)sqrt|x|, x ~ truncated normal on
  * [-2,2] (ref: networks.py:142-144), from a counter-based generator keyed by
  * (seed, counter).  Distribution-equivalent to the reference, not bit-equal

@@ -1,0 +1,165 @@
+"""Rainbow agent drop-in behaviour on the GPU (surface of rainbow/agent.py):
+run_loop smoke mirroring rainbow/run_atari_test.py:31-41 (replay 1000, batch
+10, learn_period 2) on a synthetic environment, the learning gates, the
+inference entry point against the oracle and get_state/set_state."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qnet_oracle as qo
+
+pytestmark = pytest.mark.gpu
+
+A = 4
+SUPPORT = np.linspace(-10.0, 10.0, 51).astype(np.float32)
+
+
+class SyntheticEnv:
+  """Preprocessed-observation environment: uint8 84x84x4 stacks, episodes of
+  fixed length, rewards in {-1,0,1} (what processors.atari would emit)."""
+
+  def __init__(self, seed, episode_length=17):
+    self.rs = np.random.RandomState(seed)
+    self.n = episode_length
+
+  def _obs(self):
+    return self.rs.randint(0, 256, (84, 84, 4)).astype(np.uint8)
+
+  def reset(self):
+    from dqn_zoo_amd import dm_env_shim as dm_env
+    self.t = 0
+    return dm_env.restart(self._obs())
+
+  def step(self, action):
+    from dqn_zoo_amd import dm_env_shim as dm_env
+    assert 0 <= action < A
+    self.t += 1
+    r = float(self.rs.randint(-1, 2))
+    if self.t == self.n:
+      return dm_env.termination(r, self._obs())
+    return dm_env.transition(r, self._obs(), 0.99)
+
+
+def _make_agent(seed=1, capacity=1000, batch=10, learn_period=2,
+                target_period=40, min_frac=0.05):
+  from dqn_zoo_amd import learner, networks, parts, processors
+  from dqn_zoo_amd import replay as replay_lib
+  from dqn_zoo_amd.rainbow import agent as agent_lib
+  net = networks.RainbowNetwork(A, SUPPORT, 0.1)
+  rep = replay_lib.PrioritizedTransitionReplay(
+      capacity, replay_lib.Transition(None, None, None, None, None), 0.5,
+      parts.LinearSchedule(begin_t=50, end_t=500, begin_value=0.4,
+                           end_value=1.0), 1e-3, True,
+      np.random.RandomState(seed))
+  ag = agent_lib.Rainbow(
+      preprocessor=processors.Identity(),
+      sample_network_input=np.zeros((84, 84, 4), np.uint8), network=net,
+      support=SUPPORT, optimizer=learner.AdamConfig(),
+      transition_accumulator=replay_lib.NStepTransitionAccumulator(3),
+      replay=rep, batch_size=batch, min_replay_capacity_fraction=min_frac,
+      learn_period=learn_period, target_network_update_period=target_period,
+      rng_key=seed)
+  return ag, rep
+
+
+def test_run_loop_smoke_and_gates():
+  import itertools
+  from dqn_zoo_amd import parts
+  ag, rep = _make_agent()
+  env = SyntheticEnv(0)
+  p0 = ag.online_params
+  assert np.isnan(ag.statistics['state_value']) and ag.max_seen_priority == 1.0
+  seq = itertools.islice(parts.run_loop(ag, env, max_steps_per_episode=50), 120)
+  stats = parts.generate_statistics(parts.make_default_trackers(ag), seq)
+  rep.check_status()
+  assert stats['num_steps_since_reset'] == 120 and stats['num_episodes'] >= 5
+  assert np.isfinite(stats['state_value'])
+  # every step adds transitions (n-step flush at episode ends): size grew
+  assert 90 <= rep.size <= 120
+  # learning started once size >= 5% of capacity (= 50): parameters moved
+  p1 = ag.online_params
+  assert any(np.abs(p1[k] - p0[k]).max() > 0 for k in p1)
+  steps_learned = int(ag.learner.adam_count.item())
+  assert 25 <= steps_learned <= 40   # every 2nd frame after ~50 frames
+  assert ag.max_seen_priority >= 1.0
+  assert 0.4 <= ag.importance_sampling_exponent <= 1.0
+  assert rep.check_valid()[0]
+  # repeat-without-action error (rainbow/agent.py:142-143)
+  ag2, _ = _make_agent()
+  ag2._preprocessor = lambda ts: None
+  with pytest.raises(RuntimeError, match='Cannot repeat if action'):
+    ag2.step(env.reset())
+
+
+def test_target_sync_period():
+  # min replay = 4 items: with a 3-step accumulator the replay reaches 4 items
+  # at frame 6; learning every frame from then on, target sync when
+  # frame_t % 7 == 0 (rainbow/agent.py:151-158).
+  ag, rep = _make_agent(target_period=7, min_frac=0.004, learn_period=1)
+  env = SyntheticEnv(1, episode_length=100)
+  ts = env.reset()
+  ag.reset()
+  synced = []
+  for t in range(16):
+    a = ag.step(ts)
+    ts = env.step(a)
+    tgt = ag.learner.get_params('target')
+    onl = ag.online_params
+    synced.append(all(np.array_equal(tgt[k], onl[k]) for k in tgt))
+  learned_at = int(ag.learner.adam_count.item())
+  assert learned_at == 16 - 6
+  assert synced[:6] == [True] * 6          # nothing learned yet
+  assert synced[6] is False                # learned at frame 6, no sync
+  assert synced[7] is True and synced[14] is True
+  assert not any(synced[8:14]) and synced[15] is False
+
+
+def test_apply_matches_oracle_forward():
+  from dqn_zoo_amd import learner, networks
+  rs = np.random.RandomState(5)
+  params = qo.init_params('rainbow', A, rs)
+  for k in params:
+    if 'sigma' in k:
+      params[k] = (params[k] * 3).astype(np.float32)
+  ln = learner.RainbowLearner(networks.RainbowNetwork(A, SUPPORT),
+                              learner.AdamConfig(), 8, params=params)
+  for b in (1, 5):
+    x = rs.randint(0, 256, (b, 84, 84, 4)).astype(np.uint8)
+    nz = qo.sample_noise(rs, A)
+    q, greedy, vmax = ln.apply(torch.from_numpy(x).cuda(), noise=nz)
+    _, q_ref, _ = qo.rainbow_fwd(params, x, nz, SUPPORT, A)
+    np.testing.assert_allclose(q.cpu().numpy(), q_ref, rtol=2e-4, atol=2e-5)
+    np.testing.assert_array_equal(greedy.cpu().numpy(), q_ref.argmax(axis=1))
+    np.testing.assert_allclose(vmax.cpu().numpy(), q_ref.max(axis=1), rtol=2e-4,
+                               atol=2e-5)
+  # fresh noise per apply (networks.py:169-170): same input, different output
+  xs = torch.from_numpy(x).cuda()
+  q1, _, _ = ln.apply(xs)
+  q2, _, _ = ln.apply(xs)
+  assert not torch.equal(q1, q2)
+
+
+def test_get_state_set_state_roundtrip():
+  ag, rep = _make_agent(capacity=64, batch=8, min_frac=0.1)
+  env = SyntheticEnv(2)
+  ts = env.reset()
+  ag.reset()
+  for _ in range(40):
+    ts = env.step(ag.step(ts)) if not ts.last() else env.reset()
+  state = ag.get_state()
+  assert set(state) == {'rng_key', 'frame_t', 'opt_state', 'online_params',
+                        'target_params', 'replay', 'max_seen_priority'}
+  ag2, rep2 = _make_agent(capacity=64, batch=8, min_frac=0.1, seed=99)
+  ag2.set_state(state)
+  s2 = ag2.get_state()
+  assert s2['frame_t'] == state['frame_t']
+  assert s2['max_seen_priority'] == state['max_seen_priority']
+  for k in state['online_params']:
+    np.testing.assert_array_equal(s2['online_params'][k],
+                                  state['online_params'][k])
+    np.testing.assert_array_equal(s2['opt_state']['nu'][k],
+                                  state['opt_state']['nu'][k])
+  np.testing.assert_array_equal(s2['replay']['sum_tree_storage'],
+                                state['replay']['sum_tree_storage'])
+  assert rep2.size == rep.size and list(rep2.ids()) == list(rep.ids())
