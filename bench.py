@@ -52,6 +52,12 @@ def parse_args():
   ap.add_argument('--cpu-seconds', type=float, default=15.0,
                   help='CPU-baseline time budget (0 disables)')
   ap.add_argument('--prof-steps', type=int, default=100)
+  ap.add_argument('--no-graphs', action='store_true',
+                  help='launch the learner kernels eagerly instead of hipGraph replay')
+  ap.add_argument('--pipelined', action='store_true',
+                  help='run replay write-back/sample on a side stream under the '
+                       'backward pass (measured slower here: cross-stream event '
+                       'hops cost 7-14 us each)')
   return ap.parse_args()
 
 
@@ -98,12 +104,51 @@ def build_workload(args, device, seed):
 
 
 def make_step(replay, learner, batch):
+  """Sequential form of the step (sample -> update -> priority write-back),
+  exactly the order of rainbow/agent.py:181-198."""
 
   def step():
     s = replay.sample_device(batch)
     t = s.transitions
     learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32)
     replay.update_priorities(s.ids, learner.priorities)
+
+  return step
+
+
+def make_step_pipelined(replay, learner, batch, device):
+  """Same steps, same order of replay operations (sample k+1 still sees the
+  priorities written by step k), but the latency-bound replay kernels run on a
+  second HIP stream underneath the backward pass and the optimiser of step k:
+      main : forward+loss(k) ................ backward + clip/Adam(k) | forward(k+1)
+      side :                 write-back(k), sample(k+1), gather(k+1)  |
+  """
+  from dqn_zoo_amd import _lib
+  main = torch.cuda.current_stream(device)
+  side = torch.cuda.Stream(device)
+  ev_sample = torch.cuda.Event()
+  ev_fwd = torch.cuda.Event()
+  nxt = [None]
+
+  def step():
+    if nxt[0] is None:
+      with torch.cuda.stream(side):
+        nxt[0] = replay.sample_device(batch)
+        ev_sample.record(side)
+    s = nxt[0]
+    main.wait_event(ev_sample)
+    t = s.transitions
+    learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
+                 phases=_lib.PHASE_FORWARD)
+    ev_fwd.record(main)
+    with torch.cuda.stream(side):
+      side.wait_event(ev_fwd)
+      replay.update_priorities(s.ids, learner.priorities)
+      nxt[0] = replay.sample_device(batch)
+      ev_sample.record(side)
+    learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
+                 phases=_lib.PHASE_BACKWARD | _lib.PHASE_OPTIMIZER,
+                 resample_noise=False)
 
   return step
 
@@ -124,14 +169,15 @@ def kernel_work(b, a=NUM_ACTIONS, k=NUM_ATOMS):
   # (online, target) streamed once
   w['fc1_fwd'] = (2 * f(g * b, 1024, 3136), 2 * 2 * 3136 * 1024 * 4)
   w['fc2_fwd'] = (2 * f(g * b, na + k, 512), 2 * 2 * 512 * (na + k) * 4)
-  w['fc1_wgrad'] = (f(3136, 1024, b), 2 * 3136 * 1024 * 4)
-  w['fc1_dgrad'] = (2 * f(b, 3136, 1024), 2 * 3136 * 1024 * 4)
-  w['fc2_wgrad'] = (f(512, na + k, b), 2 * 512 * (na + k) * 4)
-  w['fc2_dgrad'] = (2 * f(b, 1024, (na + k) / 2.0), 2 * 512 * (na + k) * 4)
-  w['conv3_wgrad'] = (f(576, 64, b * 49), b * (5184 + 3136) * 4)
-  w['conv3_dgrad'] = (f(b * 81, 64, 576), b * (3136 + 5184) * 4)
-  w['conv2_wgrad'] = (f(512, 64, b * 81), b * (12800 + 5184) * 4)
-  w['conv2_dgrad'] = (f(b * 400, 32, 256), b * (5184 + 12800) * 4)
+  # weight gradient + input gradient of a layer are ONE fused launch
+  w['fc1_wgrad'] = (f(3136, 1024, b), 2 * 3136 * 1024 * 4)     # write dW mu,sigma
+  w['fc1_dgrad'] = (2 * f(b, 3136, 1024), 2 * 3136 * 1024 * 4)  # read W mu,sigma
+  w['fc2_wgrad+dgrad'] = (f(512, na + k, b) + 2 * f(b, 1024, (na + k) / 2.0),
+                          2 * 2 * 512 * (na + k) * 4)
+  w['conv3_wgrad+dgrad'] = (f(576, 64, b * 49) + f(b * 81, 64, 576),
+                            2 * b * (5184 + 3136) * 4)
+  w['conv2_wgrad+dgrad'] = (f(512, 64, b * 81) + f(b * 400, 32, 256),
+                            2 * b * (12800 + 5184) * 4)
   w['conv1_wgrad'] = (f(256, 32, b * 400), b * 28224 + b * 12800 * 4)
   w['adam'] = (0.0, 7.0 * p_ref * 4)           # read g,p,m,v; write p,m,v
   w['grad_sumsq'] = (0.0, 1.0 * p_ref * 4)
@@ -291,7 +337,17 @@ def main():
                             device_id=device)
 
   replay, learner, _ = build_workload(args, device, args.seed + 1000 * rank)
-  step = make_step(replay, learner, args.batch)
+  # hipGraph capture is illegal on the legacy default stream: everything from
+  # here on runs on an explicit stream.
+  torch.cuda.synchronize(device)
+  torch.cuda.set_stream(torch.cuda.Stream(device))
+  learner.use_graphs = not args.no_graphs
+  args.sequential = not args.pipelined
+  if args.sequential:
+    step = make_step(replay, learner, args.batch)
+  else:
+    step = make_step_pipelined(replay, learner, args.batch, device)
+  seq_step = make_step(replay, learner, args.batch)
 
   for _ in range(args.warmup):
     step()
@@ -336,10 +392,14 @@ def main():
                         'backward + clip/Adam + priority write-back',
             'replay_capacity': args.capacity, 'global_batch': args.batch * world,
             'state': '84x84x4 uint8', 'num_actions': NUM_ACTIONS,
-            'num_atoms': NUM_ATOMS, 'parallelism': 'replicas x%d' % world},
+            'num_atoms': NUM_ATOMS, 'parallelism': 'replicas x%d' % world,
+            'launch': 'eager' if args.no_graphs else 'hipGraph replay',
+            'streams': 'sequential' if args.sequential else
+                       'replay ops overlapped on a side stream'},
     }
     if args.prof_steps > 0:
-      out['roofline'] = measure_roofline(step, args.prof_steps, args.batch)
+      learner.use_graphs = False  # per-kernel events need eager launches
+      out['roofline'] = measure_roofline(seq_step, args.prof_steps, args.batch)
     if world == 1 and args.cpu_seconds > 0:
       out['cpu_baseline'] = cpu_baseline(args, args.seed, args.cpu_seconds)
       out['speedup_vs_cpu_baseline'] = round(

@@ -74,7 +74,8 @@ class RainbowArgs(ctypes.Structure):
       ('a_tm1', c_vp), ('r_t', c_vp), ('discount_t', c_vp), ('weights', c_vp),
       ('support', c_vp), ('noise', c_vp), ('ws', c_vp), ('losses', c_vp),
       ('priorities', c_vp), ('lr', c_f32), ('b1', c_f32), ('b2', c_f32),
-      ('eps', c_f32), ('max_norm', c_f32),
+      ('eps', c_f32), ('max_norm', c_f32), ('resample_noise', c_i32),
+      ('noise_seed', ctypes.c_uint64),
   ]
 
 
@@ -95,6 +96,10 @@ SIGNATURES = {
     'dz_rainbow_learn': (c_int, [ctypes.POINTER(RainbowArgs), c_int, c_vp]),
     'dz_rainbow_apply': (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                                  c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'dz_rainbow_graph_capture': (c_int, [ctypes.POINTER(RainbowArgs), c_int, c_vp,
+                                         ctypes.POINTER(c_vp)]),
+    'dz_graph_launch': (c_int, [c_vp, c_vp]),
+    'dz_graph_destroy': (c_int, [c_vp]),
     'dz_noise_fill': (c_int, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64,
                               c_vp]),
     'dz_param_copy': (c_int, [c_vp, c_vp, c_i64, c_vp]),

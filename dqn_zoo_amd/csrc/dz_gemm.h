@@ -89,22 +89,31 @@ struct DzLdsTile {
 //   (same three forms for load_b; rows are tile columns)
 //   void  store(p, t, wm, wn, lane, acc)
 template <class Op>
-__global__ __launch_bounds__(256) void dz_mfma_gemm(typename Op::Params p) {
+struct DzGemmSmem {
+  static constexpr int CPS = Op::WK * Op::KT;
+  using AT = DzLdsTile<32 * Op::WM, CPS, Op::A_LAYOUT>;
+  using BT = DzLdsTile<32 * Op::WN, CPS, Op::B_LAYOUT>;
+  static constexpr int RED = (Op::WK > 1) ? (Op::WK - 1) * Op::WM * Op::WN * 16 * 64 : 0;
+  static constexpr int TILE = AT::ELEMS + BT::ELEMS;
+  static constexpr int ELEMS = TILE > RED ? TILE : RED;
+};
+
+// One workgroup's worth of the contraction; `bid` is the (possibly virtual)
+// block index the Op decodes its tile from, `smem` >= DzGemmSmem<Op>::ELEMS.
+template <class Op>
+__device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const dim3& bid,
+                                             float* smem) {
   constexpr int WM = Op::WM, WN = Op::WN, WK = Op::WK, KT = Op::KT;
   constexpr int CPS = WK * KT;  // 16-deep chunks per stage
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
   constexpr int BM = 32 * WM, BN = 32 * WN;
   using AT = DzLdsTile<BM, CPS, Op::A_LAYOUT>;
   using BT = DzLdsTile<BN, CPS, Op::B_LAYOUT>;
-  constexpr int RED_ELEMS = (WK > 1) ? (WK - 1) * WM * WN * 16 * 64 : 0;
-  constexpr int TILE_ELEMS = AT::ELEMS + BT::ELEMS;
-  constexpr int SMEM = TILE_ELEMS > RED_ELEMS ? TILE_ELEMS : RED_ELEMS;
-  __shared__ __attribute__((aligned(16))) float smem[SMEM];
   float* As = smem;
   float* Bs = smem + AT::ELEMS;
 
   DzTile t;
-  if (!Op::tile(p, t)) return;
+  if (!Op::tile(p, bid, t)) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -281,9 +290,69 @@ __device__ __forceinline__ int dz_acc_row(int r, int lane) {
 }
 
 template <class Op>
+__global__ __launch_bounds__(256) void dz_mfma_gemm(typename Op::Params p) {
+  __shared__ __attribute__((aligned(16))) float smem[DzGemmSmem<Op>::ELEMS];
+  dz_gemm_body<Op>(p, dim3(blockIdx.x, blockIdx.y, blockIdx.z), smem);
+}
+
+template <class Op>
 static inline int dz_launch_gemm(const typename Op::Params& p, dim3 grid,
                                  hipStream_t s) {
   hipLaunchKernelGGL(dz_mfma_gemm<Op>, grid, dim3(256), 0, s, p);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
+// Horizontal fusion: up to three INDEPENDENT contractions in one launch (e.g. a
+// layer's weight gradient and input gradient).  Each fills only part of the
+// 256 CUs on its own; fused they overlap with no stream/event traffic (a
+// cross-stream event hop measured 7-14 us on this stack) and one launch floor
+// (~4.5 us) instead of three.  Blocks [0,na) run OpA, [na,na+nb) OpB, rest OpC.
+__device__ __forceinline__ dim3 dz_unflatten(unsigned i, dim3 g) {
+  return dim3(i % g.x, (i / g.x) % g.y, i / (g.x * g.y));
+}
+static inline unsigned dz_count(dim3 g) { return g.x * g.y * g.z; }
+
+template <class OpA, class OpB>
+__global__ __launch_bounds__(256) void dz_mfma_gemm2(typename OpA::Params pa, dim3 ga,
+                                                     typename OpB::Params pb, dim3 gb) {
+  constexpr int SM = DzGemmSmem<OpA>::ELEMS > DzGemmSmem<OpB>::ELEMS
+                         ? DzGemmSmem<OpA>::ELEMS : DzGemmSmem<OpB>::ELEMS;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  const unsigned na = ga.x * ga.y * ga.z;
+  if (blockIdx.x < na) dz_gemm_body<OpA>(pa, dz_unflatten(blockIdx.x, ga), smem);
+  else dz_gemm_body<OpB>(pb, dz_unflatten(blockIdx.x - na, gb), smem);
+}
+
+template <class OpA, class OpB, class OpC>
+__global__ __launch_bounds__(256) void dz_mfma_gemm3(typename OpA::Params pa, dim3 ga,
+                                                     typename OpB::Params pb, dim3 gb,
+                                                     typename OpC::Params pc, dim3 gc) {
+  constexpr int S1 = DzGemmSmem<OpA>::ELEMS > DzGemmSmem<OpB>::ELEMS
+                         ? DzGemmSmem<OpA>::ELEMS : DzGemmSmem<OpB>::ELEMS;
+  constexpr int SM = S1 > DzGemmSmem<OpC>::ELEMS ? S1 : DzGemmSmem<OpC>::ELEMS;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  const unsigned na = ga.x * ga.y * ga.z, nb = gb.x * gb.y * gb.z;
+  if (blockIdx.x < na) dz_gemm_body<OpA>(pa, dz_unflatten(blockIdx.x, ga), smem);
+  else if (blockIdx.x < na + nb) dz_gemm_body<OpB>(pb, dz_unflatten(blockIdx.x - na, gb), smem);
+  else dz_gemm_body<OpC>(pc, dz_unflatten(blockIdx.x - na - nb, gc), smem);
+}
+
+template <class OpA, class OpB>
+static inline int dz_launch_gemm2(const typename OpA::Params& pa, dim3 ga,
+                                  const typename OpB::Params& pb, dim3 gb, hipStream_t s) {
+  hipLaunchKernelGGL((dz_mfma_gemm2<OpA, OpB>), dim3(dz_count(ga) + dz_count(gb)),
+                     dim3(256), 0, s, pa, ga, pb, gb);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+template <class OpA, class OpB, class OpC>
+static inline int dz_launch_gemm3(const typename OpA::Params& pa, dim3 ga,
+                                  const typename OpB::Params& pb, dim3 gb,
+                                  const typename OpC::Params& pc, dim3 gc, hipStream_t s) {
+  hipLaunchKernelGGL((dz_mfma_gemm3<OpA, OpB, OpC>),
+                     dim3(dz_count(ga) + dz_count(gb) + dz_count(gc)), dim3(256), 0, s, pa,
+                     ga, pb, gb, pc, gc);
   DZ_LAUNCH_CHECK();
   return DZ_OK;
 }

@@ -62,11 +62,11 @@ struct ConvFwdOp {
 
   static int tiles_per_group(int B) { return (B * OH * OW + BM - 1) / BM; }
 
-  __device__ static bool tile(const Params& p, DzTile& t) {
+  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
     const int tpg = (p.B * OH * OW + BM - 1) / BM;
-    t.z = blockIdx.y / tpg;
-    t.m0 = (blockIdx.y % tpg) * BM;
-    t.n0 = blockIdx.x * BN;
+    t.z = bid.y / tpg;
+    t.m0 = (bid.y % tpg) * BM;
+    t.n0 = bid.x * BN;
     t.st_begin = 0;
     t.st_end = K / BK;
     return t.z < p.G;
@@ -169,14 +169,14 @@ struct FcFwdOp {
   static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   typedef FcFwdParams Params;
 
-  __device__ static bool tile(const Params& p, DzTile& t) {
-    const int split = blockIdx.z % p.S;
-    const int gh = blockIdx.z / p.S;
+  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+    const int split = bid.z % p.S;
+    const int gh = bid.z / p.S;
     const int h = gh % p.NH, g = gh / p.NH;
     const FcHead& hd = p.head[h];
     t.z = g; t.z2 = h | (split << 8);
-    t.m0 = blockIdx.y * BM;
-    t.n0 = blockIdx.x * BN;
+    t.m0 = bid.y * BM;
+    t.n0 = bid.x * BN;
     const int chunks = (hd.K / 16) * (p.noisy ? 2 : 1);
     const int stages = (chunks + CPS - 1) / CPS;
     const int per = (stages + p.S - 1) / p.S;
@@ -280,13 +280,13 @@ struct FcDgradOp {
     L.w = L.sig ? (h1 ? b.w_sig : a.w_sig) : (h1 ? b.w_mu : a.w_mu);
     return L;
   }
-  __device__ static bool tile(const Params& p, DzTile& t) {
+  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
     const int chunks = chunks_of(p, 0) + (p.NH > 1 ? chunks_of(p, 1) : 0);
     const int stages = (chunks + CPS - 1) / CPS;
     const int per = (stages + p.S - 1) / p.S;
-    t.z = blockIdx.z;  // split
-    t.m0 = blockIdx.y * BM;
-    t.n0 = blockIdx.x * BN;
+    t.z = bid.z;  // split
+    t.m0 = bid.y * BM;
+    t.n0 = bid.x * BN;
     t.st_begin = t.z * per;
     t.st_end = min(stages, t.st_begin + per);
     return t.n0 < p.K && t.m0 < p.M;
@@ -346,11 +346,11 @@ struct FcWgradOp {
   static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   typedef FcWgradParams Params;
 
-  __device__ static bool tile(const Params& p, DzTile& t) {
-    t.z = blockIdx.z;  // head
+  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+    t.z = bid.z;  // head
     const FcHead& hd = p.head[t.z];
-    t.m0 = blockIdx.y * BM;  // k rows
-    t.n0 = blockIdx.x * BN;
+    t.m0 = bid.y * BM;  // k rows
+    t.n0 = bid.x * BN;
     t.st_begin = 0;
     t.st_end = (p.M + BK - 1) / BK;
     return t.z < p.NH && t.m0 < hd.K && t.n0 < hd.N;
@@ -416,12 +416,12 @@ struct ConvWgradOp {
   static_assert(K % BM == 0 && CO % BN == 0 && C % 4 == 0, "tile shape");
   typedef ConvWgradParams Params;
 
-  __device__ static bool tile(const Params& p, DzTile& t) {
+  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
     const int stages = (p.B * OH * OW + BK - 1) / BK;
     const int per = (stages + p.S - 1) / p.S;
-    t.z = blockIdx.z;
-    t.m0 = blockIdx.y * BM;
-    t.n0 = blockIdx.x * BN;
+    t.z = bid.z;
+    t.m0 = bid.y * BM;
+    t.n0 = bid.x * BN;
     t.st_begin = t.z * per;
     t.st_end = min(stages, t.st_begin + per);
     return true;
@@ -493,10 +493,10 @@ struct ConvDgradOp {
 
   static int tiles(int B) { return (B * HP * WP + BM - 1) / BM; }
 
-  __device__ static bool tile(const Params& p, DzTile& t) {
-    t.z = blockIdx.z;  // parity class
-    t.m0 = blockIdx.y * BM;
-    t.n0 = blockIdx.x * BN;
+  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+    t.z = bid.z;  // parity class
+    t.m0 = bid.y * BM;
+    t.n0 = bid.x * BN;
     t.st_begin = 0;
     t.st_end = RED / BK;
     return true;

@@ -32,6 +32,17 @@ int g_fc1_variant = 9;   // 8/9 = weight-streaming kernels (dz_fc_stream.h)
 int g_fc1_splits = 32;
 int g_fc1_dgrad_stream = 0;  // measured: tile-GEMM 26 us vs streaming 35 us
 int g_fc1_blocked_experiment = 0;
+int g_overlap = 1;           // weight gradients on an auxiliary stream
+hipStream_t g_aux_stream = nullptr;
+hipEvent_t g_ev[5];
+
+int ensure_aux() {
+  if (g_aux_stream) return DZ_OK;
+  DZ_HIP_CHECK(hipStreamCreateWithFlags(&g_aux_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 5; ++i)
+    DZ_HIP_CHECK(hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming));
+  return DZ_OK;
+}
 
 // conv geometries (networks.py:194-198)
 //                      U8  H   W   C  KS S  OH  OW  CO
@@ -113,6 +124,51 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumJobs jobs) {
   const int c = blockIdx.x * 64 + l;
   if (blockIdx.x * 64 >= jb.cols) return;
   float v = 0.f;
+  if (c < jb.cols) {
+#pragma unroll 4
+    for (int r = w; r < jb.rows; r += 4) v += jb.m[(long)r * jb.ld + c];
+  }
+  red[w][l] = v;
+  __syncthreads();
+  if (w == 0 && c < jb.cols) {
+    const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    if (jb.out) jb.out[c] = s;
+    if (jb.out_scaled) jb.out_scaled[c] = s * jb.scale[c];
+  }
+}
+
+// Gradient finalisation in ONE launch: the split-K partial slabs of the three
+// convolution weight(+bias) gradients are reduced into the gradient buffer and
+// the linear-layer bias gradients (column sums) are formed.  blockIdx.x ranges:
+// [0, t0) reduce job 0, [t0, t1) job 1, [t1, t2) job 2, then the colsum tiles.
+struct ReduceJob { const float* part; int S; long n; float* out; };
+struct FinalizeJobs {
+  ReduceJob r[3];
+  unsigned r_end[3];      // exclusive prefix of 64-wide tiles
+  ColsumJob c[2];
+  unsigned c_tiles[2];    // tiles per colsum job
+};
+__global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned b = blockIdx.x;
+  float v = 0.f;
+  if (b < J.r_end[2]) {
+    const int j = b < J.r_end[0] ? 0 : (b < J.r_end[1] ? 1 : 2);
+    const ReduceJob jb = J.r[j];
+    const long i = (long)(b - (j ? J.r_end[j - 1] : 0)) * 64 + l;
+    if (i < jb.n)
+      for (int s = w; s < jb.S; s += 4) v += jb.part[(long)s * jb.n + i];
+    red[w][l] = v;
+    __syncthreads();
+    if (w == 0 && i < jb.n)
+      jb.out[i] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    return;
+  }
+  b -= J.r_end[2];
+  const int j = b < J.c_tiles[0] ? 0 : 1;
+  const ColsumJob jb = J.c[j];
+  const int c = (int)(b - (j ? J.c_tiles[0] : 0)) * 64 + l;
   if (c < jb.cols) {
 #pragma unroll 4
     for (int r = w; r < jb.rows; r += 4) v += jb.m[(long)r * jb.ld + c];
@@ -243,10 +299,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // One block: global norm, clip decision, Adam bias corrections, mean loss.
+// (A single-launch "last workgroup finishes" form with agent-scope fences was
+// measured slower than this second tiny launch: 20 us vs 9 + 8 us.)
 __global__ __launch_bounds__(256) void opt_scalars_kernel(
     const float* __restrict__ part, int nparts, int32_t* count, float b1, float b2,
     float max_norm, const float* __restrict__ losses, const float* __restrict__ weights,
@@ -258,7 +316,7 @@ __global__ __launch_bounds__(256) void opt_scalars_kernel(
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float gn = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float gn = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
     const int c = *count + 1;  // optax: count_inc = count + 1
     *count = c;
     sc[DZ_SC_GNORM] = gn;
@@ -311,9 +369,10 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   return x ^ (x >> 31);
 }
 __global__ void noise_fill_kernel(float* __restrict__ out, long n, uint64_t seed,
-                                  uint64_t counter) {
+                                  uint64_t counter, const int32_t* __restrict__ step) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (step) counter += (uint64_t)(*step) * (uint64_t)n;  // per-step stream offset
   const uint64_t h = mix64(mix64(seed) ^ mix64(counter + (uint64_t)i));
   // jax.random.truncated_normal: sqrt2 * erfinv(U(erf(lo/sqrt2), erf(hi/sqrt2)))
   const float u01 = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
@@ -560,9 +619,9 @@ extern "C" int dz_rainbow_layout(int A, int K, int B, dz_rainbow_layout_t* L) {
   L->ws_dfeat = take((int64_t)B * kFlat);
   L->ws_dact2 = take((int64_t)B * 81 * 64);
   L->ws_dact1 = take((int64_t)B * 400 * 32);
-  int64_t wp = (int64_t)kS_cw1 * Conv1Wg::KROWS * 32;
-  if ((int64_t)kS_cw2 * Conv2Wg::KROWS * 64 > wp) wp = (int64_t)kS_cw2 * Conv2Wg::KROWS * 64;
-  if ((int64_t)kS_cw3 * Conv3Wg::KROWS * 64 > wp) wp = (int64_t)kS_cw3 * Conv3Wg::KROWS * 64;
+  const int64_t wp = (int64_t)kS_cw1 * Conv1Wg::KROWS * 32 +
+                     (int64_t)kS_cw2 * Conv2Wg::KROWS * 64 +
+                     (int64_t)kS_cw3 * Conv3Wg::KROWS * 64;  // one slab per conv
   L->ws_wgrad_part = take(wp);
   L->ws_norm_part = take(kNormBlocks);
   L->ws_colsum_part = take(4);
@@ -596,6 +655,15 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   const FcHead* fc2h = H.fc2h;
 
   if (g_dz_prof_on) dz_prof_begin(s);
+  if ((phases & DZ_PHASE_FORWARD) && a->resample_noise) {
+    DZ_REQUIRE(a->adam_count);
+    const long n = 3 * L.noise_stride;
+    hipLaunchKernelGGL(noise_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       s, const_cast<float*>(a->noise), n, a->noise_seed,
+                       (uint64_t)0x5eed, a->adam_count);
+    DZ_LAUNCH_CHECK();
+    DZ_PROF(s, "noise");
+  }
   if (phases & DZ_PHASE_FORWARD) {
     {
       const uint8_t* in[kG] = {a->s_tm1, a->s_t, a->s_t};
@@ -613,124 +681,106 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   if (phases & DZ_PHASE_BACKWARD) {
     DZ_REQUIRE(a->grad);
     float* grad = a->grad;
-    {  // fc2 weight gradients (mu and sigma) from h1 (group 0) and dout2
-      FcWgradParams p;
-      p.x = ws + L.ws_h1; p.ldx = 1024; p.dy = ws + L.ws_dout2; p.ldy = ld2; p.M = B;
-      p.NH = 2; p.noisy = 1; p.noise = nz[0]; p.head[0] = fc2h[0]; p.head[1] = fc2h[1];
-      p.grad = grad;
-      rc = dz_launch_gemm<FcWg>(p, dim3((NA + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 2), s);
-      if (rc) return rc;
-      DZ_PROF(s, "fc2_wgrad");
-    }
-    {  // fc2 input gradient -> dh1, masked by relu(h1)
+    // Every layer's weight gradient and input gradient are independent, so each
+    // pair is ONE launch (dz_mfma_gemm2/3: horizontal fusion); the conv partial
+    // reductions and the bias column sums are one launch at the end.
+    float* part1 = ws + L.ws_wgrad_part;
+    float* part2 = part1 + (long)kS_cw1 * Conv1Wg::KROWS * 32;
+    float* part3 = part2 + (long)kS_cw2 * Conv2Wg::KROWS * 64;
+    {  // fc2: weight gradients (both heads) + input gradient of each head
+      FcWgradParams w;
+      w.x = ws + L.ws_h1; w.ldx = 1024; w.dy = ws + L.ws_dout2; w.ldy = ld2; w.M = B;
+      w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc2h[0]; w.head[1] = fc2h[1];
+      w.grad = grad;
+      FcDgradParams d[2];
       for (int h = 0; h < 2; ++h) {
-        FcDgradParams p;
-        p.dy = ws + L.ws_dout2; p.ldy = ld2; p.M = B; p.NH = 1; p.S = kS_dh1; p.noisy = 1;
-        p.params = a->online; p.noise = nz[0]; p.head[0] = fc2h[h];
-        p.part = ws + L.ws_dfeat_part; p.ldo = 1024; p.K = kHid; p.x_off = 512 * h;
-        rc = dz_launch_gemm<FcDg>(p, dim3(kHid / FcDg::BN, (B + 31) / 32, kS_dh1), s);
-        if (rc) return rc;
+        d[h].dy = ws + L.ws_dout2; d[h].ldy = ld2; d[h].M = B; d[h].NH = 1;
+        d[h].S = kS_dh1; d[h].noisy = 1; d[h].params = a->online; d[h].noise = nz[0];
+        d[h].head[0] = fc2h[h]; d[h].head[1] = fc2h[h];
+        d[h].part = ws + L.ws_dfeat_part; d[h].ldo = 1024; d[h].K = kHid;
+        d[h].x_off = 512 * h;
       }
+      const dim3 gd(kHid / FcDg::BN, (B + 31) / 32, kS_dh1);
+      rc = dz_launch_gemm3<FcWg, FcDg, FcDg>(
+          w, dim3((NA + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 2), d[0], gd, d[1], gd, s);
+      if (rc) return rc;
+      DZ_PROF(s, "fc2_wgrad+dgrad");
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * 1024 + 63) / 64), dim3(256), 0,
                          s, ws + L.ws_dfeat_part, kS_dh1, (long)B * 1024, ws + L.ws_h1,
                          ws + L.ws_dh1);
       DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "fc2_dgrad");
+      DZ_PROF(s, "dh1_reduce");
     }
-    {  // fc1 weight gradients
-      FcWgradParams p;
-      p.x = ws + L.ws_feat; p.ldx = kFlat; p.dy = ws + L.ws_dh1; p.ldy = 1024; p.M = B;
-      p.NH = 2; p.noisy = 1; p.noise = nz[0]; p.head[0] = fc1h[0]; p.head[1] = fc1h[1];
-      p.grad = grad;
-      rc = dz_launch_gemm<FcWg>(p, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
+    {  // fc1: weight gradients + input gradient (adv1 + val1 paths) -> dfeat
+      FcWgradParams w;
+      w.x = ws + L.ws_feat; w.ldx = kFlat; w.dy = ws + L.ws_dh1; w.ldy = 1024; w.M = B;
+      w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc1h[0]; w.head[1] = fc1h[1];
+      w.grad = grad;
+      FcDgradParams d;
+      d.dy = ws + L.ws_dh1; d.ldy = 1024; d.M = B; d.NH = 2; d.S = kS_dfeat; d.noisy = 1;
+      d.params = a->online; d.noise = nz[0]; d.head[0] = fc1h[0]; d.head[1] = fc1h[1];
+      d.part = ws + L.ws_dfeat_part; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
+      // (measured: fusing these two HBM-heavy contractions is slower, 48 us vs
+      // 15 + 23 us back to back, so this pair stays two launches)
+      rc = dz_launch_gemm<FcWg>(w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
       if (rc) return rc;
       DZ_PROF(s, "fc1_wgrad");
-    }
-    if (g_fc1_dgrad_stream && B <= 32) {
-      // fc1 input gradient, weight-streaming form: writes dfeat directly
-      FcStreamDgradParams q;
-      q.dy = ws + L.ws_dh1; q.ldy = 1024; q.M = B; q.NH = 2; q.noisy = 1;
-      q.params = a->online; q.noise = nz[0]; q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
-      q.act = ws + L.ws_feat; q.dx = ws + L.ws_dfeat; q.ldo = kFlat; q.K = kFlat;
-      hipLaunchKernelGGL(dz_fc_stream_dgrad, dim3(kFlat / 32), dim3(256), 0, s, q);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "fc1_dgrad");
-    } else {
-      // fc1 input gradient (adv1 + val1 paths) -> dfeat, masked by relu(conv3)
-      FcDgradParams p;
-      p.dy = ws + L.ws_dh1; p.ldy = 1024; p.M = B; p.NH = 2; p.S = kS_dfeat; p.noisy = 1;
-      p.params = a->online; p.noise = nz[0]; p.head[0] = fc1h[0]; p.head[1] = fc1h[1];
-      p.part = ws + L.ws_dfeat_part; p.ldo = kFlat; p.K = kFlat; p.x_off = 0;
-      rc = dz_launch_gemm<FcDg>(p, dim3(kFlat / FcDg::BN, (B + 31) / 32, kS_dfeat), s);
+      rc = dz_launch_gemm<FcDg>(d, dim3(kFlat / FcDg::BN, (B + 31) / 32, kS_dfeat), s);
       if (rc) return rc;
       DZ_PROF(s, "fc1_dgrad");
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0,
                          s, ws + L.ws_dfeat_part, kS_dfeat, (long)B * kFlat,
                          ws + L.ws_feat, ws + L.ws_dfeat);
       DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "fc1_dgrad_reduce");
+      DZ_PROF(s, "dfeat_reduce");
     }
-    {  // conv3: weight gradient, then input gradient (masked by relu(conv2))
-      ConvWgradParams p;
-      p.in = ws + L.ws_act2; p.dy = ws + L.ws_dfeat; p.part = ws + L.ws_wgrad_part;
-      p.B = B; p.S = kS_cw3;
-      rc = dz_launch_gemm<Conv3Wg>(p, dim3(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), s);
-      if (rc) return rc;
-      DZ_PROF(s, "conv3_wgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((577 * 64 + 63) / 64), dim3(256), 0,
-                         s, ws + L.ws_wgrad_part, kS_cw3, (long)577 * 64,
-                         (const float*)nullptr, grad + L.conv_w[2]);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "conv3_wgrad_reduce");
+    {  // conv3: weight+bias gradient partials + input gradient (relu(conv2) mask)
+      ConvWgradParams w;
+      w.in = ws + L.ws_act2; w.dy = ws + L.ws_dfeat; w.part = part3; w.B = B; w.S = kS_cw3;
       ConvDgradParams d;
       d.dy = ws + L.ws_dfeat; d.w = a->online + L.conv_w[2]; d.act = ws + L.ws_act2;
       d.dx = ws + L.ws_dact2; d.B = B;
-      rc = dz_launch_gemm<Conv3Dg>(d, dim3(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1), s);
+      rc = dz_launch_gemm2<Conv3Wg, Conv3Dg>(
+          w, dim3(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), d,
+          dim3(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1), s);
       if (rc) return rc;
-      DZ_PROF(s, "conv3_dgrad");
+      DZ_PROF(s, "conv3_wgrad+dgrad");
     }
     {  // conv2
-      ConvWgradParams p;
-      p.in = ws + L.ws_act1; p.dy = ws + L.ws_dact2; p.part = ws + L.ws_wgrad_part;
-      p.B = B; p.S = kS_cw2;
-      rc = dz_launch_gemm<Conv2Wg>(p, dim3(64 / Conv2Wg::BN, Conv2Wg::MT, kS_cw2), s);
-      if (rc) return rc;
-      DZ_PROF(s, "conv2_wgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((513 * 64 + 63) / 64), dim3(256), 0,
-                         s, ws + L.ws_wgrad_part, kS_cw2, (long)513 * 64,
-                         (const float*)nullptr, grad + L.conv_w[1]);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "conv2_wgrad_reduce");
+      ConvWgradParams w;
+      w.in = ws + L.ws_act1; w.dy = ws + L.ws_dact2; w.part = part2; w.B = B; w.S = kS_cw2;
       ConvDgradParams d;
       d.dy = ws + L.ws_dact2; d.w = a->online + L.conv_w[1]; d.act = ws + L.ws_act1;
       d.dx = ws + L.ws_dact1; d.B = B;
-      rc = dz_launch_gemm<Conv2Dg>(d, dim3(32 / Conv2Dg::BN, Conv2Dg::tiles(B), 4), s);
+      rc = dz_launch_gemm2<Conv2Wg, Conv2Dg>(
+          w, dim3(64 / Conv2Wg::BN, Conv2Wg::MT, kS_cw2), d,
+          dim3(32 / Conv2Dg::BN, Conv2Dg::tiles(B), 4), s);
       if (rc) return rc;
-      DZ_PROF(s, "conv2_dgrad");
+      DZ_PROF(s, "conv2_wgrad+dgrad");
     }
-    {  // conv1 weight gradient straight from the uint8 states
+    {  // conv1 weight+bias gradient partials straight from the uint8 states
       ConvWgradParams p;
-      p.in = a->s_tm1; p.dy = ws + L.ws_dact1; p.part = ws + L.ws_wgrad_part;
-      p.B = B; p.S = kS_cw1;
+      p.in = a->s_tm1; p.dy = ws + L.ws_dact1; p.part = part1; p.B = B; p.S = kS_cw1;
       rc = dz_launch_gemm<Conv1Wg>(p, dim3(32 / Conv1Wg::BN, Conv1Wg::MT, kS_cw1), s);
       if (rc) return rc;
       DZ_PROF(s, "conv1_wgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((257 * 32 + 63) / 64), dim3(256), 0,
-                         s, ws + L.ws_wgrad_part, kS_cw1, (long)257 * 32,
-                         (const float*)nullptr, grad + L.conv_w[0]);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "conv1_wgrad_reduce");
     }
-    {  // linear-layer bias gradients = column sums of the output gradients
-      ColsumJobs J;
-      J.n = 2;
-      J.j[0] = {ws + L.ws_dh1, B, 1024, 1024, grad + L.fc1_mu_b, nz[0] + L.n_fc1_out,
+    {  // reduce the three conv partial slabs; linear-layer bias gradients
+      FinalizeJobs J;
+      J.r[0] = {part1, kS_cw1, (long)Conv1Wg::KROWS * 32, grad + L.conv_w[0]};
+      J.r[1] = {part2, kS_cw2, (long)Conv2Wg::KROWS * 64, grad + L.conv_w[1]};
+      J.r[2] = {part3, kS_cw3, (long)Conv3Wg::KROWS * 64, grad + L.conv_w[2]};
+      unsigned acc = 0;
+      for (int j = 0; j < 3; ++j) { acc += (unsigned)((J.r[j].n + 63) / 64); J.r_end[j] = acc; }
+      J.c[0] = {ws + L.ws_dh1, B, 1024, 1024, grad + L.fc1_mu_b, nz[0] + L.n_fc1_out,
                 grad + L.fc1_sig_b};
-      J.j[1] = {ws + L.ws_dout2, B, ld2, ld2, nullptr, nz[0] + L.n_fc2_out,
+      J.c[1] = {ws + L.ws_dout2, B, ld2, ld2, nullptr, nz[0] + L.n_fc2_out,
                 grad + L.fc2_sig_b};
-      hipLaunchKernelGGL(colsum_kernel, dim3(16, J.n), dim3(256), 0, s, J);
+      J.c_tiles[0] = 16; J.c_tiles[1] = (unsigned)((ld2 + 63) / 64);
+      hipLaunchKernelGGL(finalize_grads_kernel, dim3(acc + J.c_tiles[0] + J.c_tiles[1]),
+                         dim3(256), 0, s, J);
       DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "bias_colsum");
+      DZ_PROF(s, "finalize_grads");
     }
   }
 
@@ -740,18 +790,50 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
                        (long)L.param_count, ws + L.ws_norm_part);
     DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "grad_sumsq");
+    DZ_PROF(s, "grad_sumsq");
     hipLaunchKernelGGL(opt_scalars_kernel, dim3(1), dim3(256), 0, s,
                        ws + L.ws_norm_part, kNormBlocks, a->adam_count, a->b1, a->b2,
                        a->max_norm, a->losses, a->weights, B, sc);
     DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "opt_scalars");
+    DZ_PROF(s, "opt_scalars");
     hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
                        a->adam_m, a->adam_v, (long)(L.param_count >> 2), sc, a->lr,
                        a->b1, a->b2, a->eps, a->max_norm);
     DZ_LAUNCH_CHECK();
       DZ_PROF(s, "adam");
   }
+  return DZ_OK;
+}
+
+extern "C" int dz_rainbow_graph_capture(const dz_rainbow_args_t* args, int phases,
+                                        dz_stream_t stream, void** graph_exec_out) {
+  DZ_REQUIRE(args && graph_exec_out && stream && !g_dz_prof_on);
+  int rc = ensure_aux();  // no resource creation inside the capture
+  if (rc) return rc;
+  hipStream_t s = dz_s(stream);
+  hipGraph_t graph = nullptr;
+  DZ_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  rc = dz_rainbow_learn(args, phases, stream);
+  hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  DZ_HIP_CHECK(e);
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  DZ_HIP_CHECK(e);
+  *graph_exec_out = (void*)exec;
+  return DZ_OK;
+}
+
+extern "C" int dz_graph_launch(void* graph_exec, dz_stream_t stream) {
+  DZ_REQUIRE(graph_exec);
+  DZ_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, dz_s(stream)));
+  return DZ_OK;
+}
+
+extern "C" int dz_graph_destroy(void* graph_exec) {
+  DZ_REQUIRE(graph_exec);
+  DZ_HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
   return DZ_OK;
 }
 
@@ -788,6 +870,7 @@ extern "C" int dz_set_tuning(int key, int value) {
     case 1: DZ_REQUIRE(value >= 1 && value <= kMaxSplitFc1); g_fc1_splits = value; return DZ_OK;
     case 2: g_fc1_dgrad_stream = value; return DZ_OK;
     case 3: g_fc1_blocked_experiment = value; return DZ_OK;
+    case 4: g_overlap = value; return DZ_OK;
     default: return DZ_ERR_INVALID_ARG;
   }
 }
@@ -796,7 +879,8 @@ extern "C" int dz_noise_fill(float* noise, int64_t count, uint64_t seed,
                              uint64_t counter, dz_stream_t stream) {
   DZ_REQUIRE(noise && count > 0);
   hipLaunchKernelGGL(noise_fill_kernel, dim3((unsigned)((count + 255) / 256)),
-                     dim3(256), 0, dz_s(stream), noise, (long)count, seed, counter);
+                     dim3(256), 0, dz_s(stream), noise, (long)count, seed, counter,
+                     (const int32_t*)nullptr);
   DZ_LAUNCH_CHECK();
   return DZ_OK;
 }

@@ -58,6 +58,9 @@ class RainbowLearner:
     self.support = torch.from_numpy(network.support).to(self.device)
     self._noise_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     self._noise_counter = 0
+    self._args = None
+    self._graphs = {}        # (input pointers, phases, noise flag) -> hipGraphExec
+    self.use_graphs = False  # replay each distinct call signature from a hipGraph
     # inference (acting) side: own workspace + one noise block, so that an
     # apply never aliases the buffers of an enqueued learner step.
     self._act_batch = 0
@@ -160,34 +163,61 @@ class RainbowLearner:
     assert tuple(s_tm1.shape) == (b, 84, 84, 4) and tuple(s_t.shape) == (b, 84, 84, 4)
     assert a_tm1.dtype == torch.int64 and r_t.dtype == torch.float64
     assert discount_t.dtype == torch.float64 and weights.dtype == torch.float32
-    if resample_noise:
-      self.resample_noise()
-    a = _lib.RainbowArgs()
-    a.num_actions = self.network.num_actions
-    a.num_atoms = self.network.num_atoms
-    a.batch = b
-    a.online = self.online.data_ptr()
-    a.target = self.target.data_ptr()
-    a.grad = self.grad.data_ptr()
-    a.adam_m = self.adam_m.data_ptr()
-    a.adam_v = self.adam_v.data_ptr()
-    a.adam_count = self.adam_count.data_ptr()
+    a = self._args
+    if a is None:  # everything that never changes is filled once
+      a = self._args = _lib.RainbowArgs()
+      a.num_actions = self.network.num_actions
+      a.num_atoms = self.network.num_atoms
+      a.batch = b
+      a.online = self.online.data_ptr()
+      a.target = self.target.data_ptr()
+      a.grad = self.grad.data_ptr()
+      a.adam_m = self.adam_m.data_ptr()
+      a.adam_v = self.adam_v.data_ptr()
+      a.adam_count = self.adam_count.data_ptr()
+      a.support = self.support.data_ptr()
+      a.noise = self.noise.data_ptr()
+      a.ws = self.ws.data_ptr()
+      a.losses = self.losses.data_ptr()
+      a.priorities = self.priorities.data_ptr()
+      a.lr = self.opt.learning_rate
+      a.b1 = self.opt.b1
+      a.b2 = self.opt.b2
+      a.eps = self.opt.eps
+      a.max_norm = self.opt.max_global_grad_norm
+      a.noise_seed = self._noise_seed
     a.s_tm1 = s_tm1.data_ptr()
     a.s_t = s_t.data_ptr()
     a.a_tm1 = a_tm1.data_ptr()
     a.r_t = r_t.data_ptr()
     a.discount_t = discount_t.data_ptr()
     a.weights = weights.data_ptr()
-    a.support = self.support.data_ptr()
-    a.noise = self.noise.data_ptr()
-    a.ws = self.ws.data_ptr()
-    a.losses = self.losses.data_ptr()
-    a.priorities = self.priorities.data_ptr()
-    a.lr = self.opt.learning_rate
-    a.b1 = self.opt.b1
-    a.b2 = self.opt.b2
-    a.eps = self.opt.eps
-    a.max_norm = self.opt.max_global_grad_norm
-    _lib.check(self._lib.dz_rainbow_learn(
-        ctypes.byref(a), phases,
-        torch.cuda.current_stream(self.device).cuda_stream), 'dz_rainbow_learn')
+    # fresh noise for the 3 applies is generated by the step itself from
+    # (seed, Adam step count): no per-step host argument, graph-replayable.
+    a.resample_noise = int(bool(resample_noise) and bool(phases & _lib.PHASE_FORWARD))
+    stream = torch.cuda.current_stream(self.device).cuda_stream
+    if self.use_graphs:
+      if not stream:
+        raise RuntimeError(
+            'hipGraph capture needs a non-default stream: run the learner under '
+            '`torch.cuda.stream(torch.cuda.Stream())` (bench.py does)')
+      key = (a.s_tm1, a.s_t, a.a_tm1, a.r_t, a.discount_t, a.weights, phases,
+             a.resample_noise)
+      g = self._graphs.get(key)
+      if g is None:
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.dz_rainbow_graph_capture(
+            ctypes.byref(a), phases, stream, ctypes.byref(h)),
+                   'dz_rainbow_graph_capture')
+        g = self._graphs[key] = h
+      _lib.check(self._lib.dz_graph_launch(g, stream), 'dz_graph_launch')
+      return
+    _lib.check(self._lib.dz_rainbow_learn(ctypes.byref(a), phases, stream),
+               'dz_rainbow_learn')
+
+  def __del__(self):
+    try:
+      for g in self._graphs.values():
+        self._lib.dz_graph_destroy(g)
+    except Exception:  # pylint: disable=broad-except
+      pass

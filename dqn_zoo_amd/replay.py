@@ -645,16 +645,103 @@ class PrioritizedTransitionReplay(_ReplayBase):
     see DESIGN.md).  Assumes root() != 0, which holds whenever priorities come
     from max_seen_priority >= 1 (rainbow/agent.py:79,149); a zero root raises
     through the sticky status word at the next `check_status()`.
+
+    Outputs live in a ring of `SAMPLE_RING_DEPTH` preallocated slots (no
+    allocator traffic, pinned staging for the 3xB RNG draws): a returned
+    DeviceSample stays valid until that many further calls.
     """
     if self._size == 0:
       raise RuntimeError('No IDs to sample.')
     beta = float(self.importance_sampling_exponent)
     if not 0.0 <= beta <= 1.0:
       raise ValueError('Require 0 <= exponent <= 1.')
-    draws = self._draw(size, zero_root=False)
-    ids, probs, w64, w32 = self._launch_sample(size, draws, True, True)
-    outs = self._ring.gather(ids, size, self._stream())
-    return DeviceSample(type(self._structure)(*outs), ids, probs, w64, w32)
+    slot = self._ring_slot(size)
+    # host RNG draws in the reference's order (replay.py:551-566), written
+    # straight into the slot's pinned staging buffer.
+    if slot.copied is not None:
+      slot.copied.synchronize()  # the previous upload from this slot finished
+    rs = self._random_state
+    h = slot.host_np
+    h[:size] = rs.randint(self._size, size=size)
+    h[size:2 * size] = rs.uniform(size=size).view(np.int64)
+    h[2 * size:] = rs.uniform(size=size).view(np.int64)
+    slot.draws.copy_(slot.host, non_blocking=True)
+    if slot.copied is None:
+      slot.copied = torch.cuda.Event()
+    slot.copied.record(torch.cuda.current_stream(self._device))
+    a = slot.args
+    a.size = self._size
+    a.t = self._t
+    up = 1.0 / self._size
+    a.usp_times_up = self._usp * up
+    a.uniform_prob = up
+    a.beta = beta
+    lib = _lib.load()
+    stream = self._stream()
+    _lib.check(lib.dz_prioritized_sample(
+        ctypes.byref(a), size, slot.ids.data_ptr(), None, slot.probs.data_ptr(),
+        slot.w64.data_ptr(), slot.w32.data_ptr(), self._status.word.data_ptr(),
+        stream), 'dz_prioritized_sample')
+    _lib.check(lib.dz_replay_gather(slot.fields, len(self._ring.fields),
+                                    slot.ids.data_ptr(), size, self._capacity,
+                                    stream), 'dz_replay_gather')
+    return slot.sample
+
+  SAMPLE_RING_DEPTH = 4
+
+  def _ring_slot(self, size):
+    ring = getattr(self, '_sample_ring', None)
+    if ring is None or ring[0].size != size or ring[0].nfields != len(
+        self._ring.fields):
+      ring = [self._make_slot(size) for _ in range(self.SAMPLE_RING_DEPTH)]
+      self._sample_ring = ring
+      self._sample_ring_pos = 0
+    slot = ring[self._sample_ring_pos % len(ring)]
+    self._sample_ring_pos += 1
+    return slot
+
+  def _make_slot(self, size):
+    dev = self._device
+
+    class Slot:
+      pass
+
+    sl = Slot()
+    sl.size = size
+    sl.nfields = len(self._ring.fields)
+    sl.host = torch.empty(3 * size, dtype=torch.int64).pin_memory()
+    sl.host_np = sl.host.numpy()
+    sl.draws = torch.empty(3 * size, dtype=torch.int64, device=dev)
+    sl.copied = None
+    sl.ids = torch.empty(size, dtype=torch.int64, device=dev)
+    sl.probs = torch.empty(size, dtype=torch.float64, device=dev)
+    sl.w64 = torch.empty(size, dtype=torch.float64, device=dev)
+    sl.w32 = torch.empty(size, dtype=torch.float32, device=dev)
+    outs = [torch.empty((size,) + tuple(f.shape[1:]), dtype=f.dtype, device=dev)
+            for f in self._ring.fields]
+    arr = (_lib.FieldDesc * len(outs))()
+    for i, (f, o) in enumerate(zip(self._ring.fields, outs)):
+      arr[i].src = f.data_ptr()
+      arr[i].dst = o.data_ptr()
+      arr[i].row_bytes = f[0].numel() * f.element_size()
+    sl.fields = arr
+    a = _lib.PrioSampleArgs()
+    a.node = self._tree.data_ptr()
+    a.cap_pow2 = self._cap_pow2
+    a.capacity = self._capacity
+    base = sl.draws.data_ptr()
+    a.pos = base
+    a.u_target = base + 8 * size
+    a.u_mix = base + 16 * size
+    a.usp = self._usp
+    a.one_minus_usp = 1.0 - self._usp
+    a.normalize = int(self._normalize_weights)
+    a.compute_weights = 1
+    a.assume_nonzero_root = 1
+    sl.args = a
+    sl.sample = DeviceSample(type(self._structure)(*outs), sl.ids, sl.probs,
+                             sl.w64, sl.w32)
+    return sl
 
   def sample(self, size: int) -> Tuple[ReplayStructure, np.ndarray, np.ndarray]:
     """Samples a batch of transitions (ref: replay.py:706-723).
@@ -744,6 +831,7 @@ class PrioritizedTransitionReplay(_ReplayBase):
         dst.copy_(torch.from_numpy(src))
     self._tree.copy_(torch.from_numpy(state['sum_tree_storage']))
     self.max_seen_priority_device.fill_(state['max_seen_priority'])
+    self._sample_ring = None  # field arrays may have been re-allocated
 
   def check_valid(self) -> Tuple[bool, str]:
     if self._t < self._size:

@@ -250,6 +250,11 @@ typedef struct {
   float* priorities;         /* [B] clip(|loss|,0,100) (rainbow/agent.py:194) */
   /* optimizer: optax.chain(clip_by_global_norm(max_norm), adam(lr, eps))     */
   float lr, b1, b2, eps, max_norm;
+  /* if non-zero, the forward phase first regenerates the 3 noise blocks on the
+   * device from (noise_seed, *adam_count) -- fresh noise per step without any
+   * per-step host argument, so that the step can be replayed from a hipGraph  */
+  int32_t resample_noise;
+  uint64_t noise_seed;
 } dz_rainbow_args_t;
 
 #define DZ_PHASE_FORWARD 1   /* 3 applies + loss (+ dlogits)                  */
@@ -270,6 +275,17 @@ int dz_rainbow_apply(int num_actions, int num_atoms, int batch, const float* par
                      float* ws, float* q_values_out, int32_t* greedy_out,
                      float* vmax_out, dz_stream_t stream);
 
+/* hipGraph form of dz_rainbow_learn: captures the launches of one call (same
+ * args, same phases; every pointer in `args` is baked in) on `stream` and
+ * returns an executable graph; dz_graph_launch replays it with one API call
+ * (host cost ~10 us instead of ~35 kernel launches).  Requires
+ * args->resample_noise or externally supplied noise; the event profiler must
+ * be off.  dz_graph_destroy releases it.                                    */
+int dz_rainbow_graph_capture(const dz_rainbow_args_t* args, int phases,
+                             dz_stream_t stream, void** graph_exec_out);
+int dz_graph_launch(void* graph_exec, dz_stream_t stream);
+int dz_graph_destroy(void* graph_exec);
+
 /* Fills n noise blocks with f(x)=sign(x)sqrt|x|, x ~ truncated normal on
  * [-2,2] (ref: networks.py:142-144), from a counter-based generator keyed by
  * (seed, counter).  Distribution-equivalent to the reference, not bit-equal
@@ -288,7 +304,8 @@ int dz_prof_read(int max_marks, float* ms_out, char* names_out);
 
 /* Tuning knobs for tools/tune.py (kernel variant / split-K sweeps in one GPU
  * session): key 0 = fc1 forward variant (8 = weight-streaming kernel),
- * 1 = fc1 forward split-K factor, 2 = fc1 dgrad streaming kernel on/off.     */
+ * 1 = fc1 forward split-K factor, 2 = fc1 dgrad streaming kernel on/off,
+ * 4 = run weight gradients on the auxiliary stream (default 1).             */
 int dz_set_tuning(int key, int value);
 
 /* dst = src for a parameter buffer (target network sync,
