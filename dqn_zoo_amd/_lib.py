@@ -79,10 +79,40 @@ class RainbowArgs(ctypes.Structure):
   ]
 
 
+class DenseLayout(ctypes.Structure):
+  _fields_ = (
+      [('num_outputs', c_i32), ('shared_bias', c_i32), ('batch', c_i32),
+       ('groups', c_i32), ('fc1_ld', c_i32), ('fc2_ld', c_i32),
+       ('param_count', c_i64), ('param_count_ref', c_i64),
+       ('conv_w', c_i64 * 3), ('conv_b', c_i64 * 3)] +
+      [(n, c_i64) for n in (
+          'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'ws_count', 'ws_act1', 'ws_act2',
+          'ws_feat', 'ws_fc1_part', 'ws_h1', 'ws_fc2_part', 'ws_out', 'ws_dout',
+          'ws_dh1', 'ws_dfeat_part', 'ws_dfeat', 'ws_dact2', 'ws_dact1',
+          'ws_wgrad_part', 'ws_norm_part', 'ws_scalars', 'ws_zeros')])
+
+
+class DenseArgs(ctypes.Structure):
+  _fields_ = [
+      ('loss', c_i32), ('optimizer', c_i32), ('num_actions', c_i32),
+      ('num_outputs', c_i32), ('batch', c_i32), ('shared_bias', c_i32),
+      ('num_atoms', c_i32), ('online', c_vp), ('target', c_vp), ('grad', c_vp),
+      ('opt_m', c_vp), ('opt_v', c_vp), ('opt_count', c_vp), ('s_tm1', c_vp),
+      ('s_t', c_vp), ('a_tm1', c_vp), ('r_t', c_vp), ('discount_t', c_vp),
+      ('weights', c_vp), ('aux', c_vp), ('ws', c_vp), ('losses', c_vp),
+      ('priorities', c_vp), ('lr', c_f32), ('decay_or_b1', c_f32), ('b2', c_f32),
+      ('eps', c_f32), ('max_norm', c_f32), ('grad_error_bound', c_f32),
+      ('huber', c_f32),
+  ]
+
+
+LOSS_Q, LOSS_DOUBLE_Q, LOSS_CATEGORICAL, LOSS_QUANTILE = 0, 1, 2, 3
+OPT_RMSPROP, OPT_ADAM = 0, 1
 SC_GNORM, SC_LOSS, SC_BC1, SC_BC2, SC_CLIP = 0, 1, 2, 3, 4
 PHASE_FORWARD, PHASE_BACKWARD, PHASE_OPTIMIZER, PHASE_ALL = 1, 2, 4, 7
 
-STRUCT_IDS = {0: FieldDesc, 1: PrioSampleArgs, 2: RainbowLayout, 3: RainbowArgs}
+STRUCT_IDS = {0: FieldDesc, 1: PrioSampleArgs, 2: RainbowLayout, 3: RainbowArgs,
+              4: DenseLayout, 5: DenseArgs}
 
 # name -> (restype, argtypes).  tests/test_abi.py checks this table against
 # the prototypes in include/dqnzoo_hip.h and against the built library.
@@ -100,6 +130,11 @@ SIGNATURES = {
                                          ctypes.POINTER(c_vp)]),
     'dz_graph_launch': (c_int, [c_vp, c_vp]),
     'dz_graph_destroy': (c_int, [c_vp]),
+    'dz_dense_layout': (c_int, [c_int, c_int, c_int, c_int,
+                                ctypes.POINTER(DenseLayout)]),
+    'dz_dense_learn': (c_int, [ctypes.POINTER(DenseArgs), c_int, c_vp]),
+    'dz_dense_apply': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
+                               c_vp, c_vp, c_vp, c_vp]),
     'dz_noise_fill': (c_int, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64,
                               c_vp]),
     'dz_param_copy': (c_int, [c_vp, c_vp, c_i64, c_vp]),

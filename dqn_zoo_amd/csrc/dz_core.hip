@@ -13,6 +13,8 @@ extern "C" int dz_struct_size(int which) {
     case 1: return (int)sizeof(dz_prio_sample_args_t);
     case 2: return (int)sizeof(dz_rainbow_layout_t);
     case 3: return (int)sizeof(dz_rainbow_args_t);
+    case 4: return (int)sizeof(dz_dense_layout_t);
+    case 5: return (int)sizeof(dz_dense_args_t);
     default: return -1;
   }
 }

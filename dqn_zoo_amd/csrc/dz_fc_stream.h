@@ -21,6 +21,8 @@
 
 #include "dz_qnet_ops.h"
 
+namespace {  // internal linkage: this header is included by several .hip files
+
 // ------------------------------- forward ------------------------------------ //
 // part[split][g*M + m][out_off + n] = sum over the split's k of
 //     x[m][k] Wmu[k][n]  (+ (x[m][k] eps_in[k]) (Wsig[k][n] eps_out[n]) when noisy)
@@ -366,3 +368,5 @@ __global__ __launch_bounds__(256) void dz_fc_stream_dgrad(FcStreamDgradParams p)
     }
   }
 }
+
+}  // namespace

@@ -1,0 +1,543 @@
+// Kernels and tile configurations shared by the learner steps of every agent
+// (dz_rainbow.hip: noisy dueling C51; dz_dense.hip: DQN / double-Q / prioritized /
+// C51 / QR dense heads): split-K epilogues, partial reductions, gradient
+// finalisation, global norm, optimisers, noise, loss heads.
+#pragma once
+
+#include "dz_fc_stream.h"
+
+namespace {
+
+constexpr int kFlat = 3136;   // 7*7*64 torso features
+constexpr int kHid = 512;
+constexpr int kG = 3;         // applies: online(s_tm1), online(s_t), target(s_t)
+constexpr int kS_fc1 = 7;     // grid split-K factors
+constexpr int kS_fc2 = 4;
+constexpr int kS_dh1 = 5;
+constexpr int kS_dfeat = 8;
+constexpr int kS_cw1 = 50, kS_cw2 = 27, kS_cw3 = 14;
+constexpr int kNormBlocks = 512;
+
+inline int64_t align4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+constexpr int kMaxSplitFc1 = 32;
+
+// conv geometries (networks.py:194-198)
+//                      U8  H   W   C  KS S  OH  OW  CO
+//                                                       WM WN WK KT
+using Conv1Fwd = ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 4, 1, 1, 4>;
+using Conv2Fwd = ConvFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 1, 2, 2, 4>;
+using Conv3Fwd = ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 2, 2, 3>;
+using Conv1Wg = ConvWgradOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 2, 1, 2, 2>;
+using Conv2Wg = ConvWgradOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 2, 2, 1, 2>;
+using Conv3Wg = ConvWgradOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 2, 2, 1, 2>;
+using Conv2Dg = ConvDgradOp<20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4, 1>;
+using Conv3Dg = ConvDgradOp<9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4, 3>;
+using FcFwd = FcFwdOp<1, 2, 2, 4>;
+using FcDg = FcDgradOp<1, 2, 2, 4>;
+using FcWg = FcWgradOp<2, 2, 1, 2>;
+
+// ---- small kernels ----------------------------------------------------------
+
+// out[r][c] = act( sum_s part[s][r][c] + b_mu[c] + b_sig[c]*eps_out[g][c] )
+// block = 64 columns x 4 waves striding over the split slabs (LDS combine).
+__global__ __launch_bounds__(256) void fc_epilogue_kernel(
+    const float* __restrict__ part, int S, int rows, int cols, int ld,
+    int rows_per_group, const float* p0, const float* p1, const float* p2, long b_mu,
+    long b_sig, const float* n0, const float* n1, const float* n2, int eps_out, int relu,
+    float* __restrict__ out, int bias_shared = 0) {
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l;
+  const int r = blockIdx.y;
+  float v = 0.f;
+  if (c < cols)
+    for (int s = w; s < S; s += 4) v += part[((long)s * rows + r) * ld + c];
+  red[w][l] = v;
+  __syncthreads();
+  if (w != 0 || c >= cols) return;
+  v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  const int g = r / rows_per_group;
+  const float* prm = g == 0 ? p0 : (g == 1 ? p1 : p2);
+  const float* nz = g == 0 ? n0 : (g == 1 ? n1 : n2);
+  if (b_mu >= 0) v += prm[b_mu + (bias_shared ? 0 : c)];  // networks.py:120-134
+  if (b_sig >= 0) v += prm[b_sig + c] * nz[eps_out + c];
+  if (relu) v = v > 0.f ? v : 0.f;
+  out[(long)r * ld + c] = v;
+}
+
+// out[i] = (mask? mask[i] > 0 : 1) * sum_s part[s][i].  64 outputs per block;
+// the 4 waves stride over the S partial slabs and combine through LDS, so the
+// dependent-add chain is S/4 long and every load is a coalesced 256-byte row.
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* part, int S,
+                                                           long n, const float* mask,
+                                                           float* out) {
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + l;
+  float v = 0.f;
+  if (i < n)
+    for (int s = w; s < S; s += 4) v += part[(long)s * n + i];
+  red[w][l] = v;
+  __syncthreads();
+  if (w == 0 && i < n) {
+    v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    if (mask && !(mask[i] > 0.f)) v = 0.f;
+    out[i] = v;
+  }
+}
+
+// Column sums of the (short) linear-layer output gradients: out[c] = sum_r m[r][c],
+// out_scaled[c] = out[c] * scale[c] (the sigma-bias gradient).  Convolution
+// bias gradients come out of the wgrad GEMM (ConvWgradOp's extra row).
+struct ColsumJob {
+  const float* m; int rows; int cols; int ld; float* out; const float* scale;
+  float* out_scaled;
+};
+struct ColsumJobs { ColsumJob j[4]; int n; };
+__global__ __launch_bounds__(256) void colsum_kernel(ColsumJobs jobs) {
+  __shared__ float red[4][64];
+  const ColsumJob jb = jobs.j[blockIdx.y];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l;
+  if (blockIdx.x * 64 >= jb.cols) return;
+  float v = 0.f;
+  if (c < jb.cols) {
+#pragma unroll 4
+    for (int r = w; r < jb.rows; r += 4) v += jb.m[(long)r * jb.ld + c];
+  }
+  red[w][l] = v;
+  __syncthreads();
+  if (w == 0 && c < jb.cols) {
+    const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    if (jb.out) jb.out[c] = s;
+    if (jb.out_scaled) jb.out_scaled[c] = s * jb.scale[c];
+  }
+}
+
+// Gradient finalisation in ONE launch: the split-K partial slabs of the three
+// convolution weight(+bias) gradients are reduced into the gradient buffer and
+// the linear-layer bias gradients (column sums) are formed.  blockIdx.x ranges:
+// [0, t0) reduce job 0, [t0, t1) job 1, [t1, t2) job 2, then the colsum tiles.
+struct ReduceJob { const float* part; int S; long n; float* out; };
+struct FinalizeJobs {
+  ReduceJob r[3];
+  unsigned r_end[3];      // exclusive prefix of 64-wide tiles
+  ColsumJob c[2];
+  unsigned c_tiles[2];    // tiles per colsum job
+};
+__global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned b = blockIdx.x;
+  float v = 0.f;
+  if (b < J.r_end[2]) {
+    const int j = b < J.r_end[0] ? 0 : (b < J.r_end[1] ? 1 : 2);
+    const ReduceJob jb = J.r[j];
+    const long i = (long)(b - (j ? J.r_end[j - 1] : 0)) * 64 + l;
+    if (i < jb.n)
+      for (int s = w; s < jb.S; s += 4) v += jb.part[(long)s * jb.n + i];
+    red[w][l] = v;
+    __syncthreads();
+    if (w == 0 && i < jb.n)
+      jb.out[i] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    return;
+  }
+  b -= J.r_end[2];
+  const int j = b < J.c_tiles[0] ? 0 : 1;
+  const ColsumJob jb = J.c[j];
+  const int c = (int)(b - (j ? J.c_tiles[0] : 0)) * 64 + l;
+  if (c < jb.cols) {
+#pragma unroll 4
+    for (int r = w; r < jb.rows; r += 4) v += jb.m[(long)r * jb.ld + c];
+  }
+  red[w][l] = v;
+  __syncthreads();
+  if (w == 0 && c < jb.cols) {
+    const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    if (jb.out) jb.out[c] = s;
+    if (jb.out_scaled) jb.out_scaled[c] = s * jb.scale[c];
+  }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// One wave per sample; lane k owns atom k (K <= 64).
+// ref: networks.py:254-258 (dueling, softmax, expectation),
+//      rainbow/agent.py:97-109 + rlax.categorical_double_q_learning,
+//      rainbow/agent.py:194 (priorities).
+__global__ __launch_bounds__(64) void rainbow_head_loss_kernel(
+    const float* __restrict__ fc2_out, int ld, int val_off, int B, int A, int K,
+    int dueling, int sel_group, int tgt_group, const int64_t* __restrict__ a_tm1, const double* __restrict__ r_t,
+    const double* __restrict__ d_t, const float* __restrict__ weights,
+    const float* __restrict__ support, float* __restrict__ dout2,
+    float* __restrict__ losses, float* __restrict__ priorities,
+    float* __restrict__ q_sel_out, float* __restrict__ target_out) {
+  __shared__ float s_p[64];
+  __shared__ float s_z[64];
+  const int b = blockIdx.x, k = threadIdx.x;
+  const bool on = k < K;
+  const int NA = val_off;  // value-head columns start at the padded offset
+  const float z = on ? support[k] : 0.f;
+  const float invA = 1.0f / (float)A;
+
+  // logits of action a: dueling  v + adv_a - mean_a adv  (networks.py:254) or the
+  // head output itself (c51_atari_network, networks.py:329).
+  // ---- selector network: q_values -> argmax.  Rainbow: online(s_t)
+  // (double-Q, rainbow/agent.py:91-93); C51: the target network itself
+  // (rlax.categorical_q_learning) ----
+  const float* o1 = fc2_out + (long)(sel_group * B + b) * ld;
+  float mean_adv = 0.f;
+  if (dueling) {
+    for (int a = 0; a < A; ++a) mean_adv += on ? o1[a * K + k] : 0.f;
+    mean_adv /= (float)A;
+  }
+  const float v1 = (on && dueling) ? o1[NA + k] : 0.f;
+  float best_q = -__builtin_inff();
+  int a_star = 0;
+  for (int a = 0; a < A; ++a) {
+    const float lg = on ? (v1 + o1[a * K + k] - mean_adv) : -__builtin_inff();
+    const float mx = wave_max(lg);
+    const float e = on ? expf(lg - mx) : 0.f;
+    const float sm = wave_sum(e);
+    const float q = wave_sum((e / sm) * z);
+    if (k == 0 && q_sel_out) q_sel_out[b * A + a] = q;
+    if (q > best_q) { best_q = q; a_star = a; }  // first maximum, as jnp.argmax
+  }
+  // ---- target distribution of the selected action ----
+  const float* o2 = fc2_out + (long)(tgt_group * B + b) * ld;
+  float mean2 = 0.f;
+  if (dueling) {
+    for (int a = 0; a < A; ++a) mean2 += on ? o2[a * K + k] : 0.f;
+    mean2 /= (float)A;
+  }
+  const float lg2 = on ? ((dueling ? o2[NA + k] : 0.f) + o2[a_star * K + k] - mean2)
+                       : -__builtin_inff();
+  const float mx2 = wave_max(lg2);
+  const float e2 = on ? expf(lg2 - mx2) : 0.f;
+  const float p_t = e2 / wave_sum(e2);
+  // ---- Cramer projection of (r + g z, p_t) onto the support ----
+  const float r = (float)r_t[b], g = (float)d_t[b];  // f64 -> f32 at the jit boundary
+  const float vmin = support[0], vmax = support[K - 1];
+  float zp = r + g * z;
+  zp = fminf(fmaxf(zp, vmin), vmax);
+  s_p[k] = on ? p_t : 0.f;
+  s_z[k] = zp;
+  __syncthreads();
+  float m = 0.f;
+  if (on) {
+    const float zq = z;
+    const float dpos = (k + 1 < K ? support[k + 1] : support[0]) - zq;
+    const float dneg = zq - (k > 0 ? support[k - 1] : support[K - 1]);
+    const float rpos = dpos > 0.f ? 1.0f / dpos : 0.f;
+    const float rneg = dneg > 0.f ? 1.0f / dneg : 0.f;
+    for (int j = 0; j < K; ++j) {
+      const float delta = s_z[j] - zq;
+      const float dh = delta >= 0.f ? delta * rpos : -(delta * rneg);
+      const float c = fminf(fmaxf(1.0f - dh, 0.f), 1.f);
+      m += c * s_p[j];
+    }
+  }
+  if (target_out && on) target_out[b * K + k] = m;
+  // ---- group 0: cross-entropy with log_softmax(logits_tm1[a_tm1]) ----
+  const int a0 = (int)a_tm1[b];
+  const float* o0 = fc2_out + (long)(0 * B + b) * ld;
+  float mean0 = 0.f;
+  if (dueling) {
+    for (int a = 0; a < A; ++a) mean0 += on ? o0[a * K + k] : 0.f;
+    mean0 /= (float)A;
+  }
+  const float lg0 = on ? ((dueling ? o0[NA + k] : 0.f) + o0[a0 * K + k] - mean0)
+                       : -__builtin_inff();
+  const float mx0 = wave_max(lg0);
+  const float sh = lg0 - mx0;
+  const float e0 = on ? expf(sh) : 0.f;
+  const float se0 = wave_sum(e0);
+  const float lsm = sh - logf(se0);
+  const float loss = -wave_sum(on ? m * lsm : 0.f);
+  const float msum = wave_sum(m);
+  // d loss / d logits_tm1[a0][k], scaled by w/B (loss = mean(losses*w))
+  const float gk = on ? ((e0 / se0) * msum - m) * (weights[b] / (float)B) : 0.f;
+  if (on) {
+    float* d = dout2 + (long)b * ld;
+    for (int a = 0; a < A; ++a)  // dueling: dadv[a][k] = G[a][k] - mean_a G[.][k]
+      d[a * K + k] = (a == a0 ? gk : 0.f) - (dueling ? gk * invA : 0.f);
+    if (dueling) d[NA + k] = gk;  // dval[k] = sum_a G[a][k]
+  }
+  if (k == 0) {
+    losses[b] = loss;
+    priorities[b] = fminf(fmaxf(fabsf(loss), 0.f), 100.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
+                                                    long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = ((const float4*)g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// One block: global norm, clip decision, Adam bias corrections, mean loss.
+// (A single-launch "last workgroup finishes" form with agent-scope fences was
+// measured slower than this second tiny launch: 20 us vs 9 + 8 us.)
+__global__ __launch_bounds__(256) void opt_scalars_kernel(
+    const float* __restrict__ part, int nparts, int32_t* count, float b1, float b2,
+    float max_norm, const float* __restrict__ losses, const float* __restrict__ weights,
+    int B, float* __restrict__ sc) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float gn = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    const int c = *count + 1;  // optax: count_inc = count + 1
+    *count = c;
+    sc[DZ_SC_GNORM] = gn;
+    sc[DZ_SC_BC1] = 1.0f - powf(b1, (float)c);
+    sc[DZ_SC_BC2] = 1.0f - powf(b2, (float)c);
+    sc[DZ_SC_CLIP] = (max_norm > 0.f && !(gn < max_norm)) ? 0.f : 1.f;
+    float l = 0.f;
+    for (int i = 0; i < B; ++i) l += losses[i] * weights[i];
+    sc[DZ_SC_LOSS] = l / (float)B;
+  }
+}
+
+// optax.clip_by_global_norm then optax.adam, then apply_updates.
+__global__ __launch_bounds__(256) void adam_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+    float* __restrict__ v, long n4, const float* __restrict__ sc, float lr, float b1,
+    float b2, float eps, float max_norm) {
+  const float gn = sc[DZ_SC_GNORM], bc1 = sc[DZ_SC_BC1], bc2 = sc[DZ_SC_BC2];
+  const bool pass = sc[DZ_SC_CLIP] != 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 gv = ((const float4*)g)[i];
+    float4 mv = ((float4*)m)[i], vv = ((float4*)v)[i], pv = ((float4*)p)[i];
+    float* G = (float*)&gv; float* M = (float*)&mv; float* V = (float*)&vv;
+    float* P = (float*)&pv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = pass ? G[j] : (G[j] / gn) * max_norm;
+      M[j] = (1.0f - b1) * gj + b1 * M[j];
+      V[j] = (1.0f - b2) * (gj * gj) + b2 * V[j];
+      const float upd = (M[j] / bc1) / (sqrtf(V[j] / bc2) + eps);
+      P[j] = P[j] + (-lr) * upd;
+    }
+    ((float4*)m)[i] = mv; ((float4*)v)[i] = vv; ((float4*)p)[i] = pv;
+  }
+}
+
+__global__ void copy_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                            long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long)gridDim.x * blockDim.x)
+    ((float4*)dst)[i] = ((const float4*)src)[i];
+}
+
+// Counter-based generator (splitmix64 finaliser on (seed, counter+i)), two
+// 24-bit uniforms -> standard normal via inverse CDF restricted to [-2,2].
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ void noise_fill_kernel(float* __restrict__ out, long n, uint64_t seed,
+                                  uint64_t counter, const int32_t* __restrict__ step) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (step) counter += (uint64_t)(*step) * (uint64_t)n;  // per-step stream offset
+  const uint64_t h = mix64(mix64(seed) ^ mix64(counter + (uint64_t)i));
+  // jax.random.truncated_normal: sqrt2 * erfinv(U(erf(lo/sqrt2), erf(hi/sqrt2)))
+  const float u01 = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+  const float e = 0.9544997361036416f;  // erf(2/sqrt(2))
+  const float u = (2.0f * u01 - 1.0f) * e;
+  float x = 1.4142135623730951f * erfinvf(u);
+  x = fminf(fmaxf(x, -2.0f), 2.0f);
+  const float s = sqrtf(fabsf(x));
+  out[i] = x < 0.f ? -s : (x > 0.f ? s : 0.f);  // sign(x) * sqrt|x| (networks.py:144)
+}
+
+// q_values[b][a] = sum_k softmax(v + adv_a - mean_a adv)[k] * support[k]
+// (ref: networks.py:254-258); also the greedy action and its value
+// (ref: rainbow/agent.py:125-131, first maximum).
+__global__ __launch_bounds__(64) void rainbow_q_values_kernel(
+    const float* __restrict__ fc2_out, int ld, int val_off, int A, int K,
+    const float* __restrict__ support, float* __restrict__ q_out,
+    int32_t* __restrict__ greedy_out, float* __restrict__ vmax_out) {
+  const int b = blockIdx.x, k = threadIdx.x;
+  const bool on = k < K;
+  const float z = on ? support[k] : 0.f;
+  const float* o = fc2_out + (long)b * ld;
+  float mean_adv = 0.f;
+  for (int a = 0; a < A; ++a) mean_adv += on ? o[a * K + k] : 0.f;
+  mean_adv /= (float)A;
+  const float v = on ? o[val_off + k] : 0.f;
+  float best = -__builtin_inff();
+  int arg = 0;
+  for (int a = 0; a < A; ++a) {
+    const float lg = on ? (v + o[a * K + k] - mean_adv) : -__builtin_inff();
+    const float mx = wave_max(lg);
+    const float e = on ? expf(lg - mx) : 0.f;
+    const float sm = wave_sum(e);
+    const float q = wave_sum((e / sm) * z);
+    if (k == 0) q_out[b * A + a] = q;
+    if (q > best) { best = q; arg = a; }
+  }
+  if (k == 0) {
+    if (greedy_out) greedy_out[b] = arg;
+    if (vmax_out) vmax_out[b] = best;
+  }
+}
+
+// rlax.q_learning / double_q_learning + clip_gradient + l2_loss (+ IS weights):
+//   td = r + g * q_target[a*] - q_tm1[a],  a* = argmax(selector)
+//   loss = mean(0.5 td^2 w);  d loss / d q_tm1[a] = -clip(w td / B, +-bound)
+// ref: dqn/agent.py:94-106, double_q/agent.py:97-111, prioritized/agent.py:98-113.
+// One thread per sample.  out rows: group g at (g*B + b)*ld.
+__global__ void td_loss_kernel(const float* __restrict__ out, int ld, int B, int A,
+                               int sel_group, int tgt_group,
+                               const int64_t* __restrict__ a_tm1,
+                               const double* __restrict__ r_t,
+                               const double* __restrict__ d_t,
+                               const float* __restrict__ weights, float bound,
+                               float* __restrict__ dout, float* __restrict__ td_out,
+                               float* __restrict__ prio_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* q0 = out + (long)b * ld;
+  const float* qs = out + (long)(sel_group * B + b) * ld;
+  const float* qt = out + (long)(tgt_group * B + b) * ld;
+  int a_star = 0;
+  float best = qs[0];
+  for (int a = 1; a < A; ++a)
+    if (qs[a] > best) { best = qs[a]; a_star = a; }
+  const int a0 = (int)a_tm1[b];
+  const float td = ((float)r_t[b] + (float)d_t[b] * qt[a_star]) - q0[a0];
+  const float w = weights ? weights[b] : 1.0f;
+  float g = td * w / (float)B;
+  g = fminf(fmaxf(g, -bound), bound);
+  float* d = dout + (long)b * ld;
+  for (int a = 0; a < A; ++a) d[a] = (a == a0) ? -g : 0.f;
+  td_out[b] = td;
+  if (prio_out) prio_out[b] = fabsf(td);  // prioritized/agent.py:202
+}
+
+// vmap(rlax.quantile_q_learning), no double-Q (qrdqn/agent.py:98-107).
+// dist layout [N][A] (quantile-major, networks.py:308).  One block per sample,
+// thread i owns quantile theta_i.
+__global__ __launch_bounds__(256) void quantile_loss_kernel(
+    const float* __restrict__ out, int ld, int B, int A, int N, int sel_group,
+    int tgt_group, const float* __restrict__ tau, const int64_t* __restrict__ a_tm1,
+    const double* __restrict__ r_t, const double* __restrict__ d_t, float kappa,
+    float* __restrict__ dout, float* __restrict__ losses) {
+  __shared__ float s_t[256];
+  __shared__ float s_red[4];
+  __shared__ int s_astar;
+  const int b = blockIdx.x, i = threadIdx.x;
+  const float* ds = out + (long)(sel_group * B + b) * ld;
+  const float* dt = out + (long)(tgt_group * B + b) * ld;
+  const float* d0 = out + (long)b * ld;
+  if (i < 64) {  // a* = argmax_a mean_n dist_sel[n][a]
+    float best = -__builtin_inff();
+    int arg = 0;
+    for (int a = 0; a < A; ++a) {
+      float sum = 0.f;
+      for (int n = i; n < N; n += 64) sum += ds[n * A + a];
+      sum = wave_sum(sum) / (float)N;
+      if (sum > best) { best = sum; arg = a; }
+    }
+    if (i == 0) s_astar = arg;
+  }
+  __syncthreads();
+  const int a_star = s_astar, a0 = (int)a_tm1[b];
+  const float r = (float)r_t[b], g = (float)d_t[b];
+  if (i < N) s_t[i] = r + g * dt[i * A + a_star];
+  __syncthreads();
+  float li = 0.f, gi = 0.f;
+  if (i < N) {
+    const float theta = d0[i * A + a0], ti = tau[i];
+    for (int j = 0; j < N; ++j) {
+      const float delta = s_t[j] - theta;
+      const float wgt = fabsf(ti - (delta < 0.f ? 1.f : 0.f));
+      const float ad = fabsf(delta);
+      float hub, dh;
+      if (kappa > 0.f) {
+        const float q = fminf(ad, kappa);
+        hub = 0.5f * q * q + kappa * (ad - q);
+        dh = ad <= kappa ? delta : (delta > 0.f ? kappa : -kappa);
+      } else {
+        hub = ad;
+        dh = delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f);
+      }
+      li += wgt * hub;
+      gi += wgt * dh;
+    }
+    li /= (float)N;           // mean over targets j
+    gi = -gi / (float)N;      // d loss_i / d theta_i
+  }
+  // loss = sum_i mean_j; scaled by 1/B for the batch mean
+  float s = wave_sum(li);
+  if ((i & 63) == 0) s_red[i >> 6] = s;
+  __syncthreads();
+  if (i == 0) losses[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  float* d = dout + (long)b * ld;
+  if (i < N)
+    for (int a = 0; a < A; ++a) d[i * A + a] = (a == a0) ? gi / (float)B : 0.f;
+}
+
+// optax.rmsprop(lr, decay, eps, centered=True) + apply_updates
+// (dqn/run_atari.py:205-210): eps INSIDE the sqrt, no bias correction.
+__global__ __launch_bounds__(256) void rmsprop_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
+    float* __restrict__ nu, long n4, float lr, float decay, float eps) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 gv = ((const float4*)g)[i];
+    float4 mv = ((float4*)mu)[i], vv = ((float4*)nu)[i], pv = ((float4*)p)[i];
+    float* G = (float*)&gv; float* M = (float*)&mv; float* V = (float*)&vv;
+    float* P = (float*)&pv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      M[j] = (1.0f - decay) * G[j] + decay * M[j];
+      V[j] = (1.0f - decay) * (G[j] * G[j]) + decay * V[j];
+      const float upd = G[j] / sqrtf(V[j] - M[j] * M[j] + eps);
+      P[j] = P[j] + (-lr) * upd;
+    }
+    ((float4*)mu)[i] = mv; ((float4*)nu)[i] = vv; ((float4*)p)[i] = pv;
+  }
+}
+
+// q_values of a plain Q head + greedy action + max (dqn/agent.py:121-131)
+__global__ void dense_q_values_kernel(const float* __restrict__ out, int ld, int B, int A,
+                                      float* __restrict__ q_out,
+                                      int32_t* __restrict__ greedy_out,
+                                      float* __restrict__ vmax_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* q = out + (long)b * ld;
+  int arg = 0;
+  float best = q[0];
+  for (int a = 0; a < A; ++a) {
+    q_out[b * A + a] = q[a];
+    if (q[a] > best) { best = q[a]; arg = a; }
+  }
+  if (greedy_out) greedy_out[b] = arg;
+  if (vmax_out) vmax_out[b] = best;
+}
+
+}  // namespace

@@ -221,3 +221,164 @@ class RainbowLearner:
         self._lib.dz_graph_destroy(g)
     except Exception:  # pylint: disable=broad-except
       pass
+
+
+# --------------------------------------------------------------------------- #
+#  Dense-head learners (DQN, double-Q, prioritized, C51, QR-DQN)
+# --------------------------------------------------------------------------- #
+class RmsPropConfig(typing.NamedTuple):
+  """optax.rmsprop(learning_rate, decay, eps, centered=True)
+  (ref: dqn/run_atari.py:78-83, 205-210)."""
+  learning_rate: float = 0.00025
+  decay: float = 0.95
+  eps: float = 0.01 / 32 ** 2
+
+
+class DenseLearner:
+  """The jitted `update` of the dense-head agents as one C-ABI call.
+
+  loss: 'q' (dqn/agent.py:85-117), 'double_q' (double_q/agent.py:85-120 and,
+  with importance weights, prioritized/agent.py:86-122), 'categorical'
+  (c51/agent.py:87-116), 'quantile' (qrdqn/agent.py:88-119).
+  optimizer: RmsPropConfig or AdamConfig."""
+
+  LOSSES = {'q': _lib.LOSS_Q, 'double_q': _lib.LOSS_DOUBLE_Q,
+            'categorical': _lib.LOSS_CATEGORICAL, 'quantile': _lib.LOSS_QUANTILE}
+
+  def __init__(self, network: networks.DenseNetwork, loss: str, optimizer,
+               batch_size: int, grad_error_bound: float = 1.0 / 32,
+               huber_param: float = 1.0, seed: int = 1, device=None, params=None):
+    self._lib = _lib.load()
+    if not torch.cuda.is_available():
+      raise _lib.HipLibraryError('DenseLearner needs an AMD GPU; no CPU fallback')
+    self.device = torch.device('cuda', torch.cuda.current_device()) \
+        if device is None else torch.device(device)
+    self.network = network
+    self.loss = loss
+    self.loss_id = self.LOSSES[loss]
+    self.opt = optimizer
+    self.batch_size = int(batch_size)
+    self.groups = 3 if loss == 'double_q' else 2
+    self.layout = network.layout(self.batch_size, self.groups)
+    L = self.layout
+    if params is None:
+      params = network.init(np.random.RandomState(seed))
+    f32 = dict(dtype=torch.float32, device=self.device)
+    self.online = torch.from_numpy(L.pack(params)).to(self.device)
+    self.target = self.online.clone()
+    self.grad = torch.zeros(L.param_count, **f32)
+    self.opt_m = torch.zeros(L.param_count, **f32)
+    self.opt_v = torch.zeros(L.param_count, **f32)
+    self.opt_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+    self.ws = torch.zeros(L.ws_count, **f32)
+    self.losses = torch.zeros(self.batch_size, **f32)      # td errors or losses
+    self.priorities = torch.zeros(self.batch_size, **f32)  # |td|
+    self.ones = torch.ones(self.batch_size, **f32)
+    aux = network.support if network.kind == 'c51' else network.quantiles
+    self.aux = None if aux is None else torch.from_numpy(aux).to(self.device)
+    self.grad_error_bound = float(grad_error_bound)
+    self.huber_param = float(huber_param)
+    self._act_ws = None
+    self._act_batch = 0
+
+  def get_params(self, which='online') -> dict:
+    t = self.online if which == 'online' else self.target
+    return self.layout.unpack(t.cpu().numpy())
+
+  def set_params(self, params: dict, which='online') -> None:
+    t = self.online if which == 'online' else self.target
+    t.copy_(torch.from_numpy(self.layout.pack(params)))
+
+  def sync_target(self) -> None:
+    _lib.check(self._lib.dz_param_copy(
+        self.target.data_ptr(), self.online.data_ptr(), self.layout.param_count,
+        torch.cuda.current_stream(self.device).cuda_stream), 'dz_param_copy')
+
+  def get_opt_state(self) -> dict:
+    return dict(count=int(self.opt_count.item()),
+                mu=self.layout.unpack(self.opt_m.cpu().numpy()),
+                nu=self.layout.unpack(self.opt_v.cpu().numpy()))
+
+  def set_opt_state(self, state: dict) -> None:
+    self.opt_count.fill_(int(state['count']))
+    self.opt_m.copy_(torch.from_numpy(self.layout.pack(state['mu'])))
+    self.opt_v.copy_(torch.from_numpy(self.layout.pack(state['nu'])))
+
+  def ws_view(self, name: str, count: int) -> torch.Tensor:
+    off = int(getattr(self.layout.c, 'ws_' + name))
+    return self.ws[off:off + count]
+
+  def step(self, s_tm1, a_tm1, r_t, discount_t, s_t, weights=None,
+           phases: int = _lib.PHASE_ALL) -> None:
+    b = self.batch_size
+    assert s_tm1.dtype == torch.uint8 and s_t.dtype == torch.uint8
+    assert tuple(s_tm1.shape) == (b, 84, 84, 4) and s_tm1.is_contiguous()
+    assert a_tm1.dtype == torch.int64 and r_t.dtype == torch.float64
+    assert discount_t.dtype == torch.float64
+    a = _lib.DenseArgs()
+    net = self.network
+    a.loss = self.loss_id
+    adam = isinstance(self.opt, AdamConfig)
+    a.optimizer = _lib.OPT_ADAM if adam else _lib.OPT_RMSPROP
+    a.num_actions = net.num_actions
+    a.num_outputs = net.num_outputs
+    a.batch = b
+    a.shared_bias = int(net.shared_bias)
+    a.num_atoms = net.num_atoms
+    a.online = self.online.data_ptr()
+    a.target = self.target.data_ptr()
+    a.grad = self.grad.data_ptr()
+    a.opt_m = self.opt_m.data_ptr()
+    a.opt_v = self.opt_v.data_ptr()
+    a.opt_count = self.opt_count.data_ptr()
+    a.s_tm1 = s_tm1.data_ptr()
+    a.s_t = s_t.data_ptr()
+    a.a_tm1 = a_tm1.data_ptr()
+    a.r_t = r_t.data_ptr()
+    a.discount_t = discount_t.data_ptr()
+    if weights is None and self.loss == 'categorical':
+      weights = self.ones   # the categorical head kernel always takes weights
+    if weights is not None:
+      assert weights.dtype == torch.float32
+      a.weights = weights.data_ptr()
+    a.aux = None if self.aux is None else self.aux.data_ptr()
+    a.ws = self.ws.data_ptr()
+    a.losses = self.losses.data_ptr()
+    a.priorities = self.priorities.data_ptr()
+    if adam:
+      a.lr, a.decay_or_b1, a.b2 = self.opt.learning_rate, self.opt.b1, self.opt.b2
+      a.eps, a.max_norm = self.opt.eps, self.opt.max_global_grad_norm
+    else:
+      a.lr, a.decay_or_b1, a.b2 = self.opt.learning_rate, self.opt.decay, 0.0
+      a.eps, a.max_norm = self.opt.eps, 0.0
+    a.grad_error_bound = self.grad_error_bound
+    a.huber = self.huber_param
+    _lib.check(self._lib.dz_dense_learn(
+        ctypes.byref(a), phases,
+        torch.cuda.current_stream(self.device).cuda_stream), 'dz_dense_learn')
+
+  def apply(self, states: torch.Tensor, which: str = 'online'):
+    """Head outputs [B, num_outputs] for uint8 states; for Q heads also
+    (q_values, greedy, max).  ref: dqn/agent.py:121-131."""
+    assert states.dtype == torch.uint8 and states.is_contiguous()
+    b = int(states.shape[0])
+    net = self.network
+    if self._act_batch != b:
+      self._act_ws = torch.zeros(net.layout(b, 1).ws_count, dtype=torch.float32,
+                                 device=self.device)
+      self._act_batch = b
+    out = torch.empty((b, net.num_outputs), dtype=torch.float32, device=self.device)
+    is_q = net.num_outputs == net.num_actions
+    q = torch.empty((b, net.num_actions), dtype=torch.float32, device=self.device) \
+        if is_q else None
+    greedy = torch.empty(b, dtype=torch.int32, device=self.device) if is_q else None
+    vmax = torch.empty(b, dtype=torch.float32, device=self.device) if is_q else None
+    params = self.online if which == 'online' else self.target
+    _lib.check(self._lib.dz_dense_apply(
+        net.num_actions, net.num_outputs, int(net.shared_bias), b,
+        params.data_ptr(), states.data_ptr(), self._act_ws.data_ptr(),
+        out.data_ptr(), None if q is None else q.data_ptr(),
+        None if greedy is None else greedy.data_ptr(),
+        None if vmax is None else vmax.data_ptr(),
+        torch.cuda.current_stream(self.device).cuda_stream), 'dz_dense_apply')
+    return out, q, greedy, vmax

@@ -169,3 +169,115 @@ class RainbowParamLayout:
         'val2/out': block[c.n_fc2_out + self.val_off:
                           c.n_fc2_out + self.val_off + self.num_atoms].copy(),
     }
+
+
+# --------------------------------------------------------------------------- #
+#  Dense-head networks: dqn, double_dqn, c51, qr (ref: networks.py:295-363)
+# --------------------------------------------------------------------------- #
+class QNetworkOutputs(typing.NamedTuple):
+  q_values: typing.Any
+
+
+class QRNetworkOutputs(typing.NamedTuple):
+  q_values: typing.Any
+  q_dist: typing.Any
+
+
+class DenseNetwork:
+  """Descriptor of `dqn_atari_network` / `double_dqn_atari_network` /
+  `c51_atari_network` / `qr_atari_network`: dqn_torso + linear(512) + ReLU +
+  linear(num_outputs); `shared_bias` is the single scalar bias of the
+  double-DQN head (ref: networks.py:120-134, 338-349)."""
+
+  KINDS = ('dqn', 'double_dqn', 'c51', 'qr')
+
+  def __init__(self, kind: str, num_actions: int, support=None, quantiles=None):
+    if kind not in self.KINDS:
+      raise ValueError('unknown network kind %r' % kind)
+    self.kind = kind
+    self.num_actions = int(num_actions)
+    self.shared_bias = kind == 'double_dqn'
+    self.support = None
+    self.quantiles = None
+    self.num_atoms = 0
+    if kind == 'c51':
+      self.support = np.asarray(support, dtype=np.float32)
+      if self.support.ndim != 1:
+        raise ValueError('support must have rank 1')
+      self.num_atoms = int(self.support.shape[0])
+    elif kind == 'qr':
+      self.quantiles = np.asarray(quantiles, dtype=np.float32)
+      if self.quantiles.ndim != 1:
+        raise ValueError('quantiles must have rank 1')
+      self.num_atoms = int(self.quantiles.shape[0])
+    self.num_outputs = self.num_actions * max(self.num_atoms, 1)
+
+  def layout(self, batch_size: int, groups: int = 2) -> 'DenseParamLayout':
+    return DenseParamLayout(self.num_outputs, self.shared_bias, batch_size, groups)
+
+  def init(self, random_state: np.random.RandomState) -> dict:
+    """U(+-1/sqrt(fan_in)) for weights and biases (ref: networks.py:58-79)."""
+    p = {}
+
+    def uni(shape, fan):
+      c = np.sqrt(1.0 / fan)
+      return random_state.uniform(-c, c, size=shape).astype(np.float32)
+
+    for name, ks, ci, co in (('conv1', 8, 4, 32), ('conv2', 4, 32, 64),
+                             ('conv3', 3, 64, 64)):
+      p[name + '/w'] = uni((ks, ks, ci, co), ci * ks * ks)
+      p[name + '/b'] = uni((co,), ci * ks * ks)
+    p['fc1/w'] = uni((FLAT, HIDDEN), FLAT)
+    p['fc1/b'] = uni((HIDDEN,), FLAT)
+    p['fc2/w'] = uni((HIDDEN, self.num_outputs), HIDDEN)
+    p['fc2/b'] = uni((1,) if self.shared_bias else (self.num_outputs,), HIDDEN)
+    return p
+
+
+class DenseParamLayout:
+
+  def __init__(self, num_outputs, shared_bias, batch_size, groups):
+    self.c = _lib.DenseLayout()
+    _lib.check(_lib.load().dz_dense_layout(num_outputs, int(shared_bias),
+                                           batch_size, groups,
+                                           ctypes.byref(self.c)),
+               'dz_dense_layout')
+    self.num_outputs = num_outputs
+    self.shared_bias = bool(shared_bias)
+
+  @property
+  def param_count(self):
+    return int(self.c.param_count)
+
+  @property
+  def ws_count(self):
+    return int(self.c.ws_count)
+
+  def _views(self, flat):
+    c = self.c
+    v = {}
+    shapes = [(8, 8, 4, 32), (4, 4, 32, 64), (3, 3, 64, 64)]
+    for i, shp in enumerate(shapes):
+      n = int(np.prod(shp))
+      v['conv%d/w' % (i + 1)] = flat[c.conv_w[i]:c.conv_w[i] + n].reshape(shp)
+      v['conv%d/b' % (i + 1)] = flat[c.conv_b[i]:c.conv_b[i] + shp[3]]
+    l1, l2, n = int(c.fc1_ld), int(c.fc2_ld), self.num_outputs
+    v['fc1/w'] = flat[c.fc1_w:c.fc1_w + FLAT * l1].reshape(FLAT, l1)[:, :HIDDEN]
+    v['fc1/b'] = flat[c.fc1_b:c.fc1_b + HIDDEN]
+    v['fc2/w'] = flat[c.fc2_w:c.fc2_w + HIDDEN * l2].reshape(HIDDEN, l2)[:, :n]
+    v['fc2/b'] = flat[c.fc2_b:c.fc2_b + (1 if self.shared_bias else n)]
+    return v
+
+  def pack(self, params: dict) -> np.ndarray:
+    flat = np.zeros(self.param_count, np.float32)
+    views = self._views(flat)
+    if set(views) != set(params):
+      raise ValueError('parameter names differ: %s' %
+                       sorted(set(views) ^ set(params)))
+    for name, view in views.items():
+      view[...] = np.asarray(params[name], dtype=np.float32)
+    return flat
+
+  def unpack(self, flat: np.ndarray) -> dict:
+    flat = np.asarray(flat, dtype=np.float32)
+    return {k: np.array(v) for k, v in self._views(flat).items()}

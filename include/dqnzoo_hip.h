@@ -52,7 +52,8 @@ int dz_last_hip_error(void);
 const char* dz_built_arch(void);
 /* sizeof() of the ABI structs as the library was compiled, so that a binding
  * can verify its mirror: 0 dz_field_t, 1 dz_prio_sample_args_t,
- * 2 dz_rainbow_layout_t, 3 dz_rainbow_args_t.  -1 for an unknown id.        */
+ * 2 dz_rainbow_layout_t, 3 dz_rainbow_args_t, 4 dz_dense_layout_t,
+ * 5 dz_dense_args_t.  -1 for an unknown id.                                */
 int dz_struct_size(int which);
 
 /* ------------------------------------------------------------------------- *
@@ -292,6 +293,73 @@ int dz_graph_destroy(void* graph_exec);
  * to JAX's threefry stream.                                     */
 int dz_noise_fill(float* noise, int64_t count, uint64_t seed, uint64_t counter,
                   dz_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  Dense-head agents: DQN, double-Q, prioritized (double-Q + importance
+ *  weights), C51 and QR-DQN.  Network = dqn_torso + linear(512) + ReLU +
+ *  linear(num_outputs) (ref: networks.py:181-221, 295-363); the learner step is
+ *  the agent's jitted `update` (ref: dqn/agent.py:85-117, double_q/agent.py:
+ *  85-120, prioritized/agent.py:86-122, c51/agent.py:87-116, qrdqn/agent.py:
+ *  88-119) with the optimizer of its run_atari.py.
+ * ------------------------------------------------------------------------- */
+#define DZ_LOSS_Q 0            /* rlax.q_learning, 2 applies                      */
+#define DZ_LOSS_DOUBLE_Q 1     /* rlax.double_q_learning, 3 applies (+ weights)   */
+#define DZ_LOSS_CATEGORICAL 2  /* rlax.categorical_q_learning (C51), 2 applies    */
+#define DZ_LOSS_QUANTILE 3     /* rlax.quantile_q_learning (QR-DQN), 2 applies    */
+#define DZ_OPT_RMSPROP 0       /* optax.rmsprop(lr, decay, eps, centered=True)    */
+#define DZ_OPT_ADAM 1          /* optax.chain(clip_by_global_norm, adam)          */
+
+typedef struct {
+  int32_t num_outputs, shared_bias, batch, groups;
+  int32_t fc1_ld, fc2_ld;
+  int64_t param_count, param_count_ref;
+  int64_t conv_w[3], conv_b[3];
+  int64_t fc1_w, fc1_b;          /* [3136][fc1_ld] (512 used), [512]            */
+  int64_t fc2_w, fc2_b;          /* [512][fc2_ld], [num_outputs] or [1] shared   */
+  int64_t ws_count;
+  int64_t ws_act1, ws_act2, ws_feat, ws_fc1_part, ws_h1, ws_fc2_part, ws_out;
+  int64_t ws_dout, ws_dh1, ws_dfeat_part, ws_dfeat, ws_dact2, ws_dact1;
+  int64_t ws_wgrad_part, ws_norm_part, ws_scalars, ws_zeros;
+} dz_dense_layout_t;
+
+/* groups: 2 (Q / categorical / quantile) or 3 (double-Q).                     */
+int dz_dense_layout(int num_outputs, int shared_bias, int batch, int groups,
+                    dz_dense_layout_t* out);
+
+typedef struct {
+  int32_t loss, optimizer;
+  int32_t num_actions, num_outputs, batch, shared_bias;
+  int32_t num_atoms;         /* categorical: K; quantile: N; else 0             */
+  float* online;
+  const float* target;
+  float* grad;
+  float* opt_m;              /* rmsprop mu / adam m                             */
+  float* opt_v;              /* rmsprop nu / adam v                             */
+  int32_t* opt_count;        /* adam step count (device int32)                  */
+  const uint8_t* s_tm1;
+  const uint8_t* s_t;
+  const int64_t* a_tm1;
+  const double* r_t;
+  const double* discount_t;
+  const float* weights;      /* NULL = unweighted                               */
+  const float* aux;          /* categorical: support[K]; quantile: tau[N]       */
+  float* ws;
+  float* losses;             /* [B]: td errors (Q, double-Q) or per-sample loss */
+  float* priorities;         /* [B] |td| (prioritized/agent.py:202) or NULL     */
+  float lr, decay_or_b1, b2, eps, max_norm;
+  float grad_error_bound;    /* Q / double-Q: clip of the td gradient           */
+  float huber;               /* quantile: kappa                                 */
+} dz_dense_args_t;
+
+int dz_dense_learn(const dz_dense_args_t* args, int phases, dz_stream_t stream);
+
+/* One apply of a dense-head network: raw head outputs [batch][num_outputs]
+ * into out (may be NULL) and, for Q heads (num_outputs == num_actions), the
+ * q-values, greedy action and max.  ref: dqn/agent.py:121-131.               */
+int dz_dense_apply(int num_actions, int num_outputs, int shared_bias, int batch,
+                   const float* params, const uint8_t* states, float* ws,
+                   float* out, float* q_values_out, int32_t* greedy_out,
+                   float* vmax_out, dz_stream_t stream);
 
 /* Optional per-kernel timing: when enabled, dz_rainbow_learn records a HIP
  * event on the launch stream before its first kernel and after every kernel.

@@ -484,3 +484,43 @@ def dqn_family_loss_and_grads(kind, online, target, batch, weights, bound,
   dq[np.arange(len(a_tm1)), a_tm1] = dq_a
   grads = mlp_head_bwd(online, cache, dq)
   return loss, td, grads, dict(q_tm1=q_tm1, q_target=q_tgt, q_sel=q_sel)
+
+
+def c51_loss_and_grads(online, target, batch, support, num_actions, dt=np.float32):
+  """c51/agent.py:87-107: categorical_q_learning on the dense C51 head
+  (networks.py:316-335: q_logits = reshape(head, (-1, A, K)))."""
+  s_tm1, a_tm1, r_t, d_t, s_t = batch
+  r_t = np.asarray(r_t).astype(dt)
+  d_t = np.asarray(d_t).astype(dt)
+  support = support.astype(dt)
+  k = len(support)
+  out_tm1, cache = mlp_head_fwd(online, s_tm1, dt)
+  out_tgt, _ = mlp_head_fwd(target, s_t, dt)
+  bsz = out_tm1.shape[0]
+  losses, dlog, _ = categorical_q_losses(
+      support, out_tm1.reshape(bsz, num_actions, k), np.asarray(a_tm1), r_t, d_t,
+      out_tgt.reshape(bsz, num_actions, k))
+  loss = losses.mean()
+  grads = mlp_head_bwd(online, cache, (dlog / dt(bsz)).reshape(bsz, -1))
+  return loss, losses, grads, dict(out_tm1=out_tm1, out_target=out_tgt)
+
+
+def qr_loss_and_grads(online, target, batch, quantiles, num_actions, kappa,
+                      dt=np.float32):
+  """qrdqn/agent.py:88-110: quantile_q_learning, no double-Q; head output is
+  reshaped (-1, N, A) -- quantile-major (networks.py:308)."""
+  s_tm1, a_tm1, r_t, d_t, s_t = batch
+  r_t = np.asarray(r_t).astype(dt)
+  d_t = np.asarray(d_t).astype(dt)
+  n = len(quantiles)
+  out_tm1, cache = mlp_head_fwd(online, s_tm1, dt)
+  out_tgt, _ = mlp_head_fwd(target, s_t, dt)
+  bsz = out_tm1.shape[0]
+  dist_tm1 = out_tm1.reshape(bsz, n, num_actions)
+  dist_t = out_tgt.reshape(bsz, n, num_actions)
+  tau = np.tile(quantiles.astype(dt)[None, :], (bsz, 1))
+  losses, dd = quantile_q_losses(dist_tm1, tau, np.asarray(a_tm1), r_t, d_t, dist_t,
+                                 dist_t, dt(kappa))
+  loss = losses.mean()
+  grads = mlp_head_bwd(online, cache, (dd / dt(bsz)).reshape(bsz, -1))
+  return loss, losses, grads, dict(out_tm1=out_tm1, out_target=out_tgt)

@@ -1,0 +1,158 @@
+"""GPU parity of the dense-head learner steps (dz_dense_learn) against the NumPy
+oracle: DQN, double-Q, prioritized (double-Q + importance weights), C51 and
+QR-DQN -- head outputs, td errors / per-sample losses (<= 1e-5 relative),
+every gradient tensor against the float64 truth, and the optimiser step
+(centred RMSProp or clip + Adam)."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qnet_oracle as qo
+
+pytestmark = pytest.mark.gpu
+
+A, B = 6, 32
+K = 51
+SUPPORT = np.linspace(-10.0, 10.0, K).astype(np.float32)
+NQ = 201
+QUANTILES = ((np.arange(NQ) + 0.5) / NQ).astype(np.float32)
+
+
+def _batch(rs, scale_r=1.0):
+  s_tm1 = rs.randint(0, 256, (B, 84, 84, 4)).astype(np.uint8)
+  s_t = rs.randint(0, 256, (B, 84, 84, 4)).astype(np.uint8)
+  a = rs.randint(A, size=B).astype(np.int64)
+  r = rs.choice([-1.0, 0.0, 1.0], size=B) * scale_r
+  d = rs.choice([0.0, 0.99], size=B)
+  return s_tm1, a, r, d, s_t
+
+
+def _dev(batch):
+  return [torch.from_numpy(x).cuda() for x in batch]
+
+
+def _f64(t):
+  return {k: v.astype(np.float64) for k, v in t.items()}
+
+
+def _check_grads(g_dev, g32, g64):
+  assert set(g_dev) == set(g64)
+  for k in sorted(g64):
+    scale = max(np.abs(g64[k]).max(), 1e-30)
+    e_dev = np.abs(g_dev[k] - g64[k]).max() / scale
+    e_orc = np.abs(g32[k] - g64[k]).max() / scale
+    assert e_dev < max(1e-4, 4 * e_orc), (k, e_dev, e_orc)
+
+
+def _make(kind_net, loss, opt, seed, **kw):
+  from dqn_zoo_amd import learner as ll, networks
+  rs = np.random.RandomState(seed)
+  online = qo.init_params(kind_net, A, rs, num_atoms=K, num_quantiles=NQ)
+  target = qo.init_params(kind_net, A, rs, num_atoms=K, num_quantiles=NQ)
+  net = networks.DenseNetwork(kind_net, A, support=SUPPORT, quantiles=QUANTILES)
+  ln = ll.DenseLearner(net, loss, opt, B, params=online, **kw)
+  ln.set_params(target, 'target')
+  return rs, online, target, ln
+
+
+@pytest.mark.parametrize('kind', ['dqn', 'double_q', 'prioritized'])
+def test_dqn_family_step(kind):
+  from dqn_zoo_amd import learner as ll, _lib
+  net = 'dqn' if kind == 'dqn' else 'double_dqn'
+  loss = 'q' if kind == 'dqn' else 'double_q'
+  opt = ll.RmsPropConfig(learning_rate=0.00025, decay=0.95, eps=0.01 / 32 ** 2)
+  rs, online, target, ln = _make(net, loss, opt, 3 + len(kind),
+                                 grad_error_bound=1.0 / 32)
+  batch = _batch(rs, scale_r=2.5)   # some |td| > 1 so the gradient clip binds
+  w = rs.uniform(0.2, 1.0, size=B).astype(np.float32) if kind == 'prioritized' \
+      else None
+  wd = None if w is None else torch.from_numpy(w).cuda()
+  ln.step(*_dev(batch), wd, phases=_lib.PHASE_FORWARD | _lib.PHASE_BACKWARD)
+  torch.cuda.synchronize()
+  l32, td, g32, aux = qo.dqn_family_loss_and_grads(kind, online, target, batch, w,
+                                                   1.0 / 32)
+  _, _, g64, _ = qo.dqn_family_loss_and_grads(kind, _f64(online), _f64(target),
+                                              batch, w, 1.0 / 32, np.float64)
+  L = ln.layout
+  out = ln.ws_view('out', ln.groups * B * L.c.fc2_ld).cpu().numpy().reshape(
+      ln.groups, B, L.c.fc2_ld)[:, :, :A]
+  np.testing.assert_allclose(out[0], aux['q_tm1'], rtol=2e-5, atol=2e-6)
+  np.testing.assert_allclose(out[1], aux['q_target'], rtol=2e-5, atol=2e-6)
+  if kind != 'dqn':
+    np.testing.assert_allclose(out[2], aux['q_sel'], rtol=2e-5, atol=2e-6)
+  np.testing.assert_allclose(ln.losses.cpu().numpy(), td, rtol=1e-5, atol=2e-6)
+  np.testing.assert_allclose(ln.priorities.cpu().numpy(), np.abs(td), rtol=1e-5,
+                             atol=2e-6)
+  assert (np.abs(td) > 1.0).any() and (np.abs(td) < 1.0).any()
+  g_dev = L.unpack(ln.grad.cpu().numpy())
+  _check_grads(g_dev, g32, g64)
+  # centred RMSProp fed with the device gradients
+  p, st = dict(online), qo.rmsprop_init(online)
+  for it in range(2):
+    ln.step(*_dev(batch), wd)
+    torch.cuda.synchronize()
+    g_dev = L.unpack(ln.grad.cpu().numpy())
+    p, st = qo.rmsprop_centered_update(p, g_dev, st, opt.learning_rate, opt.decay,
+                                       opt.eps)
+    p_dev = ln.get_params()
+    mu_dev = L.unpack(ln.opt_m.cpu().numpy())
+    for k in p:
+      np.testing.assert_allclose(mu_dev[k], st['mu'][k], rtol=1e-5, atol=1e-12)
+      assert np.abs(p_dev[k] - p[k]).max() <= 2e-3 * opt.learning_rate * 40, k
+    p, st = p_dev, dict(mu=mu_dev, nu=L.unpack(ln.opt_v.cpu().numpy()))
+
+
+@pytest.mark.parametrize('kind', ['c51', 'qr'])
+def test_distributional_dense_step(kind):
+  from dqn_zoo_amd import learner as ll, _lib
+  opt = ll.AdamConfig(learning_rate=0.00025, eps=0.01 / 32,
+                      max_global_grad_norm=10.0)
+  loss = 'categorical' if kind == 'c51' else 'quantile'
+  rs, online, target, ln = _make(kind, loss, opt, 11 if kind == 'c51' else 12,
+                                 huber_param=1.0)
+  batch = _batch(rs)
+  ln.step(*_dev(batch), phases=_lib.PHASE_FORWARD | _lib.PHASE_BACKWARD)
+  torch.cuda.synchronize()
+  if kind == 'c51':
+    f = lambda o, t, dt: qo.c51_loss_and_grads(o, t, batch, SUPPORT.astype(dt), A, dt)
+  else:
+    f = lambda o, t, dt: qo.qr_loss_and_grads(o, t, batch, QUANTILES.astype(dt), A,
+                                              1.0, dt)
+  l32, losses, g32, aux = f(online, target, np.float32)
+  _, _, g64, _ = f(_f64(online), _f64(target), np.float64)
+  L = ln.layout
+  n_out = ln.network.num_outputs
+  out = ln.ws_view('out', 2 * B * L.c.fc2_ld).cpu().numpy().reshape(
+      2, B, L.c.fc2_ld)[:, :, :n_out]
+  np.testing.assert_allclose(out[0], aux['out_tm1'], rtol=3e-5, atol=3e-6)
+  np.testing.assert_allclose(out[1], aux['out_target'], rtol=3e-5, atol=3e-6)
+  np.testing.assert_allclose(ln.losses.cpu().numpy(), losses, rtol=1e-5)
+  _check_grads(L.unpack(ln.grad.cpu().numpy()), g32, g64)
+  # clip + Adam fed with the device gradients
+  ln.step(*_dev(batch))
+  torch.cuda.synchronize()
+  g_dev = L.unpack(ln.grad.cpu().numpy())
+  clipped, gn = qo.clip_by_global_norm(g_dev, 10.0)
+  p, st = qo.adam_update(online, clipped, qo.adam_init(online), opt.learning_rate,
+                         opt.eps)
+  p_dev = ln.get_params()
+  for k in p:
+    assert np.abs(p_dev[k] - p[k]).max() <= 2e-3 * opt.learning_rate + 1e-9, k
+  assert int(ln.opt_count.item()) == 1
+
+
+def test_dense_apply_and_shared_bias():
+  from dqn_zoo_amd import learner as ll
+  rs, online, target, ln = _make('double_dqn', 'double_q', ll.RmsPropConfig(), 30)
+  assert online['fc2/b'].shape == (1,)
+  x = rs.randint(0, 256, (3, 84, 84, 4)).astype(np.uint8)
+  out, q, greedy, vmax = ln.apply(torch.from_numpy(x).cuda())
+  ref, _ = qo.mlp_head_fwd(online, x)
+  np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
+  np.testing.assert_array_equal(q.cpu().numpy(), out.cpu().numpy())
+  np.testing.assert_array_equal(greedy.cpu().numpy(), ref.argmax(axis=1))
+  np.testing.assert_allclose(vmax.cpu().numpy(), ref.max(axis=1), rtol=2e-5)
+  ln.sync_target()
+  for k, v in ln.get_params('target').items():
+    np.testing.assert_array_equal(v, online[k])

@@ -320,3 +320,35 @@ def test_torch_cpu_port_matches_oracle():
   for k in newp:
     diff = np.abs(port.p[k].detach().numpy() - newp[k])
     assert np.percentile(diff, 99) <= 0.02 * lr and diff.max() <= 1.01 * lr, k
+
+
+@pytest.mark.parametrize('kind', ['c51', 'qr'])
+def test_distributional_dense_losses_finite_differences_f64(kind):
+  dt = np.float64
+  rs = np.random.RandomState(21)
+  nq = 9
+  quant = (np.arange(nq) + 0.5) / nq
+  online = qo.init_params(kind, A, rs, dt, num_atoms=K, num_quantiles=nq)
+  target = qo.init_params(kind, A, rs, dt, num_atoms=K, num_quantiles=nq)
+  batch = _batch(rs, 3)
+
+  def f(p):
+    if kind == 'c51':
+      return qo.c51_loss_and_grads(p, target, batch, SUPPORT, A, dt)
+    return qo.qr_loss_and_grads(p, target, batch, quant, A, 1.0, dt)
+
+  loss, losses, grads, _ = f(online)
+  assert losses.shape == (3,) and np.isfinite(loss)
+  for k in ['conv2/w', 'fc1/b', 'fc2/w', 'fc2/b']:
+    g = grads[k].reshape(-1)
+    for j in np.argsort(-np.abs(g))[:3]:
+      h = 1e-5
+      vals = []
+      for sgn in (+1, -1):
+        p2 = dict(online)
+        arr = online[k].copy().reshape(-1)
+        arr[j] += sgn * h
+        p2[k] = arr.reshape(online[k].shape)
+        vals.append(f(p2)[0])
+      fd = (vals[0] - vals[1]) / (2 * h)
+      assert abs(fd - g[j]) <= 2e-6 * max(1.0, abs(g[j])) + 1e-9, (k, j, fd, g[j])
