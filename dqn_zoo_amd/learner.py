@@ -382,3 +382,75 @@ class DenseLearner:
         None if vmax is None else vmax.data_ptr(),
         torch.cuda.current_stream(self.device).cuda_stream), 'dz_dense_apply')
     return out, q, greedy, vmax
+
+
+# --------------------------------------------------------------------------- #
+#  Inference-only network (evaluation actor)
+# --------------------------------------------------------------------------- #
+class InferenceNet:
+  """Parameters + workspace for network applies only (no optimiser state):
+  what `parts.EpsilonGreedyActor` needs (ref: parts.py:342-411)."""
+
+  def __init__(self, network, seed: int = 1, device=None):
+    self._lib = _lib.load()
+    if not torch.cuda.is_available():
+      raise _lib.HipLibraryError('InferenceNet needs an AMD GPU; no CPU fallback')
+    self.device = torch.device('cuda', torch.cuda.current_device()) \
+        if device is None else torch.device(device)
+    self.network = network
+    self.is_rainbow = isinstance(network, networks.RainbowNetwork)
+    self.layout = network.layout(1) if self.is_rainbow else network.layout(1, 1)
+    self.params = torch.zeros(self.layout.param_count, dtype=torch.float32,
+                              device=self.device)
+    self.ws = torch.zeros(self.layout.ws_count, dtype=torch.float32,
+                          device=self.device)
+    self._has_params = False
+    if self.is_rainbow:
+      self.noise = torch.zeros(self.layout.noise_stride, dtype=torch.float32,
+                               device=self.device)
+      self.support = torch.from_numpy(network.support).to(self.device)
+    self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    self._counter = 0
+
+  def set_params(self, params) -> None:
+    """params: dict of Haiku-shaped arrays (what `agent.online_params` returns)
+    or a flat device tensor with the learner's layout."""
+    if isinstance(params, torch.Tensor):
+      self.params.copy_(params)
+    else:
+      self.params.copy_(torch.from_numpy(self.layout.pack(params)))
+    self._has_params = True
+
+  def q_values(self, obs_u8: torch.Tensor) -> np.ndarray:
+    """Host Q-values [A] for ONE uint8 state tensor [1,84,84,4] on the device."""
+    if not self._has_params:
+      raise RuntimeError('network_params have not been set')
+    net = self.network
+    stream = torch.cuda.current_stream(self.device).cuda_stream
+    if self.is_rainbow:
+      n = self.noise.numel()
+      _lib.check(self._lib.dz_noise_fill(self.noise.data_ptr(), n, self._seed,
+                                         self._counter, stream), 'dz_noise_fill')
+      self._counter += n
+      q = torch.empty((1, net.num_actions), dtype=torch.float32, device=self.device)
+      _lib.check(self._lib.dz_rainbow_apply(
+          net.num_actions, net.num_atoms, 1, self.params.data_ptr(),
+          obs_u8.data_ptr(), self.noise.data_ptr(), self.support.data_ptr(),
+          self.ws.data_ptr(), q.data_ptr(), None, None, stream),
+                 'dz_rainbow_apply')
+      return q[0].cpu().numpy()
+    out = torch.empty((1, net.num_outputs), dtype=torch.float32, device=self.device)
+    _lib.check(self._lib.dz_dense_apply(
+        net.num_actions, net.num_outputs, int(net.shared_bias), 1,
+        self.params.data_ptr(), obs_u8.data_ptr(), self.ws.data_ptr(),
+        out.data_ptr(), None, None, None, stream), 'dz_dense_apply')
+    h = out[0].cpu().numpy()
+    if net.kind == 'c51':
+      lg = h.reshape(net.num_actions, net.num_atoms).astype(np.float64)
+      lg -= lg.max(axis=1, keepdims=True)
+      p = np.exp(lg)
+      p /= p.sum(axis=1, keepdims=True)
+      return (p * net.support[None, :]).sum(axis=1)
+    if net.kind == 'qr':
+      return h.reshape(net.num_atoms, net.num_actions).mean(axis=0)
+    return h

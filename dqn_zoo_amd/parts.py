@@ -301,3 +301,66 @@ class NullCheckpoint:
 
   def restore(self) -> None:
     pass
+
+
+class EpsilonGreedyActor(Agent):
+  """Agent that acts epsilon-greedily with externally set network parameters
+  (the evaluation actor; ref: parts.py:342-411).  `network` is a descriptor
+  (`networks.RainbowNetwork` / `networks.DenseNetwork`), `rng_key` an int seed;
+  assign `network_params = train_agent.online_params` before stepping
+  (rainbow/run_atari.py:284-288)."""
+
+  def __init__(self, preprocessor, network, exploration_epsilon: float,
+               rng_key: int):
+    import torch  # pylint: disable=import-outside-toplevel
+    from dqn_zoo_amd import learner as learner_lib  # pylint: disable=import-outside-toplevel
+    self._preprocessor = preprocessor
+    self._epsilon = exploration_epsilon
+    self._rng = np.random.RandomState(int(rng_key) % (2 ** 32))
+    self._net = learner_lib.InferenceNet(network, seed=int(rng_key))
+    self._obs = torch.empty((1, 84, 84, 4), dtype=torch.uint8,
+                            device=self._net.device)
+    self._torch = torch
+    self._action = None
+    self._network_params = None
+
+  @property
+  def network_params(self):
+    return self._network_params
+
+  @network_params.setter
+  def network_params(self, params) -> None:
+    self._network_params = params
+    if params is not None:
+      self._net.set_params(params)
+
+  def step(self, timestep) -> Action:
+    timestep = self._preprocessor(timestep)
+    if timestep is None:  # repeat action
+      if self._action is None:
+        raise RuntimeError('Cannot repeat if action has never been selected.')
+      return self._action
+    obs = np.ascontiguousarray(timestep.observation, dtype=np.uint8)
+    self._obs[0].copy_(self._torch.from_numpy(obs))
+    q = np.asarray(self._net.q_values(self._obs), dtype=np.float64)
+    greedy = (q == q.max())
+    probs = self._epsilon / len(q) + (1.0 - self._epsilon) * greedy / greedy.sum()
+    self._action = Action(self._rng.choice(len(q), p=probs / probs.sum()))
+    return self._action
+
+  def reset(self) -> None:
+    from dqn_zoo_amd import processors  # pylint: disable=import-outside-toplevel
+    processors.reset(self._preprocessor)
+    self._action = None
+
+  def get_state(self) -> Mapping[str, Any]:
+    return {'rng_key': self._rng.get_state(),
+            'network_params': self._network_params}
+
+  def set_state(self, state: Mapping[str, Any]) -> None:
+    self._rng.set_state(state['rng_key'])
+    self.network_params = state['network_params']
+
+  @property
+  def statistics(self) -> Mapping[str, float]:
+    return {}
