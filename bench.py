@@ -184,6 +184,18 @@ def kernel_work(b, a=NUM_ACTIONS, k=NUM_ATOMS):
   return w
 
 
+def pmc_traffic(kernel):
+  """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+  (profiles/r1_hbm_traffic.json: FETCH_SIZE/WRITE_SIZE collected separately and
+  corrected as MI355X_MICROARCH.md prescribes); None if not collected."""
+  try:
+    with open(os.path.join(ROOT, 'profiles', 'r1_hbm_traffic.json')) as f:
+      k = json.load(f)['kernels'].get(kernel)
+    return None if k is None else k.get('hbm_bytes_corrected')
+  except (OSError, ValueError, KeyError):
+    return None
+
+
 def measure_roofline(step, prof_steps, batch):
   """Per-kernel average durations from HIP events recorded on the launch
   stream (dz_prof_*), then the roofline fraction of the dominant kernel."""
@@ -204,7 +216,8 @@ def measure_roofline(step, prof_steps, batch):
   avg = {k: float(np.mean(v)) for k, v in acc.items()}
   work = kernel_work(batch)
   dom = max(avg, key=avg.get)
-  out = {'kernel': dom, 'avg_us': round(avg[dom] * 1e6, 2), 'traffic': None}
+  out = {'kernel': dom, 'avg_us': round(avg[dom] * 1e6, 2),
+         'traffic': pmc_traffic(dom)}
   if dom in work:
     flops, nbytes = work[dom]
     t_m, t_h = flops / PEAK_F32_MFMA, nbytes / PEAK_HBM
