@@ -15,6 +15,8 @@ constexpr int kS_fc1 = 7;     // grid split-K factors
 constexpr int kS_fc2 = 4;
 constexpr int kS_dh1 = 5;
 constexpr int kS_dfeat = 8;
+constexpr int kMaxS_dfeat = 32;
+constexpr int kMaxS_fc2 = 8;
 constexpr int kS_cw1 = 50, kS_cw2 = 27, kS_cw3 = 14;
 constexpr int kNormBlocks = 512;
 

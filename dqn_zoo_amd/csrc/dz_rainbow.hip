@@ -19,7 +19,11 @@ int g_fc1_variant = 9;   // 8/9 = weight-streaming kernels (dz_fc_stream.h)
 int g_fc1_splits = 32;
 int g_fc1_dgrad_stream = 0;  // measured: tile-GEMM 26 us vs streaming 35 us
 int g_fc1_blocked_experiment = 0;
-int g_overlap = 1;           // weight gradients on an auxiliary stream
+int g_overlap = 1;           // (unused) weight gradients on an auxiliary stream
+int g_fc1_dgrad_first = 1;
+int g_fc1_dgrad_variant = 2;   // FcDgradOp<1,2,2,KT=1> x 32 splits: 24 us (KT=4 x 8: 34 us)
+int g_fc1_dgrad_splits = 32;
+int g_fc2_splits = 8;          // 12 us (4 splits: 19 us)
 hipStream_t g_aux_stream = nullptr;
 hipEvent_t g_ev[5];
 
@@ -140,17 +144,17 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
   }
   {  // fc2: noisy adv2 (no mu bias) and val2 (no mu bias)
     FcFwdParams p;
-    p.x = ws + L.ws_h1; p.ldx = 1024; p.M = B; p.G = G; p.NH = 2; p.S = kS_fc2;
+    p.x = ws + L.ws_h1; p.ldx = 1024; p.M = B; p.G = G; p.NH = 2; p.S = g_fc2_splits;
     p.noisy = 1;
     for (int g = 0; g < G; ++g) { p.params[g] = prm[g]; p.noise[g] = nz[g]; }
     p.head[0] = fc2h[0]; p.head[1] = fc2h[1];
     p.part = ws + L.ws_fc2_part; p.ldo = ld2;
     rc = dz_launch_gemm<FcFwd>(p, dim3((NA + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32,
-                                      G * 2 * kS_fc2), s);
+                                      G * 2 * g_fc2_splits), s);
     if (rc) return rc;
     DZ_PROF(s, "fc2_fwd");
     hipLaunchKernelGGL(fc_epilogue_kernel, dim3((ld2 + 63) / 64, G * B), dim3(256),
-                       0, s, ws + L.ws_fc2_part, kS_fc2, G * B, ld2, ld2, B,
+                       0, s, ws + L.ws_fc2_part, g_fc2_splits, G * B, ld2, ld2, B,
                        prm[0], prm[1], prm[2], (long)-1, (long)L.fc2_sig_b, nz[0],
                        nz[1], nz[2], (int)L.n_fc2_out, 0, ws + L.ws_fc2_out);
     DZ_LAUNCH_CHECK();
@@ -226,11 +230,11 @@ extern "C" int dz_rainbow_layout(int A, int K, int B, dz_rainbow_layout_t* L) {
   L->ws_feat = take(GB * kFlat);
   L->ws_fc1_part = take((int64_t)kMaxSplitFc1 * GB * 1024);
   L->ws_h1 = take(GB * 1024);
-  L->ws_fc2_part = take((int64_t)kS_fc2 * GB * ld2);
+  L->ws_fc2_part = take((int64_t)kMaxS_fc2 * GB * ld2);
   L->ws_fc2_out = take(GB * ld2);
   L->ws_dout2 = take((int64_t)B * ld2);
   L->ws_dh1 = take((int64_t)B * 1024);
-  L->ws_dfeat_part = take((int64_t)kS_dfeat * B * kFlat);
+  L->ws_dfeat_part = take((int64_t)kMaxS_dfeat * B * kFlat);
   L->ws_dfeat = take((int64_t)B * kFlat);
   L->ws_dact2 = take((int64_t)B * 81 * 64);
   L->ws_dact1 = take((int64_t)B * 400 * 32);
@@ -336,15 +340,44 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       d.params = a->online; d.noise = nz[0]; d.head[0] = fc1h[0]; d.head[1] = fc1h[1];
       d.part = ws + L.ws_dfeat_part; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
       // (measured: fusing these two HBM-heavy contractions is slower, 48 us vs
-      // 15 + 23 us back to back, so this pair stays two launches)
-      rc = dz_launch_gemm<FcWg>(w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
-      if (rc) return rc;
-      DZ_PROF(s, "fc1_wgrad");
-      rc = dz_launch_gemm<FcDg>(d, dim3(kFlat / FcDg::BN, (B + 31) / 32, kS_dfeat), s);
-      if (rc) return rc;
-      DZ_PROF(s, "fc1_dgrad");
+      // 15 + 23 us back to back, so this pair stays two launches; the
+      // read-only input gradient goes first so that it does not queue behind
+      // the 25 MB of dirty lines the weight gradient leaves)
+      if (g_fc1_dgrad_first) {
+        d.S = g_fc1_dgrad_splits;
+        switch (g_fc1_dgrad_variant) {
+          default:
+          case 0: rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 4>>(d, dim3(kFlat / 64, (B + 31) / 32, d.S), s); break;
+          case 1: rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 2>>(d, dim3(kFlat / 64, (B + 31) / 32, d.S), s); break;
+          case 2: rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 1>>(d, dim3(kFlat / 64, (B + 31) / 32, d.S), s); break;
+          case 3: rc = dz_launch_gemm<FcDgradOp<1, 1, 4, 2>>(d, dim3(kFlat / 32, (B + 31) / 32, d.S), s); break;
+          case 4: rc = dz_launch_gemm<FcDgradOp<1, 1, 4, 1>>(d, dim3(kFlat / 32, (B + 31) / 32, d.S), s); break;
+          case 5: rc = dz_launch_gemm<FcDgradOp<1, 4, 1, 2>>(d, dim3((kFlat + 127) / 128, (B + 31) / 32, d.S), s); break;
+        }
+        if (rc) return rc;
+        DZ_PROF(s, "fc1_dgrad");
+        rc = dz_launch_gemm<FcWg>(w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
+        if (rc) return rc;
+        DZ_PROF(s, "fc1_wgrad");
+      } else {
+        rc = dz_launch_gemm<FcWg>(w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
+        if (rc) return rc;
+        DZ_PROF(s, "fc1_wgrad");
+        d.S = g_fc1_dgrad_splits;
+        switch (g_fc1_dgrad_variant) {
+          default:
+          case 0: rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 4>>(d, dim3(kFlat / 64, (B + 31) / 32, d.S), s); break;
+          case 1: rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 2>>(d, dim3(kFlat / 64, (B + 31) / 32, d.S), s); break;
+          case 2: rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 1>>(d, dim3(kFlat / 64, (B + 31) / 32, d.S), s); break;
+          case 3: rc = dz_launch_gemm<FcDgradOp<1, 1, 4, 2>>(d, dim3(kFlat / 32, (B + 31) / 32, d.S), s); break;
+          case 4: rc = dz_launch_gemm<FcDgradOp<1, 1, 4, 1>>(d, dim3(kFlat / 32, (B + 31) / 32, d.S), s); break;
+          case 5: rc = dz_launch_gemm<FcDgradOp<1, 4, 1, 2>>(d, dim3((kFlat + 127) / 128, (B + 31) / 32, d.S), s); break;
+        }
+        if (rc) return rc;
+        DZ_PROF(s, "fc1_dgrad");
+      }
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0,
-                         s, ws + L.ws_dfeat_part, kS_dfeat, (long)B * kFlat,
+                         s, ws + L.ws_dfeat_part, g_fc1_dgrad_splits, (long)B * kFlat,
                          ws + L.ws_feat, ws + L.ws_dfeat);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "dfeat_reduce");
@@ -486,6 +519,10 @@ extern "C" int dz_set_tuning(int key, int value) {
     case 2: g_fc1_dgrad_stream = value; return DZ_OK;
     case 3: g_fc1_blocked_experiment = value; return DZ_OK;
     case 4: g_overlap = value; return DZ_OK;
+    case 5: g_fc1_dgrad_first = value; return DZ_OK;
+    case 6: g_fc1_dgrad_variant = value; return DZ_OK;
+    case 7: DZ_REQUIRE(value >= 1 && value <= kMaxS_dfeat); g_fc1_dgrad_splits = value; return DZ_OK;
+    case 8: DZ_REQUIRE(value >= 1 && value <= kMaxS_fc2); g_fc2_splits = value; return DZ_OK;
     default: return DZ_ERR_INVALID_ARG;
   }
 }

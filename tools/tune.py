@@ -44,25 +44,18 @@ def main():
   lib = _lib.load()
   names = {0: '<1,2,2,KT4>', 1: '<1,2,2,KT2>', 2: '<1,2,2,KT1>', 3: '<1,4,1,KT4>',
            4: '<1,4,1,KT2>', 5: '<1,1,4,KT2>', 6: '<1,1,4,KT1>', 7: '<1,4,1,KT1>'}
-  names[8] = 'stream'; names[9] = 'stream2'
-  for dg in (0, 1):
-    lib.dz_set_tuning(2, dg)
-    lib.dz_set_tuning(0, 8); lib.dz_set_tuning(1, 8)
+  lib.dz_set_tuning(2, 0); lib.dz_set_tuning(0, 9); lib.dz_set_tuning(1, 32)
+  for var, spl in ((1, 16), (1, 32), (2, 32), (3, 32)):
+    lib.dz_set_tuning(6, var); lib.dz_set_tuning(7, spl)
     t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
-    print('fc1_dgrad stream=%d: %.2f us (+reduce %.2f)  fc1_wgrad %.2f adam %.2f' % (
-        dg, t['fc1_dgrad'], t.get('fc1_dgrad_reduce', 0.0), t['fc1_wgrad'], t['adam']))
-  lib.dz_set_tuning(3, 1); lib.dz_set_tuning(0, 9); lib.dz_set_tuning(1, 32)
-  t = timings(ln, dev, steps=20, phases=_lib.PHASE_FORWARD)
-  print('fc1 stream2 BLOCKED-ADDRESS experiment S=32: fc1_fwd %.2f us' % t['fc1_fwd'])
-  lib.dz_set_tuning(3, 0)
-  for var in (9, 8):
-    for splits in ((32,) if var == 9 else (8,)):
-      lib.dz_set_tuning(0, var)
-      lib.dz_set_tuning(1, splits)
-      t = timings(ln, dev, steps=20, phases=_lib.PHASE_FORWARD)
-      print('fc1 %-12s S=%2d  fc1_fwd %7.2f us  fc1_epi %5.2f  (conv1 %5.1f conv2 %5.1f conv3 %5.1f fc2 %5.1f head %5.1f)' % (
-          names[var], splits, t['fc1_fwd'], t['fc1_epilogue'], t['conv1_fwd'],
-          t['conv2_fwd'], t['conv3_fwd'], t['fc2_fwd'], t['head_loss']), flush=True)
+    print('fc1 dgrad var %d S=%2d: fc1_dgrad %.2f dfeat_reduce %.2f' % (
+        var, spl, t['fc1_dgrad'], t['dfeat_reduce']), flush=True)
+  lib.dz_set_tuning(6, 1); lib.dz_set_tuning(7, 16)
+  for spl in (1, 2, 4, 8):
+    lib.dz_set_tuning(8, spl)
+    t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
+    print('fc2 fwd S=%d: fc2_fwd %.2f fc2_epilogue %.2f total %.1f' % (
+        spl, t['fc2_fwd'], t['fc2_epilogue'], sum(t.values())), flush=True)
 
 
 if __name__ == '__main__':
