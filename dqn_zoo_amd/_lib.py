@@ -106,13 +106,48 @@ class DenseArgs(ctypes.Structure):
   ]
 
 
+class IqnLayout(ctypes.Structure):
+  """dz_iqn_layout_t."""
+  _fields_ = [
+      ('num_actions', c_i32), ('latent_dim', c_i32), ('batch', c_i32),
+      ('samples', c_i32 * 3), ('emb_ld', c_i32), ('fc1_ld', c_i32),
+      ('fc2_ld', c_i32), ('pad_', c_i32),
+      ('conv_w', c_i64 * 3), ('conv_b', c_i64 * 3),
+      ('emb_w', c_i64), ('emb_b', c_i64), ('fc1_w', c_i64), ('fc1_b', c_i64),
+      ('fc2_w', c_i64), ('fc2_b', c_i64),
+      ('param_count', c_i64), ('param_count_ref', c_i64), ('ws_count', c_i64),
+      ('ws_act1', c_i64), ('ws_act2', c_i64), ('ws_feat', c_i64),
+      ('ws_cos', c_i64), ('ws_hin', c_i64), ('ws_temb', c_i64),
+      ('ws_h1', c_i64), ('ws_out', c_i64), ('ws_dout', c_i64),
+      ('ws_dh1', c_i64), ('ws_dhin', c_i64), ('ws_dfeat', c_i64),
+      ('ws_dact2', c_i64), ('ws_dact1', c_i64), ('ws_wgrad_part', c_i64),
+      ('ws_fc2w_part', c_i64), ('ws_embw_part', c_i64),
+      ('ws_bias_part', c_i64), ('ws_norm_part', c_i64), ('ws_scalars', c_i64),
+      ('ws_zeros', c_i64),
+  ]
+
+
+class IqnArgs(ctypes.Structure):
+  """dz_iqn_args_t."""
+  _fields_ = [
+      ('num_actions', c_i32), ('latent_dim', c_i32), ('batch', c_i32),
+      ('samples', c_i32 * 3),
+      ('online', c_vp), ('target', c_vp), ('grad', c_vp), ('opt_m', c_vp),
+      ('opt_v', c_vp), ('opt_count', c_vp), ('s_tm1', c_vp), ('s_t', c_vp),
+      ('a_tm1', c_vp), ('r_t', c_vp), ('discount_t', c_vp), ('tau_tm1', c_vp),
+      ('tau_sel', c_vp), ('tau_t', c_vp), ('ws', c_vp), ('losses', c_vp),
+      ('lr', c_f32), ('b1', c_f32), ('b2', c_f32), ('eps', c_f32),
+      ('max_norm', c_f32), ('huber', c_f32),
+  ]
+
+
 LOSS_Q, LOSS_DOUBLE_Q, LOSS_CATEGORICAL, LOSS_QUANTILE = 0, 1, 2, 3
 OPT_RMSPROP, OPT_ADAM = 0, 1
 SC_GNORM, SC_LOSS, SC_BC1, SC_BC2, SC_CLIP = 0, 1, 2, 3, 4
 PHASE_FORWARD, PHASE_BACKWARD, PHASE_OPTIMIZER, PHASE_ALL = 1, 2, 4, 7
 
 STRUCT_IDS = {0: FieldDesc, 1: PrioSampleArgs, 2: RainbowLayout, 3: RainbowArgs,
-              4: DenseLayout, 5: DenseArgs}
+              4: DenseLayout, 5: DenseArgs, 6: IqnLayout, 7: IqnArgs}
 
 # name -> (restype, argtypes).  tests/test_abi.py checks this table against
 # the prototypes in include/dqnzoo_hip.h and against the built library.
@@ -135,6 +170,13 @@ SIGNATURES = {
     'dz_dense_learn': (c_int, [ctypes.POINTER(DenseArgs), c_int, c_vp]),
     'dz_dense_apply': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                                c_vp, c_vp, c_vp, c_vp]),
+    'dz_iqn_layout': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int,
+                              ctypes.POINTER(IqnLayout)]),
+    'dz_iqn_learn': (c_int, [ctypes.POINTER(IqnArgs), c_int, c_vp]),
+    'dz_iqn_apply': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
+                             c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'dz_uniform_fill': (c_int, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64,
+                                c_vp, c_vp]),
     'dz_noise_fill': (c_int, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64,
                               c_vp]),
     'dz_param_copy': (c_int, [c_vp, c_vp, c_i64, c_vp]),

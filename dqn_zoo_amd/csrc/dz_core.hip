@@ -15,6 +15,8 @@ extern "C" int dz_struct_size(int which) {
     case 3: return (int)sizeof(dz_rainbow_args_t);
     case 4: return (int)sizeof(dz_dense_layout_t);
     case 5: return (int)sizeof(dz_dense_args_t);
+    case 6: return (int)sizeof(dz_iqn_layout_t);
+    case 7: return (int)sizeof(dz_iqn_args_t);
     default: return -1;
   }
 }

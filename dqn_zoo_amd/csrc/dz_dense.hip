@@ -3,7 +3,7 @@
 // Rainbow step (dz_qnet_kernels.h) around a plain (non-noisy) two-layer head.
 //   groups: g0 = online(s_tm1) [gradient], g1 = target(s_t), g2 = online(s_t)
 //   (double-Q selector only).
-#include "dz_qnet_kernels.h"
+#include "dz_torso.h"
 
 namespace {
 constexpr int kS_dfc1 = 16;  // fc1 forward k-splits (3136 rows / 16 = 196 = 2*NLOAD)
@@ -47,9 +47,7 @@ extern "C" int dz_dense_layout(int N, int shared_bias, int B, int G,
   L->ws_dfeat = take((int64_t)B * kFlat);
   L->ws_dact2 = take((int64_t)B * 81 * 64);
   L->ws_dact1 = take((int64_t)B * 400 * 32);
-  L->ws_wgrad_part = take((int64_t)kS_cw1 * Conv1Wg::KROWS * 32 +
-                          (int64_t)kS_cw2 * Conv2Wg::KROWS * 64 +
-                          (int64_t)kS_cw3 * Conv3Wg::KROWS * 64);
+  L->ws_wgrad_part = take(torso_wgrad_part_elems());
   L->ws_norm_part = take(kNormBlocks);
   L->ws_scalars = take(16);
   L->ws_zeros = take(kFlat + 1024);   // stands in for the (absent) noise vectors
@@ -71,39 +69,9 @@ static int dense_forward(const dz_dense_layout_t& L, int G, int B, const float* 
   const float* zeros = ws + L.ws_zeros;
   FcHead h1, h2;
   dense_heads(L, h1, h2);
-  {
-    ConvFwdParams p;
-    for (int g = 0; g < G; ++g) {
-      p.in[g] = in[g]; p.in_img_base[g] = 0;
-      p.w[g] = prm[g] + L.conv_w[0]; p.bias[g] = prm[g] + L.conv_b[0];
-    }
-    p.out = ws + L.ws_act1; p.B = B; p.G = G;
-    rc = dz_launch_gemm<Conv1Fwd>(p, dim3(1, G * Conv1Fwd::tiles_per_group(B)), s);
-    if (rc) return rc;
-    DZ_PROF(s, "conv1_fwd");
-  }
-  {
-    ConvFwdParams p;
-    for (int g = 0; g < G; ++g) {
-      p.in[g] = ws + L.ws_act1; p.in_img_base[g] = g * B;
-      p.w[g] = prm[g] + L.conv_w[1]; p.bias[g] = prm[g] + L.conv_b[1];
-    }
-    p.out = ws + L.ws_act2; p.B = B; p.G = G;
-    rc = dz_launch_gemm<Conv2Fwd>(p, dim3(1, G * Conv2Fwd::tiles_per_group(B)), s);
-    if (rc) return rc;
-    DZ_PROF(s, "conv2_fwd");
-  }
-  {
-    ConvFwdParams p;
-    for (int g = 0; g < G; ++g) {
-      p.in[g] = ws + L.ws_act2; p.in_img_base[g] = g * B;
-      p.w[g] = prm[g] + L.conv_w[2]; p.bias[g] = prm[g] + L.conv_b[2];
-    }
-    p.out = ws + L.ws_feat; p.B = B; p.G = G;
-    rc = dz_launch_gemm<Conv3Fwd>(p, dim3(1, G * Conv3Fwd::tiles_per_group(B)), s);
-    if (rc) return rc;
-    DZ_PROF(s, "conv3_fwd");
-  }
+  const TorsoBufs T = {L.conv_w, L.conv_b, ws + L.ws_act1, ws + L.ws_act2, ws + L.ws_feat};
+  rc = torso_forward(T, G, B, prm, in, s);
+  if (rc) return rc;
   const float* p3[3] = {prm[0], prm[G > 1 ? 1 : 0], prm[G > 2 ? 2 : 0]};
   {  // fc1 (3136 -> 512): weight-streaming kernel when the batch fits one tile
     if (B <= 32) {
@@ -221,9 +189,6 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
   if (phases & DZ_PHASE_BACKWARD) {
     DZ_REQUIRE(a->grad);
     float* grad = a->grad;
-    float* part1 = ws + L.ws_wgrad_part;
-    float* part2 = part1 + (long)kS_cw1 * Conv1Wg::KROWS * 32;
-    float* part3 = part2 + (long)kS_cw2 * Conv2Wg::KROWS * 64;
     {  // fc2: weight gradient + input gradient -> dh1 (relu(h1) mask)
       FcWgradParams w;
       w.x = ws + L.ws_h1; w.ldx = kHid; w.dy = ws + L.ws_dout; w.ldy = ld2; w.M = B;
@@ -265,42 +230,14 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "dfeat_reduce");
     }
-    {
-      ConvWgradParams w;
-      w.in = ws + L.ws_act2; w.dy = ws + L.ws_dfeat; w.part = part3; w.B = B; w.S = kS_cw3;
-      ConvDgradParams d;
-      d.dy = ws + L.ws_dfeat; d.w = a->online + L.conv_w[2]; d.act = ws + L.ws_act2;
-      d.dx = ws + L.ws_dact2; d.B = B;
-      rc = dz_launch_gemm2<Conv3Wg, Conv3Dg>(
-          w, dim3(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), d,
-          dim3(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1), s);
-      if (rc) return rc;
-      DZ_PROF(s, "conv3_wgrad+dgrad");
-    }
-    {
-      ConvWgradParams w;
-      w.in = ws + L.ws_act1; w.dy = ws + L.ws_dact2; w.part = part2; w.B = B; w.S = kS_cw2;
-      ConvDgradParams d;
-      d.dy = ws + L.ws_dact2; d.w = a->online + L.conv_w[1]; d.act = ws + L.ws_act1;
-      d.dx = ws + L.ws_dact1; d.B = B;
-      rc = dz_launch_gemm2<Conv2Wg, Conv2Dg>(
-          w, dim3(64 / Conv2Wg::BN, Conv2Wg::MT, kS_cw2), d,
-          dim3(32 / Conv2Dg::BN, Conv2Dg::tiles(B), 4), s);
-      if (rc) return rc;
-      DZ_PROF(s, "conv2_wgrad+dgrad");
-    }
-    {
-      ConvWgradParams p;
-      p.in = a->s_tm1; p.dy = ws + L.ws_dact1; p.part = part1; p.B = B; p.S = kS_cw1;
-      rc = dz_launch_gemm<Conv1Wg>(p, dim3(32 / Conv1Wg::BN, Conv1Wg::MT, kS_cw1), s);
-      if (rc) return rc;
-      DZ_PROF(s, "conv1_wgrad");
-    }
+    ReduceJob conv_jobs[3];
+    const TorsoBufs T = {L.conv_w, L.conv_b, ws + L.ws_act1, ws + L.ws_act2, ws + L.ws_feat};
+    rc = torso_backward(T, B, a->online, a->s_tm1, ws + L.ws_dfeat, ws + L.ws_dact2,
+                        ws + L.ws_dact1, ws + L.ws_wgrad_part, grad, conv_jobs, s);
+    if (rc) return rc;
     {
       FinalizeJobs J;
-      J.r[0] = {part1, kS_cw1, (long)Conv1Wg::KROWS * 32, grad + L.conv_w[0]};
-      J.r[1] = {part2, kS_cw2, (long)Conv2Wg::KROWS * 64, grad + L.conv_w[1]};
-      J.r[2] = {part3, kS_cw3, (long)Conv3Wg::KROWS * 64, grad + L.conv_w[2]};
+      for (int j = 0; j < 3; ++j) J.r[j] = conv_jobs[j];
       unsigned acc = 0;
       for (int j = 0; j < 3; ++j) { acc += (unsigned)((J.r[j].n + 63) / 64); J.r_end[j] = acc; }
       J.c[0] = {ws + L.ws_dh1, B, kHid, kHid, grad + L.fc1_b, nullptr, nullptr};

@@ -1,0 +1,326 @@
+// Learner step and actor apply of the IQN agent on one MI355X
+// (ref: iqn/agent.py:176-247, networks.py:264-292).
+//
+// Row layout: every per-sample tensor has one row per (apply, batch element,
+// tau sample): rows [0, B*n0) online(s_tm1, tau_tm1), then B*n1 rows
+// target(s_t, tau_sel), then B*n2 rows target(s_t, tau_t).  Torso groups:
+// g0 = online(s_tm1), g1 = target(s_t) -- shared by the two target applies.
+#include "dz_iqn_ops.h"
+#include "dz_torso.h"
+
+namespace {
+constexpr int kS_iqn_fc2w = 32;   // row splits of the fc2 weight gradient
+constexpr int kS_iqn_embw = 8;    // row splits of the embedding weight gradient
+constexpr int kS_iqn_bias = 32;   // row splits of the bias column sums
+}
+
+extern "C" int dz_iqn_layout(int A, int latent, int B, int n0, int n1, int n2,
+                             dz_iqn_layout_t* L) {
+  DZ_REQUIRE(L && A > 0 && B > 0 && B <= 1024 && latent >= 16 && latent % 16 == 0);
+  DZ_REQUIRE(n0 > 0 && n0 <= 256 && n1 > 0 && n2 > 0 && n2 <= 256);
+  L->num_actions = A; L->latent_dim = latent; L->batch = B;
+  L->samples[0] = n0; L->samples[1] = n1; L->samples[2] = n2;
+  L->emb_ld = kFlat; L->fc1_ld = kHid; L->fc2_ld = (int32_t)align4(A); L->pad_ = 0;
+  int64_t o = 0;
+  const int64_t cw[3] = {256 * 32, 512 * 64, 576 * 64};
+  const int64_t cb[3] = {32, 64, 64};
+  for (int i = 0; i < 3; ++i) {
+    L->conv_w[i] = o; o = align4(o + cw[i]);
+    L->conv_b[i] = o; o = align4(o + cb[i]);
+  }
+  L->emb_w = o; o = align4(o + (int64_t)latent * kFlat);
+  L->emb_b = o; o = align4(o + kFlat);
+  L->fc1_w = o; o = align4(o + (int64_t)kFlat * kHid);
+  L->fc1_b = o; o = align4(o + kHid);
+  L->fc2_w = o; o = align4(o + (int64_t)kHid * L->fc2_ld);
+  L->fc2_b = o; o = align4(o + A);
+  L->param_count = o;
+  L->param_count_ref = 77984 + (int64_t)latent * kFlat + kFlat + (int64_t)kFlat * kHid +
+                       kHid + (int64_t)kHid * A + A;
+  const int64_t M0 = (int64_t)B * n0, Mt = (int64_t)B * (n0 + n1 + n2), ld2 = L->fc2_ld;
+  int64_t w = 0;
+  auto take = [&](int64_t n) { int64_t r = w; w = align4(w + n); return r; };
+  L->ws_act1 = take(2LL * B * 400 * 32);
+  L->ws_act2 = take(2LL * B * 81 * 64);
+  L->ws_feat = take(2LL * B * kFlat);
+  L->ws_cos = take(Mt * latent);
+  L->ws_hin = take(Mt * kFlat);
+  L->ws_temb = take(M0 * kFlat);
+  L->ws_h1 = take(Mt * kHid);
+  L->ws_out = take(Mt * ld2);
+  L->ws_dout = take(M0 * ld2);
+  L->ws_dh1 = take(M0 * kHid);
+  L->ws_dhin = take(M0 * kFlat);
+  L->ws_dfeat = take((int64_t)B * kFlat);
+  L->ws_dact2 = take((int64_t)B * 81 * 64);
+  L->ws_dact1 = take((int64_t)B * 400 * 32);
+  L->ws_wgrad_part = take(torso_wgrad_part_elems());
+  L->ws_fc2w_part = take((int64_t)kS_iqn_fc2w * kHid * ld2);
+  L->ws_embw_part = take((int64_t)kS_iqn_embw * latent * kFlat);
+  L->ws_bias_part = take((int64_t)kS_iqn_bias * (kFlat + kHid + ld2));
+  L->ws_norm_part = take(kNormBlocks);
+  L->ws_scalars = take(16);
+  L->ws_zeros = take(kFlat + 1024);
+  L->ws_count = w;
+  return DZ_OK;
+}
+
+namespace {
+
+struct IqnApplies {
+  int G;                          // applies (row groups)
+  int rows[3], row0[3], samples[3];
+  int feat_row0[3];               // first torso-feature row of each apply
+  const float* params[3];
+  const float* tau[3];
+};
+
+// tau embedding -> mix with the state embedding -> value head, for every apply.
+int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
+                     float* temb, hipStream_t s) {
+  int rc;
+  const int latent = L.latent_dim, ld2 = L.fc2_ld;
+  int Mt = 0, max_rows = 0;
+  for (int g = 0; g < ap.G; ++g) { Mt += ap.rows[g]; if (ap.rows[g] > max_rows) max_rows = ap.rows[g]; }
+  {
+    const long total = (long)Mt * latent;
+    hipLaunchKernelGGL(iqn_cos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       ap.tau[0], ap.tau[ap.G > 1 ? 1 : 0], ap.tau[ap.G > 2 ? 2 : 0],
+                       ap.rows[0], ap.G > 1 ? ap.rows[1] : 0, ap.G > 2 ? ap.rows[2] : 0,
+                       latent, ws + L.ws_cos);
+    DZ_LAUNCH_CHECK();
+    DZ_PROF(s, "tau_cos");
+  }
+  IqnLinParams p;
+  p.G = ap.G;
+  for (int g = 0; g < 3; ++g) {
+    const int gg = g < ap.G ? g : 0;
+    p.row0[g] = ap.row0[gg]; p.rows[g] = ap.rows[gg]; p.params[g] = ap.params[gg];
+    p.feat_row0[g] = ap.feat_row0[gg]; p.samples[g] = ap.samples[gg];
+  }
+  const unsigned my = (unsigned)((max_rows + IqnLin::BM - 1) / IqnLin::BM);
+  {  // relu(cos @ Wemb + b) * feat -> head_in
+    p.x = ws + L.ws_cos; p.ldx = latent; p.w_off = L.emb_w; p.b_off = L.emb_b;
+    p.ldw = L.emb_ld; p.K = latent; p.N = kFlat; p.epi = IQN_EPI_MIX;
+    p.out = ws + L.ws_hin; p.ldo = kFlat; p.feat = ws + L.ws_feat; p.temb = temb;
+    rc = dz_launch_gemm<IqnLin>(p, dim3(kFlat / IqnLin::BN, my, ap.G), s);
+    if (rc) return rc;
+    DZ_PROF(s, "emb_fwd");
+  }
+  {  // relu(head_in @ W1 + b1)
+    p.x = ws + L.ws_hin; p.ldx = kFlat; p.w_off = L.fc1_w; p.b_off = L.fc1_b;
+    p.ldw = L.fc1_ld; p.K = kFlat; p.N = kHid; p.epi = IQN_EPI_BIAS_RELU;
+    p.out = ws + L.ws_h1; p.ldo = kHid; p.feat = nullptr; p.temb = nullptr;
+    rc = dz_launch_gemm<IqnLin>(p, dim3(kHid / IqnLin::BN, my, ap.G), s);
+    if (rc) return rc;
+    DZ_PROF(s, "fc1_fwd");
+  }
+  {  // h1 @ W2 + b2
+    p.x = ws + L.ws_h1; p.ldx = kHid; p.w_off = L.fc2_w; p.b_off = L.fc2_b;
+    p.ldw = ld2; p.K = kHid; p.N = L.num_actions; p.epi = IQN_EPI_BIAS;
+    p.out = ws + L.ws_out; p.ldo = ld2;
+    rc = dz_launch_gemm<IqnLin>(
+        p, dim3((L.num_actions + IqnLin::BN - 1) / IqnLin::BN, my, ap.G), s);
+    if (rc) return rc;
+    DZ_PROF(s, "fc2_fwd");
+  }
+  return DZ_OK;
+}
+
+}  // namespace
+
+extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stream) {
+  DZ_REQUIRE(a && a->online && a->target && a->ws && a->s_tm1 && a->s_t && a->a_tm1 &&
+             a->r_t && a->discount_t && a->losses && a->tau_tm1 && a->tau_sel && a->tau_t);
+  dz_iqn_layout_t L;
+  int rc = dz_iqn_layout(a->num_actions, a->latent_dim, a->batch, a->samples[0],
+                         a->samples[1], a->samples[2], &L);
+  if (rc) return rc;
+  hipStream_t s = dz_s(stream);
+  float* ws = a->ws;
+  const int B = a->batch, A = a->num_actions, ld2 = L.fc2_ld, latent = L.latent_dim;
+  const int n0 = a->samples[0], n1 = a->samples[1], n2 = a->samples[2];
+  const int M0 = B * n0;
+  const float* zeros = ws + L.ws_zeros;
+  const TorsoBufs T = {L.conv_w, L.conv_b, ws + L.ws_act1, ws + L.ws_act2, ws + L.ws_feat};
+  if (g_dz_prof_on) dz_prof_begin(s);
+
+  if (phases & DZ_PHASE_FORWARD) {
+    const float* prm[2] = {a->online, a->target};
+    const uint8_t* in[2] = {a->s_tm1, a->s_t};
+    rc = torso_forward(T, 2, B, prm, in, s);
+    if (rc) return rc;
+    IqnApplies ap;
+    ap.G = 3;
+    ap.rows[0] = B * n0; ap.rows[1] = B * n1; ap.rows[2] = B * n2;
+    ap.row0[0] = 0; ap.row0[1] = ap.rows[0]; ap.row0[2] = ap.rows[0] + ap.rows[1];
+    ap.samples[0] = n0; ap.samples[1] = n1; ap.samples[2] = n2;
+    ap.feat_row0[0] = 0; ap.feat_row0[1] = B; ap.feat_row0[2] = B;
+    ap.params[0] = a->online; ap.params[1] = a->target; ap.params[2] = a->target;
+    ap.tau[0] = a->tau_tm1; ap.tau[1] = a->tau_sel; ap.tau[2] = a->tau_t;
+    rc = iqn_head_forward(L, ap, ws, ws + L.ws_temb, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(256), 0, s, ws + L.ws_out, ld2, B, A,
+                       n0, n1, n2, a->tau_tm1, a->a_tm1, a->r_t, a->discount_t, a->huber,
+                       ws + L.ws_dout, a->losses);
+    DZ_LAUNCH_CHECK();
+    DZ_PROF(s, "loss");
+  }
+
+  if (phases & DZ_PHASE_BACKWARD) {
+    DZ_REQUIRE(a->grad);
+    float* grad = a->grad;
+    FcHead h1, h2;
+    h1.w_mu = L.fc1_w; h1.w_sig = L.fc1_w; h1.ldw = L.fc1_ld; h1.N = kHid; h1.K = kFlat;
+    h1.x_off = 0; h1.eps_in = 0; h1.eps_out = 0; h1.out_off = 0;
+    h2 = h1;
+    h2.w_mu = L.fc2_w; h2.w_sig = L.fc2_w; h2.ldw = ld2; h2.N = A; h2.K = kHid;
+    {  // fc2: weight-gradient partials + input gradient
+      IqnWgradParams w;
+      w.x = ws + L.ws_h1; w.ldx = kHid; w.dy = ws + L.ws_dout; w.ldy = ld2; w.M = M0;
+      w.K = kHid; w.N = A; w.ldw = ld2; w.S = kS_iqn_fc2w; w.part = ws + L.ws_fc2w_part;
+      FcDgradParams d;
+      d.dy = ws + L.ws_dout; d.ldy = ld2; d.M = M0; d.NH = 1; d.S = 1; d.noisy = 0;
+      d.params = a->online; d.noise = zeros; d.head[0] = h2; d.head[1] = h2;
+      d.part = ws + L.ws_dh1; d.ldo = kHid; d.K = kHid; d.x_off = 0;
+      rc = dz_launch_gemm2<IqnWg, IqnDg>(
+          w, dim3((A + IqnWg::BN - 1) / IqnWg::BN, kHid / IqnWg::BM, kS_iqn_fc2w), d,
+          dim3(kHid / IqnDg::BN, (M0 + IqnDg::BM - 1) / IqnDg::BM, 1), s);
+      if (rc) return rc;
+      DZ_PROF(s, "fc2_wgrad+dgrad");
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)(((long)M0 * kHid + 63) / 64)),
+                         dim3(256), 0, s, ws + L.ws_dh1, 1, (long)M0 * kHid, ws + L.ws_h1,
+                         ws + L.ws_dh1);
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "dh1_mask");
+    }
+    {  // fc1: weight gradient (straight into grad) + input gradient
+      IqnWgradParams w;
+      w.x = ws + L.ws_hin; w.ldx = kFlat; w.dy = ws + L.ws_dh1; w.ldy = kHid; w.M = M0;
+      w.K = kFlat; w.N = kHid; w.ldw = L.fc1_ld; w.S = 1; w.part = grad + L.fc1_w;
+      FcDgradParams d;
+      d.dy = ws + L.ws_dh1; d.ldy = kHid; d.M = M0; d.NH = 1; d.S = 1; d.noisy = 0;
+      d.params = a->online; d.noise = zeros; d.head[0] = h1; d.head[1] = h1;
+      d.part = ws + L.ws_dhin; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
+      rc = dz_launch_gemm2<IqnWg, IqnDg>(
+          w, dim3(kHid / IqnWg::BN, kFlat / IqnWg::BM, 1), d,
+          dim3(kFlat / IqnDg::BN, (M0 + IqnDg::BM - 1) / IqnDg::BM, 1), s);
+      if (rc) return rc;
+      DZ_PROF(s, "fc1_wgrad+dgrad");
+    }
+    hipLaunchKernelGGL(iqn_mix_bwd_kernel, dim3((kFlat + 255) / 256, B), dim3(256), 0, s,
+                       ws + L.ws_dhin, ws + L.ws_temb, ws + L.ws_feat, B, n0, kFlat,
+                       ws + L.ws_dfeat);
+    DZ_LAUNCH_CHECK();
+    DZ_PROF(s, "mix_bwd");
+    {  // tau-embedding weight-gradient partials
+      IqnWgradParams w;
+      w.x = ws + L.ws_cos; w.ldx = latent; w.dy = ws + L.ws_dhin; w.ldy = kFlat; w.M = M0;
+      w.K = latent; w.N = kFlat; w.ldw = L.emb_ld; w.S = kS_iqn_embw;
+      w.part = ws + L.ws_embw_part;
+      rc = dz_launch_gemm<IqnWg>(
+          w, dim3(kFlat / IqnWg::BN, (latent + IqnWg::BM - 1) / IqnWg::BM, kS_iqn_embw), s);
+      if (rc) return rc;
+      DZ_PROF(s, "emb_wgrad");
+    }
+    float* bpart = ws + L.ws_bias_part;
+    float* bp_emb = bpart;
+    float* bp_fc1 = bp_emb + (long)kS_iqn_bias * kFlat;
+    float* bp_fc2 = bp_fc1 + (long)kS_iqn_bias * kHid;
+    {
+      ColPartJobs J;
+      J.j[0] = {ws + L.ws_dhin, M0, kFlat, kFlat, bp_emb};
+      J.j[1] = {ws + L.ws_dh1, M0, kHid, kHid, bp_fc1};
+      J.j[2] = {ws + L.ws_dout, M0, A, ld2, bp_fc2};
+      hipLaunchKernelGGL(colsum_part_kernel, dim3(kFlat / 64, kS_iqn_bias, 3), dim3(256), 0,
+                         s, J, kS_iqn_bias);
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "bias_colsum");
+    }
+    ReduceJob conv_jobs[3];
+    rc = torso_backward(T, B, a->online, a->s_tm1, ws + L.ws_dfeat, ws + L.ws_dact2,
+                        ws + L.ws_dact1, ws + L.ws_wgrad_part, grad, conv_jobs, s);
+    if (rc) return rc;
+    {
+      ReduceJobs8 J;
+      J.n = 8;
+      for (int j = 0; j < 3; ++j) J.r[j] = conv_jobs[j];
+      J.r[3] = {ws + L.ws_fc2w_part, kS_iqn_fc2w, (long)kHid * ld2, grad + L.fc2_w};
+      J.r[4] = {ws + L.ws_embw_part, kS_iqn_embw, (long)latent * kFlat, grad + L.emb_w};
+      J.r[5] = {bp_emb, kS_iqn_bias, (long)kFlat, grad + L.emb_b};
+      J.r[6] = {bp_fc1, kS_iqn_bias, (long)kHid, grad + L.fc1_b};
+      J.r[7] = {bp_fc2, kS_iqn_bias, (long)A, grad + L.fc2_b};
+      unsigned acc = 0;
+      for (int j = 0; j < 8; ++j) { acc += (unsigned)((J.r[j].n + 63) / 64); J.r_end[j] = acc; }
+      hipLaunchKernelGGL(reduce_jobs_kernel, dim3(acc), dim3(256), 0, s, J);
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "finalize_grads");
+    }
+  }
+
+  if (phases & DZ_PHASE_OPTIMIZER) {
+    DZ_REQUIRE(a->grad && a->opt_m && a->opt_v && a->opt_count);
+    float* sc = ws + L.ws_scalars;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
+                       (long)L.param_count, ws + L.ws_norm_part);
+    DZ_LAUNCH_CHECK();
+    DZ_PROF(s, "grad_sumsq");
+    hipLaunchKernelGGL(opt_scalars_kernel, dim3(1), dim3(256), 0, s, ws + L.ws_norm_part,
+                       kNormBlocks, a->opt_count, a->b1, a->b2, a->max_norm, a->losses,
+                       zeros, B, sc);
+    DZ_LAUNCH_CHECK();
+    DZ_PROF(s, "opt_scalars");
+    hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad, a->opt_m,
+                       a->opt_v, (long)(L.param_count >> 2), sc, a->lr, a->b1, a->b2, a->eps,
+                       a->max_norm);
+    DZ_LAUNCH_CHECK();
+    DZ_PROF(s, "adam");
+  }
+  return DZ_OK;
+}
+
+extern "C" int dz_iqn_apply(int A, int latent, int B, int samples, const float* params,
+                            const uint8_t* states, const float* taus, float* ws,
+                            float* q_dist_out, float* q_values_out, int32_t* greedy_out,
+                            float* vmax_out, dz_stream_t stream) {
+  DZ_REQUIRE(params && states && taus && ws);
+  dz_iqn_layout_t L;
+  // the workspace of a (B, samples, 1, 1) layout is a prefix-compatible subset
+  int rc = dz_iqn_layout(A, latent, B, samples, 1, 1, &L);
+  if (rc) return rc;
+  hipStream_t s = dz_s(stream);
+  const TorsoBufs T = {L.conv_w, L.conv_b, ws + L.ws_act1, ws + L.ws_act2, ws + L.ws_feat};
+  const float* prm[1] = {params};
+  const uint8_t* in[1] = {states};
+  const bool prof = g_dz_prof_on;
+  g_dz_prof_on = false;
+  rc = torso_forward(T, 1, B, prm, in, s);
+  if (!rc) {
+    IqnApplies ap;
+    ap.G = 1;
+    ap.rows[0] = B * samples; ap.row0[0] = 0; ap.samples[0] = samples; ap.feat_row0[0] = 0;
+    ap.params[0] = params; ap.tau[0] = taus;
+    rc = iqn_head_forward(L, ap, ws, nullptr, s);
+  }
+  g_dz_prof_on = prof;
+  if (rc) return rc;
+  if (q_dist_out)
+    DZ_HIP_CHECK(hipMemcpy2DAsync(q_dist_out, (size_t)A * sizeof(float), ws + L.ws_out,
+                                  (size_t)L.fc2_ld * sizeof(float), (size_t)A * sizeof(float),
+                                  (size_t)B * samples, hipMemcpyDeviceToDevice, s));
+  if (q_values_out || greedy_out || vmax_out) {
+    hipLaunchKernelGGL(iqn_q_values_kernel, dim3(B), dim3(64), 0, s, ws + L.ws_out, L.fc2_ld,
+                       A, samples, q_values_out, greedy_out, vmax_out);
+    DZ_LAUNCH_CHECK();
+  }
+  return DZ_OK;
+}
+
+extern "C" int dz_uniform_fill(float* out, int64_t n, uint64_t seed, uint64_t counter,
+                               const int32_t* step, dz_stream_t stream) {
+  DZ_REQUIRE(out && n > 0);
+  hipLaunchKernelGGL(uniform_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     dz_s(stream), out, (long)n, seed, counter, step);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}

@@ -1,0 +1,328 @@
+// Operand views and small kernels of the IQN learner step
+// (ref: networks.py:264-292 iqn_atari_network, iqn/agent.py:176-216).
+//
+// IQN evaluates the value head on batch x tau-samples rows, so unlike the other
+// agents its linear layers are real GEMMs (2048 x 3136 x 512 per apply at the
+// reference configuration): 64x64 output tiles, full-depth contraction, and the
+// layer's elementwise tail fused into the accumulator store.
+#pragma once
+
+#include "dz_qnet_kernels.h"
+
+namespace {
+
+enum { IQN_EPI_BIAS = 0, IQN_EPI_BIAS_RELU = 1, IQN_EPI_MIX = 2 };
+
+// out[row][n] = epi( sum_k x[row][k] W_g[k][n] + b_g[n] )  for the rows of up to
+// three groups (row ranges [row0[g], row0[g]+rows[g]) with parameters params[g]).
+//   IQN_EPI_MIX (tau embedding, networks.py:281-285):
+//     e = relu(.);  temb[row] = e (group 0 only);  out = e * feat[feat_row0[g] + r/samples[g]]
+struct IqnLinParams {
+  const float* x;
+  int ldx;
+  int G;
+  int row0[DZ_MAX_GROUPS];
+  int rows[DZ_MAX_GROUPS];
+  const float* params[DZ_MAX_GROUPS];
+  long w_off;
+  long b_off;
+  int ldw;
+  int K;      // multiple of 16
+  int N;
+  int epi;
+  float* out;
+  int ldo;
+  const float* feat;  // [*][N] (MIX)
+  int feat_row0[DZ_MAX_GROUPS];
+  int samples[DZ_MAX_GROUPS];
+  float* temb;        // [rows[0]][N] or null (MIX)
+};
+
+template <int WM_, int WN_, int WK_, int KT_>
+struct IqnLinOp {
+  static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
+  static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_RC, A_MAP = DZ_MAP_QUAD;
+  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
+  typedef IqnLinParams Params;
+
+  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+    t.z = bid.z;
+    t.m0 = bid.y * BM;
+    t.n0 = bid.x * BN;
+    t.st_begin = 0;
+    t.st_end = (p.K / 16 + CPS - 1) / CPS;
+    return t.z < p.G && t.m0 < p.rows[t.z] && t.n0 < p.N;
+  }
+  __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
+                                  int row, int q) {
+    const int gc = st * CPS + c, total = p.K / 16;
+    const int m = t.m0 + row;
+    const bool ok = (m < p.rows[t.z]) & (gc < total);
+    const int k = min(gc, total - 1) * 16 + 4 * q;
+    return dz_sel4(ok, dz_ld4(p.x + (long)(p.row0[t.z] + min(m, p.rows[t.z] - 1)) * p.ldx + k));
+  }
+  __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
+                                  int kk, int rq) {
+    const int gc = st * CPS + c, total = p.K / 16;
+    const int k = min(gc, total - 1) * 16 + kk;
+    const int n = min(t.n0 + 4 * rq, p.ldw - 4);
+    return dz_sel4(gc < total, dz_ld4(p.params[t.z] + p.w_off + (long)k * p.ldw + n));
+  }
+  __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
+                               int lane, const f32x16& acc) {
+    const int col = t.n0 + wn * 32 + (lane & 31);
+    if (col >= p.N) return;
+    const int g = t.z;
+    const float b = p.params[g][p.b_off + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = t.m0 + wm * 32 + dz_acc_row(r, lane);
+      if (m >= p.rows[g]) continue;
+      float v = acc[r] + b;
+      if (p.epi != IQN_EPI_BIAS) v = v > 0.f ? v : 0.f;
+      if (p.epi == IQN_EPI_MIX) {
+        if (g == 0 && p.temb) p.temb[(long)m * p.N + col] = v;
+        v = v * p.feat[(long)(p.feat_row0[g] + m / p.samples[g]) * p.N + col];
+      }
+      p.out[(long)(p.row0[g] + m) * p.ldo + col] = v;
+    }
+  }
+};
+
+// Weight gradient with the batch-row reduction split over the grid:
+// part[split][k][n] = sum_{m in split} x[m][k] dy[m][n]   (k < K, n < ldw)
+struct IqnWgradParams {
+  const float* x; int ldx;
+  const float* dy; int ldy;
+  int M;       // reduction rows
+  int K, N, ldw;
+  int S;
+  float* part; // [S][K][ldw]
+};
+
+template <int WM_, int WN_, int WK_, int KT_>
+struct IqnWgradOp {
+  static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
+  static constexpr int A_LAYOUT = DZ_RC, B_LAYOUT = DZ_RC, A_MAP = DZ_MAP_QUAD;
+  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
+  typedef IqnWgradParams Params;
+
+  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+    t.z = bid.z;
+    t.m0 = bid.y * BM;  // k rows
+    t.n0 = bid.x * BN;
+    const int stages = (p.M + BK - 1) / BK;
+    const int per = (stages + p.S - 1) / p.S;
+    t.st_begin = t.z * per;
+    t.st_end = min(stages, t.st_begin + per);
+    return t.m0 < p.K && t.n0 < p.N;
+  }
+  __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
+                                  int kk, int rq) {
+    const int m = st * BK + c * 16 + kk;
+    const int k = min(t.m0 + 4 * rq, p.K - 4);
+    return dz_sel4(m < p.M, dz_ld4(p.x + (long)min(m, p.M - 1) * p.ldx + k));
+  }
+  __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
+                                  int kk, int rq) {
+    const int m = st * BK + c * 16 + kk;
+    const int n = min(t.n0 + 4 * rq, p.ldw - 4);
+    return dz_sel4(m < p.M, dz_ld4(p.dy + (long)min(m, p.M - 1) * p.ldy + n));
+  }
+  __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
+                               int lane, const f32x16& acc) {
+    const int col = t.n0 + wn * 32 + (lane & 31);
+    if (col >= p.ldw) return;
+    float* base = p.part + (long)t.z * p.K * p.ldw + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = t.m0 + wm * 32 + dz_acc_row(r, lane);
+      if (k < p.K) base[(long)k * p.ldw] = col < p.N ? acc[r] : 0.f;
+    }
+  }
+};
+
+using IqnLin = IqnLinOp<2, 2, 1, 2>;
+using IqnWg = IqnWgradOp<2, 2, 1, 2>;
+using IqnDg = FcDgradOp<2, 2, 1, 2>;
+
+// cosemb[row][i] = cos(pi_i * tau[row]),  pi_i = float32(i+1) * float32(pi)
+// (networks.py:277-278; both products in float32 as in the reference).
+__global__ void iqn_cos_kernel(const float* t0, const float* t1, const float* t2, int n0,
+                               int n1, int n2, int latent, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)(n0 + n1 + n2) * latent;
+  if (i >= total) return;
+  const int row = (int)(i / latent), l = (int)(i % latent);
+  const float tau = row < n0 ? t0[row] : (row < n0 + n1 ? t1[row - n0] : t2[row - n0 - n1]);
+  const float pm = (float)(l + 1) * 3.14159274101257324f;
+  out[i] = cosf(pm * tau);
+}
+
+// U[0,1) samples for the tau draws (iqn/agent.py:47-51 jax.random.uniform: 23
+// random mantissa bits), counter-based so a step's draws depend only on (seed,
+// step, index).
+__global__ void uniform_fill_kernel(float* __restrict__ out, long n, uint64_t seed,
+                                    uint64_t counter, const int32_t* __restrict__ step) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (step) counter += (uint64_t)(*step) * (uint64_t)n;
+  const uint64_t h = mix64(mix64(seed) ^ mix64(counter + (uint64_t)i));
+  out[i] = (float)(h >> 41) * (1.0f / 8388608.0f);
+}
+
+// vmap(rlax.quantile_q_learning) over the batch (iqn/agent.py:199-209).  One block
+// per batch element; rows of `out` are (batch element, sample) pairs.
+//   a* = argmax_a mean_n out_sel[b][n][a];  target_j = r + g * out_t[b][j][a*]
+//   loss_b = sum_i mean_j |tau_i - 1{delta_ij < 0}| huber_kappa(delta_ij),
+//   delta_ij = target_j - out_0[b][i][a_tm1];  dout = d(mean_b loss_b)/d out_0
+__global__ __launch_bounds__(256) void iqn_loss_kernel(
+    const float* __restrict__ out, int ld, int B, int A, int n0, int n1, int n2,
+    const float* __restrict__ tau0, const int64_t* __restrict__ a_tm1,
+    const double* __restrict__ r_t, const double* __restrict__ d_t, float kappa,
+    float* __restrict__ dout, float* __restrict__ losses) {
+  __shared__ float s_t[256];
+  __shared__ float s_red[4];
+  __shared__ int s_astar;
+  const int b = blockIdx.x, i = threadIdx.x;
+  const float* o0 = out + (long)b * n0 * ld;
+  const float* o1 = out + ((long)B * n0 + (long)b * n1) * ld;
+  const float* o2 = out + ((long)B * (n0 + n1) + (long)b * n2) * ld;
+  if (i < 64) {
+    float best = -__builtin_inff();
+    int arg = 0;
+    for (int a = 0; a < A; ++a) {
+      float sum = 0.f;
+      for (int n = i; n < n1; n += 64) sum += o1[(long)n * ld + a];
+      sum = wave_sum(sum) / (float)n1;
+      if (sum > best) { best = sum; arg = a; }
+    }
+    if (i == 0) s_astar = arg;
+  }
+  __syncthreads();
+  const int a_star = s_astar, a0 = (int)a_tm1[b];
+  const float r = (float)r_t[b], g = (float)d_t[b];
+  if (i < n2) s_t[i] = r + g * o2[(long)i * ld + a_star];
+  __syncthreads();
+  float li = 0.f, gi = 0.f;
+  if (i < n0) {
+    const float theta = o0[(long)i * ld + a0], ti = tau0[b * n0 + i];
+    for (int j = 0; j < n2; ++j) {
+      const float delta = s_t[j] - theta;
+      const float wgt = fabsf(ti - (delta < 0.f ? 1.f : 0.f));
+      const float ad = fabsf(delta);
+      float hub, dh;
+      if (kappa > 0.f) {
+        const float q = fminf(ad, kappa);
+        hub = 0.5f * q * q + kappa * (ad - q);
+        dh = ad <= kappa ? delta : (delta > 0.f ? kappa : -kappa);
+      } else {
+        hub = ad;
+        dh = delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f);
+      }
+      li += wgt * hub;
+      gi += wgt * dh;
+    }
+    li /= (float)n2;
+    gi = -gi / (float)n2;
+  }
+  const float s = wave_sum(li);
+  if ((i & 63) == 0) s_red[i >> 6] = s;
+  __syncthreads();
+  if (i == 0) losses[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  if (i < n0) {
+    float* d = dout + ((long)b * n0 + i) * ld;
+    for (int a = 0; a < ld; ++a) d[a] = (a == a0) ? gi / (float)B : 0.f;
+  }
+}
+
+// Backward of head_in = temb * feat[b] (networks.py:285) for the online apply:
+//   dzt[row][c]  = dhin[row][c] * feat[b][c] * (temb[row][c] > 0)     (in place)
+//   dfeat[b][c]  = (feat[b][c] > 0) * sum_n dhin[b*N+n][c] * temb[b*N+n][c]
+__global__ __launch_bounds__(256) void iqn_mix_bwd_kernel(float* __restrict__ dhin,
+                                                          const float* __restrict__ temb,
+                                                          const float* __restrict__ feat,
+                                                          int B, int samples, int F,
+                                                          float* __restrict__ dfeat) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (c >= F) return;
+  const float f = feat[(long)b * F + c];
+  float acc = 0.f;
+  long o = (long)b * samples * F + c;
+#pragma unroll 4
+  for (int n = 0; n < samples; ++n, o += F) {
+    const float d = dhin[o], e = temb[o];
+    acc += d * e;
+    dhin[o] = e > 0.f ? d * f : 0.f;
+  }
+  dfeat[(long)b * F + c] = f > 0.f ? acc : 0.f;
+}
+
+// part[split][c] = sum of rows [split*rps, (split+1)*rps) of m[.][c]; a set of
+// matrices per launch (blockIdx.z).  The S partial rows are folded by
+// reduce_jobs_kernel.
+struct ColPartJob { const float* m; int rows; int cols; int ld; float* part; };
+struct ColPartJobs { ColPartJob j[3]; };
+__global__ __launch_bounds__(256) void colsum_part_kernel(ColPartJobs jobs, int S) {
+  __shared__ float red[4][64];
+  const ColPartJob jb = jobs.j[blockIdx.z];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l;
+  if (blockIdx.x * 64 >= jb.cols) return;
+  const int rps = (jb.rows + S - 1) / S;
+  const int r0 = blockIdx.y * rps, r1 = min(jb.rows, r0 + rps);
+  float v = 0.f;
+  if (c < jb.cols) {
+#pragma unroll 4
+    for (int r = r0 + w; r < r1; r += 4) v += jb.m[(long)r * jb.ld + c];
+  }
+  red[w][l] = v;
+  __syncthreads();
+  if (w == 0 && c < jb.cols)
+    jb.part[(long)blockIdx.y * jb.cols + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+}
+
+// out[i] = sum_s part[s][i] for up to 8 jobs in one launch.
+struct ReduceJobs8 { ReduceJob r[8]; unsigned r_end[8]; int n; };
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceJobs8 J) {
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned b = blockIdx.x;
+  int j = 0;
+  while (j < J.n - 1 && b >= J.r_end[j]) ++j;
+  const ReduceJob jb = J.r[j];
+  const long i = (long)(b - (j ? J.r_end[j - 1] : 0)) * 64 + l;
+  float v = 0.f;
+  if (i < jb.n)
+    for (int s = w; s < jb.S; s += 4) v += jb.part[(long)s * jb.n + i];
+  red[w][l] = v;
+  __syncthreads();
+  if (w == 0 && i < jb.n) jb.out[i] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+}
+
+// q_values[b][a] = mean_n q_dist[b][n][a] (networks.py:288), greedy action (first
+// maximum) and its value.
+__global__ __launch_bounds__(64) void iqn_q_values_kernel(const float* __restrict__ out,
+                                                          int ld, int A, int samples,
+                                                          float* __restrict__ q_out,
+                                                          int32_t* __restrict__ greedy_out,
+                                                          float* __restrict__ vmax_out) {
+  const int b = blockIdx.x, i = threadIdx.x;
+  const float* o = out + (long)b * samples * ld;
+  float best = -__builtin_inff();
+  int arg = 0;
+  for (int a = 0; a < A; ++a) {
+    float sum = 0.f;
+    for (int n = i; n < samples; n += 64) sum += o[(long)n * ld + a];
+    sum = wave_sum(sum) / (float)samples;
+    if (i == 0 && q_out) q_out[b * A + a] = sum;
+    if (sum > best) { best = sum; arg = a; }
+  }
+  if (i == 0) {
+    if (greedy_out) greedy_out[b] = arg;
+    if (vmax_out) vmax_out[b] = best;
+  }
+}
+
+}  // namespace

@@ -1,0 +1,108 @@
+// The convolutional torso shared by the dense-head and IQN learner steps
+// (ref: networks.py:186-204 dqn_torso): forward for G parameter/input groups
+// and the backward pass of group 0, as launches of the implicit-GEMM Ops.
+#pragma once
+
+#include "dz_qnet_kernels.h"
+
+namespace {
+
+struct TorsoBufs {
+  const int64_t* conv_w;   // [3] parameter offsets
+  const int64_t* conv_b;   // [3]
+  float* act1;             // [G*B][20][20][32]
+  float* act2;             // [G*B][9][9][64]
+  float* feat;             // [G*B][3136]
+};
+
+// relu(conv3(relu(conv2(relu(conv1(u8/255)))))) for G groups; group g reads
+// images in[g] with parameters prm[g].
+inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* prm,
+                         const uint8_t* const* in, hipStream_t s) {
+  int rc;
+  {
+    ConvFwdParams p;
+    for (int g = 0; g < G; ++g) {
+      p.in[g] = in[g]; p.in_img_base[g] = 0;
+      p.w[g] = prm[g] + T.conv_w[0]; p.bias[g] = prm[g] + T.conv_b[0];
+    }
+    p.out = T.act1; p.B = B; p.G = G;
+    rc = dz_launch_gemm<Conv1Fwd>(p, dim3(1, G * Conv1Fwd::tiles_per_group(B)), s);
+    if (rc) return rc;
+    DZ_PROF(s, "conv1_fwd");
+  }
+  {
+    ConvFwdParams p;
+    for (int g = 0; g < G; ++g) {
+      p.in[g] = T.act1; p.in_img_base[g] = g * B;
+      p.w[g] = prm[g] + T.conv_w[1]; p.bias[g] = prm[g] + T.conv_b[1];
+    }
+    p.out = T.act2; p.B = B; p.G = G;
+    rc = dz_launch_gemm<Conv2Fwd>(p, dim3(1, G * Conv2Fwd::tiles_per_group(B)), s);
+    if (rc) return rc;
+    DZ_PROF(s, "conv2_fwd");
+  }
+  {
+    ConvFwdParams p;
+    for (int g = 0; g < G; ++g) {
+      p.in[g] = T.act2; p.in_img_base[g] = g * B;
+      p.w[g] = prm[g] + T.conv_w[2]; p.bias[g] = prm[g] + T.conv_b[2];
+    }
+    p.out = T.feat; p.B = B; p.G = G;
+    rc = dz_launch_gemm<Conv3Fwd>(p, dim3(1, G * Conv3Fwd::tiles_per_group(B)), s);
+    if (rc) return rc;
+    DZ_PROF(s, "conv3_fwd");
+  }
+  return DZ_OK;
+}
+
+inline int64_t torso_wgrad_part_elems() {
+  return (int64_t)kS_cw1 * Conv1Wg::KROWS * 32 + (int64_t)kS_cw2 * Conv2Wg::KROWS * 64 +
+         (int64_t)kS_cw3 * Conv3Wg::KROWS * 64;
+}
+
+// Backward of group 0 from dfeat (already masked by feat > 0): split-K partial
+// slabs of the three weight(+bias-row) gradients are left in `part`; the three
+// ReduceJobs that fold them into the gradient buffer are returned in `jobs`.
+inline int torso_backward(const TorsoBufs& T, int B, const float* online,
+                          const uint8_t* s_tm1, const float* dfeat, float* dact2,
+                          float* dact1, float* part, float* grad, ReduceJob* jobs,
+                          hipStream_t s) {
+  int rc;
+  float* part1 = part;
+  float* part2 = part1 + (long)kS_cw1 * Conv1Wg::KROWS * 32;
+  float* part3 = part2 + (long)kS_cw2 * Conv2Wg::KROWS * 64;
+  {
+    ConvWgradParams w;
+    w.in = T.act2; w.dy = dfeat; w.part = part3; w.B = B; w.S = kS_cw3;
+    ConvDgradParams d;
+    d.dy = dfeat; d.w = online + T.conv_w[2]; d.act = T.act2; d.dx = dact2; d.B = B;
+    rc = dz_launch_gemm2<Conv3Wg, Conv3Dg>(w, dim3(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), d,
+                                          dim3(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1), s);
+    if (rc) return rc;
+    DZ_PROF(s, "conv3_wgrad+dgrad");
+  }
+  {
+    ConvWgradParams w;
+    w.in = T.act1; w.dy = dact2; w.part = part2; w.B = B; w.S = kS_cw2;
+    ConvDgradParams d;
+    d.dy = dact2; d.w = online + T.conv_w[1]; d.act = T.act1; d.dx = dact1; d.B = B;
+    rc = dz_launch_gemm2<Conv2Wg, Conv2Dg>(w, dim3(64 / Conv2Wg::BN, Conv2Wg::MT, kS_cw2), d,
+                                          dim3(32 / Conv2Dg::BN, Conv2Dg::tiles(B), 4), s);
+    if (rc) return rc;
+    DZ_PROF(s, "conv2_wgrad+dgrad");
+  }
+  {
+    ConvWgradParams p;
+    p.in = s_tm1; p.dy = dact1; p.part = part1; p.B = B; p.S = kS_cw1;
+    rc = dz_launch_gemm<Conv1Wg>(p, dim3(32 / Conv1Wg::BN, Conv1Wg::MT, kS_cw1), s);
+    if (rc) return rc;
+    DZ_PROF(s, "conv1_wgrad");
+  }
+  jobs[0] = {part1, kS_cw1, (long)Conv1Wg::KROWS * 32, grad + T.conv_w[0]};
+  jobs[1] = {part2, kS_cw2, (long)Conv2Wg::KROWS * 64, grad + T.conv_w[1]};
+  jobs[2] = {part3, kS_cw3, (long)Conv3Wg::KROWS * 64, grad + T.conv_w[2]};
+  return DZ_OK;
+}
+
+}  // namespace

@@ -385,6 +385,136 @@ class DenseLearner:
 
 
 # --------------------------------------------------------------------------- #
+#  IQN learner
+# --------------------------------------------------------------------------- #
+class IqnLearner:
+  """The jitted `update` of the IQN agent (ref: iqn/agent.py:176-232) as one
+  C-ABI call.  The three tau draws of a step (`_sample_tau`, iqn/agent.py:47-51)
+  are made on the device by a counter-based generator unless given."""
+
+  def __init__(self, network: networks.IqnNetwork, optimizer: AdamConfig,
+               batch_size: int, tau_samples=(64, 64, 64), huber_param: float = 1.0,
+               seed: int = 1, device=None, params=None):
+    self._lib = _lib.load()
+    if not torch.cuda.is_available():
+      raise _lib.HipLibraryError('IqnLearner needs an AMD GPU; no CPU fallback')
+    self.device = torch.device('cuda', torch.cuda.current_device()) \
+        if device is None else torch.device(device)
+    self.network = network
+    self.opt = optimizer
+    self.batch_size = int(batch_size)
+    self.tau_samples = tuple(int(x) for x in tau_samples)  # (s_tm1, policy, s_t)
+    self.layout = network.layout(self.batch_size, self.tau_samples)
+    L = self.layout
+    if params is None:
+      params = network.init(np.random.RandomState(seed))
+    f32 = dict(dtype=torch.float32, device=self.device)
+    self.online = torch.from_numpy(L.pack(params)).to(self.device)
+    self.target = self.online.clone()
+    self.grad = torch.zeros(L.param_count, **f32)
+    self.opt_m = torch.zeros(L.param_count, **f32)
+    self.opt_v = torch.zeros(L.param_count, **f32)
+    self.opt_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+    self.ws = torch.zeros(L.ws_count, **f32)
+    self.losses = torch.zeros(self.batch_size, **f32)
+    b = self.batch_size
+    self.taus = torch.zeros(b * sum(self.tau_samples), **f32)
+    n0, n1, n2 = self.tau_samples
+    self.tau_tm1 = self.taus[:b * n0].view(b, n0)
+    self.tau_sel = self.taus[b * n0:b * (n0 + n1)].view(b, n1)
+    self.tau_t = self.taus[b * (n0 + n1):].view(b, n2)
+    self.huber_param = float(huber_param)
+    self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    self._act_ws = {}
+
+  get_params = DenseLearner.get_params
+  set_params = DenseLearner.set_params
+  sync_target = DenseLearner.sync_target
+  get_opt_state = DenseLearner.get_opt_state
+  set_opt_state = DenseLearner.set_opt_state
+  ws_view = DenseLearner.ws_view
+
+  def sample_taus(self) -> None:
+    """Fresh U[0,1) draws for the three tau sets; the stream position is the
+    optimiser step count, read on the device (no host sync)."""
+    _lib.check(self._lib.dz_uniform_fill(
+        self.taus.data_ptr(), self.taus.numel(), self._seed, 0,
+        self.opt_count.data_ptr(),
+        torch.cuda.current_stream(self.device).cuda_stream), 'dz_uniform_fill')
+
+  def step(self, s_tm1, a_tm1, r_t, discount_t, s_t, taus=None,
+           phases: int = _lib.PHASE_ALL) -> None:
+    """taus: optional (tau_tm1 [B,N0], tau_sel [B,N1], tau_t [B,N2]) float32
+    device tensors; default: drawn on the device."""
+    b = self.batch_size
+    assert s_tm1.dtype == torch.uint8 and s_t.dtype == torch.uint8
+    assert tuple(s_tm1.shape) == (b, 84, 84, 4) and s_tm1.is_contiguous()
+    assert a_tm1.dtype == torch.int64 and r_t.dtype == torch.float64
+    assert discount_t.dtype == torch.float64
+    if taus is None:
+      self.sample_taus()
+    else:
+      for dst, src in zip((self.tau_tm1, self.tau_sel, self.tau_t), taus):
+        dst.copy_(src)
+    a = _lib.IqnArgs()
+    net = self.network
+    a.num_actions, a.latent_dim, a.batch = net.num_actions, net.latent_dim, b
+    for i in range(3):
+      a.samples[i] = self.tau_samples[i]
+    a.online = self.online.data_ptr()
+    a.target = self.target.data_ptr()
+    a.grad = self.grad.data_ptr()
+    a.opt_m = self.opt_m.data_ptr()
+    a.opt_v = self.opt_v.data_ptr()
+    a.opt_count = self.opt_count.data_ptr()
+    a.s_tm1 = s_tm1.data_ptr()
+    a.s_t = s_t.data_ptr()
+    a.a_tm1 = a_tm1.data_ptr()
+    a.r_t = r_t.data_ptr()
+    a.discount_t = discount_t.data_ptr()
+    a.tau_tm1 = self.tau_tm1.data_ptr()
+    a.tau_sel = self.tau_sel.data_ptr()
+    a.tau_t = self.tau_t.data_ptr()
+    a.ws = self.ws.data_ptr()
+    a.losses = self.losses.data_ptr()
+    a.lr, a.b1, a.b2 = self.opt.learning_rate, self.opt.b1, self.opt.b2
+    a.eps, a.max_norm = self.opt.eps, self.opt.max_global_grad_norm
+    a.huber = self.huber_param
+    _lib.check(self._lib.dz_iqn_learn(
+        ctypes.byref(a), phases,
+        torch.cuda.current_stream(self.device).cuda_stream), 'dz_iqn_learn')
+
+  def apply(self, states: torch.Tensor, taus: torch.Tensor, which: str = 'online'):
+    """(q_dist [B,N,A], q_values [B,A], greedy [B], max [B]) for uint8 states
+    and taus [B,N].  ref: iqn/agent.py:234-247."""
+    return iqn_apply(self._lib, self.network, self._act_ws,
+                     self.online if which == 'online' else self.target, states,
+                     taus, self.device)
+
+
+def iqn_apply(lib, net, ws_cache, params, states, taus, device):
+  assert states.dtype == torch.uint8 and states.is_contiguous()
+  assert taus.dtype == torch.float32 and taus.is_contiguous()
+  b, n = int(taus.shape[0]), int(taus.shape[1])
+  assert int(states.shape[0]) == b
+  key = (b, n)
+  if key not in ws_cache:
+    ws_cache[key] = torch.zeros(net.layout(b, (n, 1, 1)).ws_count,
+                                dtype=torch.float32, device=device)
+  f32 = dict(dtype=torch.float32, device=device)
+  q_dist = torch.empty((b, n, net.num_actions), **f32)
+  q = torch.empty((b, net.num_actions), **f32)
+  greedy = torch.empty(b, dtype=torch.int32, device=device)
+  vmax = torch.empty(b, **f32)
+  _lib.check(lib.dz_iqn_apply(
+      net.num_actions, net.latent_dim, b, n, params.data_ptr(), states.data_ptr(),
+      taus.data_ptr(), ws_cache[key].data_ptr(), q_dist.data_ptr(), q.data_ptr(),
+      greedy.data_ptr(), vmax.data_ptr(),
+      torch.cuda.current_stream(device).cuda_stream), 'dz_iqn_apply')
+  return q_dist, q, greedy, vmax
+
+
+# --------------------------------------------------------------------------- #
 #  Inference-only network (evaluation actor)
 # --------------------------------------------------------------------------- #
 class InferenceNet:
@@ -399,7 +529,12 @@ class InferenceNet:
         if device is None else torch.device(device)
     self.network = network
     self.is_rainbow = isinstance(network, networks.RainbowNetwork)
-    self.layout = network.layout(1) if self.is_rainbow else network.layout(1, 1)
+    self.is_iqn = isinstance(network, networks.IqnNetwork)
+    if self.is_iqn:
+      self.layout = network.layout(1, (1, 1, 1))  # parameters only; ws per apply
+    else:
+      self.layout = network.layout(1) if self.is_rainbow else network.layout(1, 1)
+    self._iqn_ws = {}
     self.params = torch.zeros(self.layout.param_count, dtype=torch.float32,
                               device=self.device)
     self.ws = torch.zeros(self.layout.ws_count, dtype=torch.float32,
@@ -420,6 +555,21 @@ class InferenceNet:
     else:
       self.params.copy_(torch.from_numpy(self.layout.pack(params)))
     self._has_params = True
+
+  def iqn_q_values(self, obs_u8: torch.Tensor, tau_samples: int) -> np.ndarray:
+    """Host Q-values [A] of the IQN net for one state with `tau_samples` fresh
+    tau draws (ref: iqn/agent.py:72-83)."""
+    if not self._has_params:
+      raise RuntimeError('network_params have not been set')
+    stream = torch.cuda.current_stream(self.device).cuda_stream
+    taus = torch.empty((1, tau_samples), dtype=torch.float32, device=self.device)
+    _lib.check(self._lib.dz_uniform_fill(taus.data_ptr(), tau_samples, self._seed,
+                                         self._counter, None, stream),
+               'dz_uniform_fill')
+    self._counter += tau_samples
+    _, q, _, _ = iqn_apply(self._lib, self.network, self._iqn_ws, self.params,
+                           obs_u8, taus, self.device)
+    return q[0].cpu().numpy()
 
   def q_values(self, obs_u8: torch.Tensor) -> np.ndarray:
     """Host Q-values [A] for ONE uint8 state tensor [1,84,84,4] on the device."""

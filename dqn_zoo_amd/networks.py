@@ -281,3 +281,106 @@ class DenseParamLayout:
   def unpack(self, flat: np.ndarray) -> dict:
     flat = np.asarray(flat, dtype=np.float32)
     return {k: np.array(v) for k, v in self._views(flat).items()}
+
+
+# --------------------------------------------------------------------------- #
+#  IQN (ref: networks.py:40-53, 264-292)
+# --------------------------------------------------------------------------- #
+class IqnInputs(typing.NamedTuple):
+  state: typing.Any
+  taus: typing.Any
+
+
+class IqnOutputs(typing.NamedTuple):
+  q_values: typing.Any
+  q_dist: typing.Any
+
+
+class IqnNetwork:
+  """Descriptor of `iqn_atari_network(num_actions, latent_dim)`: dqn_torso, a
+  cosine tau embedding mapped by linear(3136) + ReLU, multiplied into the state
+  embedding, then the dqn value head applied per (batch, sample) row."""
+
+  kind = 'iqn'
+
+  def __init__(self, num_actions: int, latent_dim: int = 64):
+    if latent_dim % 16 or latent_dim < 16:
+      raise ValueError('latent_dim must be a positive multiple of 16')
+    self.num_actions = int(num_actions)
+    self.latent_dim = int(latent_dim)
+
+  def layout(self, batch_size: int, samples=(64, 64, 64)) -> 'IqnParamLayout':
+    return IqnParamLayout(self.num_actions, self.latent_dim, batch_size, samples)
+
+  def init(self, random_state: np.random.RandomState) -> dict:
+    """U(+-1/sqrt(fan_in)) (ref: networks.py:58-79); creation order torso,
+    tau-embedding linear, value head (networks.py:272-287)."""
+    p = {}
+
+    def uni(shape, fan):
+      c = np.sqrt(1.0 / fan)
+      return random_state.uniform(-c, c, size=shape).astype(np.float32)
+
+    for name, ks, ci, co in (('conv1', 8, 4, 32), ('conv2', 4, 32, 64),
+                             ('conv3', 3, 64, 64)):
+      p[name + '/w'] = uni((ks, ks, ci, co), ci * ks * ks)
+      p[name + '/b'] = uni((co,), ci * ks * ks)
+    p['emb/w'] = uni((self.latent_dim, FLAT), self.latent_dim)
+    p['emb/b'] = uni((FLAT,), self.latent_dim)
+    p['fc1/w'] = uni((FLAT, HIDDEN), FLAT)
+    p['fc1/b'] = uni((HIDDEN,), FLAT)
+    p['fc2/w'] = uni((HIDDEN, self.num_actions), HIDDEN)
+    p['fc2/b'] = uni((self.num_actions,), HIDDEN)
+    return p
+
+
+class IqnParamLayout:
+
+  def __init__(self, num_actions, latent_dim, batch_size, samples):
+    self.c = _lib.IqnLayout()
+    n0, n1, n2 = (int(x) for x in samples)
+    _lib.check(_lib.load().dz_iqn_layout(num_actions, latent_dim, batch_size, n0,
+                                         n1, n2, ctypes.byref(self.c)),
+               'dz_iqn_layout')
+    self.num_actions = int(num_actions)
+    self.latent_dim = int(latent_dim)
+
+  @property
+  def param_count(self):
+    return int(self.c.param_count)
+
+  @property
+  def ws_count(self):
+    return int(self.c.ws_count)
+
+  def _views(self, flat):
+    c = self.c
+    v = {}
+    shapes = [(8, 8, 4, 32), (4, 4, 32, 64), (3, 3, 64, 64)]
+    for i, shp in enumerate(shapes):
+      n = int(np.prod(shp))
+      v['conv%d/w' % (i + 1)] = flat[c.conv_w[i]:c.conv_w[i] + n].reshape(shp)
+      v['conv%d/b' % (i + 1)] = flat[c.conv_b[i]:c.conv_b[i] + shp[3]]
+    le, l1, l2 = int(c.emb_ld), int(c.fc1_ld), int(c.fc2_ld)
+    a, lat = self.num_actions, self.latent_dim
+    v['emb/w'] = flat[c.emb_w:c.emb_w + lat * le].reshape(lat, le)[:, :FLAT]
+    v['emb/b'] = flat[c.emb_b:c.emb_b + FLAT]
+    v['fc1/w'] = flat[c.fc1_w:c.fc1_w + FLAT * l1].reshape(FLAT, l1)[:, :HIDDEN]
+    v['fc1/b'] = flat[c.fc1_b:c.fc1_b + HIDDEN]
+    v['fc2/w'] = flat[c.fc2_w:c.fc2_w + HIDDEN * l2].reshape(HIDDEN, l2)[:, :a]
+    v['fc2/b'] = flat[c.fc2_b:c.fc2_b + a]
+    return v
+
+  def pack(self, params: dict) -> np.ndarray:
+    flat = np.zeros(self.param_count, np.float32)
+    views = self._views(flat)
+    if set(views) != set(params):
+      raise ValueError('parameter names differ: %s' %
+                       sorted(set(views) ^ set(params)))
+    for name, view in views.items():
+      view[...] = np.asarray(params[name], dtype=np.float32)
+    return flat
+
+  def unpack(self, flat: np.ndarray) -> dict:
+    flat = np.asarray(flat, dtype=np.float32)
+    return {k: np.array(v) for k, v in self._views(flat).items()}

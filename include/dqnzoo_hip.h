@@ -53,7 +53,7 @@ const char* dz_built_arch(void);
 /* sizeof() of the ABI structs as the library was compiled, so that a binding
  * can verify its mirror: 0 dz_field_t, 1 dz_prio_sample_args_t,
  * 2 dz_rainbow_layout_t, 3 dz_rainbow_args_t, 4 dz_dense_layout_t,
- * 5 dz_dense_args_t.  -1 for an unknown id.                                */
+ * 5 dz_dense_args_t, 6 dz_iqn_layout_t, 7 dz_iqn_args_t.  -1 for unknown.    */
 int dz_struct_size(int which);
 
 /* ------------------------------------------------------------------------- *
@@ -361,6 +361,73 @@ int dz_dense_apply(int num_actions, int num_outputs, int shared_bias, int batch,
                    float* out, float* q_values_out, int32_t* greedy_out,
                    float* vmax_out, dz_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ *  IQN learner step (ref: iqn/agent.py:176-232 loss_fn/update,
+ *  networks.py:264-292 iqn_atari_network).  Three applies, each on
+ *  batch x samples rows: online(s_tm1, tau_tm1) [gradient],
+ *  target(s_t, tau_sel) [greedy-action selector], target(s_t, tau_t) [targets];
+ *  the two target applies share one torso pass.  The tau draws are INPUTS
+ *  (device arrays [batch][samples]); dz_uniform_fill produces them on the device.
+ *  Parameter vector: conv1..3 (w,b), tau-embedding linear [latent][3136] + b,
+ *  fc1 [3136][512] + b, fc2 [512][fc2_ld] + b  (haiku creation order).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  int32_t num_actions, latent_dim, batch;
+  int32_t samples[3];        /* tau_samples_s_tm1, _policy, _s_t                */
+  int32_t emb_ld, fc1_ld, fc2_ld;
+  int32_t pad_;
+  int64_t conv_w[3], conv_b[3];
+  int64_t emb_w, emb_b, fc1_w, fc1_b, fc2_w, fc2_b;
+  int64_t param_count, param_count_ref;
+  int64_t ws_count;
+  int64_t ws_act1, ws_act2, ws_feat, ws_cos, ws_hin, ws_temb, ws_h1, ws_out;
+  int64_t ws_dout, ws_dh1, ws_dhin, ws_dfeat, ws_dact2, ws_dact1;
+  int64_t ws_wgrad_part, ws_fc2w_part, ws_embw_part, ws_bias_part;
+  int64_t ws_norm_part, ws_scalars, ws_zeros;
+} dz_iqn_layout_t;
+
+int dz_iqn_layout(int num_actions, int latent_dim, int batch, int samples_tm1,
+                  int samples_sel, int samples_t, dz_iqn_layout_t* out);
+
+typedef struct {
+  int32_t num_actions, latent_dim, batch;
+  int32_t samples[3];
+  float* online;
+  const float* target;
+  float* grad;
+  float* opt_m;
+  float* opt_v;
+  int32_t* opt_count;
+  const uint8_t* s_tm1;
+  const uint8_t* s_t;
+  const int64_t* a_tm1;
+  const double* r_t;
+  const double* discount_t;
+  const float* tau_tm1;      /* [batch][samples[0]]                             */
+  const float* tau_sel;      /* [batch][samples[1]]                             */
+  const float* tau_t;        /* [batch][samples[2]]                             */
+  float* ws;
+  float* losses;             /* [batch] per-sample quantile-regression loss     */
+  float lr, b1, b2, eps;
+  float max_norm;            /* <= 0: no clipping (iqn/run_atari.py:213-215)    */
+  float huber;               /* kappa                                           */
+} dz_iqn_args_t;
+
+int dz_iqn_learn(const dz_iqn_args_t* args, int phases, dz_stream_t stream);
+
+/* One IQN apply on batch x samples rows: q_dist [batch][samples][num_actions]
+ * (may be NULL), q_values = mean over samples, greedy action (first maximum)
+ * and its value.  ref: iqn/agent.py:72-83 (actor), 234-247 (select_action).   */
+int dz_iqn_apply(int num_actions, int latent_dim, int batch, int samples,
+                 const float* params, const uint8_t* states, const float* taus,
+                 float* ws, float* q_dist_out, float* q_values_out,
+                 int32_t* greedy_out, float* vmax_out, dz_stream_t stream);
+
+/* out[i] = U[0,1) from the counter-based generator keyed by (seed, counter +
+ * *step * n + i); `step` may be NULL.  The tau draws of iqn/agent.py:47-51.     */
+int dz_uniform_fill(float* out, int64_t n, uint64_t seed, uint64_t counter,
+                    const int32_t* step, dz_stream_t stream);
+
 /* Optional per-kernel timing: when enabled, dz_rainbow_learn records a HIP
  * event on the launch stream before its first kernel and after every kernel.
  * dz_prof_read (call after synchronising the stream) returns the number of
@@ -373,7 +440,9 @@ int dz_prof_read(int max_marks, float* ms_out, char* names_out);
 /* Tuning knobs for tools/tune.py (kernel variant / split-K sweeps in one GPU
  * session): key 0 = fc1 forward variant (8 = weight-streaming kernel),
  * 1 = fc1 forward split-K factor, 2 = fc1 dgrad streaming kernel on/off,
- * 4 = run weight gradients on the auxiliary stream (default 1).             */
+ * 5 = fused fc1 launch runs the input gradient's blocks first, 6 = fc1 input-
+ * gradient tile variant, 7 = its split factor (<= 32), 8 = fc2 forward split-K
+ * factor (<= 8).  Keys 3 and 4 are retired experiments (ignored).            */
 int dz_set_tuning(int key, int value);
 
 /* dst = src for a parameter buffer (target network sync,

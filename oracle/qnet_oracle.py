@@ -114,9 +114,14 @@ def init_noisy(rs, p, name, nin, nout, dt, with_bias, sigma0=0.1):
 
 def init_params(kind, num_actions, rs, dt=np.float32, num_atoms=51,
                 num_quantiles=201):
-  """kind in {dqn, double_dqn, c51, qr, rainbow}."""
+  """kind in {dqn, double_dqn, c51, qr, iqn, rainbow}."""
   p = init_torso(rs, dt)
   a = num_actions
+  if kind == 'iqn':  # creation order: torso, tau embedding, value head (networks.py:272-287)
+    init_linear(rs, p, 'emb', IQN_LATENT, FLAT, dt)
+    init_linear(rs, p, 'fc1', FLAT, 512, dt)
+    init_linear(rs, p, 'fc2', 512, a, dt)
+    return p
   if kind == 'rainbow':  # creation order adv1, adv2, val1, val2 (networks.py:239-251)
     init_noisy(rs, p, 'adv1', FLAT, 512, dt, True)
     init_noisy(rs, p, 'adv2', 512, a * num_atoms, dt, False)
@@ -242,6 +247,52 @@ def rainbow_bwd(p, cache, noise, dlogits, num_actions):
   da1 = dha * (cache['a1'] > 0)
   dfeat = dfeat + noisy_bwd(p, 'adv1', cache['feat'], noise['adv1/in'],
                             noise['adv1/out'], da1, grads)
+  torso_bwd(p, cache['torso'], dfeat, grads)
+  return grads
+
+
+IQN_LATENT = 64  # iqn/run_atari.py:97 tau_latent_dim
+
+
+def iqn_fwd(p, x_u8, taus, dt=np.float32):
+  """iqn_atari_network (networks.py:264-292).  taus [B,N] -> q_dist [B,N,A],
+  q_values [B,A] (mean over samples)."""
+  feat, tc = torso_fwd(p, x_u8, dt)
+  taus = np.asarray(taus).astype(dt)
+  b, n = taus.shape
+  latent = p['emb/w'].shape[0]
+  pi_mult = (np.arange(1, latent + 1, dtype=np.float32) * np.float32(np.pi)).astype(dt)
+  cosemb = np.cos(pi_mult[None, None, :] * taus[:, :, None]).astype(dt)   # [B,N,L]
+  e2 = cosemb.reshape(b * n, latent)
+  zt = e2 @ p['emb/w'] + p['emb/b']
+  temb = relu(zt)                                                         # [B*N,F]
+  hin = temb * np.repeat(feat, n, axis=0)
+  z1 = hin @ p['fc1/w'] + p['fc1/b']
+  h = relu(z1)
+  out = h @ p['fc2/w'] + p['fc2/b']
+  q_dist = out.reshape(b, n, -1)
+  cache = dict(torso=tc, feat=feat, cosemb=e2, zt=zt, temb=temb, hin=hin, z1=z1, h=h,
+               n=n)
+  return q_dist, q_dist.mean(axis=1), cache
+
+
+def iqn_bwd(p, cache, dq_dist):
+  """Gradients of sum(q_dist * dq_dist) wrt the parameters (taus are data)."""
+  grads = {}
+  n = cache['n']
+  dout = dq_dist.reshape(-1, dq_dist.shape[-1])
+  grads['fc2/w'] = cache['h'].T @ dout
+  grads['fc2/b'] = dout.sum(axis=0)
+  dz1 = (dout @ p['fc2/w'].T) * (cache['z1'] > 0)
+  grads['fc1/w'] = cache['hin'].T @ dz1
+  grads['fc1/b'] = dz1.sum(axis=0)
+  dhin = dz1 @ p['fc1/w'].T
+  feat = cache['feat']
+  b = feat.shape[0]
+  dzt = dhin * np.repeat(feat, n, axis=0) * (cache['zt'] > 0)
+  grads['emb/w'] = cache['cosemb'].T @ dzt
+  grads['emb/b'] = dzt.sum(axis=0)
+  dfeat = (dhin * cache['temb']).reshape(b, n, -1).sum(axis=1)
   torso_bwd(p, cache['torso'], dfeat, grads)
   return grads
 
@@ -524,3 +575,22 @@ def qr_loss_and_grads(online, target, batch, quantiles, num_actions, kappa,
   loss = losses.mean()
   grads = mlp_head_bwd(online, cache, (dd / dt(bsz)).reshape(bsz, -1))
   return loss, losses, grads, dict(out_tm1=out_tm1, out_target=out_tgt)
+
+
+def iqn_loss_and_grads(online, target, batch, taus, kappa, dt=np.float32):
+  """iqn/agent.py:176-216: three tau sets (tau_tm1, tau_t_selector, tau_t), the
+  selector and the target distribution both from the TARGET network on s_t,
+  vmap(rlax.quantile_q_learning), mean over the batch."""
+  s_tm1, a_tm1, r_t, d_t, s_t = batch
+  r_t = np.asarray(r_t).astype(dt)
+  d_t = np.asarray(d_t).astype(dt)
+  tau_tm1, tau_sel, tau_t = [np.asarray(t).astype(dt) for t in taus]
+  dist_tm1, _, cache = iqn_fwd(online, s_tm1, tau_tm1, dt)
+  dist_sel, _, _ = iqn_fwd(target, s_t, tau_sel, dt)
+  dist_t, _, _ = iqn_fwd(target, s_t, tau_t, dt)
+  losses, dd = quantile_q_losses(dist_tm1, tau_tm1, np.asarray(a_tm1), r_t, d_t,
+                                 dist_sel, dist_t, dt(kappa))
+  bsz = losses.shape[0]
+  loss = losses.mean()
+  grads = iqn_bwd(online, cache, dd / dt(bsz))
+  return loss, losses, grads, dict(dist_tm1=dist_tm1, dist_sel=dist_sel, dist_t=dist_t)

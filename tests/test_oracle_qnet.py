@@ -352,3 +352,60 @@ def test_distributional_dense_losses_finite_differences_f64(kind):
         vals.append(f(p2)[0])
       fd = (vals[0] - vals[1]) / (2 * h)
       assert abs(fd - g[j]) <= 2e-6 * max(1.0, abs(g[j])) + 1e-9, (k, j, fd, g[j])
+
+
+def test_iqn_vs_torch_autograd_f64():
+  """IQN oracle (networks.py:264-292, iqn/agent.py:176-216) against an
+  independent torch-autograd float64 model (broadcast [B,N,F] formulation,
+  NCHW convs, vectorised quantile-regression loss)."""
+  dt = np.float64
+  rs = np.random.RandomState(31)
+  b, n0, n1, n2, kappa = 4, 5, 6, 7, 1.0
+  online = qo.init_params('iqn', A, rs, dt)
+  target = qo.init_params('iqn', A, rs, dt)
+  assert sum(v.size for v in qo.init_params('iqn', 6, rs).values()) == (
+      77984 + 64 * 3136 + 3136 + 3136 * 512 + 512 + 512 * 6 + 6)
+  batch = _batch(rs, b)
+  batch = (batch[0], batch[1], batch[2] * 2.0, batch[3], batch[4])
+  taus = [rs.uniform(size=(b, n)) for n in (n0, n1, n2)]
+  loss, losses, grads, aux = qo.iqn_loss_and_grads(online, target, batch, taus,
+                                                   kappa, dt)
+  tp = {k: torch.tensor(v, requires_grad=True) for k, v in online.items()}
+  tt = {k: torch.tensor(v) for k, v in target.items()}
+
+  def fwd(p, x_u8, tau):
+    x = torch.from_numpy(x_u8.astype(np.float64) / 255.0).permute(0, 3, 1, 2)
+    for name, stride in (('conv1', 4), ('conv2', 2), ('conv3', 1)):
+      x = torch.relu(torch.nn.functional.conv2d(
+          x, p[name + '/w'].permute(3, 2, 0, 1), p[name + '/b'], stride=stride))
+    f = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+    t = torch.from_numpy(tau)
+    # float32 multiples of pi, as jnp.arange(..., float32) * jnp.pi (networks.py:277)
+    i = torch.from_numpy((np.arange(1, 65, dtype=np.float32) *
+                          np.float32(np.pi)).astype(np.float64))
+    emb = torch.relu(torch.cos(t[:, :, None] * i) @ p['emb/w'] + p['emb/b'])
+    hin = emb * f[:, None, :]
+    return torch.relu(hin @ p['fc1/w'] + p['fc1/b']) @ p['fc2/w'] + p['fc2/b']
+
+  s_tm1, a, r, d, s_t = batch
+  q0 = fwd(tp, s_tm1, taus[0])                       # [B,N0,A]
+  with torch.no_grad():
+    qs = fwd(tt, s_t, taus[1])
+    qt = fwd(tt, s_t, taus[2])
+  np.testing.assert_allclose(aux['dist_tm1'], q0.detach().numpy(), rtol=1e-9, atol=1e-12)
+  np.testing.assert_allclose(aux['dist_t'], qt.numpy(), rtol=1e-9, atol=1e-12)
+  idx = torch.arange(b)
+  a_star = qs.mean(1).argmax(1)
+  tgt = torch.from_numpy(r)[:, None] + torch.from_numpy(d)[:, None] * qt[idx, :, a_star]
+  theta = q0[idx, :, torch.from_numpy(a)]            # [B,N0]
+  delta = tgt[:, None, :] - theta[:, :, None]        # [B,N0,N2]
+  wgt = (torch.from_numpy(taus[0])[:, :, None] - (delta < 0).double()).abs()
+  hub = torch.nn.functional.huber_loss(delta, torch.zeros_like(delta),
+                                       reduction='none', delta=kappa)
+  tl = (wgt * hub).mean(2).sum(1)
+  np.testing.assert_allclose(losses, tl.detach().numpy(), rtol=1e-10)
+  tl.mean().backward()
+  for k in online:
+    g = tp[k].grad.numpy()
+    assert np.abs(grads[k] - g).max() / max(np.abs(g).max(), 1e-12) < 1e-9, k
+  assert np.abs(grads['emb/w']).max() > 0 and np.abs(grads['conv1/w']).max() > 0
