@@ -82,7 +82,10 @@ struct DzLdsTile {
 // The kernel.  Op interface (all static, __device__):
 //   constants  WM, WN, WK, A_LAYOUT, B_LAYOUT, A_MAP (KC only)
 //   struct Params
-//   bool  tile(const Params&, DzTile&)                       -- from blockIdx
+//   struct Tile : DzTile (or DzTile itself): tile coordinates plus per-group
+//          pointers / scalars the Op resolves ONCE (see the loader rule in
+//          dz_qnet_ops.h: no dynamically indexed kernel-argument arrays in loaders)
+//   bool  tile(const Params&, bid, Tile&)                    -- from blockIdx
 //   KC+QUAD : float4 load_a(p, t, st, c, row, q)  4 consecutive reduction idx
 //   KC+ROW16: void   load_a16(p, t, st, c, row, float4 (&v)[4])
 //   RC      : float4 load_a(p, t, st, c, kk, rq)  4 consecutive rows
@@ -112,7 +115,7 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
   float* As = smem;
   float* Bs = smem + AT::ELEMS;
 
-  DzTile t;
+  typename Op::Tile t;  // DzTile + whatever the Op resolves once per workgroup
   if (!Op::tile(p, bid, t)) return;
 
   const int tid = threadIdx.x;
@@ -129,6 +132,11 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
   constexpr int NB = BT::PER_THREAD;
   float4 ra[NA];
   float4 rb[NB];
+  // When the slot count is a multiple of the workgroup size every thread's slot
+  // is real: the bounds test must fold away (a residual runtime test makes the
+  // compiler wrap each load in its own exec-mask block with a vmcnt(0) wait).
+  constexpr bool A_FULL = A_ROW16 ? ((BM * CPS) % 256 == 0) : (AT::SLOTS % 256 == 0);
+  constexpr bool B_FULL = BT::SLOTS % 256 == 0;
 
   auto load_stage = [&](int st) {
     if constexpr (A_ROW16) {
@@ -136,7 +144,7 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
       for (int j = 0; j < NA / 4; ++j) {
         const int idx = tid + j * 256;
         float4 v[4] = {dz_f4zero(), dz_f4zero(), dz_f4zero(), dz_f4zero()};
-        if (idx < BM * CPS) Op::load_a16(p, t, st, idx % CPS, idx / CPS, v);
+        if (A_FULL || idx < BM * CPS) Op::load_a16(p, t, st, idx % CPS, idx / CPS, v);
         ra[4 * j] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3];
       }
     } else if constexpr (Op::A_LAYOUT == DZ_KC) {
@@ -144,16 +152,16 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
       for (int j = 0; j < NA; ++j) {
         const int idx = tid + j * 256;
         const int row = idx / (4 * CPS), rem = idx % (4 * CPS);
-        ra[j] = (idx < AT::SLOTS) ? Op::load_a(p, t, st, rem >> 2, row, rem & 3)
-                                  : dz_f4zero();
+        ra[j] = (A_FULL || idx < AT::SLOTS) ? Op::load_a(p, t, st, rem >> 2, row, rem & 3)
+                                            : dz_f4zero();
       }
     } else {
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         const int idx = tid + j * 256;
         const int kidx = idx / (BM / 4), rq = idx % (BM / 4);
-        ra[j] = (idx < AT::SLOTS) ? Op::load_a(p, t, st, kidx >> 4, kidx & 15, rq)
-                                  : dz_f4zero();
+        ra[j] = (A_FULL || idx < AT::SLOTS) ? Op::load_a(p, t, st, kidx >> 4, kidx & 15, rq)
+                                            : dz_f4zero();
       }
     }
     if constexpr (Op::B_LAYOUT == DZ_KC) {
@@ -161,16 +169,16 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
       for (int j = 0; j < NB; ++j) {
         const int idx = tid + j * 256;
         const int row = idx / (4 * CPS), rem = idx % (4 * CPS);
-        rb[j] = (idx < BT::SLOTS) ? Op::load_b(p, t, st, rem >> 2, row, rem & 3)
-                                  : dz_f4zero();
+        rb[j] = (B_FULL || idx < BT::SLOTS) ? Op::load_b(p, t, st, rem >> 2, row, rem & 3)
+                                            : dz_f4zero();
       }
     } else {
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int idx = tid + j * 256;
         const int kidx = idx / (BN / 4), rq = idx % (BN / 4);
-        rb[j] = (idx < BT::SLOTS) ? Op::load_b(p, t, st, kidx >> 4, kidx & 15, rq)
-                                  : dz_f4zero();
+        rb[j] = (B_FULL || idx < BT::SLOTS) ? Op::load_b(p, t, st, kidx >> 4, kidx & 15, rq)
+                                            : dz_f4zero();
       }
     }
   };
@@ -180,7 +188,7 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
 #pragma unroll
       for (int j = 0; j < NA / 4; ++j) {
         const int idx = tid + j * 256;
-        if (idx < BM * CPS) {
+        if (A_FULL || idx < BM * CPS) {
           float* dst = As + (idx % CPS) * AT::CHUNK + (idx / CPS) * 20;
 #pragma unroll
           for (int q = 0; q < 4; ++q) *(float4*)(dst + 4 * q) = ra[4 * j + q];
@@ -191,7 +199,7 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
       for (int j = 0; j < NA; ++j) {
         const int idx = tid + j * 256;
         const int row = idx / (4 * CPS), rem = idx % (4 * CPS);
-        if (idx < AT::SLOTS)
+        if (A_FULL || idx < AT::SLOTS)
           *(float4*)(As + (rem >> 2) * AT::CHUNK + row * 20 + 4 * (rem & 3)) = ra[j];
       }
     } else {
@@ -199,7 +207,7 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
       for (int j = 0; j < NA; ++j) {
         const int idx = tid + j * 256;
         const int kidx = idx / (BM / 4), rq = idx % (BM / 4);
-        if (idx < AT::SLOTS)
+        if (A_FULL || idx < AT::SLOTS)
           *(float4*)(As + (kidx >> 4) * AT::CHUNK + (kidx & 15) * BM + 4 * rq) = ra[j];
       }
     }
@@ -208,7 +216,7 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
       for (int j = 0; j < NB; ++j) {
         const int idx = tid + j * 256;
         const int row = idx / (4 * CPS), rem = idx % (4 * CPS);
-        if (idx < BT::SLOTS)
+        if (B_FULL || idx < BT::SLOTS)
           *(float4*)(Bs + (rem >> 2) * BT::CHUNK + row * 20 + 4 * (rem & 3)) = rb[j];
       }
     } else {
@@ -216,7 +224,7 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
       for (int j = 0; j < NB; ++j) {
         const int idx = tid + j * 256;
         const int kidx = idx / (BN / 4), rq = idx % (BN / 4);
-        if (idx < BT::SLOTS)
+        if (B_FULL || idx < BT::SLOTS)
           *(float4*)(Bs + (kidx >> 4) * BT::CHUNK + (kidx & 15) * BN + 4 * rq) = rb[j];
       }
     }

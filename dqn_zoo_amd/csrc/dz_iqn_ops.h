@@ -44,47 +44,51 @@ struct IqnLinOp {
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_RC, A_MAP = DZ_MAP_QUAD;
   static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   typedef IqnLinParams Params;
+  struct Tile : DzTile { const float* prm; int row0, rows, feat_row0, samples; };
 
-  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+  __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
     t.z = bid.z;
     t.m0 = bid.y * BM;
     t.n0 = bid.x * BN;
     t.st_begin = 0;
     t.st_end = (p.K / 16 + CPS - 1) / CPS;
-    return t.z < p.G && t.m0 < p.rows[t.z] && t.n0 < p.N;
+    t.prm = dz_pick3(p.params, t.z);
+    t.row0 = dz_pick3(p.row0, t.z); t.rows = dz_pick3(p.rows, t.z);
+    t.feat_row0 = dz_pick3(p.feat_row0, t.z); t.samples = dz_pick3(p.samples, t.z);
+    return t.z < p.G && t.m0 < t.rows && t.n0 < p.N;
   }
-  __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {
     const int gc = st * CPS + c, total = p.K / 16;
     const int m = t.m0 + row;
-    const bool ok = (m < p.rows[t.z]) & (gc < total);
+    const bool ok = (m < t.rows) & (gc < total);
     const int k = min(gc, total - 1) * 16 + 4 * q;
-    return dz_sel4(ok, dz_ld4(p.x + (long)(p.row0[t.z] + min(m, p.rows[t.z] - 1)) * p.ldx + k));
+    return dz_sel4(ok, dz_ld4(p.x + (long)(t.row0 + min(m, t.rows - 1)) * p.ldx + k));
   }
-  __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
     const int gc = st * CPS + c, total = p.K / 16;
     const int k = min(gc, total - 1) * 16 + kk;
     const int n = min(t.n0 + 4 * rq, p.ldw - 4);
-    return dz_sel4(gc < total, dz_ld4(p.params[t.z] + p.w_off + (long)k * p.ldw + n));
+    return dz_sel4(gc < total, dz_ld4(t.prm + p.w_off + (long)k * p.ldw + n));
   }
-  __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
+  __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
     const int col = t.n0 + wn * 32 + (lane & 31);
     if (col >= p.N) return;
     const int g = t.z;
-    const float b = p.params[g][p.b_off + col];
+    const float b = t.prm[p.b_off + col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = t.m0 + wm * 32 + dz_acc_row(r, lane);
-      if (m >= p.rows[g]) continue;
+      if (m >= t.rows) continue;
       float v = acc[r] + b;
       if (p.epi != IQN_EPI_BIAS) v = v > 0.f ? v : 0.f;
       if (p.epi == IQN_EPI_MIX) {
         if (g == 0 && p.temb) p.temb[(long)m * p.N + col] = v;
-        v = v * p.feat[(long)(p.feat_row0[g] + m / p.samples[g]) * p.N + col];
+        v = v * p.feat[(long)(t.feat_row0 + m / t.samples) * p.N + col];
       }
-      p.out[(long)(p.row0[g] + m) * p.ldo + col] = v;
+      p.out[(long)(t.row0 + m) * p.ldo + col] = v;
     }
   }
 };
@@ -106,8 +110,9 @@ struct IqnWgradOp {
   static constexpr int A_LAYOUT = DZ_RC, B_LAYOUT = DZ_RC, A_MAP = DZ_MAP_QUAD;
   static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   typedef IqnWgradParams Params;
+  typedef DzTile Tile;
 
-  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+  __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
     t.z = bid.z;
     t.m0 = bid.y * BM;  // k rows
     t.n0 = bid.x * BN;
@@ -117,19 +122,19 @@ struct IqnWgradOp {
     t.st_end = min(stages, t.st_begin + per);
     return t.m0 < p.K && t.n0 < p.N;
   }
-  __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
     const int m = st * BK + c * 16 + kk;
     const int k = min(t.m0 + 4 * rq, p.K - 4);
     return dz_sel4(m < p.M, dz_ld4(p.x + (long)min(m, p.M - 1) * p.ldx + k));
   }
-  __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
     const int m = st * BK + c * 16 + kk;
     const int n = min(t.n0 + 4 * rq, p.ldw - 4);
     return dz_sel4(m < p.M, dz_ld4(p.dy + (long)min(m, p.M - 1) * p.ldy + n));
   }
-  __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
+  __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
     const int col = t.n0 + wn * 32 + (lane & 31);
     if (col >= p.ldw) return;

@@ -12,6 +12,13 @@
 // (measured: 385 s_and_saveexec / 40 vmcnt waits in the fc1 kernel, 65 us
 // instead of ~15 us).  All operand rows are 16-byte aligned by construction
 // (leading dimensions are multiples of 4 floats), so loads are always float4.
+//
+// SECOND LOADER RULE: loaders never index a kernel-argument array with a runtime
+// value (p.in[g], p.head[h] ...).  The compiler turns that into a LOAD of the
+// pointer from the kernarg segment followed by s_waitcnt vmcnt(0) in front of
+// every operand load -- two dependent memory round trips per stage (seen in the
+// conv1 ISA).  tile() resolves the group's pointers and scalars once into the
+// Op's Tile with static-index selects (dz_pick3), so they live in SGPRs.
 #pragma once
 
 #include "dz_gemm.h"
@@ -27,10 +34,27 @@ __device__ __forceinline__ float4 dz_mask4(float4 v, int i, int n) {
   return dz_f4(i < n ? v.x : 0.f, i + 1 < n ? v.y : 0.f, i + 2 < n ? v.z : 0.f,
                i + 3 < n ? v.w : 0.f);
 }
+// x / 255.0f for x in [0, 255], bit-identical to the IEEE division
+// (networks.py:193 `x.astype(float32) / 255.0`) in 3 instructions instead of the
+// ~11 of v_div_*: y = x * fl(1/255) and one Newton correction with FMAs; checked
+// exhaustively for all 256 inputs (tests/test_abi.py::test_div255_identity).
+__device__ __forceinline__ float dz_div255(float x) {
+  const float rc = 1.0f / 255.0f;
+  const float y = x * rc;
+  const float r = __builtin_fmaf(-y, 255.0f, x);
+  return __builtin_fmaf(r, rc, y);
+}
 __device__ __forceinline__ float4 dz_u8x4_to_unit(unsigned w) {
-  // networks.py:193: x.astype(float32) / 255.0 (a true division).
-  return dz_f4((float)(w & 0xff) / 255.0f, (float)((w >> 8) & 0xff) / 255.0f,
-               (float)((w >> 16) & 0xff) / 255.0f, (float)(w >> 24) / 255.0f);
+  return dz_f4(dz_div255((float)(w & 0xff)), dz_div255((float)((w >> 8) & 0xff)),
+               dz_div255((float)((w >> 16) & 0xff)), dz_div255((float)(w >> 24)));
+}
+// arr[g] for g in [0, 3) with static indices only (see the second loader rule).
+template <class T>
+__device__ __forceinline__ T dz_pick3(const T* arr, int g) {
+  T v = arr[0];
+  v = g == 1 ? arr[1] : v;
+  v = g == 2 ? arr[2] : v;
+  return v;
 }
 
 // --------------------------------------------------------------------------- //
@@ -60,59 +84,63 @@ struct ConvFwdOp {
   static_assert(CO % BN == 0, "column tiles are full");
   typedef ConvFwdParams Params;
 
+  struct Tile : DzTile { const void* in; const float* w; const float* bias; int img_base; };
+
   static int tiles_per_group(int B) { return (B * OH * OW + BM - 1) / BM; }
 
-  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+  __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
     const int tpg = (p.B * OH * OW + BM - 1) / BM;
     t.z = bid.y / tpg;
     t.m0 = (bid.y % tpg) * BM;
     t.n0 = bid.x * BN;
     t.st_begin = 0;
     t.st_end = K / BK;
+    t.in = dz_pick3(p.in, t.z); t.w = dz_pick3(p.w, t.z); t.bias = dz_pick3(p.bias, t.z);
+    t.img_base = dz_pick3(p.in_img_base, t.z);
     return t.z < p.G;
   }
   // pixel index (within group, clamped) -> element offset of input pixel
   // (oh*S, ow*S, 0); returns whether the row is real.
-  __device__ static bool pixel_base(const Params& p, const DzTile& t, int row,
+  __device__ static bool pixel_base(const Params& p, const Tile& t, int row,
                                     long& off) {
     const int rows = p.B * OH * OW;
     const int ml = t.m0 + row;
     const int mc = min(ml, rows - 1);
     const int img = mc / (OH * OW), pix = mc % (OH * OW);
     const int oh = pix / OW, ow = pix % OW;
-    off = (((long)(p.in_img_base[t.z] + img) * H + oh * S) * W + ow * S) * C;
+    off = (((long)(t.img_base + img) * H + oh * S) * W + ow * S) * C;
     return ml < rows;
   }
-  __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {
     long off;
     const bool ok = pixel_base(p, t, row, off);
     const int k0 = st * BK + c * 16 + 4 * q;
     const int tap = k0 / C, ci = k0 % C;
     const int kh = tap / KS, kw = tap % KS;
-    return dz_sel4(ok, dz_ld4((const float*)p.in[t.z] + off + ((long)kh * W + kw) * C + ci));
+    return dz_sel4(ok, dz_ld4((const float*)t.in + off + ((long)kh * W + kw) * C + ci));
   }
-  __device__ static void load_a16(const Params& p, const DzTile& t, int st, int c,
+  __device__ static void load_a16(const Params& p, const Tile& t, int st, int c,
                                   int row, float4 (&v)[4]) {
     long off;
     const bool ok = pixel_base(p, t, row, off);
     const int k0 = st * BK + c * 16;  // KS*C == 32 bytes per kernel row
     const int kh = k0 / 32, o = k0 % 32;
-    const uint4 raw = *(const uint4*)((const uint8_t*)p.in[t.z] + off + (long)kh * W * C + o);
+    const uint4 raw = *(const uint4*)((const uint8_t*)t.in + off + (long)kh * W * C + o);
     v[0] = dz_sel4(ok, dz_u8x4_to_unit(raw.x));
     v[1] = dz_sel4(ok, dz_u8x4_to_unit(raw.y));
     v[2] = dz_sel4(ok, dz_u8x4_to_unit(raw.z));
     v[3] = dz_sel4(ok, dz_u8x4_to_unit(raw.w));
   }
-  __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
     const int k = st * BK + c * 16 + kk;
-    return dz_ld4(p.w[t.z] + (long)k * CO + t.n0 + 4 * rq);
+    return dz_ld4(t.w + (long)k * CO + t.n0 + 4 * rq);
   }
-  __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
+  __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
     const int col = t.n0 + wn * 32 + (lane & 31);
-    const float b = p.bias[t.z][col];
+    const float b = t.bias[col];
     const int rows = p.B * OH * OW;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -147,6 +175,18 @@ struct FcHead {
   int out_off;   // column offset in the output row (multiple of 4)
 };
 
+// head[h] for h in {0, 1}, field by field (scalar selects, no memory indexing).
+__device__ __forceinline__ FcHead dz_pick_head(const FcHead* hd, int h) {
+  FcHead r;
+  const bool b = h != 0;
+  r.w_mu = b ? hd[1].w_mu : hd[0].w_mu; r.w_sig = b ? hd[1].w_sig : hd[0].w_sig;
+  r.ldw = b ? hd[1].ldw : hd[0].ldw; r.N = b ? hd[1].N : hd[0].N;
+  r.K = b ? hd[1].K : hd[0].K; r.x_off = b ? hd[1].x_off : hd[0].x_off;
+  r.eps_in = b ? hd[1].eps_in : hd[0].eps_in; r.eps_out = b ? hd[1].eps_out : hd[0].eps_out;
+  r.out_off = b ? hd[1].out_off : hd[0].out_off;
+  return r;
+}
+
 struct FcFwdParams {
   const float* x;  // [G*M][ldx]
   int ldx;
@@ -169,11 +209,15 @@ struct FcFwdOp {
   static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   typedef FcFwdParams Params;
 
-  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+  struct Tile : DzTile { FcHead hd; const float* prm; const float* nz; };
+
+  __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
     const int split = bid.z % p.S;
     const int gh = bid.z / p.S;
     const int h = gh % p.NH, g = gh / p.NH;
-    const FcHead& hd = p.head[h];
+    t.hd = dz_pick_head(p.head, h);
+    t.prm = dz_pick3(p.params, g); t.nz = dz_pick3(p.noise, g);
+    const FcHead& hd = t.hd;
     t.z = g; t.z2 = h | (split << 8);
     t.m0 = bid.y * BM;
     t.n0 = bid.x * BN;
@@ -184,9 +228,9 @@ struct FcFwdOp {
     t.st_end = min(stages, t.st_begin + per);
     return g < p.G && t.n0 < hd.N && t.m0 < p.M;
   }
-  __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {
-    const FcHead& hd = p.head[t.z2 & 0xff];
+    const FcHead& hd = t.hd;
     const int kc = hd.K / 16, total = kc * (p.noisy ? 2 : 1);
     const int gc = st * CPS + c;
     const int m = t.m0 + row;
@@ -195,12 +239,12 @@ struct FcFwdOp {
     const bool sig = gcc >= kc;
     const int k = (gcc - (sig ? kc : 0)) * 16 + 4 * q;
     const float4 v = dz_ld4(p.x + (long)(t.z * p.M + min(m, p.M - 1)) * p.ldx + hd.x_off + k);
-    const float4 e = dz_ld4(p.noise[t.z] + hd.eps_in + k);  // L2-resident, tiny
+    const float4 e = dz_ld4(t.nz + hd.eps_in + k);  // L2-resident, tiny
     return dz_sel4(ok, sig ? dz_mul4(v, e) : v);
   }
-  __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
-    const FcHead& hd = p.head[t.z2 & 0xff];
+    const FcHead& hd = t.hd;
     const int kc = hd.K / 16, total = kc * (p.noisy ? 2 : 1);
     const int gc = st * CPS + c;
     const bool ok = gc < total;
@@ -208,13 +252,13 @@ struct FcFwdOp {
     const bool sig = gcc >= kc;
     const int k = (gcc - (sig ? kc : 0)) * 16 + kk;
     const int n = min(t.n0 + 4 * rq, hd.ldw - 4);
-    const float4 v = dz_ld4(p.params[t.z] + (sig ? hd.w_sig : hd.w_mu) + (long)k * hd.ldw + n);
-    const float4 e = dz_ld4(p.noise[t.z] + hd.eps_out + n);
+    const float4 v = dz_ld4(t.prm + (sig ? hd.w_sig : hd.w_mu) + (long)k * hd.ldw + n);
+    const float4 e = dz_ld4(t.nz + hd.eps_out + n);
     return dz_sel4(ok, sig ? dz_mul4(v, e) : v);
   }
-  __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
+  __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
-    const FcHead& hd = p.head[t.z2 & 0xff];
+    const FcHead& hd = t.hd;
     const int split = t.z2 >> 8;
     const int col = t.n0 + wn * 32 + (lane & 31);
     if (col >= hd.N) return;
@@ -254,11 +298,12 @@ struct FcDgradOp {
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_KC, A_MAP = DZ_MAP_QUAD;
   static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   typedef FcDgradParams Params;
+  typedef DzTile Tile;
 
   struct Loc { int N, ldw, eps_in, eps_out, out_off, n0; long w; bool sig, ok; };
 
   __device__ static int chunks_of(const Params& p, int h) {
-    return ((p.head[h].N + 15) / 16) * (p.noisy ? 2 : 1);
+    return (((h ? p.head[1].N : p.head[0].N) + 15) / 16) * (p.noisy ? 2 : 1);
   }
   // global chunk -> (head, mu|sigma, first n), arithmetic only (NH <= 2).
   __device__ static Loc locate(const Params& p, int gc) {
@@ -269,7 +314,7 @@ struct FcDgradOp {
     gc = min(gc, tot0 + tot1 - 1);
     const bool h1 = gc >= tot0;
     const FcHead& a = p.head[0];
-    const FcHead& b = p.head[p.NH > 1 ? 1 : 0];
+    const FcHead& b = p.head[1];  // == head[0] when NH == 1 (callers fill both)
     L.N = h1 ? b.N : a.N; L.ldw = h1 ? b.ldw : a.ldw;
     L.eps_in = h1 ? b.eps_in : a.eps_in; L.eps_out = h1 ? b.eps_out : a.eps_out;
     L.out_off = h1 ? b.out_off : a.out_off;
@@ -280,7 +325,7 @@ struct FcDgradOp {
     L.w = L.sig ? (h1 ? b.w_sig : a.w_sig) : (h1 ? b.w_mu : a.w_mu);
     return L;
   }
-  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+  __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
     const int chunks = chunks_of(p, 0) + (p.NH > 1 ? chunks_of(p, 1) : 0);
     const int stages = (chunks + CPS - 1) / CPS;
     const int per = (stages + p.S - 1) / p.S;
@@ -291,7 +336,7 @@ struct FcDgradOp {
     t.st_end = min(stages, t.st_begin + per);
     return t.n0 < p.K && t.m0 < p.M;
   }
-  __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {
     const Loc L = locate(p, st * CPS + c);
     const int m = t.m0 + row;
@@ -303,7 +348,7 @@ struct FcDgradOp {
     return dz_mask4(dz_sel4(L.ok & (m < p.M), v), n, L.N);
   }
   // B tile row = output column k; 4 consecutive reduction indices n.
-  __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {
     const Loc L = locate(p, st * CPS + c);
     const int k = min(t.n0 + row, p.K - 1);
@@ -312,7 +357,7 @@ struct FcDgradOp {
     const float e = p.noise[L.eps_in + k];
     return L.sig ? dz_scale4(v, e) : v;
   }
-  __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
+  __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
     const int col = t.n0 + wn * 32 + (lane & 31);
     if (col >= p.K) return;
@@ -346,32 +391,35 @@ struct FcWgradOp {
   static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   typedef FcWgradParams Params;
 
-  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+  struct Tile : DzTile { FcHead hd; };
+
+  __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
     t.z = bid.z;  // head
-    const FcHead& hd = p.head[t.z];
+    t.hd = dz_pick_head(p.head, t.z);
+    const FcHead& hd = t.hd;
     t.m0 = bid.y * BM;  // k rows
     t.n0 = bid.x * BN;
     t.st_begin = 0;
     t.st_end = (p.M + BK - 1) / BK;
     return t.z < p.NH && t.m0 < hd.K && t.n0 < hd.N;
   }
-  __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
-    const FcHead& hd = p.head[t.z];
+    const FcHead& hd = t.hd;
     const int m = st * BK + c * 16 + kk;
     const int k = min(t.m0 + 4 * rq, hd.K - 4);
     return dz_sel4(m < p.M, dz_ld4(p.x + (long)min(m, p.M - 1) * p.ldx + hd.x_off + k));
   }
-  __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
-    const FcHead& hd = p.head[t.z];
+    const FcHead& hd = t.hd;
     const int m = st * BK + c * 16 + kk;
     const int n = min(t.n0 + 4 * rq, hd.ldw - 4);
     return dz_sel4(m < p.M, dz_ld4(p.dy + (long)min(m, p.M - 1) * p.ldy + hd.out_off + n));
   }
-  __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
+  __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
-    const FcHead& hd = p.head[t.z];
+    const FcHead& hd = t.hd;
     const int col = t.n0 + wn * 32 + (lane & 31);
     if (col >= hd.N) return;
     const float eo = p.noisy ? p.noise[hd.eps_out + col] : 0.f;
@@ -415,8 +463,9 @@ struct ConvWgradOp {
   static constexpr int MT = (KROWS + BM - 1) / BM;     // row tiles
   static_assert(K % BM == 0 && CO % BN == 0 && C % 4 == 0, "tile shape");
   typedef ConvWgradParams Params;
+  typedef DzTile Tile;
 
-  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+  __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
     const int stages = (p.B * OH * OW + BK - 1) / BK;
     const int per = (stages + p.S - 1) / p.S;
     t.z = bid.z;
@@ -426,7 +475,7 @@ struct ConvWgradOp {
     t.st_end = min(stages, t.st_begin + per);
     return true;
   }
-  __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
     const int rows = p.B * OH * OW;
     const int ml = st * BK + c * 16 + kk;
@@ -445,13 +494,13 @@ struct ConvWgradOp {
     v = k < K ? v : dz_f4(k == K ? 1.f : 0.f, 0.f, 0.f, 0.f);
     return dz_sel4(ml < rows, v);
   }
-  __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
     const int rows = p.B * OH * OW;
     const int ml = st * BK + c * 16 + kk;
     return dz_sel4(ml < rows, dz_ld4(p.dy + (long)min(ml, rows - 1) * CO + t.n0 + 4 * rq));
   }
-  __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
+  __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
     const int col = t.n0 + wn * 32 + (lane & 31);
     float* base = p.part + (long)t.z * KROWS * CO + col;
@@ -490,10 +539,11 @@ struct ConvDgradOp {
   static_assert(CO % 16 == 0 && RED % BK == 0 && C % BN == 0, "tile shape");
   static_assert(H % S == 0 && W % S == 0 && KS % S == 0, "uniform parity classes");
   typedef ConvDgradParams Params;
+  typedef DzTile Tile;
 
   static int tiles(int B) { return (B * HP * WP + BM - 1) / BM; }
 
-  __device__ static bool tile(const Params& p, const dim3& bid, DzTile& t) {
+  __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
     t.z = bid.z;  // parity class
     t.m0 = bid.y * BM;
     t.n0 = bid.x * BN;
@@ -501,7 +551,7 @@ struct ConvDgradOp {
     t.st_end = RED / BK;
     return true;
   }
-  __device__ static bool pixel(const Params& p, const DzTile& t, int row, int& img,
+  __device__ static bool pixel(const Params& p, const Tile& t, int row, int& img,
                                int& h, int& w) {
     const int rows = p.B * HP * WP;
     const int ml = t.m0 + row;
@@ -512,7 +562,7 @@ struct ConvDgradOp {
     w = (pix % WP) * S + t.z % S;
     return ml < rows;
   }
-  __device__ static float4 load_a(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {
     int img, h, w;
     bool ok = pixel(p, t, row, img, h, w);
@@ -524,7 +574,7 @@ struct ConvDgradOp {
     const int ohc = min(max(oh, 0), OH - 1), owc = min(max(ow, 0), OW - 1);
     return dz_sel4(ok, dz_ld4(p.dy + (((long)img * OH + ohc) * OW + owc) * CO + co));
   }
-  __device__ static float4 load_b(const Params& p, const DzTile& t, int st, int c,
+  __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {
     const int ci = t.n0 + row;
     const int r0 = st * BK + c * 16 + 4 * q;
@@ -532,7 +582,7 @@ struct ConvDgradOp {
     const int kh = (t.z / S) + (tap / TS) * S, kw = (t.z % S) + (tap % TS) * S;
     return dz_ld4(p.w + ((long)(kh * KS + kw) * C + ci) * CO + co);
   }
-  __device__ static void store(const Params& p, const DzTile& t, int wm, int wn,
+  __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
     const int ci = t.n0 + wn * 32 + (lane & 31);
 #pragma unroll

@@ -93,3 +93,19 @@ def test_product_fails_loudly_without_gpu():
   with pytest.raises(_lib.HipLibraryError):
     replay.TransitionReplay(8, replay.Transition(None, None, None, None, None),
                             np.random.RandomState(0))
+
+
+def test_div255_identity():
+  """dz_div255 (csrc/dz_qnet_ops.h): y = x*fl(1/255); r = fma(-y, 255, x);
+  y' = fma(r, fl(1/255), y) equals the IEEE float32 division x/255 for every
+  uint8 x (networks.py:193).  FMAs are emulated exactly in float64 (24-bit x
+  8-bit products and their sums fit in 53 bits)."""
+  import numpy as np
+  x = np.arange(256, dtype=np.float32)
+  true = x / np.float32(255.0)
+  rc = np.float32(1.0) / np.float32(255.0)
+  y = x * rc
+  r = (-y.astype(np.float64) * 255.0 + x.astype(np.float64)).astype(np.float32)
+  y2 = (r.astype(np.float64) * np.float64(rc) + y.astype(np.float64)).astype(np.float32)
+  assert (y != true).any()          # the plain reciprocal multiply is NOT exact
+  np.testing.assert_array_equal(y2, true)
