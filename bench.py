@@ -163,6 +163,7 @@ def kernel_work(b, a=NUM_ACTIONS, k=NUM_ATOMS):
   f = lambda m, n, kk: 2.0 * m * n * kk
   w = {}
   w['conv1_fwd'] = (f(g * b * 400, 32, 256), g * b * 28224 + g * b * 400 * 32 * 4)
+  w['conv1_fwd+noise'] = w['conv1_fwd']   # the noise draw rides in the same launch
   w['conv2_fwd'] = (f(g * b * 81, 64, 512), g * b * (12800 + 5184) * 4)
   w['conv3_fwd'] = (f(g * b * 49, 64, 576), g * b * (5184 + 3136) * 4)
   # noisy layers in the reference's two-GEMM form; weights of each parameter set

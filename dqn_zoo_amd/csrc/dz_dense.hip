@@ -262,17 +262,13 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
     const float* wts = a->weights ? a->weights : zeros;
     if (a->optimizer == DZ_OPT_ADAM) {
       hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
-                         (long)L.param_count, ws + L.ws_norm_part);
+                         (long)L.param_count, ws + L.ws_norm_part, a->opt_count);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "grad_sumsq");
-      hipLaunchKernelGGL(opt_scalars_kernel, dim3(1), dim3(256), 0, s, ws + L.ws_norm_part,
-                         kNormBlocks, a->opt_count, a->decay_or_b1, a->b2, a->max_norm,
-                         a->losses, wts, B, sc);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "opt_scalars");
       hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
-                         a->opt_m, a->opt_v, (long)(L.param_count >> 2), sc, a->lr,
-                         a->decay_or_b1, a->b2, a->eps, a->max_norm);
+                         a->opt_m, a->opt_v, (long)(L.param_count >> 2),
+                         ws + L.ws_norm_part, kNormBlocks, a->opt_count, a->losses, wts, B,
+                         sc, a->lr, a->decay_or_b1, a->b2, a->eps, a->max_norm);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "adam");
     } else {

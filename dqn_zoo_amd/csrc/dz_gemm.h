@@ -346,6 +346,27 @@ __global__ __launch_bounds__(256) void dz_mfma_gemm3(typename OpA::Params pa, di
   else dz_gemm_body<OpC>(pc, dz_unflatten(blockIdx.x - na - nb, gc), smem);
 }
 
+// A contraction plus an unrelated small elementwise job in the same launch
+// (blocks beyond the GEMM grid run Side::run): saves the ~5 us launch floor of a
+// tiny kernel that nothing in the GEMM depends on.
+template <class Op, class Side>
+__global__ __launch_bounds__(256) void dz_mfma_gemm_side(typename Op::Params p, dim3 g,
+                                                         typename Side::Params sp) {
+  __shared__ __attribute__((aligned(16))) float smem[DzGemmSmem<Op>::ELEMS];
+  const unsigned n = g.x * g.y * g.z;
+  if (blockIdx.x < n) dz_gemm_body<Op>(p, dz_unflatten(blockIdx.x, g), smem);
+  else Side::run(sp, blockIdx.x - n);
+}
+template <class Op, class Side>
+static inline int dz_launch_gemm_side(const typename Op::Params& p, dim3 g,
+                                      const typename Side::Params& sp, unsigned side_blocks,
+                                      hipStream_t s) {
+  hipLaunchKernelGGL((dz_mfma_gemm_side<Op, Side>), dim3(dz_count(g) + side_blocks),
+                     dim3(256), 0, s, p, g, sp);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
 template <class OpA, class OpB>
 static inline int dz_launch_gemm2(const typename OpA::Params& pa, dim3 ga,
                                   const typename OpB::Params& pb, dim3 gb, hipStream_t s) {

@@ -278,8 +278,12 @@ __global__ __launch_bounds__(64) void rainbow_head_loss_kernel(
   }
 }
 
+// Partial sums of squares of the gradient (global norm) -- and the optimiser step
+// count: thread 0 of block 0 performs optax's `count_inc = count + 1`, so the
+// Adam launch that follows reads the incremented count without a race.
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
-                                                    long n, float* __restrict__ part) {
+                                                    long n, float* __restrict__ part,
+                                                    int32_t* __restrict__ count) {
   __shared__ float red[4];
   float s = 0.f;
   const long n4 = n >> 2;
@@ -290,43 +294,40 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (blockIdx.x == 0) *count = *count + 1;
+  }
 }
 
-// One block: global norm, clip decision, Adam bias corrections, mean loss.
-// (A single-launch "last workgroup finishes" form with agent-scope fences was
-// measured slower than this second tiny launch: 20 us vs 9 + 8 us.)
-__global__ __launch_bounds__(256) void opt_scalars_kernel(
-    const float* __restrict__ part, int nparts, int32_t* count, float b1, float b2,
-    float max_norm, const float* __restrict__ losses, const float* __restrict__ weights,
-    int B, float* __restrict__ sc) {
+// optax.clip_by_global_norm then optax.adam, then apply_updates.  Every block
+// folds the `nparts` norm partials itself (same order everywhere: identical
+// scalars in all blocks) instead of waiting on a one-block "scalars" launch
+// (that launch cost ~5 us + a ~2 us gap for 2 KB of work); block 0 publishes
+// the scalars (global norm, bias corrections, clip flag, mean weighted loss).
+__global__ __launch_bounds__(256) void adam_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+    float* __restrict__ v, long n4, const float* __restrict__ part, int nparts,
+    const int32_t* __restrict__ count, const float* __restrict__ losses,
+    const float* __restrict__ weights, int B, float* __restrict__ sc, float lr, float b1,
+    float b2, float eps, float max_norm) {
   __shared__ float red[4];
   float s = 0.f;
   for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float gn = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-    const int c = *count + 1;  // optax: count_inc = count + 1
-    *count = c;
-    sc[DZ_SC_GNORM] = gn;
-    sc[DZ_SC_BC1] = 1.0f - powf(b1, (float)c);
-    sc[DZ_SC_BC2] = 1.0f - powf(b2, (float)c);
-    sc[DZ_SC_CLIP] = (max_norm > 0.f && !(gn < max_norm)) ? 0.f : 1.f;
+  const float gn = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+  const int c = *count;  // already incremented (sumsq_kernel)
+  const float bc1 = 1.0f - powf(b1, (float)c), bc2 = 1.0f - powf(b2, (float)c);
+  const bool pass = !(max_norm > 0.f && !(gn < max_norm));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sc[DZ_SC_GNORM] = gn; sc[DZ_SC_BC1] = bc1; sc[DZ_SC_BC2] = bc2;
+    sc[DZ_SC_CLIP] = pass ? 1.f : 0.f;
     float l = 0.f;
     for (int i = 0; i < B; ++i) l += losses[i] * weights[i];
     sc[DZ_SC_LOSS] = l / (float)B;
   }
-}
-
-// optax.clip_by_global_norm then optax.adam, then apply_updates.
-__global__ __launch_bounds__(256) void adam_kernel(
-    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-    float* __restrict__ v, long n4, const float* __restrict__ sc, float lr, float b1,
-    float b2, float eps, float max_norm) {
-  const float gn = sc[DZ_SC_GNORM], bc1 = sc[DZ_SC_BC1], bc2 = sc[DZ_SC_BC2];
-  const bool pass = sc[DZ_SC_CLIP] != 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 gv = ((const float4*)g)[i];
     float4 mv = ((float4*)m)[i], vv = ((float4*)v)[i], pv = ((float4*)p)[i];
@@ -359,12 +360,12 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
 }
-__global__ void noise_fill_kernel(float* __restrict__ out, long n, uint64_t seed,
-                                  uint64_t counter, const int32_t* __restrict__ step) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (step) counter += (uint64_t)(*step) * (uint64_t)n;  // per-step stream offset
-  const uint64_t h = mix64(mix64(seed) ^ mix64(counter + (uint64_t)i));
+struct NoiseParams { float* out; long n; uint64_t seed; uint64_t counter; const int32_t* step; };
+__device__ __forceinline__ void noise_fill_at(const NoiseParams& q, long i) {
+  if (i >= q.n) return;
+  uint64_t counter = q.counter;
+  if (q.step) counter += (uint64_t)(*q.step) * (uint64_t)q.n;  // per-step stream offset
+  const uint64_t h = mix64(mix64(q.seed) ^ mix64(counter + (uint64_t)i));
   // jax.random.truncated_normal: sqrt2 * erfinv(U(erf(lo/sqrt2), erf(hi/sqrt2)))
   const float u01 = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
   const float e = 0.9544997361036416f;  // erf(2/sqrt(2))
@@ -372,8 +373,18 @@ __global__ void noise_fill_kernel(float* __restrict__ out, long n, uint64_t seed
   float x = 1.4142135623730951f * erfinvf(u);
   x = fminf(fmaxf(x, -2.0f), 2.0f);
   const float s = sqrtf(fabsf(x));
-  out[i] = x < 0.f ? -s : (x > 0.f ? s : 0.f);  // sign(x) * sqrt|x| (networks.py:144)
+  q.out[i] = x < 0.f ? -s : (x > 0.f ? s : 0.f);  // sign(x) * sqrt|x| (networks.py:144)
 }
+__global__ void noise_fill_kernel(NoiseParams q) {
+  noise_fill_at(q, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// The same job as extra blocks of a GEMM launch (dz_mfma_gemm_side).
+struct NoiseSide {
+  typedef NoiseParams Params;
+  __device__ static void run(const Params& q, unsigned block) {
+    noise_fill_at(q, (long)block * 256 + threadIdx.x);
+  }
+};
 
 // q_values[b][a] = sum_k softmax(v + adv_a - mean_a adv)[k] * support[k]
 // (ref: networks.py:254-258); also the greedy action and its value

@@ -43,7 +43,8 @@ int ensure_aux() {
 struct FwdHeads { FcHead fc1h[2]; FcHead fc2h[2]; };
 static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int G, int B,
                            const float* const* prm, const float* const* nz,
-                           const uint8_t* const* in, float* ws, hipStream_t s) {
+                           const uint8_t* const* in, float* ws, hipStream_t s,
+                           const NoiseParams* resample = nullptr) {
   int rc = DZ_OK;
   const int NA = L.num_actions * L.num_atoms;
   const int ld2 = L.adv2_ld + L.val2_ld;
@@ -57,9 +58,15 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
       p.in_img_base[g] = 0; p.w[g] = prm[g] + L.conv_w[0]; p.bias[g] = prm[g] + L.conv_b[0];
     }
     p.out = ws + L.ws_act1; p.B = B; p.G = G;
-    rc = dz_launch_gemm<Conv1Fwd>(p, dim3(1, G * Conv1Fwd::tiles_per_group(B)), s);
+    // the step's noise draw rides along as extra blocks: conv1 does not read it
+    if (resample)
+      rc = dz_launch_gemm_side<Conv1Fwd, NoiseSide>(
+          p, dim3(1, G * Conv1Fwd::tiles_per_group(B), 1), *resample,
+          (unsigned)((resample->n + 255) / 256), s);
+    else
+      rc = dz_launch_gemm<Conv1Fwd>(p, dim3(1, G * Conv1Fwd::tiles_per_group(B)), s);
     if (rc) return rc;
-    DZ_PROF(s, "conv1_fwd");
+    DZ_PROF(s, resample ? "conv1_fwd+noise" : "conv1_fwd");
   }
   {  // conv2
     ConvFwdParams p;
@@ -274,19 +281,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   const FcHead* fc2h = H.fc2h;
 
   if (g_dz_prof_on) dz_prof_begin(s);
-  if ((phases & DZ_PHASE_FORWARD) && a->resample_noise) {
-    DZ_REQUIRE(a->adam_count);
-    const long n = 3 * L.noise_stride;
-    hipLaunchKernelGGL(noise_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       s, const_cast<float*>(a->noise), n, a->noise_seed,
-                       (uint64_t)0x5eed, a->adam_count);
-    DZ_LAUNCH_CHECK();
-    DZ_PROF(s, "noise");
-  }
+  NoiseParams nq = {const_cast<float*>(a->noise), 3 * (long)L.noise_stride, a->noise_seed,
+                    (uint64_t)0x5eed, a->adam_count};
+  if ((phases & DZ_PHASE_FORWARD) && a->resample_noise) DZ_REQUIRE(a->adam_count);
   if (phases & DZ_PHASE_FORWARD) {
     {
       const uint8_t* in[kG] = {a->s_tm1, a->s_t, a->s_t};
-      rc = rainbow_forward(L, H, kG, B, prm, nz, in, ws, s);
+      rc = rainbow_forward(L, H, kG, B, prm, nz, in, ws, s,
+                           a->resample_noise ? &nq : nullptr);
       if (rc) return rc;
     }
     hipLaunchKernelGGL(rainbow_head_loss_kernel, dim3(B), dim3(64), 0, s,
@@ -436,17 +438,13 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     DZ_REQUIRE(a->grad && a->adam_m && a->adam_v && a->adam_count);
     float* sc = ws + L.ws_scalars;
     hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
-                       (long)L.param_count, ws + L.ws_norm_part);
+                       (long)L.param_count, ws + L.ws_norm_part, a->adam_count);
     DZ_LAUNCH_CHECK();
     DZ_PROF(s, "grad_sumsq");
-    hipLaunchKernelGGL(opt_scalars_kernel, dim3(1), dim3(256), 0, s,
-                       ws + L.ws_norm_part, kNormBlocks, a->adam_count, a->b1, a->b2,
-                       a->max_norm, a->losses, a->weights, B, sc);
-    DZ_LAUNCH_CHECK();
-    DZ_PROF(s, "opt_scalars");
     hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
-                       a->adam_m, a->adam_v, (long)(L.param_count >> 2), sc, a->lr,
-                       a->b1, a->b2, a->eps, a->max_norm);
+                       a->adam_m, a->adam_v, (long)(L.param_count >> 2),
+                       ws + L.ws_norm_part, kNormBlocks, a->adam_count, a->losses,
+                       a->weights, B, sc, a->lr, a->b1, a->b2, a->eps, a->max_norm);
     DZ_LAUNCH_CHECK();
       DZ_PROF(s, "adam");
   }
@@ -530,9 +528,9 @@ extern "C" int dz_set_tuning(int key, int value) {
 extern "C" int dz_noise_fill(float* noise, int64_t count, uint64_t seed,
                              uint64_t counter, dz_stream_t stream) {
   DZ_REQUIRE(noise && count > 0);
+  NoiseParams q = {noise, (long)count, seed, counter, nullptr};
   hipLaunchKernelGGL(noise_fill_kernel, dim3((unsigned)((count + 255) / 256)),
-                     dim3(256), 0, dz_s(stream), noise, (long)count, seed, counter,
-                     (const int32_t*)nullptr);
+                     dim3(256), 0, dz_s(stream), q);
   DZ_LAUNCH_CHECK();
   return DZ_OK;
 }
