@@ -262,6 +262,142 @@ __global__ __launch_bounds__(256) void dz_fc_stream_fwd2(FcStreamFwd2Params p) {
   }
 }
 
+// ------------------ forward, shared weight stream across applies -------------- //
+// The learner evaluates the layer for up to three applies, two of which use the
+// SAME parameter set (Rainbow: online(s_tm1) and online(s_t); only the noise
+// differs).  dz_fc_stream_fwd2 streams the weights once per apply and, for noisy
+// layers, runs the contraction at depth 2K.  Here a workgroup streams its slice
+// of one parameter SET once (mu and sigma), builds each apply's effective weight
+//     W_eff[k][n] = Wmu[k][n] + Wsig[k][n] * (eps_in[k] * eps_out[n])
+// in registers (2 VALU per element -- nothing next to a 64-cycle MFMA) and feeds
+// one depth-K MFMA chain per apply:  y = x . W_eff  ==  x.Wmu + ((x.eps_in).Wsig).eps_out
+// (networks.py:168-176) up to float32 rounding order.  Rainbow fc1: weight bytes
+// 77 MB -> 51 MB (online and target once each), MFMA work halved.
+// grid = (strips of 128 columns over both heads, S k-splits, parameter sets).
+struct FcStreamFwd3Params {
+  const float* x; int ldx; int M;      // x: [groups*M][ldx]
+  int noisy;
+  const float* params[2];              // parameter sets
+  int ng[2];                           // applies per set (1 or 2)
+  int grp[2][2];                       // their group indices
+  const float* noise[DZ_MAX_GROUPS];   // noise block per group
+  int G;                               // total groups (row count of a partial slab / M)
+  FcHead head[2];                      // N multiple of 128
+  float* part;                         // [S][G*M][ldo]
+  int ldo;
+  int rows_per_split;                  // multiple of 4, <= 2*NL
+};
+
+// NL = k-pairs per lane (x2 dword loads when noisy): 50 with 32 k-splits, 100 with 16.
+template <int NOISY, int NL>
+__global__ __launch_bounds__(256) void dz_fc_stream_fwd3(FcStreamFwd3Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds3[];
+  const int R = p.rows_per_split;
+  float* xs = lds3;                  // [2][R][32]  x (batch-row minor)
+  float* es = lds3 + 2 * R * 32;     // [2][R]      eps_in
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int strips0 = p.head[0].N / 128;
+  const int h_idx = blockIdx.x >= strips0 ? 1 : 0;
+  const FcHead hd = dz_pick_head(p.head, h_idx);
+  const int n0 = (blockIdx.x - (h_idx ? strips0 : 0)) * 128 + 32 * wave;
+  const int split = blockIdx.y, set = blockIdx.z;
+  const float* __restrict__ prm = set ? p.params[1] : p.params[0];
+  const int ng = set ? p.ng[1] : p.ng[0];
+  const int g0 = set ? p.grp[1][0] : p.grp[0][0];
+  const int g1 = set ? p.grp[1][1] : p.grp[0][1];
+  const float* __restrict__ nz0 = dz_pick3(p.noise, g0);
+  const float* __restrict__ nz1 = dz_pick3(p.noise, g1);
+  const int K = hd.K;
+  const int r0 = split * R;
+  const int nrows = max(min(K, r0 + R) - r0, 0);
+  const int ncol = n0 + l31;
+
+  // (1) every weight load of the wave first: they fly during the LDS staging.
+  float wm[NL], wg[NOISY ? NL : 1];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int k = min(r0 + 2 * u + half, K - 1);
+    const long off = (long)k * hd.ldw + ncol;
+    wm[u] = prm[hd.w_mu + off];
+    if (NOISY) wg[u] = prm[hd.w_sig + off];
+  }
+
+  // (2) stage x[g][k] (k-major, 32 batch rows minor) and eps_in[g][k].
+  {
+    const int mm = threadIdx.x & 31, q0 = threadIdx.x >> 5;
+    const int mc = min(mm, p.M - 1);
+    const float ok = mm < p.M ? 1.f : 0.f;
+    constexpr int NP = (2 * NL / 4 + 7) / 8;
+    float4 v[2][NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int k = min(r0 + 4 * (q0 + 8 * j), K - 4);  // r0, K multiples of 4
+      v[0][j] = dz_scale4(dz_ld4(p.x + (long)(g0 * p.M + mc) * p.ldx + hd.x_off + k), ok);
+      v[1][j] = dz_scale4(dz_ld4(p.x + (long)(g1 * p.M + mc) * p.ldx + hd.x_off + k), ok);
+    }
+    float e0 = 0.f, e1 = 0.f;
+    if (NOISY) {
+      const int k = min(r0 + (int)threadIdx.x, K - 1);
+      e0 = nz0[hd.eps_in + k]; e1 = nz1[hd.eps_in + k];
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int q = q0 + 8 * j;
+      if (4 * q < nrows) {
+        float* d0 = xs + (4 * q) * 32 + mm;
+        d0[0] = v[0][j].x; d0[32] = v[0][j].y; d0[64] = v[0][j].z; d0[96] = v[0][j].w;
+        float* d1 = d0 + R * 32;
+        d1[0] = v[1][j].x; d1[32] = v[1][j].y; d1[64] = v[1][j].z; d1[96] = v[1][j].w;
+      }
+    }
+    if (NOISY && (int)threadIdx.x < R) { es[threadIdx.x] = e0; es[R + threadIdx.x] = e1; }
+  }
+  __syncthreads();
+
+  const float eo0 = NOISY ? nz0[hd.eps_out + ncol] : 0.f;
+  const float eo1 = NOISY ? nz1[hd.eps_out + ncol] : 0.f;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  if (ng > 1) {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int rl = 2 * u + half;
+      const int rc = min(rl, R - 1);
+      const bool live = rl < nrows;
+      const float a0 = live ? xs[rc * 32 + l31] : 0.f;
+      const float a1 = live ? xs[(R + rc) * 32 + l31] : 0.f;
+      float w0 = wm[u], w1 = wm[u];
+      if (NOISY) {
+        w0 = __builtin_fmaf(wg[u], es[rc] * eo0, wm[u]);
+        w1 = __builtin_fmaf(wg[u], es[R + rc] * eo1, wm[u]);
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w1, acc1, 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int rl = 2 * u + half;
+      const int rc = min(rl, R - 1);
+      const float a0 = rl < nrows ? xs[rc * 32 + l31] : 0.f;
+      float w0 = wm[u];
+      if (NOISY) w0 = __builtin_fmaf(wg[u], es[rc] * eo0, wm[u]);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w0, acc0, 0, 0, 0);
+    }
+  }
+  float* base = p.part + (long)split * p.G * p.M * p.ldo + hd.out_off + ncol;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mm = dz_acc_row(r, lane);
+    if (mm < p.M) {
+      base[(long)(g0 * p.M + mm) * p.ldo] = acc0[r];
+      if (ng > 1) base[(long)(g1 * p.M + mm) * p.ldo] = acc1[r];
+    }
+  }
+}
+
 // -------------------------------- dgrad -------------------------------------- //
 // dX[m][k] = relu'(act[m][k]) * sum_{head} ( sum_n dY[m][n] Wmu[k][n]
 //                                  + eps_in[k] sum_n dY[m][n] eps_out[n] Wsig[k][n] )

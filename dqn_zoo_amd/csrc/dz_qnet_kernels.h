@@ -19,6 +19,8 @@ constexpr int kMaxS_dfeat = 32;
 constexpr int kMaxS_fc2 = 8;
 constexpr int kS_cw1 = 50, kS_cw2 = 27, kS_cw3 = 14;
 constexpr int kNormBlocks = 512;
+constexpr int kNormFinal = 4096;    // fused-norm partials: one per finalize block
+constexpr int kNormSlots = 12288;   // per-wave slots of the weight-gradient kernels
 
 inline int64_t align4(int64_t v) { return (v + 3) & ~(int64_t)3; }
 constexpr int kMaxSplitFc1 = 32;
@@ -126,11 +128,21 @@ struct FinalizeJobs {
   unsigned r_end[3];      // exclusive prefix of 64-wide tiles
   ColsumJob c[2];
   unsigned c_tiles[2];    // tiles per colsum job
+  // Optional fused global norm (see FcWgradParams::sumsq): every block writes
+  // the sum of squares of the gradient entries it produced to sumsq[blockIdx.x];
+  // `presum_blocks` extra blocks fold the weight-gradient kernels' per-wave slots
+  // (presum_src[0..presum_n), 1024 per block) the same way, so that
+  // sumsq[0..gridDim.x) is the complete list of partials for adam_kernel.
+  float* sumsq = nullptr;           // null: off
+  const float* presum_src = nullptr;
+  int presum_n = 0;
+  int32_t* bump_count = nullptr;    // optax count_inc, done here when the optimiser follows
 };
 __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
   __shared__ float red[4][64];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   unsigned b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0 && J.bump_count) *J.bump_count = *J.bump_count + 1;
   float v = 0.f;
   if (b < J.r_end[2]) {
     const int j = b < J.r_end[0] ? 0 : (b < J.r_end[1] ? 1 : 2);
@@ -140,24 +152,52 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
       for (int s = w; s < jb.S; s += 4) v += jb.part[(long)s * jb.n + i];
     red[w][l] = v;
     __syncthreads();
-    if (w == 0 && i < jb.n)
-      jb.out[i] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    if (w != 0) return;
+    float o = 0.f;
+    if (i < jb.n) {
+      o = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+      jb.out[i] = o;
+    }
+    if (J.sumsq) {
+      o = dz_wave_sum(o * o);
+      if (l == 0) J.sumsq[blockIdx.x] = o;
+    }
     return;
   }
   b -= J.r_end[2];
-  const int j = b < J.c_tiles[0] ? 0 : 1;
-  const ColsumJob jb = J.c[j];
-  const int c = (int)(b - (j ? J.c_tiles[0] : 0)) * 64 + l;
-  if (c < jb.cols) {
+  if (b < J.c_tiles[0] + J.c_tiles[1]) {
+    const int j = b < J.c_tiles[0] ? 0 : 1;
+    const ColsumJob jb = J.c[j];
+    const int c = (int)(b - (j ? J.c_tiles[0] : 0)) * 64 + l;
+    if (c < jb.cols) {
 #pragma unroll 4
-    for (int r = w; r < jb.rows; r += 4) v += jb.m[(long)r * jb.ld + c];
+      for (int r = w; r < jb.rows; r += 4) v += jb.m[(long)r * jb.ld + c];
+    }
+    red[w][l] = v;
+    __syncthreads();
+    if (w != 0) return;
+    float sq = 0.f;
+    if (c < jb.cols) {
+      const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+      if (jb.out) { jb.out[c] = s; sq += s * s; }
+      if (jb.out_scaled) { const float t = s * jb.scale[c]; jb.out_scaled[c] = t; sq += t * t; }
+    }
+    if (J.sumsq) {
+      sq = dz_wave_sum(sq);
+      if (l == 0) J.sumsq[blockIdx.x] = sq;
+    }
+    return;
   }
-  red[w][l] = v;
-  __syncthreads();
-  if (w == 0 && c < jb.cols) {
-    const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
-    if (jb.out) jb.out[c] = s;
-    if (jb.out_scaled) jb.out_scaled[c] = s * jb.scale[c];
+  b -= J.c_tiles[0] + J.c_tiles[1];  // presum block
+  {
+    const int i0 = (int)b * 1024 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v += (i0 + 256 * j) < J.presum_n ? J.presum_src[i0 + 256 * j] : 0.f;
+    v = dz_wave_sum(v);
+    if (l == 0) red[0][w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      J.sumsq[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
   }
 }
 

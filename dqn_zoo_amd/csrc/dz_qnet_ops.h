@@ -48,6 +48,10 @@ __device__ __forceinline__ float4 dz_u8x4_to_unit(unsigned w) {
   return dz_f4(dz_div255((float)(w & 0xff)), dz_div255((float)((w >> 8) & 0xff)),
                dz_div255((float)((w >> 16) & 0xff)), dz_div255((float)(w >> 24)));
 }
+__device__ __forceinline__ float dz_wave_sum(float v) {
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 // arr[g] for g in [0, 3) with static indices only (see the second loader rule).
 template <class T>
 __device__ __forceinline__ T dz_pick3(const T* arr, int g) {
@@ -382,6 +386,12 @@ struct FcWgradParams {
   const float* noise;
   FcHead head[2];
   float* grad;      // gradient buffer with the parameter layout
+  // Optional fused global-norm partials: every storing wave writes the sum of
+  // squares of the gradient elements it produced (mu and sigma) to
+  //   sumsq[((z*sq_ny + y)*sq_nx + x) * WM*WN + wave]   (x,y,z = tile index),
+  // tiles outside the problem write zeros, so the slot array is always complete.
+  float* sumsq = nullptr;     // null: off
+  int sq_nx = 0, sq_ny = 0;   // grid dimensions of this Op's launch
 };
 
 template <int WM_, int WN_, int WK_, int KT_ = 1>
@@ -401,7 +411,10 @@ struct FcWgradOp {
     t.n0 = bid.x * BN;
     t.st_begin = 0;
     t.st_end = (p.M + BK - 1) / BK;
-    return t.z < p.NH && t.m0 < hd.K && t.n0 < hd.N;
+    t.z2 = (int)(((bid.z * p.sq_ny + bid.y) * p.sq_nx + bid.x) * (WM * WN));
+    const bool ok = t.z < p.NH && t.m0 < hd.K && t.n0 < hd.N;
+    if (!ok && p.sumsq && threadIdx.x < WM * WN) p.sumsq[t.z2 + threadIdx.x] = 0.f;
+    return ok;
   }
   __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
@@ -421,16 +434,26 @@ struct FcWgradOp {
                                int lane, const f32x16& acc) {
     const FcHead& hd = t.hd;
     const int col = t.n0 + wn * 32 + (lane & 31);
-    if (col >= hd.N) return;
-    const float eo = p.noisy ? p.noise[hd.eps_out + col] : 0.f;
+    const bool colok = col < hd.N;
+    const float eo = (p.noisy && colok) ? p.noise[hd.eps_out + col] : 0.f;
+    float sq = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = t.m0 + wm * 32 + dz_acc_row(r, lane);
-      if (k < hd.K) {
-        p.grad[hd.w_mu + (long)k * hd.ldw + col] = acc[r];
-        if (p.noisy)
-          p.grad[hd.w_sig + (long)k * hd.ldw + col] = acc[r] * (p.noise[hd.eps_in + k] * eo);
+      if (colok && k < hd.K) {
+        const float v = acc[r];
+        p.grad[hd.w_mu + (long)k * hd.ldw + col] = v;
+        sq += v * v;
+        if (p.noisy) {
+          const float vs = v * (p.noise[hd.eps_in + k] * eo);
+          p.grad[hd.w_sig + (long)k * hd.ldw + col] = vs;
+          sq += vs * vs;
+        }
       }
+    }
+    if (p.sumsq) {
+      sq = dz_wave_sum(sq);
+      if (lane == 0) p.sumsq[t.z2 + wm * WN + wn] = sq;
     }
   }
 };

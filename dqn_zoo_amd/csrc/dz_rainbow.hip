@@ -9,13 +9,13 @@
 //             wgrad/dgrad, conv1 wgrad, bias column sums
 //   update  : sum of squares -> global norm/clip scale -> Adam
 // Roofline notes per kernel are in DESIGN.md.
-#include "dz_qnet_kernels.h"
+#include "dz_torso.h"
 
 namespace {
 
 // Run-time tuning knobs (dz_set_tuning): kernel variant and split factors, used
 // by tools/tune.py to sweep configurations in ONE GPU session.
-int g_fc1_variant = 9;   // 8/9 = weight-streaming kernels (dz_fc_stream.h)
+int g_fc1_variant = 10;  // 10 = shared weight stream (dz_fc_stream_fwd3); 8/9 = per-apply streams
 int g_fc1_splits = 32;
 int g_fc1_dgrad_stream = 0;  // measured: tile-GEMM 26 us vs streaming 35 us
 int g_fc1_blocked_experiment = 0;
@@ -51,42 +51,10 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
   const FcHead* fc1h = H.fc1h;
   const FcHead* fc2h = H.fc2h;
   (void)NA;
-    {  // conv1: uint8 states -> act1, u8->f32 /255 fused into the A-tile load
-    ConvFwdParams p;
-    for (int g = 0; g < G; ++g) p.in[g] = in[g];
-    for (int g = 0; g < G; ++g) {
-      p.in_img_base[g] = 0; p.w[g] = prm[g] + L.conv_w[0]; p.bias[g] = prm[g] + L.conv_b[0];
-    }
-    p.out = ws + L.ws_act1; p.B = B; p.G = G;
-    // the step's noise draw rides along as extra blocks: conv1 does not read it
-    if (resample)
-      rc = dz_launch_gemm_side<Conv1Fwd, NoiseSide>(
-          p, dim3(1, G * Conv1Fwd::tiles_per_group(B), 1), *resample,
-          (unsigned)((resample->n + 255) / 256), s);
-    else
-      rc = dz_launch_gemm<Conv1Fwd>(p, dim3(1, G * Conv1Fwd::tiles_per_group(B)), s);
+  {
+    const TorsoBufs T = {L.conv_w, L.conv_b, ws + L.ws_act1, ws + L.ws_act2, ws + L.ws_feat};
+    rc = torso_forward(T, G, B, prm, in, s, resample);
     if (rc) return rc;
-    DZ_PROF(s, resample ? "conv1_fwd+noise" : "conv1_fwd");
-  }
-  {  // conv2
-    ConvFwdParams p;
-    for (int g = 0; g < G; ++g) {
-      p.in[g] = ws + L.ws_act1; p.in_img_base[g] = g * B; p.w[g] = prm[g] + L.conv_w[1]; p.bias[g] = prm[g] + L.conv_b[1];
-    }
-    p.out = ws + L.ws_act2; p.B = B; p.G = G;
-    rc = dz_launch_gemm<Conv2Fwd>(p, dim3(1, G * Conv2Fwd::tiles_per_group(B)), s);
-    if (rc) return rc;
-    DZ_PROF(s, "conv2_fwd");
-  }
-  {  // conv3 (+ flatten: NHWC rows are already (h,w,c) order)
-    ConvFwdParams p;
-    for (int g = 0; g < G; ++g) {
-      p.in[g] = ws + L.ws_act2; p.in_img_base[g] = g * B; p.w[g] = prm[g] + L.conv_w[2]; p.bias[g] = prm[g] + L.conv_b[2];
-    }
-    p.out = ws + L.ws_feat; p.B = B; p.G = G;
-    rc = dz_launch_gemm<Conv3Fwd>(p, dim3(1, G * Conv3Fwd::tiles_per_group(B)), s);
-    if (rc) return rc;
-    DZ_PROF(s, "conv3_fwd");
   }
   {  // fc1: noisy adv1 | val1, split-K partials
     FcFwdParams p;
@@ -135,6 +103,38 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
         q.blocked = g_fc1_blocked_experiment;
         hipLaunchKernelGGL(dz_fc_stream_fwd2, dim3(8, G * g_fc1_splits), dim3(256),
                            (size_t)q.rows_per_split * 32 * sizeof(float), s, q);
+        DZ_LAUNCH_CHECK();
+        rc = DZ_OK;
+        break;
+      }
+      case 10: {  // one weight stream per parameter set, W_eff built in registers
+        DZ_REQUIRE(B <= 32);
+        FcStreamFwd3Params q;
+        q.x = p.x; q.ldx = p.ldx; q.M = B; q.noisy = 1; q.G = G;
+        int ns = 0;
+        for (int g = 0; g < G; ++g) {
+          q.noise[g] = nz[g];
+          int st = -1;
+          for (int j = 0; j < ns; ++j)
+            if (q.params[j] == prm[g] && q.ng[j] < 2) st = j;
+          if (st < 0) { DZ_REQUIRE(ns < 2); st = ns++; q.params[st] = prm[g]; q.ng[st] = 0; }
+          q.grp[st][q.ng[st]++] = g;
+        }
+        for (int j = 0; j < ns; ++j)
+          if (q.ng[j] == 1) q.grp[j][1] = q.grp[j][0];
+        for (int g = G; g < DZ_MAX_GROUPS; ++g) q.noise[g] = nz[0];
+        if (ns == 1) { q.params[1] = q.params[0]; q.ng[1] = q.ng[0]; q.grp[1][0] = q.grp[0][0]; q.grp[1][1] = q.grp[0][1]; }
+        q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
+        q.part = p.part; q.ldo = p.ldo;
+        q.rows_per_split = ((kFlat + g_fc1_splits - 1) / g_fc1_splits + 3) & ~3;
+        DZ_REQUIRE(q.rows_per_split <= 200);
+        const size_t lds = (size_t)q.rows_per_split * (2 * 32 + 2) * sizeof(float);
+        if (q.rows_per_split <= 100)
+          hipLaunchKernelGGL((dz_fc_stream_fwd3<1, 50>), dim3(8, g_fc1_splits, ns), dim3(256),
+                             lds, s, q);
+        else
+          hipLaunchKernelGGL((dz_fc_stream_fwd3<1, 100>), dim3(8, g_fc1_splits, ns), dim3(256),
+                             lds, s, q);
         DZ_LAUNCH_CHECK();
         rc = DZ_OK;
         break;
@@ -249,7 +249,7 @@ extern "C" int dz_rainbow_layout(int A, int K, int B, dz_rainbow_layout_t* L) {
                      (int64_t)kS_cw2 * Conv2Wg::KROWS * 64 +
                      (int64_t)kS_cw3 * Conv3Wg::KROWS * 64;  // one slab per conv
   L->ws_wgrad_part = take(wp);
-  L->ws_norm_part = take(kNormBlocks);
+  L->ws_norm_part = take(kNormFinal + kNormSlots);
   L->ws_colsum_part = take(4);
   L->ws_scalars = take(16);
   L->ws_q_sel = take((int64_t)B * A);
@@ -299,12 +299,21 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       DZ_PROF(s, "head_loss");
   }
 
+  int n_final = 0;  // fused-norm partials left by this call's backward phase
   if (phases & DZ_PHASE_BACKWARD) {
     DZ_REQUIRE(a->grad);
     float* grad = a->grad;
     // Every layer's weight gradient and input gradient are independent, so each
     // pair is ONE launch (dz_mfma_gemm2/3: horizontal fusion); the conv partial
     // reductions and the bias column sums are one launch at the end.
+    // fused global norm: the weight-gradient kernels leave per-wave sums of
+    // squares in sq_slots (fc2 first, then fc1), finalize_grads folds them and
+    // adds its own -> ws_norm_part[0..n_final) is the partial list for Adam.
+    float* sq_final = ws + L.ws_norm_part;
+    float* sq_slots = sq_final + kNormFinal;
+    const int fc2_slots = ((NA + FcWg::BN - 1) / FcWg::BN) * (kHid / FcWg::BM) * 2 * 4;
+    const int fc1_slots = (512 / FcWg::BN) * (kFlat / FcWg::BM) * 2 * 4;
+    DZ_REQUIRE(fc2_slots + fc1_slots <= kNormSlots);
     float* part1 = ws + L.ws_wgrad_part;
     float* part2 = part1 + (long)kS_cw1 * Conv1Wg::KROWS * 32;
     float* part3 = part2 + (long)kS_cw2 * Conv2Wg::KROWS * 64;
@@ -313,6 +322,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       w.x = ws + L.ws_h1; w.ldx = 1024; w.dy = ws + L.ws_dout2; w.ldy = ld2; w.M = B;
       w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc2h[0]; w.head[1] = fc2h[1];
       w.grad = grad;
+      w.sumsq = sq_slots; w.sq_nx = (NA + FcWg::BN - 1) / FcWg::BN; w.sq_ny = kHid / FcWg::BM;
       FcDgradParams d[2];
       for (int h = 0; h < 2; ++h) {
         d[h].dy = ws + L.ws_dout2; d[h].ldy = ld2; d[h].M = B; d[h].NH = 1;
@@ -337,6 +347,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       w.x = ws + L.ws_feat; w.ldx = kFlat; w.dy = ws + L.ws_dh1; w.ldy = 1024; w.M = B;
       w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc1h[0]; w.head[1] = fc1h[1];
       w.grad = grad;
+      w.sumsq = sq_slots + fc2_slots; w.sq_nx = 512 / FcWg::BN; w.sq_ny = kFlat / FcWg::BM;
       FcDgradParams d;
       d.dy = ws + L.ws_dh1; d.ldy = 1024; d.M = B; d.NH = 2; d.S = kS_dfeat; d.noisy = 1;
       d.params = a->online; d.noise = nz[0]; d.head[0] = fc1h[0]; d.head[1] = fc1h[1];
@@ -427,8 +438,12 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       J.c[1] = {ws + L.ws_dout2, B, ld2, ld2, nullptr, nz[0] + L.n_fc2_out,
                 grad + L.fc2_sig_b};
       J.c_tiles[0] = 16; J.c_tiles[1] = (unsigned)((ld2 + 63) / 64);
-      hipLaunchKernelGGL(finalize_grads_kernel, dim3(acc + J.c_tiles[0] + J.c_tiles[1]),
-                         dim3(256), 0, s, J);
+      const unsigned presum = (unsigned)((fc2_slots + fc1_slots + 1023) / 1024);
+      n_final = (int)(acc + J.c_tiles[0] + J.c_tiles[1] + presum);
+      DZ_REQUIRE(n_final <= kNormFinal);
+      J.sumsq = sq_final; J.presum_src = sq_slots; J.presum_n = fc2_slots + fc1_slots;
+      J.bump_count = (phases & DZ_PHASE_OPTIMIZER) ? a->adam_count : nullptr;
+      hipLaunchKernelGGL(finalize_grads_kernel, dim3((unsigned)n_final), dim3(256), 0, s, J);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "finalize_grads");
     }
@@ -437,13 +452,17 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   if (phases & DZ_PHASE_OPTIMIZER) {
     DZ_REQUIRE(a->grad && a->adam_m && a->adam_v && a->adam_count);
     float* sc = ws + L.ws_scalars;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
-                       (long)L.param_count, ws + L.ws_norm_part, a->adam_count);
-    DZ_LAUNCH_CHECK();
-    DZ_PROF(s, "grad_sumsq");
+    int nparts = n_final;
+    if (!(phases & DZ_PHASE_BACKWARD)) {  // optimiser alone: norm from the stored gradient
+      hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
+                         (long)L.param_count, ws + L.ws_norm_part, a->adam_count);
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "grad_sumsq");
+      nparts = kNormBlocks;
+    }
     hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
                        a->adam_m, a->adam_v, (long)(L.param_count >> 2),
-                       ws + L.ws_norm_part, kNormBlocks, a->adam_count, a->losses,
+                       ws + L.ws_norm_part, nparts, a->adam_count, a->losses,
                        a->weights, B, sc, a->lr, a->b1, a->b2, a->eps, a->max_norm);
     DZ_LAUNCH_CHECK();
       DZ_PROF(s, "adam");
@@ -521,6 +540,7 @@ extern "C" int dz_set_tuning(int key, int value) {
     case 6: g_fc1_dgrad_variant = value; return DZ_OK;
     case 7: DZ_REQUIRE(value >= 1 && value <= kMaxS_dfeat); g_fc1_dgrad_splits = value; return DZ_OK;
     case 8: DZ_REQUIRE(value >= 1 && value <= kMaxS_fc2); g_fc2_splits = value; return DZ_OK;
+    case 9: case 10: case 11: g_conv_fwd_variant[key - 9] = value; return DZ_OK;
     default: return DZ_ERR_INVALID_ARG;
   }
 }

@@ -5,6 +5,8 @@
 
 #include "dz_qnet_kernels.h"
 
+extern int g_conv_fwd_variant[3];  // dz_core.hip; dz_set_tuning keys 9-11
+
 namespace {
 
 struct TorsoBufs {
@@ -15,10 +17,33 @@ struct TorsoBufs {
   float* feat;             // [G*B][3136]
 };
 
+// Tile-shape variants of the three forward convolutions (dz_set_tuning keys
+// 9-11; index 0 = the aliases of dz_qnet_kernels.h).  The M dimension (3 applies
+// x 32 images x output pixels) gives 147-300 workgroups of the default shapes on
+// 256 CUs; the variants trade tile size for workgroup count.
+template <class Op>
+inline int launch_conv_fwd(const ConvFwdParams& p, int CO, int G, int B, hipStream_t s) {
+  return dz_launch_gemm<Op>(p, dim3(CO / Op::BN, G * Op::tiles_per_group(B)), s);
+}
+template <class Op>
+inline int launch_conv1_fwd(const ConvFwdParams& p, int G, int B, const NoiseParams* side,
+                            hipStream_t s) {
+  const dim3 g(32 / Op::BN, G * Op::tiles_per_group(B), 1);
+  if (side)  // the step's noise draw rides along as extra blocks: conv1 does not read it
+    return dz_launch_gemm_side<Op, NoiseSide>(p, g, *side, (unsigned)((side->n + 255) / 256), s);
+  return dz_launch_gemm<Op>(p, g, s);
+}
+//                             U8  H   W   C  KS S  OH  OW  CO
+#define DZ_C1(...) ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, __VA_ARGS__>
+#define DZ_C2(...) ConvFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, __VA_ARGS__>
+#define DZ_C3(...) ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, __VA_ARGS__>
+
 // relu(conv3(relu(conv2(relu(conv1(u8/255)))))) for G groups; group g reads
-// images in[g] with parameters prm[g].
+// images in[g] with parameters prm[g].  `side`: optional noise draw fused into
+// the conv1 launch.
 inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* prm,
-                         const uint8_t* const* in, hipStream_t s) {
+                         const uint8_t* const* in, hipStream_t s,
+                         const NoiseParams* side = nullptr) {
   int rc;
   {
     ConvFwdParams p;
@@ -27,9 +52,16 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
       p.w[g] = prm[g] + T.conv_w[0]; p.bias[g] = prm[g] + T.conv_b[0];
     }
     p.out = T.act1; p.B = B; p.G = G;
-    rc = dz_launch_gemm<Conv1Fwd>(p, dim3(1, G * Conv1Fwd::tiles_per_group(B)), s);
+    switch (g_conv_fwd_variant[0]) {
+      default: rc = launch_conv1_fwd<Conv1Fwd>(p, G, B, side, s); break;
+      case 1: rc = launch_conv1_fwd<DZ_C1(2, 1, 2, 2)>(p, G, B, side, s); break;
+      case 2: rc = launch_conv1_fwd<DZ_C1(2, 1, 2, 4)>(p, G, B, side, s); break;
+      case 3: rc = launch_conv1_fwd<DZ_C1(4, 1, 1, 2)>(p, G, B, side, s); break;
+      case 4: rc = launch_conv1_fwd<DZ_C1(1, 1, 4, 2)>(p, G, B, side, s); break;
+      case 5: rc = launch_conv1_fwd<DZ_C1(2, 1, 2, 1)>(p, G, B, side, s); break;
+    }
     if (rc) return rc;
-    DZ_PROF(s, "conv1_fwd");
+    DZ_PROF(s, side ? "conv1_fwd+noise" : "conv1_fwd");
   }
   {
     ConvFwdParams p;
@@ -38,7 +70,14 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
       p.w[g] = prm[g] + T.conv_w[1]; p.bias[g] = prm[g] + T.conv_b[1];
     }
     p.out = T.act2; p.B = B; p.G = G;
-    rc = dz_launch_gemm<Conv2Fwd>(p, dim3(1, G * Conv2Fwd::tiles_per_group(B)), s);
+    switch (g_conv_fwd_variant[1]) {
+      default: rc = launch_conv_fwd<Conv2Fwd>(p, 64, G, B, s); break;
+      case 1: rc = launch_conv_fwd<DZ_C2(1, 1, 4, 2)>(p, 64, G, B, s); break;
+      case 2: rc = launch_conv_fwd<DZ_C2(1, 1, 4, 4)>(p, 64, G, B, s); break;
+      case 3: rc = launch_conv_fwd<DZ_C2(2, 1, 2, 4)>(p, 64, G, B, s); break;
+      case 4: rc = launch_conv_fwd<DZ_C2(1, 2, 2, 2)>(p, 64, G, B, s); break;
+      case 5: rc = launch_conv_fwd<DZ_C2(1, 1, 4, 1)>(p, 64, G, B, s); break;
+    }
     if (rc) return rc;
     DZ_PROF(s, "conv2_fwd");
   }
@@ -49,7 +88,13 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
       p.w[g] = prm[g] + T.conv_w[2]; p.bias[g] = prm[g] + T.conv_b[2];
     }
     p.out = T.feat; p.B = B; p.G = G;
-    rc = dz_launch_gemm<Conv3Fwd>(p, dim3(1, G * Conv3Fwd::tiles_per_group(B)), s);
+    switch (g_conv_fwd_variant[2]) {
+      default: rc = launch_conv_fwd<Conv3Fwd>(p, 64, G, B, s); break;
+      case 1: rc = launch_conv_fwd<DZ_C3(1, 1, 4, 3)>(p, 64, G, B, s); break;
+      case 2: rc = launch_conv_fwd<DZ_C3(1, 1, 4, 1)>(p, 64, G, B, s); break;
+      case 3: rc = launch_conv_fwd<DZ_C3(2, 1, 2, 3)>(p, 64, G, B, s); break;
+      case 4: rc = launch_conv_fwd<DZ_C3(1, 2, 2, 1)>(p, 64, G, B, s); break;
+    }
     if (rc) return rc;
     DZ_PROF(s, "conv3_fwd");
   }

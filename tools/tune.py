@@ -44,18 +44,13 @@ def main():
   lib = _lib.load()
   names = {0: '<1,2,2,KT4>', 1: '<1,2,2,KT2>', 2: '<1,2,2,KT1>', 3: '<1,4,1,KT4>',
            4: '<1,4,1,KT2>', 5: '<1,1,4,KT2>', 6: '<1,1,4,KT1>', 7: '<1,4,1,KT1>'}
-  lib.dz_set_tuning(2, 0); lib.dz_set_tuning(0, 9); lib.dz_set_tuning(1, 32)
-  for var, spl in ((1, 16), (1, 32), (2, 32), (3, 32)):
-    lib.dz_set_tuning(6, var); lib.dz_set_tuning(7, spl)
-    t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
-    print('fc1 dgrad var %d S=%2d: fc1_dgrad %.2f dfeat_reduce %.2f' % (
-        var, spl, t['fc1_dgrad'], t['dfeat_reduce']), flush=True)
-  lib.dz_set_tuning(6, 1); lib.dz_set_tuning(7, 16)
-  for spl in (1, 2, 4, 8):
-    lib.dz_set_tuning(8, spl)
-    t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
-    print('fc2 fwd S=%d: fc2_fwd %.2f fc2_epilogue %.2f total %.1f' % (
-        spl, t['fc2_fwd'], t['fc2_epilogue'], sum(t.values())), flush=True)
+  fwd = _lib.PHASE_FORWARD
+  for layer, key, nvar in ((1, 9, 6), (2, 10, 6), (3, 11, 5)):
+    for var in range(nvar):
+      lib.dz_set_tuning(key, var)
+      t = timings(ln, dev, steps=20, phases=fwd)
+      print('conv%d fwd var %d: %.2f us' % (layer, var, t['conv%d_fwd' % layer]), flush=True)
+    lib.dz_set_tuning(key, 0)
 
 
 if __name__ == '__main__':
