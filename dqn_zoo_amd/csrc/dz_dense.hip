@@ -169,11 +169,11 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
         DZ_REQUIRE(a->weights);  // c51 passes all-ones weights
         float* scratch = a->priorities ? a->priorities : ws + L.ws_scalars + 8;
         (void)scratch;
-        hipLaunchKernelGGL(rainbow_head_loss_kernel, dim3(B), dim3(64), 0, s, out, ld2, 0,
+        hipLaunchKernelGGL(rainbow_head_loss_kernel<0>, dim3(B), dim3(64), 0, s, out, ld2, 0,
                            B, A, a->num_atoms, 0, 1, 1, a->a_tm1, a->r_t, a->discount_t,
                            a->weights, a->aux, dout, a->losses,
                            a->priorities ? a->priorities : (ws + L.ws_dfeat_part),
-                           (float*)nullptr, (float*)nullptr);
+                           (float*)nullptr, (float*)nullptr, HeadPre{});
         break;
       }
       case DZ_LOSS_QUANTILE:

@@ -214,16 +214,71 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ref: networks.py:254-258 (dueling, softmax, expectation),
 //      rainbow/agent.py:97-109 + rlax.categorical_double_q_learning,
 //      rainbow/agent.py:194 (priorities).
-__global__ __launch_bounds__(64) void rainbow_head_loss_kernel(
-    const float* __restrict__ fc2_out, int ld, int val_off, int B, int A, int K,
+// PRE = 1: the fc2 split-K epilogue is done here (no separate launch): all 256
+// threads first form the block's three output rows
+//     out[g][c] = sum_s part[s][g*B + b][c] + sig_b[c] * eps_out_g[c]
+// in LDS (and write them to fc2_out for inspection), then wave 0 runs the loss
+// on LDS-resident rows.  PRE = 0: fc2_out is read as given (64 threads suffice).
+struct HeadPre {
+  const float* part;   // [S][rows][ld]
+  int S, rows;
+  const float* prm[3];
+  const float* nz[3];
+  long b_sig;          // sigma-bias offset in the parameter vector
+  int eps_out;         // its noise offset
+};
+template <int PRE>
+__global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_head_loss_kernel(
+    float* __restrict__ fc2_out, int ld, int val_off, int B, int A, int K,
     int dueling, int sel_group, int tgt_group, const int64_t* __restrict__ a_tm1, const double* __restrict__ r_t,
     const double* __restrict__ d_t, const float* __restrict__ weights,
     const float* __restrict__ support, float* __restrict__ dout2,
     float* __restrict__ losses, float* __restrict__ priorities,
-    float* __restrict__ q_sel_out, float* __restrict__ target_out) {
+    float* __restrict__ q_sel_out, float* __restrict__ target_out, HeadPre pre) {
+  extern __shared__ float s_rows[];  // PRE: [3][ld]
   __shared__ float s_p[64];
   __shared__ float s_z[64];
   const int b = blockIdx.x, k = threadIdx.x;
+  if (PRE) {
+    // All loads of a round are issued before any is consumed (the slabs were
+    // written by the previous kernel: every load is a ~2 us trip past L2, so the
+    // number of round trips, not the 34 KB, is what this phase costs).
+    constexpr int E = 5, SMAX = 8;
+    const int n = 3 * ld;
+    for (int base = 0; base < n; base += 256 * E) {
+      float v[E][SMAX];
+      float bs[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int i = min(base + (int)threadIdx.x + 256 * e, n - 1);
+        const int g = i / ld, c = i - g * ld;
+        const long row = (long)g * B + b;
+#pragma unroll
+        for (int sidx = 0; sidx < SMAX; ++sidx) {
+          const float t = pre.part[((long)min(sidx, pre.S - 1) * pre.rows + row) * ld + c];
+          v[e][sidx] = sidx < pre.S ? t : 0.f;
+        }
+        const float* prm = g == 0 ? pre.prm[0] : (g == 1 ? pre.prm[1] : pre.prm[2]);
+        const float* nz = g == 0 ? pre.nz[0] : (g == 1 ? pre.nz[1] : pre.nz[2]);
+        bs[e] = prm[pre.b_sig + c] * nz[pre.eps_out + c];
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int i = base + (int)threadIdx.x + 256 * e;
+        if (i < n) {
+          float acc = 0.f;
+#pragma unroll
+          for (int sidx = 0; sidx < SMAX; ++sidx) acc += v[e][sidx];
+          acc += bs[e];
+          s_rows[i] = acc;
+          const int g = i / ld, c = i - g * ld;
+          fc2_out[((long)g * B + b) * ld + c] = acc;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+  }
   const bool on = k < K;
   const int NA = val_off;  // value-head columns start at the padded offset
   const float z = on ? support[k] : 0.f;
@@ -234,7 +289,7 @@ __global__ __launch_bounds__(64) void rainbow_head_loss_kernel(
   // ---- selector network: q_values -> argmax.  Rainbow: online(s_t)
   // (double-Q, rainbow/agent.py:91-93); C51: the target network itself
   // (rlax.categorical_q_learning) ----
-  const float* o1 = fc2_out + (long)(sel_group * B + b) * ld;
+  const float* o1 = PRE ? s_rows + sel_group * ld : fc2_out + (long)(sel_group * B + b) * ld;
   float mean_adv = 0.f;
   if (dueling) {
     for (int a = 0; a < A; ++a) mean_adv += on ? o1[a * K + k] : 0.f;
@@ -253,7 +308,7 @@ __global__ __launch_bounds__(64) void rainbow_head_loss_kernel(
     if (q > best_q) { best_q = q; a_star = a; }  // first maximum, as jnp.argmax
   }
   // ---- target distribution of the selected action ----
-  const float* o2 = fc2_out + (long)(tgt_group * B + b) * ld;
+  const float* o2 = PRE ? s_rows + tgt_group * ld : fc2_out + (long)(tgt_group * B + b) * ld;
   float mean2 = 0.f;
   if (dueling) {
     for (int a = 0; a < A; ++a) mean2 += on ? o2[a * K + k] : 0.f;
@@ -289,7 +344,7 @@ __global__ __launch_bounds__(64) void rainbow_head_loss_kernel(
   if (target_out && on) target_out[b * K + k] = m;
   // ---- group 0: cross-entropy with log_softmax(logits_tm1[a_tm1]) ----
   const int a0 = (int)a_tm1[b];
-  const float* o0 = fc2_out + (long)(0 * B + b) * ld;
+  const float* o0 = PRE ? s_rows : fc2_out + (long)(0 * B + b) * ld;
   float mean0 = 0.f;
   if (dueling) {
     for (int a = 0; a < A; ++a) mean0 += on ? o0[a * K + k] : 0.f;

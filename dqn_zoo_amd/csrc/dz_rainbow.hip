@@ -44,7 +44,8 @@ struct FwdHeads { FcHead fc1h[2]; FcHead fc2h[2]; };
 static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int G, int B,
                            const float* const* prm, const float* const* nz,
                            const uint8_t* const* in, float* ws, hipStream_t s,
-                           const NoiseParams* resample = nullptr) {
+                           const NoiseParams* resample = nullptr,
+                           bool skip_fc2_epilogue = false) {
   int rc = DZ_OK;
   const int NA = L.num_actions * L.num_atoms;
   const int ld2 = L.adv2_ld + L.val2_ld;
@@ -160,6 +161,7 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
                                       G * 2 * g_fc2_splits), s);
     if (rc) return rc;
     DZ_PROF(s, "fc2_fwd");
+    if (skip_fc2_epilogue) return rc;  // the loss kernel folds the partial slabs itself
     hipLaunchKernelGGL(fc_epilogue_kernel, dim3((ld2 + 63) / 64, G * B), dim3(256),
                        0, s, ws + L.ws_fc2_part, g_fc2_splits, G * B, ld2, ld2, B,
                        prm[0], prm[1], prm[2], (long)-1, (long)L.fc2_sig_b, nz[0],
@@ -287,14 +289,27 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   if (phases & DZ_PHASE_FORWARD) {
     {
       const uint8_t* in[kG] = {a->s_tm1, a->s_t, a->s_t};
+      const bool fuse = (size_t)3 * ld2 * sizeof(float) <= 48 * 1024;
       rc = rainbow_forward(L, H, kG, B, prm, nz, in, ws, s,
-                           a->resample_noise ? &nq : nullptr);
+                           a->resample_noise ? &nq : nullptr, fuse);
       if (rc) return rc;
+      HeadPre pre = {};
+      if (fuse) {
+        pre.part = ws + L.ws_fc2_part; pre.S = g_fc2_splits; pre.rows = kG * B;
+        for (int g = 0; g < kG; ++g) { pre.prm[g] = prm[g]; pre.nz[g] = nz[g]; }
+        pre.b_sig = L.fc2_sig_b; pre.eps_out = (int)L.n_fc2_out;
+        hipLaunchKernelGGL(rainbow_head_loss_kernel<1>, dim3(B), dim3(256),
+                           (size_t)3 * ld2 * sizeof(float), s, ws + L.ws_fc2_out, ld2, NAp, B,
+                           A, K, 1, 1, 2, a->a_tm1, a->r_t, a->discount_t, a->weights,
+                           a->support, ws + L.ws_dout2, a->losses, a->priorities,
+                           ws + L.ws_q_sel, ws + L.ws_target_probs, pre);
+      } else {
+        hipLaunchKernelGGL(rainbow_head_loss_kernel<0>, dim3(B), dim3(64), 0, s,
+                           ws + L.ws_fc2_out, ld2, NAp, B, A, K, 1, 1, 2, a->a_tm1, a->r_t,
+                           a->discount_t, a->weights, a->support, ws + L.ws_dout2, a->losses,
+                           a->priorities, ws + L.ws_q_sel, ws + L.ws_target_probs, pre);
+      }
     }
-    hipLaunchKernelGGL(rainbow_head_loss_kernel, dim3(B), dim3(64), 0, s,
-                       ws + L.ws_fc2_out, ld2, NAp, B, A, K, 1, 1, 2, a->a_tm1, a->r_t, a->discount_t,
-                       a->weights, a->support, ws + L.ws_dout2, a->losses, a->priorities,
-                       ws + L.ws_q_sel, ws + L.ws_target_probs);
     DZ_LAUNCH_CHECK();
       DZ_PROF(s, "head_loss");
   }
