@@ -244,6 +244,37 @@ def measure_roofline(step, prof_steps, batch):
   return out
 
 
+def measure_replay(step, batch, n=100):
+  """Device time of the replay kernels from HIP event pairs recorded INSIDE the
+  C entry points (dz_prof_read_replay), medians over n steps (SURVEY.md 8d:
+  gather against HBM bandwidth; sum-tree sample / update as latency per query --
+  their bytes are trivial)."""
+  from dqn_zoo_amd import _lib
+  lib = _lib.load()
+  lib.dz_prof_enable(1)
+  ms = (ctypes.c_float * 3)()
+  acc = [[], [], []]
+  for _ in range(n):
+    step()
+    torch.cuda.synchronize()
+    lib.dz_prof_read_replay(ctypes.addressof(ms))
+    for i in range(3):
+      if ms[i] >= 0:
+        acc[i].append(ms[i] * 1e3)
+  lib.dz_prof_enable(0)
+  t_sample, t_gather, t_update = (float(np.median(a)) if a else None for a in acc)
+  gather_bytes = 2 * batch * (2 * 28224 + 4 + 8 + 8)  # read + written
+  return {
+      'sumtree_sample_us': round(t_sample, 2), 'gather_us': round(t_gather, 2),
+      'sumtree_update_us': round(t_update, 2),
+      'sumtree_sample_ns_per_query': round(1e3 * t_sample / batch, 1),
+      'sumtree_update_ns_per_leaf': round(1e3 * t_update / batch, 1),
+      'gather_GBps': round(gather_bytes / t_gather / 1e3, 1),
+      'gather_frac_of_hbm_peak': round(gather_bytes / (t_gather * 1e-6) / PEAK_HBM, 4),
+      'note': 'event pairs include ~2-3 us of event overhead each; one workgroup '
+              'walks 20 tree levels (capacity 1e6): dependent-load latency, not bytes'}
+
+
 def usable_cpus():
   """Host cores this process may actually use (affinity mask and cgroup CPU
   quota), which can be far fewer than os.cpu_count() inside a container."""
@@ -414,6 +445,7 @@ def main():
     if args.prof_steps > 0:
       learner.use_graphs = False  # per-kernel events need eager launches
       out['roofline'] = measure_roofline(seq_step, args.prof_steps, args.batch)
+      out['replay'] = measure_replay(seq_step, args.batch)
     if world == 1 and args.cpu_seconds > 0:
       out['cpu_baseline'] = cpu_baseline(args, args.seed, args.cpu_seconds)
       out['speedup_vs_cpu_baseline'] = round(

@@ -183,6 +183,7 @@ SIGNATURES = {
     'dz_set_tuning': (c_int, [c_int, c_int]),
     'dz_prof_enable': (c_int, [c_int]),
     'dz_prof_read': (c_int, [c_int, c_vp, c_vp]),
+    'dz_prof_read_replay': (c_int, [c_vp]),
     'dz_replay_gather': (c_int, [ctypes.POINTER(FieldDesc), c_int, c_vp, c_int,
                                  c_i64, c_vp]),
     'dz_uniform_pos_to_id': (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp,

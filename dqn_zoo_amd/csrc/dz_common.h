@@ -37,6 +37,7 @@ __host__ __device__ static inline int64_t dz_mod(int64_t a, int64_t b) {
 // ---- optional event profiler (dz_prof_*) ------------------------------------
 extern bool g_dz_prof_on;
 void dz_prof_begin(hipStream_t s);
+void dz_prof_pair(int which, int end, hipStream_t s);
 void dz_prof_mark(hipStream_t s, const char* name);
 #define DZ_PROF(stream, name)                         \
   do {                                                \

@@ -44,9 +44,29 @@ void dz_prof_mark(hipStream_t s, const char* name) {
   (void)hipEventRecord(g_ev[g_nmarks + 1], s);
   ++g_nmarks;
 }
+// Replay entry points (0 sample, 1 gather, 2 priority update): an event pair
+// around the launch, taken inside the C function so that no host-side work of
+// the caller lands between the two records.
+namespace { hipEvent_t g_rep_ev[3][2]; bool g_rep_seen[3] = {false, false, false}; }
+void dz_prof_pair(int which, int end, hipStream_t s) {
+  if (!g_dz_prof_on || which < 0 || which > 2) return;
+  (void)hipEventRecord(g_rep_ev[which][end], s);
+  if (end) g_rep_seen[which] = true;
+}
+extern "C" int dz_prof_read_replay(float* ms_out) {
+  DZ_REQUIRE(ms_out);
+  for (int i = 0; i < 3; ++i) {
+    ms_out[i] = -1.f;
+    if (g_ev_created && g_rep_seen[i])
+      DZ_HIP_CHECK(hipEventElapsedTime(&ms_out[i], g_rep_ev[i][0], g_rep_ev[i][1]));
+  }
+  return DZ_OK;
+}
 extern "C" int dz_prof_enable(int on) {
   if (on && !g_ev_created) {
     for (int i = 0; i <= kMaxMarks; ++i) DZ_HIP_CHECK(hipEventCreate(&g_ev[i]));
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 2; ++j) DZ_HIP_CHECK(hipEventCreate(&g_rep_ev[i][j]));
     g_ev_created = true;
   }
   g_dz_prof_on = on != 0;

@@ -304,10 +304,14 @@ struct FcDgradOp {
   typedef FcDgradParams Params;
   typedef DzTile Tile;
 
-  struct Loc { int N, ldw, eps_in, eps_out, out_off, n0; long w; bool sig, ok; };
+  struct Loc { int N, ldw, eps_in, eps_out, out_off, n0; long w, w2; bool sig, ok; };
 
+  // noisy == 1: reduction over (mu | sigma) chunks, depth 2N (two-GEMM form);
+  // noisy == 2: ONE pass of depth N over the effective weight
+  //   W_eff[k][n] = Wmu[k][n] + Wsig[k][n] * (eps_in[k] * eps_out[n])
+  // built in the B loader (two loads + 2 VALU per element, half the MFMAs).
   __device__ static int chunks_of(const Params& p, int h) {
-    return (((h ? p.head[1].N : p.head[0].N) + 15) / 16) * (p.noisy ? 2 : 1);
+    return (((h ? p.head[1].N : p.head[0].N) + 15) / 16) * (p.noisy == 1 ? 2 : 1);
   }
   // global chunk -> (head, mu|sigma, first n), arithmetic only (NH <= 2).
   __device__ static Loc locate(const Params& p, int gc) {
@@ -327,6 +331,7 @@ struct FcDgradOp {
     L.sig = gl >= cp;
     L.n0 = (gl - (L.sig ? cp : 0)) * 16;
     L.w = L.sig ? (h1 ? b.w_sig : a.w_sig) : (h1 ? b.w_mu : a.w_mu);
+    L.w2 = h1 ? b.w_sig : a.w_sig;
     return L;
   }
   __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
@@ -359,6 +364,12 @@ struct FcDgradOp {
     const int nc = min(L.n0 + 4 * q, L.ldw - 4);
     const float4 v = dz_ld4(p.params + L.w + (long)k * L.ldw + nc);
     const float e = p.noise[L.eps_in + k];
+    if (p.noisy == 2) {
+      const float4 sg = dz_ld4(p.params + L.w2 + (long)k * L.ldw + nc);
+      const float4 eo = dz_ld4(p.noise + L.eps_out + nc);
+      return dz_f4(__builtin_fmaf(sg.x, e * eo.x, v.x), __builtin_fmaf(sg.y, e * eo.y, v.y),
+                   __builtin_fmaf(sg.z, e * eo.z, v.z), __builtin_fmaf(sg.w, e * eo.w, v.w));
+    }
     return L.sig ? dz_scale4(v, e) : v;
   }
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,

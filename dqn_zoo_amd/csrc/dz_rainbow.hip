@@ -22,7 +22,8 @@ int g_fc1_blocked_experiment = 0;
 int g_overlap = 1;           // (unused) weight gradients on an auxiliary stream
 int g_fc1_dgrad_first = 1;
 int g_fc1_dgrad_variant = 2;   // FcDgradOp<1,2,2,KT=1> x 32 splits: 24 us (KT=4 x 8: 34 us)
-int g_fc1_dgrad_splits = 32;
+int g_fc1_dgrad_splits = 16;
+int g_dgrad_weff = 1;         // fc1 input gradient contracts against W_eff (depth N, not 2N): 14.2 vs 17.2 us
 int g_fc2_splits = 8;          // 12 us (4 splits: 19 us)
 hipStream_t g_aux_stream = nullptr;
 hipEvent_t g_ev[5];
@@ -341,6 +342,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       FcDgradParams d[2];
       for (int h = 0; h < 2; ++h) {
         d[h].dy = ws + L.ws_dout2; d[h].ldy = ld2; d[h].M = B; d[h].NH = 1;
+        // (the W_eff form of this small input gradient measured slower: 16.4 vs 14.1 us)
         d[h].S = kS_dh1; d[h].noisy = 1; d[h].params = a->online; d[h].noise = nz[0];
         d[h].head[0] = fc2h[h]; d[h].head[1] = fc2h[h];
         d[h].part = ws + L.ws_dfeat_part; d[h].ldo = 1024; d[h].K = kHid;
@@ -364,7 +366,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       w.grad = grad;
       w.sumsq = sq_slots + fc2_slots; w.sq_nx = 512 / FcWg::BN; w.sq_ny = kFlat / FcWg::BM;
       FcDgradParams d;
-      d.dy = ws + L.ws_dh1; d.ldy = 1024; d.M = B; d.NH = 2; d.S = kS_dfeat; d.noisy = 1;
+      d.dy = ws + L.ws_dh1; d.ldy = 1024; d.M = B; d.NH = 2; d.S = kS_dfeat; d.noisy = g_dgrad_weff ? 2 : 1;
       d.params = a->online; d.noise = nz[0]; d.head[0] = fc1h[0]; d.head[1] = fc1h[1];
       d.part = ws + L.ws_dfeat_part; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
       // (measured: fusing these two HBM-heavy contractions is slower, 48 us vs
@@ -556,6 +558,7 @@ extern "C" int dz_set_tuning(int key, int value) {
     case 7: DZ_REQUIRE(value >= 1 && value <= kMaxS_dfeat); g_fc1_dgrad_splits = value; return DZ_OK;
     case 8: DZ_REQUIRE(value >= 1 && value <= kMaxS_fc2); g_fc2_splits = value; return DZ_OK;
     case 9: case 10: case 11: g_conv_fwd_variant[key - 9] = value; return DZ_OK;
+    case 12: g_dgrad_weff = value; return DZ_OK;
     default: return DZ_ERR_INVALID_ARG;
   }
 }

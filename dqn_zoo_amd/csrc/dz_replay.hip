@@ -80,9 +80,11 @@ extern "C" int dz_replay_gather(const dz_field_t* fields, int num_fields,
   if (chunks < 1) chunks = 1;
   if (chunks > 64) chunks = 64;
   dim3 grid((unsigned)chunks, (unsigned)batch, (unsigned)num_fields);
+  dz_prof_pair(1, 0, dz_s(stream));
   hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, dz_s(stream), a,
                      ids, capacity);
   DZ_LAUNCH_CHECK();
+  dz_prof_pair(1, 1, dz_s(stream));
   return DZ_OK;
 }
 

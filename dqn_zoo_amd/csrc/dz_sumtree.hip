@@ -382,11 +382,13 @@ extern "C" int dz_prioritized_sample(const dz_prio_sample_args_t* args, int batc
   DZ_REQUIRE(args->size > 0 && args->size <= args->capacity &&
              args->t >= args->size);
   DZ_REQUIRE(args->pos && args->u_target && args->u_mix);
+  dz_prof_pair(0, 0, dz_s(stream));
   hipLaunchKernelGGL(prioritized_sample_kernel, dim3(1),
                      dim3(round_up_64(batch)), 0, dz_s(stream), *args, batch,
                      ids_out, tree_idx_out, probs_out, weights_out,
                      weights32_out, status);
   DZ_LAUNCH_CHECK();
+  dz_prof_pair(0, 1, dz_s(stream));
   return DZ_OK;
 }
 
@@ -401,10 +403,12 @@ extern "C" int dz_prioritized_update(double* node, int64_t cap_pow2,
              size <= capacity && t >= size);
   DZ_REQUIRE(n >= 0 && n <= kMaxBatch && exponent >= 0.0);
   if (n == 0) return DZ_OK;
+  dz_prof_pair(2, 0, dz_s(stream));
   hipLaunchKernelGGL(prioritized_update_kernel, dim3(1), dim3(round_up_64(n)), 0,
                      dz_s(stream), node, cap_pow2, capacity, size, t, ids,
                      priorities, prio_is_f32, exponent, n, max_seen, status);
   DZ_LAUNCH_CHECK();
+  dz_prof_pair(2, 1, dz_s(stream));
   return DZ_OK;
 }
 

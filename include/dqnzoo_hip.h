@@ -436,6 +436,11 @@ int dz_uniform_fill(float* out, int64_t n, uint64_t seed, uint64_t counter,
  * (names_out: max_marks * 32 bytes).  Used by bench.py for `roofline`.       */
 int dz_prof_enable(int on);
 int dz_prof_read(int max_marks, float* ms_out, char* names_out);
+/* With timing enabled, dz_prioritized_sample (0), dz_replay_gather (1) and
+ * dz_prioritized_update (2) record an event pair around their launch; this
+ * returns the last elapsed milliseconds of each (-1 if never run) in ms_out[3].
+ * Call after synchronising the stream.                                       */
+int dz_prof_read_replay(float* ms_out);
 
 /* Tuning knobs for tools/tune.py (kernel variant / split-K sweeps in one GPU
  * session): key 0 = fc1 forward variant (8 = weight-streaming kernel),

@@ -44,13 +44,13 @@ def main():
   lib = _lib.load()
   names = {0: '<1,2,2,KT4>', 1: '<1,2,2,KT2>', 2: '<1,2,2,KT1>', 3: '<1,4,1,KT4>',
            4: '<1,4,1,KT2>', 5: '<1,1,4,KT2>', 6: '<1,1,4,KT1>', 7: '<1,4,1,KT1>'}
-  fwd = _lib.PHASE_FORWARD
-  for layer, key, nvar in ((1, 9, 6), (2, 10, 6), (3, 11, 5)):
-    for var in range(nvar):
-      lib.dz_set_tuning(key, var)
-      t = timings(ln, dev, steps=20, phases=fwd)
-      print('conv%d fwd var %d: %.2f us' % (layer, var, t['conv%d_fwd' % layer]), flush=True)
-    lib.dz_set_tuning(key, 0)
+  for weff in (0, 1):
+    lib.dz_set_tuning(12, weff)
+    for var, spl in ((2, 32), (1, 16), (2, 16), (0, 8), (1, 32)):
+      lib.dz_set_tuning(6, var); lib.dz_set_tuning(7, spl)
+      t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
+      print('weff %d fc1 dgrad var %d S=%2d: fc1_dgrad %.2f dfeat_reduce %.2f fc2 %.2f' % (
+          weff, var, spl, t['fc1_dgrad'], t['dfeat_reduce'], t['fc2_wgrad+dgrad']), flush=True)
 
 
 if __name__ == '__main__':
