@@ -35,6 +35,12 @@ class FieldDesc(ctypes.Structure):
   _fields_ = [('src', c_vp), ('dst', c_vp), ('row_bytes', c_i64)]
 
 
+class InsertField(ctypes.Structure):
+  """dz_insert_field_t."""
+  _fields_ = [('dst', c_vp), ('src_row', c_vp), ('row_bytes', c_i64),
+              ('imm', ctypes.c_uint64)]
+
+
 class PrioSampleArgs(ctypes.Structure):
   _fields_ = [
       ('node', c_vp), ('cap_pow2', c_i64), ('capacity', c_i64),
@@ -147,7 +153,8 @@ SC_GNORM, SC_LOSS, SC_BC1, SC_BC2, SC_CLIP = 0, 1, 2, 3, 4
 PHASE_FORWARD, PHASE_BACKWARD, PHASE_OPTIMIZER, PHASE_ALL = 1, 2, 4, 7
 
 STRUCT_IDS = {0: FieldDesc, 1: PrioSampleArgs, 2: RainbowLayout, 3: RainbowArgs,
-              4: DenseLayout, 5: DenseArgs, 6: IqnLayout, 7: IqnArgs}
+              4: DenseLayout, 5: DenseArgs, 6: IqnLayout, 7: IqnArgs,
+              8: InsertField}
 
 # name -> (restype, argtypes).  tests/test_abi.py checks this table against
 # the prototypes in include/dqnzoo_hip.h and against the built library.
@@ -186,6 +193,8 @@ SIGNATURES = {
     'dz_prof_read_replay': (c_int, [c_vp]),
     'dz_replay_gather': (c_int, [ctypes.POINTER(FieldDesc), c_int, c_vp, c_int,
                                  c_i64, c_vp]),
+    'dz_replay_insert': (c_int, [ctypes.POINTER(InsertField), c_int, c_i64, c_i64,
+                                 c_vp, c_i64, c_f64, c_vp, c_f64, c_vp, c_vp]),
     'dz_uniform_pos_to_id': (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp,
                                      c_vp]),
     'dz_sumtree_set': (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_vp,

@@ -17,6 +17,7 @@ extern "C" int dz_struct_size(int which) {
     case 5: return (int)sizeof(dz_dense_args_t);
     case 6: return (int)sizeof(dz_iqn_layout_t);
     case 7: return (int)sizeof(dz_iqn_args_t);
+    case 8: return (int)sizeof(dz_insert_field_t);
     default: return -1;
   }
 }

@@ -315,6 +315,47 @@ __global__ __launch_bounds__(kMaxBatch) void prioritized_add_kernel(
   set_leaves_and_ancestors(node, cap, leaf, v, active, s_leaf, n);
 }
 
+// One transition: rows of every field (blockIdx.y < num_fields) and, in the
+// extra block row, the tree insert (leaf + its 20 ancestors, one thread: program
+// order makes every parent exactly fl(left + right) of its final children).
+struct InsertArgs { dz_insert_field_t f[DZ_MAX_FIELDS]; int num_fields; };
+__global__ __launch_bounds__(256) void replay_insert_kernel(
+    InsertArgs a, int64_t slot, double* node, int64_t cap, int64_t N, int64_t t,
+    double priority_h, const double* priority_d, double exponent, uint32_t* status) {
+  if ((int)blockIdx.y == a.num_fields) {
+    if (blockIdx.x != 0 || threadIdx.x != 0 || !node) return;
+    const double p = priority_d ? *priority_d : priority_h;
+    const double v = leaf_from_priority_f64(p, exponent);
+    if (!finite_nonneg(v)) { raise(status, DZ_ST_BAD_VALUE); return; }
+    int64_t i = cap + tree_index_of_id(t, N);
+    node[i] = v;
+    for (i >>= 1; i >= 1; i >>= 1) node[i] = node[2 * i] + node[2 * i + 1];
+    return;
+  }
+  const dz_insert_field_t fd = a.f[blockIdx.y];
+  const int64_t rb = fd.row_bytes;
+  char* dst = (char*)fd.dst + slot * rb;
+  if (!fd.src_row) {
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < rb)
+      dst[threadIdx.x] = (char)((fd.imm >> (8 * threadIdx.x)) & 0xff);
+    return;
+  }
+  const char* src = (const char*)fd.src_row;
+  const bool vec_ok = ((rb & 15) == 0) && ((((uintptr_t)src) & 15) == 0) &&
+                      ((((uintptr_t)fd.dst) & 15) == 0);
+  if (vec_ok) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int64_t nvec = rb >> 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec;
+         i += (int64_t)gridDim.x * 256)
+      ((u32x4*)dst)[i] = ((const u32x4*)src)[i];
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rb;
+         i += (int64_t)gridDim.x * 256)
+      dst[i] = src[i];
+  }
+}
+
 inline int round_up_64(int n) { return (n + 63) / 64 * 64; }
 
 }  // namespace
@@ -424,6 +465,32 @@ extern "C" int dz_prioritized_add(double* node, int64_t cap_pow2,
   hipLaunchKernelGGL(prioritized_add_kernel, dim3(1), dim3(round_up_64(n)), 0,
                      dz_s(stream), node, cap_pow2, capacity, t, n, priority_h,
                      priority_d, exponent, status);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
+extern "C" int dz_replay_insert(const dz_insert_field_t* fields, int num_fields, int64_t t,
+                                int64_t capacity, double* node, int64_t cap_pow2,
+                                double priority_h, const double* priority_d,
+                                double exponent, uint32_t* status, dz_stream_t stream) {
+  DZ_REQUIRE(fields && num_fields > 0 && num_fields <= DZ_MAX_FIELDS && capacity > 0 &&
+             t >= 0);
+  if (node) DZ_REQUIRE(dz_is_pow2(cap_pow2) && capacity <= cap_pow2 && exponent >= 0.0 && status);
+  InsertArgs a;
+  a.num_fields = num_fields;
+  int64_t max_rb = 0;
+  for (int i = 0; i < num_fields; ++i) {
+    DZ_REQUIRE(fields[i].dst && fields[i].row_bytes > 0);
+    DZ_REQUIRE(fields[i].src_row || fields[i].row_bytes <= 8);
+    a.f[i] = fields[i];
+    if (fields[i].src_row && fields[i].row_bytes > max_rb) max_rb = fields[i].row_bytes;
+  }
+  int64_t chunks = ((max_rb >> 4) + 255) / 256;
+  if (chunks < 1) chunks = 1;
+  if (chunks > 16) chunks = 16;
+  hipLaunchKernelGGL(replay_insert_kernel, dim3((unsigned)chunks, (unsigned)num_fields + 1),
+                     dim3(256), 0, dz_s(stream), a, t % capacity, node, cap_pow2, capacity, t,
+                     priority_h, priority_d, exponent, status);
   DZ_LAUNCH_CHECK();
   return DZ_OK;
 }

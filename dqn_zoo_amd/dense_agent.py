@@ -17,6 +17,7 @@ from typing import Any, Mapping
 import numpy as np
 import torch
 
+from dqn_zoo_amd import device_obs
 from dqn_zoo_amd import learner as learner_lib
 from dqn_zoo_amd import networks
 from dqn_zoo_amd import parts
@@ -69,8 +70,7 @@ class DenseAgent(parts.Agent):
     self._action = None
     self._frame_t = -1
     self._statistics = {'state_value': np.nan}
-    self._obs_device = torch.empty((1, 84, 84, 4), dtype=torch.uint8,
-                                   device=self._device)
+    self._obs = device_obs.ObservationCache(self._device)
 
   # -- stepping ---------------------------------------------------------------
   def step(self, timestep) -> parts.Action:
@@ -98,6 +98,8 @@ class DenseAgent(parts.Agent):
     self._action = None
 
   def _add(self, transition) -> None:
+    # both states are already in HBM (uploaded for acting): no re-upload
+    transition = self._obs.on_device(transition)
     if self.PRIORITIZED:  # priority = running max (prioritized/agent.py:152-153)
       self._replay.add_with_device_priority(transition)
     else:
@@ -117,9 +119,7 @@ class DenseAgent(parts.Agent):
     return head_out
 
   def _act(self, timestep) -> parts.Action:
-    obs = np.ascontiguousarray(timestep.observation, dtype=np.uint8)
-    self._obs_device[0].copy_(torch.from_numpy(obs))
-    out, _, _, _ = self._learner.apply(self._obs_device)
+    out, _, _, _ = self._learner.apply(self._obs.upload(timestep.observation))
     q = self.q_values(out[0].cpu().numpy())   # the one sync per decision
     a_t = epsilon_greedy_sample(q, self.exploration_epsilon, self._policy_rng)
     self._statistics['state_value'] = float(np.max(q))

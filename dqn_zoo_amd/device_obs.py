@@ -1,0 +1,55 @@
+"""Device copies of the observations an agent has just acted on.
+
+`agent.step()` uploads every observation once, for the action-selection
+apply.  The transitions the accumulator emits afterwards are built from those
+same observation objects (`s_t` is the current one, `s_tm1` the one from n
+steps back; ref: replay.py:771-892), so the replay insert can take both states
+from HBM instead of uploading 2 x 28 KB again per `add`.
+Identity (`is`) of the host arrays is the key: a transition field that is not
+one of the cached objects simply takes the host upload path.
+"""
+
+import numpy as np
+import torch
+
+
+class ObservationCache:
+
+  def __init__(self, device, depth: int = 8, shape=(84, 84, 4)):
+    self._depth = depth
+    self._pin = torch.empty((depth,) + tuple(shape), dtype=torch.uint8,
+                            pin_memory=True)
+    self._dev = torch.empty((depth,) + tuple(shape), dtype=torch.uint8,
+                            device=device)
+    self._host = [None] * depth
+    self._pos = 0
+
+  def upload(self, observation) -> torch.Tensor:
+    """Async upload; returns the [1, H, W, C] device view.  The pinned slot is
+    reused `depth` calls later: callers synchronise once per step (they read the
+    selected action), which is what makes that safe."""
+    k = self._pos % self._depth
+    self._pos += 1
+    a = np.ascontiguousarray(observation, dtype=np.uint8)
+    self._pin[k].copy_(torch.from_numpy(a))
+    self._dev[k].copy_(self._pin[k], non_blocking=True)
+    self._host[k] = observation
+    return self._dev[k:k + 1]
+
+  def lookup(self, observation):
+    for k in range(self._depth):
+      if self._host[k] is observation:
+        return self._dev[k]
+    return None
+
+  def on_device(self, transition):
+    """The transition with `s_tm1` / `s_t` replaced by their device copies
+    where the cache holds them."""
+    a, b = self.lookup(transition.s_tm1), self.lookup(transition.s_t)
+    if a is None and b is None:
+      return transition
+    return transition._replace(s_tm1=transition.s_tm1 if a is None else a,
+                               s_t=transition.s_t if b is None else b)
+
+  def clear(self) -> None:
+    self._host = [None] * self._depth

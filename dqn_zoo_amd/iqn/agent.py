@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from dqn_zoo_amd import dense_agent
+from dqn_zoo_amd import device_obs
 from dqn_zoo_amd import learner as learner_lib
 from dqn_zoo_amd import networks
 from dqn_zoo_amd import parts
@@ -108,8 +109,7 @@ class Iqn(dense_agent.DenseAgent):
     self._action = None
     self._frame_t = -1
     self._statistics = {'state_value': np.nan}
-    self._obs_device = torch.empty((1, 84, 84, 4), dtype=torch.uint8,
-                                   device=self._device)
+    self._obs = device_obs.ObservationCache(self._device)
     self._act_taus = torch.empty((1, self._tau_samples_policy),
                                  dtype=torch.float32, device=self._device)
     self._act_counter = 0
@@ -119,14 +119,13 @@ class Iqn(dense_agent.DenseAgent):
     """ref: iqn/agent.py:234-247 select_action: tau_samples_policy fresh draws,
     epsilon-greedy on the sample mean."""
     ln = self._learner
-    obs = np.ascontiguousarray(timestep.observation, dtype=np.uint8)
-    self._obs_device[0].copy_(torch.from_numpy(obs))
+    obs_d = self._obs.upload(timestep.observation)
     n = self._tau_samples_policy
     learner_lib._lib.check(ln._lib.dz_uniform_fill(  # pylint: disable=protected-access
         self._act_taus.data_ptr(), n, self._act_seed, self._act_counter, None,
         torch.cuda.current_stream(self._device).cuda_stream), 'dz_uniform_fill')
     self._act_counter += n
-    _, q, _, _ = ln.apply(self._obs_device, self._act_taus)
+    _, q, _, _ = ln.apply(obs_d, self._act_taus)
     q = q[0].cpu().numpy()   # the one sync per decision
     a_t = dense_agent.epsilon_greedy_sample(q, self.exploration_epsilon,
                                             self._policy_rng)

@@ -18,6 +18,16 @@ from dqn_zoo_amd import _lib
 from dqn_zoo_amd import networks
 
 
+def read_packed_action(greedy: torch.Tensor, vmax: torch.Tensor):
+  """Row 0 of (greedy int32 [B], vmax float32 [B]) that are views of ONE
+  [2, B] int32 buffer: one 8*B-byte device->host copy instead of two syncs."""
+  base = greedy._base if greedy._base is not None else None  # pylint: disable=protected-access
+  if base is None or base.dim() != 2 or vmax.data_ptr() != base[1].data_ptr():
+    return int(greedy[0].item()), float(vmax[0].item())
+  h = base.cpu()
+  return int(h[0, 0]), float(h[1].view(torch.float32)[0])
+
+
 class AdamConfig(typing.NamedTuple):
   """optax.chain(clip_by_global_norm(max_norm), adam(lr, eps=eps))
   (ref: rainbow/run_atari.py:77-81, 229-235).  max_norm <= 0 disables the clip."""
@@ -118,8 +128,10 @@ class RainbowLearner:
       self._noise_counter += n
     a = self.network.num_actions
     q = torch.empty((b, a), dtype=torch.float32, device=self.device)
-    greedy = torch.empty(b, dtype=torch.int32, device=self.device)
-    vmax = torch.empty(b, dtype=torch.float32, device=self.device)
+    # (greedy action, max q) packed in one 8-byte buffer per row so that the
+    # actor's device->host read is ONE copy (read_action)
+    packed = torch.empty((2, b), dtype=torch.int32, device=self.device)
+    greedy, vmax = packed[0], packed[1].view(torch.float32)
     params = self.online if which == 'online' else self.target
     _lib.check(self._lib.dz_rainbow_apply(
         a, self.network.num_atoms, b, params.data_ptr(), states.data_ptr(),
@@ -127,6 +139,12 @@ class RainbowLearner:
         self._act_ws.data_ptr(), q.data_ptr(), greedy.data_ptr(),
         vmax.data_ptr(), stream), 'dz_rainbow_apply')
     return q, greedy, vmax
+
+  @staticmethod
+  def read_action(greedy: torch.Tensor, vmax: torch.Tensor):
+    """(int action, float value) of row 0 with a single device->host copy;
+    `greedy`/`vmax` are the tensors `apply` returned (views of one buffer)."""
+    return read_packed_action(greedy, vmax)
 
   def get_opt_state(self) -> dict:
     return dict(count=int(self.adam_count.item()),

@@ -20,6 +20,7 @@ from typing import Any, Mapping
 import numpy as np
 import torch
 
+from dqn_zoo_amd import device_obs
 from dqn_zoo_amd import learner as learner_lib
 from dqn_zoo_amd import networks
 from dqn_zoo_amd import parts
@@ -67,8 +68,7 @@ class Rainbow(parts.Agent):
     self._action = None
     self._frame_t = -1
     self._statistics = {'state_value': np.nan}
-    self._obs_device = torch.empty((1, 84, 84, 4), dtype=torch.uint8,
-                                   device=self._device)
+    self._obs = device_obs.ObservationCache(self._device)
 
   # -- acting / stepping -------------------------------------------------------
   def step(self, timestep) -> parts.Action:
@@ -85,7 +85,8 @@ class Rainbow(parts.Agent):
       action = self._action = self._act(timestep)
       for transition in self._transition_accumulator.step(timestep, action):
         # priority = running max priority, kept on the device (agent.py:149)
-        self._replay.add_with_device_priority(transition)
+        # both states are already in HBM (uploaded for acting): no re-upload
+        self._replay.add_with_device_priority(self._obs.on_device(transition))
 
     if self._replay.size < self._min_replay_capacity:
       return action
@@ -107,11 +108,11 @@ class Rainbow(parts.Agent):
   def _act(self, timestep) -> parts.Action:
     """Greedy action w.r.t. a freshly-noised online network
     (ref: rainbow/agent.py:171-179)."""
-    obs = np.ascontiguousarray(timestep.observation, dtype=np.uint8)
-    self._obs_device[0].copy_(torch.from_numpy(obs))
-    _, greedy, vmax = self._learner.apply(self._obs_device)
-    a_t = int(greedy.item())           # the one device->host sync per decision
-    self._statistics['state_value'] = float(vmax.item())
+    obs_d = self._obs.upload(timestep.observation)
+    _, greedy, vmax = self._learner.apply(obs_d)
+    # the one device->host sync per decision: (action, value) in one read
+    a_t, v_t = self._learner.read_action(greedy, vmax)
+    self._statistics['state_value'] = v_t
     return parts.Action(a_t)
 
   def _learn(self) -> None:

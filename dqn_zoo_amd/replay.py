@@ -128,32 +128,87 @@ class _FieldRing:
     self.np_dtypes = None
     self.shapes = None
 
+  STAGE_DEPTH = 8   # in-flight host->device row uploads of insert()
+
   def allocate_like(self, item):
     fields, dts, shapes = [], [], []
     for x in item:
-      a = np.asarray(x)
+      if isinstance(x, torch.Tensor):
+        a = np.zeros(tuple(x.shape), torch.empty(0, dtype=x.dtype).numpy().dtype)
+      else:
+        a = np.asarray(x)
       dts.append(a.dtype)
       shapes.append(a.shape)
       tdt = torch.from_numpy(np.zeros(1, a.dtype)).dtype
       fields.append(torch.empty((self.capacity,) + a.shape, dtype=tdt,
                                 device=self.device))
     self.fields, self.np_dtypes, self.shapes = fields, dts, shapes
+    self._stage = None
 
   def allocate(self, shapes, np_dtypes):
     self.allocate_like([np.zeros(s, d) for s, d in zip(shapes, np_dtypes)])
 
-  def write(self, slot, item):
+  def _staging(self):
+    """Pinned host + device staging rows for array fields given as host arrays
+    (a ring: slot k is reused only after its previous upload completed)."""
+    if getattr(self, '_stage', None) is None:
+      pins, devs = [], []
+      for f, shp in zip(self.fields, self.shapes):
+        if len(shp) == 0:
+          pins.append(None); devs.append(None)
+        else:
+          pins.append(torch.empty((self.STAGE_DEPTH,) + tuple(shp), dtype=f.dtype,
+                                  pin_memory=True))
+          devs.append(torch.empty((self.STAGE_DEPTH,) + tuple(shp), dtype=f.dtype,
+                                  device=self.device))
+      self._stage = (pins, devs, [None] * self.STAGE_DEPTH)
+      self._stage_pos = 0
+      self._insert_arr = (_lib.InsertField * len(self.fields))()
+    return self._stage
+
+  def insert_fields(self, item):
+    """Fills the dz_insert_field_t array for one item: device tensors are used
+    in place, scalars travel as immediates, host arrays go through the pinned
+    staging ring (one async H2D each)."""
     if self.fields is None:
       self.allocate_like(item)
-    for f, x, dt, shp in zip(self.fields, item, self.np_dtypes, self.shapes):
+    pins, devs, events = self._staging()
+    arr = self._insert_arr
+    k = None
+    for i, (f, x, dt, shp) in enumerate(zip(self.fields, item, self.np_dtypes,
+                                            self.shapes)):
+      arr[i].dst = f.data_ptr()
+      arr[i].row_bytes = f[0].numel() * f.element_size()
+      if isinstance(x, torch.Tensor):
+        if (x.device != f.device or x.dtype != f.dtype or
+            tuple(x.shape) != tuple(shp) or not x.is_contiguous()):
+          raise ValueError('device field %d: need a contiguous %s%s tensor on %s'
+                           % (i, f.dtype, tuple(shp), f.device))
+        arr[i].src_row = x.data_ptr()
+        arr[i].imm = 0
+        continue
       a = np.asarray(x, dtype=dt)
       if a.shape != shp:
         raise ValueError('replay item field has shape %s, expected %s' %
                          (a.shape, shp))
       if a.ndim == 0:
-        f[slot] = a.item()
-      else:
-        f[slot].copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        arr[i].src_row = None
+        arr[i].imm = int.from_bytes(a.tobytes(), 'little')
+        continue
+      if k is None:
+        k = self._stage_pos % self.STAGE_DEPTH
+        self._stage_pos += 1
+        if events[k] is not None:
+          events[k].synchronize()
+      pins[i][k].copy_(torch.from_numpy(np.ascontiguousarray(a)))
+      devs[i][k].copy_(pins[i][k], non_blocking=True)
+      arr[i].src_row = devs[i][k].data_ptr()
+      arr[i].imm = 0
+    if k is not None:
+      if events[k] is None:
+        events[k] = torch.cuda.Event()
+      events[k].record(torch.cuda.current_stream(self.device))
+    return arr, len(self.fields)
 
   def read(self, slot):
     return type(self.structure)(*[
@@ -221,8 +276,14 @@ class _ReplayBase(Generic[ReplayStructure]):
   def _stream(self):
     return torch.cuda.current_stream(self._device).cuda_stream
 
-  def _store(self, item):
-    self._ring.write(self._t % self._capacity, item)
+  def _store(self, item, node=None, cap_pow2=0, priority_d=None, exponent=0.0,
+             status=None):
+    """One launch: the item's rows into slot `t mod capacity` and, if `node` is
+    given, its sum-tree leaf from the device priority (dz_replay_insert)."""
+    arr, n = self._ring.insert_fields(item)
+    _lib.check(_lib.load().dz_replay_insert(
+        arr, n, self._t, self._capacity, node, cap_pow2, 0.0, priority_d, exponent,
+        status, self._stream()), 'dz_replay_insert')
     self._t += 1
     self._size = min(self._size + 1, self._capacity)
 
@@ -559,12 +620,8 @@ class PrioritizedTransitionReplay(_ReplayBase):
     """add() whose priority is a device scalar (default: the running max);
     no host sync.  Tree-side equivalent of replay.py:690-699."""
     p = self.max_seen_priority_device if priority_d is None else priority_d
-    t = self._t
-    self._store(item)
-    _lib.check(_lib.load().dz_prioritized_add(
-        self._tree.data_ptr(), self._cap_pow2, self._capacity, t, 1, 0.0,
-        p.data_ptr(), self._priority_exponent, self._status.word.data_ptr(),
-        self._stream()), 'dz_prioritized_add')
+    self._store(item, self._tree.data_ptr(), self._cap_pow2, p.data_ptr(),
+                self._priority_exponent, self._status.word.data_ptr())
 
   def bulk_fill(self, fields, priority: float = 1.0) -> int:
     t0 = self._t

@@ -53,7 +53,8 @@ const char* dz_built_arch(void);
 /* sizeof() of the ABI structs as the library was compiled, so that a binding
  * can verify its mirror: 0 dz_field_t, 1 dz_prio_sample_args_t,
  * 2 dz_rainbow_layout_t, 3 dz_rainbow_args_t, 4 dz_dense_layout_t,
- * 5 dz_dense_args_t, 6 dz_iqn_layout_t, 7 dz_iqn_args_t.  -1 for unknown.    */
+ * 5 dz_dense_args_t, 6 dz_iqn_layout_t, 7 dz_iqn_args_t, 8 dz_insert_field_t.
+ * -1 for an unknown id.                                                      */
 int dz_struct_size(int which);
 
 /* ------------------------------------------------------------------------- *
@@ -75,6 +76,25 @@ typedef struct {
 int dz_replay_gather(const dz_field_t* fields, int num_fields,
                      const int64_t* ids, int batch, int64_t capacity,
                      dz_stream_t stream);
+
+/* One transition into the store, and (node != NULL) its sum-tree leaf, in ONE
+ * launch: field i's row `t mod capacity` is written from `src_row` (a DEVICE
+ * pointer to row_bytes bytes, e.g. the observation the actor just uploaded) or,
+ * when src_row is NULL, from the little-endian bytes of `imm` (row_bytes <= 8:
+ * the action / reward / discount scalars travel as kernel arguments).  The tree
+ * part is dz_prioritized_add for n = 1.  Replaces the per-field writes of
+ * ref: replay.py:141-150 (TransitionReplay.add) and 690-699.                 */
+typedef struct {
+  void* dst;            /* field array base, [capacity][row_bytes]            */
+  const void* src_row;  /* device pointer, or NULL to use imm                 */
+  int64_t row_bytes;
+  uint64_t imm;
+} dz_insert_field_t;
+
+int dz_replay_insert(const dz_insert_field_t* fields, int num_fields, int64_t t,
+                     int64_t capacity, double* node, int64_t cap_pow2,
+                     double priority_h, const double* priority_d, double exponent,
+                     uint32_t* status, dz_stream_t stream);
 
 /* Position -> id map of the reference's swap-remove id list under its only
  * usage pattern (one add at a time, evict oldest): closed form verified against
