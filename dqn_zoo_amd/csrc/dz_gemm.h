@@ -69,6 +69,15 @@ __device__ __forceinline__ float4 dz_load4_masked(const float* __restrict__ p,
   return v;
 }
 
+// Optional per-wave register tiling: an Op may define MI / NI (default 1): every
+// wave then owns MI x NI accumulators (a (32 MI) x (32 NI) output block), i.e.
+// MI*NI independent MFMA chains fed by MI + NI operand fragments -- twice the
+// MFMAs per LDS byte and no back-to-back dependent issue at MI = NI = 2.
+template <class Op, class = void> struct DzMI { static constexpr int v = 1; };
+template <class Op> struct DzMI<Op, decltype((void)Op::MI)> { static constexpr int v = Op::MI; };
+template <class Op, class = void> struct DzNI { static constexpr int v = 1; };
+template <class Op> struct DzNI<Op, decltype((void)Op::NI)> { static constexpr int v = Op::NI; };
+
 template <int ROWS, int CPS, int LAYOUT>
 struct DzLdsTile {
   static constexpr int LD = (LAYOUT == DZ_KC) ? 20 : ROWS;
@@ -94,9 +103,11 @@ struct DzLdsTile {
 template <class Op>
 struct DzGemmSmem {
   static constexpr int CPS = Op::WK * Op::KT;
-  using AT = DzLdsTile<32 * Op::WM, CPS, Op::A_LAYOUT>;
-  using BT = DzLdsTile<32 * Op::WN, CPS, Op::B_LAYOUT>;
-  static constexpr int RED = (Op::WK > 1) ? (Op::WK - 1) * Op::WM * Op::WN * 16 * 64 : 0;
+  static constexpr int MI = DzMI<Op>::v, NI = DzNI<Op>::v;
+  using AT = DzLdsTile<32 * Op::WM * MI, CPS, Op::A_LAYOUT>;
+  using BT = DzLdsTile<32 * Op::WN * NI, CPS, Op::B_LAYOUT>;
+  static constexpr int RED =
+      (Op::WK > 1) ? (Op::WK - 1) * Op::WM * Op::WN * MI * NI * 16 * 64 : 0;
   static constexpr int TILE = AT::ELEMS + BT::ELEMS;
   static constexpr int ELEMS = TILE > RED ? TILE : RED;
 };
@@ -109,7 +120,8 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
   constexpr int WM = Op::WM, WN = Op::WN, WK = Op::WK, KT = Op::KT;
   constexpr int CPS = WK * KT;  // 16-deep chunks per stage
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
-  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int MI = DzMI<Op>::v, NI = DzNI<Op>::v;
+  constexpr int BM = 32 * WM * MI, BN = 32 * WN * NI;
   using AT = DzLdsTile<BM, CPS, Op::A_LAYOUT>;
   using BT = DzLdsTile<BN, CPS, Op::B_LAYOUT>;
   float* As = smem;
@@ -230,9 +242,13 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
     }
   };
 
-  f32x16 acc;
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
   if (t.st_begin < t.st_end) load_stage(t.st_begin);
   for (int st = t.st_begin; st < t.st_end; ++st) {
@@ -244,51 +260,78 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       const int ch = wk * KT + kt;  // this wave's chunk of the stage
-      float fa[8], fb[8];
-      if constexpr (Op::A_LAYOUT == DZ_KC) {
-        const float* src = As + ch * AT::CHUNK + (wm * 32 + l31) * 20 + half * 8;
-        const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
-        fa[0] = v0.x; fa[1] = v0.y; fa[2] = v0.z; fa[3] = v0.w;
-        fa[4] = v1.x; fa[5] = v1.y; fa[6] = v1.z; fa[7] = v1.w;
-      } else {
-        const float* src = As + ch * AT::CHUNK + (half * 8) * BM + wm * 32 + l31;
+      float fa[MI][8], fb[NI][8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) fa[s] = src[s * BM];
+      for (int mi = 0; mi < MI; ++mi) {
+        const int r0 = (wm * MI + mi) * 32 + l31;
+        if constexpr (Op::A_LAYOUT == DZ_KC) {
+          const float* src = As + ch * AT::CHUNK + r0 * 20 + half * 8;
+          const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
+          fa[mi][0] = v0.x; fa[mi][1] = v0.y; fa[mi][2] = v0.z; fa[mi][3] = v0.w;
+          fa[mi][4] = v1.x; fa[mi][5] = v1.y; fa[mi][6] = v1.z; fa[mi][7] = v1.w;
+        } else {
+          const float* src = As + ch * AT::CHUNK + (half * 8) * BM + r0;
+#pragma unroll
+          for (int s = 0; s < 8; ++s) fa[mi][s] = src[s * BM];
+        }
       }
-      if constexpr (Op::B_LAYOUT == DZ_KC) {
-        const float* src = Bs + ch * BT::CHUNK + (wn * 32 + l31) * 20 + half * 8;
-        const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
-        fb[0] = v0.x; fb[1] = v0.y; fb[2] = v0.z; fb[3] = v0.w;
-        fb[4] = v1.x; fb[5] = v1.y; fb[6] = v1.z; fb[7] = v1.w;
-      } else {
-        const float* src = Bs + ch * BT::CHUNK + (half * 8) * BN + wn * 32 + l31;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) fb[s] = src[s * BN];
+      for (int ni = 0; ni < NI; ++ni) {
+        const int c0 = (wn * NI + ni) * 32 + l31;
+        if constexpr (Op::B_LAYOUT == DZ_KC) {
+          const float* src = Bs + ch * BT::CHUNK + c0 * 20 + half * 8;
+          const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
+          fb[ni][0] = v0.x; fb[ni][1] = v0.y; fb[ni][2] = v0.z; fb[ni][3] = v0.w;
+          fb[ni][4] = v1.x; fb[ni][5] = v1.y; fb[ni][6] = v1.z; fb[ni][7] = v1.w;
+        } else {
+          const float* src = Bs + ch * BT::CHUNK + (half * 8) * BN + c0;
+#pragma unroll
+          for (int s = 0; s < 8; ++s) fb[ni][s] = src[s * BN];
+        }
       }
 #pragma unroll
       for (int s = 0; s < 8; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][s], fb[ni][s],
+                                                               acc[mi][ni], 0, 0, 0);
     }
   }
 
   if constexpr (WK > 1) {
     __syncthreads();
     float* red = smem;
+    constexpr int PER = WM * WN * MI * NI;  // accumulator blocks per k-group
     if (wk > 0) {
-      float* dst = red + (((wk - 1) * WM * WN + wm * WN + wn) * 16) * 64 + lane;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) dst[i * 64] = acc[i];
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          float* dst = red + (((wk - 1) * PER + ((wm * WN + wn) * MI + mi) * NI + ni) * 16) * 64 + lane;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dst[i * 64] = acc[mi][ni][i];
+        }
     }
     __syncthreads();
     if (wk > 0) return;
 #pragma unroll
-    for (int k2 = 1; k2 < WK; ++k2) {
-      const float* src = red + (((k2 - 1) * WM * WN + wm * WN + wn) * 16) * 64 + lane;
+    for (int k2 = 1; k2 < WK; ++k2)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] += src[i * 64];
-    }
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const float* src = red + (((k2 - 1) * PER + ((wm * WN + wn) * MI + mi) * NI + ni) * 16) * 64 + lane;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[mi][ni][i] += src[i * 64];
+        }
   }
-  Op::store(p, t, wm, wn, lane, acc);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      Op::store(p, t, wm * MI + mi, wn * NI + ni, lane, acc[mi][ni]);
 }
 
 // C/D fragment coordinates of v_mfma_f32_32x32x2_f32 (cdna_hip_programming.md 3):
@@ -344,6 +387,60 @@ __global__ __launch_bounds__(256) void dz_mfma_gemm3(typename OpA::Params pa, di
   if (blockIdx.x < na) dz_gemm_body<OpA>(pa, dz_unflatten(blockIdx.x, ga), smem);
   else if (blockIdx.x < na + nb) dz_gemm_body<OpB>(pb, dz_unflatten(blockIdx.x - na, gb), smem);
   else dz_gemm_body<OpC>(pc, dz_unflatten(blockIdx.x - na - nb, gc), smem);
+}
+
+// XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin by linear
+// id and every XCD has its own 4 MB L2, so with the natural order (x fastest) the
+// g.x tiles that share an A-operand slab land on 8 different XCDs and the slab is
+// fetched from the fabric 8 times (IQN fc1: 8 x 77 MB per launch).  Here block L
+// runs tile  x = (L/8) % g.x,  (y,z) = ((L/8) / g.x) * 8 + L%8 : all g.x tiles of
+// one (y,z) slab run on ONE XCD, back to back.  The 1-D grid is padded to
+// 8 * g.x * ceil(g.y*g.z / 8) blocks; the surplus blocks exit.
+__device__ __forceinline__ bool dz_xcd_tile(unsigned L, dim3 g, dim3& bid) {
+  const unsigned T = g.y * g.z;
+  const unsigned xcd = L & 7, j = L >> 3;
+  const unsigned m = (j / g.x) * 8 + xcd;
+  if (m >= T) return false;
+  bid = dim3(j % g.x, m % g.y, m / g.y);
+  return true;
+}
+static inline unsigned dz_xcd_blocks(dim3 g) { return 8 * g.x * ((g.y * g.z + 7) / 8); }
+
+template <class Op>
+__global__ __launch_bounds__(256) void dz_mfma_gemm_xcd(typename Op::Params p, dim3 g) {
+  __shared__ __attribute__((aligned(16))) float smem[DzGemmSmem<Op>::ELEMS];
+  dim3 bid;
+  if (!dz_xcd_tile(blockIdx.x, g, bid)) return;
+  dz_gemm_body<Op>(p, bid, smem);
+}
+template <class Op>
+static inline int dz_launch_gemm_xcd(const typename Op::Params& p, dim3 g, hipStream_t s) {
+  hipLaunchKernelGGL(dz_mfma_gemm_xcd<Op>, dim3(dz_xcd_blocks(g)), dim3(256), 0, s, p, g);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+template <class OpA, class OpB>
+__global__ __launch_bounds__(256) void dz_mfma_gemm2_xcd(typename OpA::Params pa, dim3 ga,
+                                                         typename OpB::Params pb, dim3 gb) {
+  constexpr int SM = DzGemmSmem<OpA>::ELEMS > DzGemmSmem<OpB>::ELEMS
+                         ? DzGemmSmem<OpA>::ELEMS : DzGemmSmem<OpB>::ELEMS;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  const unsigned na = 8 * ga.x * ((ga.y * ga.z + 7) / 8);  // multiple of 8: XCD = id % 8 holds for B too
+  dim3 bid;
+  if (blockIdx.x < na) {
+    if (dz_xcd_tile(blockIdx.x, ga, bid)) dz_gemm_body<OpA>(pa, bid, smem);
+  } else {
+    if (dz_xcd_tile(blockIdx.x - na, gb, bid)) dz_gemm_body<OpB>(pb, bid, smem);
+  }
+}
+template <class OpA, class OpB>
+static inline int dz_launch_gemm2_xcd(const typename OpA::Params& pa, dim3 ga,
+                                      const typename OpB::Params& pb, dim3 gb,
+                                      hipStream_t s) {
+  hipLaunchKernelGGL((dz_mfma_gemm2_xcd<OpA, OpB>), dim3(dz_xcd_blocks(ga) + dz_xcd_blocks(gb)),
+                     dim3(256), 0, s, pa, ga, pb, gb);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
 }
 
 // A contraction plus an unrelated small elementwise job in the same launch

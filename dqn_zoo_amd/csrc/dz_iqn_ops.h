@@ -38,11 +38,12 @@ struct IqnLinParams {
   float* temb;        // [rows[0]][N] or null (MIX)
 };
 
-template <int WM_, int WN_, int WK_, int KT_>
+template <int WM_, int WN_, int WK_, int KT_, int MI_ = 1, int NI_ = 1>
 struct IqnLinOp {
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
+  static constexpr int MI = MI_, NI = NI_;
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_RC, A_MAP = DZ_MAP_QUAD;
-  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
+  static constexpr int BM = 32 * WM * MI, BN = 32 * WN * NI, BK = 16 * CPS;
   typedef IqnLinParams Params;
   struct Tile : DzTile { const float* prm; int row0, rows, feat_row0, samples; };
 
@@ -104,11 +105,12 @@ struct IqnWgradParams {
   float* part; // [S][K][ldw]
 };
 
-template <int WM_, int WN_, int WK_, int KT_>
+template <int WM_, int WN_, int WK_, int KT_, int MI_ = 1, int NI_ = 1>
 struct IqnWgradOp {
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
+  static constexpr int MI = MI_, NI = NI_;
   static constexpr int A_LAYOUT = DZ_RC, B_LAYOUT = DZ_RC, A_MAP = DZ_MAP_QUAD;
-  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
+  static constexpr int BM = 32 * WM * MI, BN = 32 * WN * NI, BK = 16 * CPS;
   typedef IqnWgradParams Params;
   typedef DzTile Tile;
 

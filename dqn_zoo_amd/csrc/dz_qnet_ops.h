@@ -296,11 +296,12 @@ struct FcDgradParams {
   int x_off;        // output column offset
 };
 
-template <int WM_, int WN_, int WK_, int KT_ = 1>
+template <int WM_, int WN_, int WK_, int KT_ = 1, int MI_ = 1, int NI_ = 1>
 struct FcDgradOp {
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
+  static constexpr int MI = MI_, NI = NI_;
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_KC, A_MAP = DZ_MAP_QUAD;
-  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
+  static constexpr int BM = 32 * WM * MI, BN = 32 * WN * NI, BK = 16 * CPS;
   typedef FcDgradParams Params;
   typedef DzTile Tile;
 

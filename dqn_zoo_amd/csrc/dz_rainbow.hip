@@ -11,6 +11,8 @@
 // Roofline notes per kernel are in DESIGN.md.
 #include "dz_torso.h"
 
+extern int g_iqn_variant;  // dz_iqn.hip (dz_set_tuning key 13)
+
 namespace {
 
 // Run-time tuning knobs (dz_set_tuning): kernel variant and split factors, used
@@ -559,6 +561,7 @@ extern "C" int dz_set_tuning(int key, int value) {
     case 8: DZ_REQUIRE(value >= 1 && value <= kMaxS_fc2); g_fc2_splits = value; return DZ_OK;
     case 9: case 10: case 11: g_conv_fwd_variant[key - 9] = value; return DZ_OK;
     case 12: g_dgrad_weff = value; return DZ_OK;
+    case 13: g_iqn_variant = value; return DZ_OK;
     default: return DZ_ERR_INVALID_ARG;
   }
 }

@@ -39,6 +39,11 @@ def main():
   w = torch.from_numpy(rs.uniform(0.2, 1, size=B).astype(np.float32)).to(dev)
   rms, adam = ll.RmsPropConfig(), ll.AdamConfig(learning_rate=5e-5, eps=0.01 / 32)
   for name in names:
+    if '=' in name:
+      k, v = name.split('=')
+      lib.dz_set_tuning(int(k), int(v))
+      print('set tuning', k, v)
+      continue
     if name == 'iqn':
       ln = ll.IqnLearner(networks.IqnNetwork(A, 64), adam._replace(max_global_grad_norm=0.0), B)
       step = lambda: ln.step(s_tm1, a, r, d, s_t)
