@@ -6,7 +6,8 @@
 #include "dz_torso.h"
 
 namespace {
-constexpr int kS_dfc1 = 16;  // fc1 forward k-splits (3136 rows / 16 = 196 = 2*NLOAD)
+constexpr int kS_dfc1 = 32;   // fc1 forward k-splits (100 rows each: dz_fc_stream_fwd3<0, 50>)
+constexpr int kS_ddfeat = 16; // fc1 input-gradient k-splits (FcDgradOp<1,2,2,1>, as tuned for Rainbow)
 }
 
 extern "C" int dz_dense_layout(int N, int shared_bias, int B, int G,
@@ -41,7 +42,7 @@ extern "C" int dz_dense_layout(int N, int shared_bias, int B, int G,
   L->ws_out = take(GB * ld2);
   L->ws_dout = take((int64_t)B * ld2);
   L->ws_dh1 = take((int64_t)B * kHid);
-  int64_t dp = (int64_t)kS_dfeat * B * kFlat;
+  int64_t dp = (int64_t)kS_ddfeat * B * kFlat;
   if ((int64_t)kS_dh1 * B * kHid > dp) dp = (int64_t)kS_dh1 * B * kHid;
   L->ws_dfeat_part = take(dp);
   L->ws_dfeat = take((int64_t)B * kFlat);
@@ -75,17 +76,32 @@ static int dense_forward(const dz_dense_layout_t& L, int G, int B, const float* 
   const float* p3[3] = {prm[0], prm[G > 1 ? 1 : 0], prm[G > 2 ? 2 : 0]};
   {  // fc1 (3136 -> 512): weight-streaming kernel when the batch fits one tile
     if (B <= 32) {
-      FcStreamFwd2Params q;
-      q.x = ws + L.ws_feat; q.ldx = kFlat; q.M = B; q.G = G; q.NH = 1; q.S = kS_dfc1;
-      q.noisy = 0;
-      for (int g = 0; g < 3; ++g) { q.params[g] = p3[g]; q.noise[g] = zeros; }
+      // one weight stream per parameter set (online is shared by the double-Q
+      // selector apply), 4 strips x 32 splits x sets workgroups
+      FcStreamFwd3Params q;
+      q.x = ws + L.ws_feat; q.ldx = kFlat; q.M = B; q.noisy = 0; q.G = G;
+      int ns = 0;
+      for (int g = 0; g < G; ++g) {
+        q.noise[g] = zeros;
+        int st = -1;
+        for (int j = 0; j < ns; ++j)
+          if (q.params[j] == p3[g] && q.ng[j] < 2) st = j;
+        if (st < 0) { DZ_REQUIRE(ns < 2); st = ns++; q.params[st] = p3[g]; q.ng[st] = 0; }
+        q.grp[st][q.ng[st]++] = g;
+      }
+      for (int j = 0; j < ns; ++j)
+        if (q.ng[j] == 1) q.grp[j][1] = q.grp[j][0];
+      for (int g = G; g < DZ_MAX_GROUPS; ++g) q.noise[g] = zeros;
+      if (ns == 1) {
+        q.params[1] = q.params[0]; q.ng[1] = q.ng[0];
+        q.grp[1][0] = q.grp[0][0]; q.grp[1][1] = q.grp[0][1];
+      }
       q.head[0] = h1; q.head[1] = h1;
       q.part = ws + L.ws_fc1_part; q.ldo = kHid;
       q.rows_per_split = ((kFlat + kS_dfc1 - 1) / kS_dfc1 + 3) & ~3;
-      q.blocked = 0;
-      DZ_REQUIRE(q.rows_per_split <= DZ_FC2_MAX_ROWS);
-      hipLaunchKernelGGL(dz_fc_stream_fwd2, dim3(kHid / 128, G * kS_dfc1), dim3(256),
-                         (size_t)q.rows_per_split * 32 * sizeof(float), s, q);
+      DZ_REQUIRE(q.rows_per_split <= 100);
+      hipLaunchKernelGGL((dz_fc_stream_fwd3<0, 50>), dim3(kHid / 128, kS_dfc1, ns), dim3(256),
+                         (size_t)q.rows_per_split * (2 * 32 + 2) * sizeof(float), s, q);
       DZ_LAUNCH_CHECK();
     } else {
       FcFwdParams p;
@@ -218,14 +234,14 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       if (rc) return rc;
       DZ_PROF(s, "fc1_wgrad");
       FcDgradParams d;
-      d.dy = ws + L.ws_dh1; d.ldy = kHid; d.M = B; d.NH = 1; d.S = kS_dfeat; d.noisy = 0;
+      d.dy = ws + L.ws_dh1; d.ldy = kHid; d.M = B; d.NH = 1; d.S = kS_ddfeat; d.noisy = 0;
       d.params = a->online; d.noise = zeros; d.head[0] = h1; d.head[1] = h1;
       d.part = ws + L.ws_dfeat_part; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
-      rc = dz_launch_gemm<FcDg>(d, dim3(kFlat / FcDg::BN, (B + 31) / 32, kS_dfeat), s);
+      rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 1>>(d, dim3(kFlat / 64, (B + 31) / 32, kS_ddfeat), s);
       if (rc) return rc;
       DZ_PROF(s, "fc1_dgrad");
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0, s,
-                         ws + L.ws_dfeat_part, kS_dfeat, (long)B * kFlat, ws + L.ws_feat,
+                         ws + L.ws_dfeat_part, kS_ddfeat, (long)B * kFlat, ws + L.ws_feat,
                          ws + L.ws_dfeat);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "dfeat_reduce");
