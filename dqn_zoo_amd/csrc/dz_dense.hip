@@ -7,6 +7,7 @@
 
 namespace {
 constexpr int kS_dfc1 = 32;   // fc1 forward k-splits (100 rows each: dz_fc_stream_fwd3<0, 50>)
+constexpr int kMaxS_ddh1 = 32; // fc2 input-gradient k-splits grow with the head width (QR: 3618 outputs)
 constexpr int kS_ddfeat = 16; // fc1 input-gradient k-splits (FcDgradOp<1,2,2,1>, as tuned for Rainbow)
 }
 
@@ -43,7 +44,7 @@ extern "C" int dz_dense_layout(int N, int shared_bias, int B, int G,
   L->ws_dout = take((int64_t)B * ld2);
   L->ws_dh1 = take((int64_t)B * kHid);
   int64_t dp = (int64_t)kS_ddfeat * B * kFlat;
-  if ((int64_t)kS_dh1 * B * kHid > dp) dp = (int64_t)kS_dh1 * B * kHid;
+  if ((int64_t)kMaxS_ddh1 * B * kHid > dp) dp = (int64_t)kMaxS_ddh1 * B * kHid;
   L->ws_dfeat_part = take(dp);
   L->ws_dfeat = take((int64_t)B * kFlat);
   L->ws_dact2 = take((int64_t)B * 81 * 64);
@@ -152,7 +153,8 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
   if (a->loss == DZ_LOSS_CATEGORICAL)
     DZ_REQUIRE(a->aux && a->num_atoms > 0 && a->num_atoms <= 64 && N == A * a->num_atoms);
   else if (a->loss == DZ_LOSS_QUANTILE)
-    DZ_REQUIRE(a->aux && a->num_atoms > 0 && a->num_atoms <= 256 && N == A * a->num_atoms);
+    DZ_REQUIRE(a->aux && a->num_atoms > 0 && a->num_atoms <= 256 && A <= 256 &&
+               N == A * a->num_atoms);
   else
     DZ_REQUIRE(N == A);
   dz_dense_layout_t L;
@@ -193,7 +195,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
         break;
       }
       case DZ_LOSS_QUANTILE:
-        hipLaunchKernelGGL(quantile_loss_kernel, dim3(B), dim3(256), 0, s, out, ld2, B, A,
+        hipLaunchKernelGGL(quantile_loss_kernel, dim3(B), dim3(1024), 0, s, out, ld2, B, A,
                            a->num_atoms, 1, 1, a->aux, a->a_tm1, a->r_t, a->discount_t,
                            a->huber, dout, a->losses);
         break;
@@ -205,22 +207,24 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
   if (phases & DZ_PHASE_BACKWARD) {
     DZ_REQUIRE(a->grad);
     float* grad = a->grad;
+    int s_dh1 = (N + 127) / 128;  // one split per 128 outputs of reduction depth
+    s_dh1 = s_dh1 < kS_dh1 ? kS_dh1 : (s_dh1 > kMaxS_ddh1 ? kMaxS_ddh1 : s_dh1);
     {  // fc2: weight gradient + input gradient -> dh1 (relu(h1) mask)
       FcWgradParams w;
       w.x = ws + L.ws_h1; w.ldx = kHid; w.dy = ws + L.ws_dout; w.ldy = ld2; w.M = B;
       w.NH = 1; w.noisy = 0; w.noise = zeros; w.head[0] = h2; w.head[1] = h2;
       w.grad = grad;
       FcDgradParams d;
-      d.dy = ws + L.ws_dout; d.ldy = ld2; d.M = B; d.NH = 1; d.S = kS_dh1; d.noisy = 0;
+      d.dy = ws + L.ws_dout; d.ldy = ld2; d.M = B; d.NH = 1; d.S = s_dh1; d.noisy = 0;
       d.params = a->online; d.noise = zeros; d.head[0] = h2; d.head[1] = h2;
       d.part = ws + L.ws_dfeat_part; d.ldo = kHid; d.K = kHid; d.x_off = 0;
       rc = dz_launch_gemm2<FcWg, FcDg>(
           w, dim3((N + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 1), d,
-          dim3(kHid / FcDg::BN, (B + 31) / 32, kS_dh1), s);
+          dim3(kHid / FcDg::BN, (B + 31) / 32, s_dh1), s);
       if (rc) return rc;
       DZ_PROF(s, "fc2_wgrad+dgrad");
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kHid + 63) / 64), dim3(256), 0, s,
-                         ws + L.ws_dfeat_part, kS_dh1, (long)B * kHid, ws + L.ws_h1,
+                         ws + L.ws_dfeat_part, s_dh1, (long)B * kHid, ws + L.ws_h1,
                          ws + L.ws_dh1);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "dh1_reduce");

@@ -548,39 +548,62 @@ __global__ void td_loss_kernel(const float* __restrict__ out, int ld, int B, int
 
 // vmap(rlax.quantile_q_learning), no double-Q (qrdqn/agent.py:98-107).
 // dist layout [N][A] (quantile-major, networks.py:308).  One block per sample,
-// thread i owns quantile theta_i.
-__global__ __launch_bounds__(256) void quantile_loss_kernel(
+// thread i owns quantile theta_i.  The per-action means and the dout row are
+// formed by coalesced sweeps over the contiguous N*A row (a fixed thread->element
+// map and a fixed-order combine: deterministic sums, first-maximum argmax).
+__global__ __launch_bounds__(1024) void quantile_loss_kernel(
     const float* __restrict__ out, int ld, int B, int A, int N, int sel_group,
     int tgt_group, const float* __restrict__ tau, const int64_t* __restrict__ a_tm1,
     const double* __restrict__ r_t, const double* __restrict__ d_t, float kappa,
     float* __restrict__ dout, float* __restrict__ losses) {
+  // 1024 threads: quantile i = t % 256, the N targets split over the 4 quarters
+  // jq = t / 256 (the N x N pair loop is the cost: 40 k pairs per sample at N = 201)
   __shared__ float s_t[256];
+  __shared__ float s_g[256];
+  __shared__ float s_part[256];
+  __shared__ float s_li[4][256];
+  __shared__ float s_gi[4][256];
   __shared__ float s_red[4];
   __shared__ int s_astar;
-  const int b = blockIdx.x, i = threadIdx.x;
+  const int b = blockIdx.x, t = threadIdx.x, i = t & 255, jq = t >> 8;
   const float* ds = out + (long)(sel_group * B + b) * ld;
   const float* dt = out + (long)(tgt_group * B + b) * ld;
   const float* d0 = out + (long)b * ld;
-  if (i < 64) {  // a* = argmax_a mean_n dist_sel[n][a]
+  // a* = argmax_a mean_n dist_sel[n][a]: thread t < GA*A sums elements
+  // t, t + GA*A, ... (all of action t % A), then thread a folds its GA partials.
+  const int GA = 256 / A;         // row groups sweeping in parallel (A <= 256)
+  const int span = GA * A;
+  if (t < 256) {
+    float part = 0.f;
+    if (t < span)
+      for (int e = t; e < N * A; e += span) part += ds[e];
+    s_part[t] = part;
+  }
+  __syncthreads();
+  if (t < A) {
+    float sum = 0.f;
+    for (int g = 0; g < GA; ++g) sum += s_part[g * A + t];
+    s_t[t] = sum / (float)N;
+  }
+  __syncthreads();
+  if (t == 0) {
     float best = -__builtin_inff();
     int arg = 0;
-    for (int a = 0; a < A; ++a) {
-      float sum = 0.f;
-      for (int n = i; n < N; n += 64) sum += ds[n * A + a];
-      sum = wave_sum(sum) / (float)N;
-      if (sum > best) { best = sum; arg = a; }
-    }
-    if (i == 0) s_astar = arg;
+    for (int a = 0; a < A; ++a)
+      if (s_t[a] > best) { best = s_t[a]; arg = a; }
+    s_astar = arg;
   }
   __syncthreads();
   const int a_star = s_astar, a0 = (int)a_tm1[b];
   const float r = (float)r_t[b], g = (float)d_t[b];
-  if (i < N) s_t[i] = r + g * dt[i * A + a_star];
+  if (t < N) s_t[t] = r + g * dt[t * A + a_star];
   __syncthreads();
   float li = 0.f, gi = 0.f;
   if (i < N) {
     const float theta = d0[i * A + a0], ti = tau[i];
-    for (int j = 0; j < N; ++j) {
+    const int per = (N + 3) / 4;
+    const int j1 = min(N, (jq + 1) * per);
+    for (int j = jq * per; j < j1; ++j) {
       const float delta = s_t[j] - theta;
       const float wgt = fabsf(ti - (delta < 0.f ? 1.f : 0.f));
       const float ad = fabsf(delta);
@@ -596,17 +619,24 @@ __global__ __launch_bounds__(256) void quantile_loss_kernel(
       li += wgt * hub;
       gi += wgt * dh;
     }
-    li /= (float)N;           // mean over targets j
-    gi = -gi / (float)N;      // d loss_i / d theta_i
   }
-  // loss = sum_i mean_j; scaled by 1/B for the batch mean
-  float s = wave_sum(li);
-  if ((i & 63) == 0) s_red[i >> 6] = s;
+  s_li[jq][i] = li;
+  s_gi[jq][i] = gi;
   __syncthreads();
-  if (i == 0) losses[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  if (t < 256) {
+    li = ((s_li[0][t] + s_li[1][t]) + (s_li[2][t] + s_li[3][t])) / (float)N;   // mean over targets
+    gi = -((s_gi[0][t] + s_gi[1][t]) + (s_gi[2][t] + s_gi[3][t])) / (float)N;  // d loss_i / d theta_i
+    s_g[t] = gi / (float)B;     // scaled for the batch mean
+    const float s = wave_sum(li);  // loss = sum_i mean_j
+    if ((t & 63) == 0) s_red[t >> 6] = s;
+  }
+  __syncthreads();
+  if (t == 0) losses[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
   float* d = dout + (long)b * ld;
-  if (i < N)
-    for (int a = 0; a < A; ++a) d[i * A + a] = (a == a0) ? gi / (float)B : 0.f;
+  for (int e = t; e < N * A; e += 1024) {
+    const int q = e / A;
+    d[e] = (e - q * A == a0) ? s_g[q] : 0.f;
+  }
 }
 
 // optax.rmsprop(lr, decay, eps, centered=True) + apply_updates
