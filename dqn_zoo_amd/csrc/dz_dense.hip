@@ -81,22 +81,9 @@ static int dense_forward(const dz_dense_layout_t& L, int G, int B, const float* 
       // selector apply), 4 strips x 32 splits x sets workgroups
       FcStreamFwd3Params q;
       q.x = ws + L.ws_feat; q.ldx = kFlat; q.M = B; q.noisy = 0; q.G = G;
-      int ns = 0;
-      for (int g = 0; g < G; ++g) {
-        q.noise[g] = zeros;
-        int st = -1;
-        for (int j = 0; j < ns; ++j)
-          if (q.params[j] == p3[g] && q.ng[j] < 2) st = j;
-        if (st < 0) { DZ_REQUIRE(ns < 2); st = ns++; q.params[st] = p3[g]; q.ng[st] = 0; }
-        q.grp[st][q.ng[st]++] = g;
-      }
-      for (int j = 0; j < ns; ++j)
-        if (q.ng[j] == 1) q.grp[j][1] = q.grp[j][0];
-      for (int g = G; g < DZ_MAX_GROUPS; ++g) q.noise[g] = zeros;
-      if (ns == 1) {
-        q.params[1] = q.params[0]; q.ng[1] = q.ng[0];
-        q.grp[1][0] = q.grp[0][0]; q.grp[1][1] = q.grp[0][1];
-      }
+      const float* zn[3] = {zeros, zeros, zeros};
+      const int ns = dz_fc3_assign_sets(q, G, p3, zn);
+      DZ_REQUIRE(ns > 0);
       q.head[0] = h1; q.head[1] = h1;
       q.part = ws + L.ws_fc1_part; q.ldo = kHid;
       q.rows_per_split = ((kFlat + kS_dfc1 - 1) / kS_dfc1 + 3) & ~3;

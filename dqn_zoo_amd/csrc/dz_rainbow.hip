@@ -16,27 +16,15 @@ extern int g_iqn_variant;  // dz_iqn.hip (dz_set_tuning key 13)
 namespace {
 
 // Run-time tuning knobs (dz_set_tuning): kernel variant and split factors, used
-// by tools/tune.py to sweep configurations in ONE GPU session.
-int g_fc1_variant = 10;  // 10 = shared weight stream (dz_fc_stream_fwd3); 8/9 = per-apply streams
+// by tools/tune.py to sweep configurations in ONE GPU session.  Defaults are the
+// measured best on MI355X at B = 32.
+int g_fc1_variant = 10;       // 10 = shared weight stream (dz_fc_stream_fwd3), 0 = tile GEMM
 int g_fc1_splits = 32;
-int g_fc1_dgrad_stream = 0;  // measured: tile-GEMM 26 us vs streaming 35 us
-int g_fc1_blocked_experiment = 0;
-int g_overlap = 1;           // (unused) weight gradients on an auxiliary stream
-int g_fc1_dgrad_first = 1;
-int g_fc1_dgrad_variant = 2;   // FcDgradOp<1,2,2,KT=1> x 32 splits: 24 us (KT=4 x 8: 34 us)
+int g_fc1_dgrad_first = 1;    // read-only input gradient before the 25 MB weight-gradient write
+int g_fc1_dgrad_variant = 2;  // FcDgradOp<1,2,2,KT=1>
 int g_fc1_dgrad_splits = 16;
-int g_dgrad_weff = 1;         // fc1 input gradient contracts against W_eff (depth N, not 2N): 14.2 vs 17.2 us
-int g_fc2_splits = 8;          // 12 us (4 splits: 19 us)
-hipStream_t g_aux_stream = nullptr;
-hipEvent_t g_ev[5];
-
-int ensure_aux() {
-  if (g_aux_stream) return DZ_OK;
-  DZ_HIP_CHECK(hipStreamCreateWithFlags(&g_aux_stream, hipStreamNonBlocking));
-  for (int i = 0; i < 5; ++i)
-    DZ_HIP_CHECK(hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming));
-  return DZ_OK;
-}
+int g_dgrad_weff = 1;         // fc1 input gradient against W_eff (depth N, not 2N): 14.2 vs 17.2 us
+int g_fc2_splits = 8;         // 12 us (4 splits: 19 us)
 
 }  // namespace
 
@@ -69,65 +57,15 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
     p.part = ws + L.ws_fc1_part; p.ldo = 1024;
     p.S = g_fc1_splits;
     const dim3 gz(1, (B + 31) / 32, G * 2 * g_fc1_splits);
-    switch (g_fc1_variant) {
-      default:
-      case 0: rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4>>(p, dim3(8, gz.y, gz.z), s); break;
-      case 1: rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 2>>(p, dim3(8, gz.y, gz.z), s); break;
-      case 2: rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 1>>(p, dim3(8, gz.y, gz.z), s); break;
-      case 3: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 4>>(p, dim3(4, gz.y, gz.z), s); break;
-      case 4: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 2>>(p, dim3(4, gz.y, gz.z), s); break;
-      case 5: rc = dz_launch_gemm<FcFwdOp<1, 1, 4, 2>>(p, dim3(16, gz.y, gz.z), s); break;
-      case 6: rc = dz_launch_gemm<FcFwdOp<1, 1, 4, 1>>(p, dim3(16, gz.y, gz.z), s); break;
-      case 7: rc = dz_launch_gemm<FcFwdOp<1, 4, 1, 1>>(p, dim3(4, gz.y, gz.z), s); break;
-      case 8: {
-        DZ_REQUIRE(B <= 32);
-        FcStreamFwdParams q;
-        q.x = p.x; q.ldx = p.ldx; q.M = B; q.G = G; q.NH = 2; q.S = g_fc1_splits;
-        q.noisy = 1;
-        for (int g = 0; g < G; ++g) { q.params[g] = prm[g]; q.noise[g] = nz[g]; }
-        q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
-        q.part = p.part; q.ldo = p.ldo;
-        hipLaunchKernelGGL(dz_fc_stream_fwd, dim3(8, G * g_fc1_splits), dim3(256), 0,
-                           s, q);
-        DZ_LAUNCH_CHECK();
-        rc = DZ_OK;
-        break;
-      }
-      case 9: {
-        DZ_REQUIRE(B <= 32);
-        FcStreamFwd2Params q;
-        q.x = p.x; q.ldx = p.ldx; q.M = B; q.G = G; q.NH = 2; q.S = g_fc1_splits;
-        q.noisy = 1;
-        for (int g = 0; g < G; ++g) { q.params[g] = prm[g]; q.noise[g] = nz[g]; }
-        q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
-        q.part = p.part; q.ldo = p.ldo;
-        const int rtotal = 2 * kFlat;
-        q.rows_per_split = ((rtotal + g_fc1_splits - 1) / g_fc1_splits + 3) & ~3;
-        DZ_REQUIRE(q.rows_per_split <= DZ_FC2_MAX_ROWS);
-        q.blocked = g_fc1_blocked_experiment;
-        hipLaunchKernelGGL(dz_fc_stream_fwd2, dim3(8, G * g_fc1_splits), dim3(256),
-                           (size_t)q.rows_per_split * 32 * sizeof(float), s, q);
-        DZ_LAUNCH_CHECK();
-        rc = DZ_OK;
-        break;
-      }
-      case 10: {  // one weight stream per parameter set, W_eff built in registers
-        DZ_REQUIRE(B <= 32);
+    if (g_fc1_variant != 10 || B > 32) {
+      // tile GEMM over the depth-2K form [x | x.eps_in] [Wmu ; Wsig.eps_out]
+      rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4>>(p, dim3(8, gz.y, gz.z), s);
+    } else {
+      {  // one weight stream per parameter set, W_eff built in registers
         FcStreamFwd3Params q;
         q.x = p.x; q.ldx = p.ldx; q.M = B; q.noisy = 1; q.G = G;
-        int ns = 0;
-        for (int g = 0; g < G; ++g) {
-          q.noise[g] = nz[g];
-          int st = -1;
-          for (int j = 0; j < ns; ++j)
-            if (q.params[j] == prm[g] && q.ng[j] < 2) st = j;
-          if (st < 0) { DZ_REQUIRE(ns < 2); st = ns++; q.params[st] = prm[g]; q.ng[st] = 0; }
-          q.grp[st][q.ng[st]++] = g;
-        }
-        for (int j = 0; j < ns; ++j)
-          if (q.ng[j] == 1) q.grp[j][1] = q.grp[j][0];
-        for (int g = G; g < DZ_MAX_GROUPS; ++g) q.noise[g] = nz[0];
-        if (ns == 1) { q.params[1] = q.params[0]; q.ng[1] = q.ng[0]; q.grp[1][0] = q.grp[0][0]; q.grp[1][1] = q.grp[0][1]; }
+        const int ns = dz_fc3_assign_sets(q, G, prm, nz);
+        DZ_REQUIRE(ns > 0);
         q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
         q.part = p.part; q.ldo = p.ldo;
         q.rows_per_split = ((kFlat + g_fc1_splits - 1) / g_fc1_splits + 3) & ~3;
@@ -141,7 +79,6 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
                              lds, s, q);
         DZ_LAUNCH_CHECK();
         rc = DZ_OK;
-        break;
       }
     }
     if (rc) return rc;
@@ -375,37 +312,27 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       // 15 + 23 us back to back, so this pair stays two launches; the
       // read-only input gradient goes first so that it does not queue behind
       // the 25 MB of dirty lines the weight gradient leaves)
-      if (g_fc1_dgrad_first) {
-        d.S = g_fc1_dgrad_splits;
+      d.S = g_fc1_dgrad_splits;
+      auto launch_dgrad = [&]() {
+        const dim3 g64(kFlat / 64, (B + 31) / 32, d.S);
         switch (g_fc1_dgrad_variant) {
-          default:
-          case 0: rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 4>>(d, dim3(kFlat / 64, (B + 31) / 32, d.S), s); break;
-          case 1: rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 2>>(d, dim3(kFlat / 64, (B + 31) / 32, d.S), s); break;
-          case 2: rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 1>>(d, dim3(kFlat / 64, (B + 31) / 32, d.S), s); break;
-          case 3: rc = dz_launch_gemm<FcDgradOp<1, 1, 4, 2>>(d, dim3(kFlat / 32, (B + 31) / 32, d.S), s); break;
-          case 4: rc = dz_launch_gemm<FcDgradOp<1, 1, 4, 1>>(d, dim3(kFlat / 32, (B + 31) / 32, d.S), s); break;
-          case 5: rc = dz_launch_gemm<FcDgradOp<1, 4, 1, 2>>(d, dim3((kFlat + 127) / 128, (B + 31) / 32, d.S), s); break;
+          case 0: return dz_launch_gemm<FcDgradOp<1, 2, 2, 4>>(d, g64, s);
+          case 1: return dz_launch_gemm<FcDgradOp<1, 2, 2, 2>>(d, g64, s);
+          default: return dz_launch_gemm<FcDgradOp<1, 2, 2, 1>>(d, g64, s);
         }
-        if (rc) return rc;
+      };
+      auto launch_wgrad = [&]() {
+        return dz_launch_gemm<FcWg>(w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
+      };
+      if (g_fc1_dgrad_first) {
+        if ((rc = launch_dgrad())) return rc;
         DZ_PROF(s, "fc1_dgrad");
-        rc = dz_launch_gemm<FcWg>(w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
-        if (rc) return rc;
+        if ((rc = launch_wgrad())) return rc;
         DZ_PROF(s, "fc1_wgrad");
       } else {
-        rc = dz_launch_gemm<FcWg>(w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
-        if (rc) return rc;
+        if ((rc = launch_wgrad())) return rc;
         DZ_PROF(s, "fc1_wgrad");
-        d.S = g_fc1_dgrad_splits;
-        switch (g_fc1_dgrad_variant) {
-          default:
-          case 0: rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 4>>(d, dim3(kFlat / 64, (B + 31) / 32, d.S), s); break;
-          case 1: rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 2>>(d, dim3(kFlat / 64, (B + 31) / 32, d.S), s); break;
-          case 2: rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 1>>(d, dim3(kFlat / 64, (B + 31) / 32, d.S), s); break;
-          case 3: rc = dz_launch_gemm<FcDgradOp<1, 1, 4, 2>>(d, dim3(kFlat / 32, (B + 31) / 32, d.S), s); break;
-          case 4: rc = dz_launch_gemm<FcDgradOp<1, 1, 4, 1>>(d, dim3(kFlat / 32, (B + 31) / 32, d.S), s); break;
-          case 5: rc = dz_launch_gemm<FcDgradOp<1, 4, 1, 2>>(d, dim3((kFlat + 127) / 128, (B + 31) / 32, d.S), s); break;
-        }
-        if (rc) return rc;
+        if ((rc = launch_dgrad())) return rc;
         DZ_PROF(s, "fc1_dgrad");
       }
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0,
@@ -492,8 +419,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
 extern "C" int dz_rainbow_graph_capture(const dz_rainbow_args_t* args, int phases,
                                         dz_stream_t stream, void** graph_exec_out) {
   DZ_REQUIRE(args && graph_exec_out && stream && !g_dz_prof_on);
-  int rc = ensure_aux();  // no resource creation inside the capture
-  if (rc) return rc;
+  int rc;
   hipStream_t s = dz_s(stream);
   hipGraph_t graph = nullptr;
   DZ_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -552,9 +478,7 @@ extern "C" int dz_set_tuning(int key, int value) {
   switch (key) {
     case 0: g_fc1_variant = value; return DZ_OK;
     case 1: DZ_REQUIRE(value >= 1 && value <= kMaxSplitFc1); g_fc1_splits = value; return DZ_OK;
-    case 2: g_fc1_dgrad_stream = value; return DZ_OK;
-    case 3: g_fc1_blocked_experiment = value; return DZ_OK;
-    case 4: g_overlap = value; return DZ_OK;
+    case 2: case 3: case 4: return DZ_OK;  // retired experiments
     case 5: g_fc1_dgrad_first = value; return DZ_OK;
     case 6: g_fc1_dgrad_variant = value; return DZ_OK;
     case 7: DZ_REQUIRE(value >= 1 && value <= kMaxS_dfeat); g_fc1_dgrad_splits = value; return DZ_OK;
