@@ -42,7 +42,6 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
   const int ld2 = L.adv2_ld + L.val2_ld;
   const FcHead* fc1h = H.fc1h;
   const FcHead* fc2h = H.fc2h;
-  (void)NA;
   {
     const TorsoBufs T = {L.conv_w, L.conv_b, ws + L.ws_act1, ws + L.ws_act2, ws + L.ws_feat};
     rc = torso_forward(T, G, B, prm, in, s, resample);
@@ -251,7 +250,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       }
     }
     DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "head_loss");
+    DZ_PROF(s, "head_loss");
   }
 
   int n_final = 0;  // fused-norm partials left by this call's backward phase
@@ -411,7 +410,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
                        ws + L.ws_norm_part, nparts, a->adam_count, a->losses,
                        a->weights, B, sc, a->lr, a->b1, a->b2, a->eps, a->max_norm);
     DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "adam");
+    DZ_PROF(s, "adam");
   }
   return DZ_OK;
 }
