@@ -56,7 +56,7 @@ def _rel(a, b):
   return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-@pytest.mark.parametrize('A,B,seed', [(6, 32, 0), (18, 32, 1), (3, 10, 2)])
+@pytest.mark.parametrize('A,B,seed', [(6, 32, 0), (18, 32, 1), (3, 10, 2), (4, 48, 3)])
 def test_forward_loss_backward_vs_oracle(A, B, seed):
   online, target, batch, w, noises = _problem(A, B, seed)
   ln = _learner(A, B, online, target, noises)
