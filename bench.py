@@ -173,6 +173,8 @@ def kernel_work(b, a=NUM_ACTIONS, k=NUM_ATOMS):
   # weight gradient + input gradient of a layer are ONE fused launch
   w['fc1_wgrad'] = (f(3136, 1024, b), 2 * 3136 * 1024 * 4)     # write dW mu,sigma
   w['fc1_dgrad'] = (2 * f(b, 3136, 1024), 2 * 3136 * 1024 * 4)  # read W mu,sigma
+  w['fc1_dgrad+wgrad'] = (w['fc1_wgrad'][0] + f(b, 3136, 1024),
+                          w['fc1_wgrad'][1] + w['fc1_dgrad'][1])  # W_eff: depth N
   w['fc2_wgrad+dgrad'] = (f(512, na + k, b) + 2 * f(b, 1024, (na + k) / 2.0),
                           2 * 2 * 512 * (na + k) * 4)
   w['conv3_wgrad+dgrad'] = (f(576, 64, b * 49) + f(b * 81, 64, 576),

@@ -206,6 +206,9 @@ SIGNATURES = {
     'dz_prioritized_sample': (c_int, [ctypes.POINTER(PrioSampleArgs), c_int,
                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                       c_vp]),
+    'dz_prioritized_sample_host_draws': (c_int, [ctypes.POINTER(PrioSampleArgs), c_int,
+                                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                 c_vp, c_vp, c_vp, c_vp]),
     'dz_prioritized_update': (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp,
                                       c_vp, c_int, c_f64, c_int, c_vp, c_vp,
                                       c_vp]),

@@ -20,7 +20,8 @@ namespace {
 // measured best on MI355X at B = 32.
 int g_fc1_variant = 10;       // 10 = shared weight stream (dz_fc_stream_fwd3), 0 = tile GEMM
 int g_fc1_splits = 32;
-int g_fc1_dgrad_first = 1;    // read-only input gradient before the 25 MB weight-gradient write
+int g_fc1_dgrad_first = 3;    // fc1 backward: 3/2 = weight + input gradient in ONE launch (19 us;
+                              // wgrad / dgrad blocks first), 1/0 = two launches (28 us)
 int g_fc1_dgrad_variant = 2;  // FcDgradOp<1,2,2,KT=1>
 int g_fc1_dgrad_splits = 16;
 int g_dgrad_weff = 1;         // fc1 input gradient against W_eff (depth N, not 2N): 14.2 vs 17.2 us
@@ -307,10 +308,9 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       d.dy = ws + L.ws_dh1; d.ldy = 1024; d.M = B; d.NH = 2; d.S = kS_dfeat; d.noisy = g_dgrad_weff ? 2 : 1;
       d.params = a->online; d.noise = nz[0]; d.head[0] = fc1h[0]; d.head[1] = fc1h[1];
       d.part = ws + L.ws_dfeat_part; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
-      // (measured: fusing these two HBM-heavy contractions is slower, 48 us vs
-      // 15 + 23 us back to back, so this pair stays two launches; the
-      // read-only input gradient goes first so that it does not queue behind
-      // the 25 MB of dirty lines the weight gradient leaves)
+      // One launch for the 25.7 MB weight read and the 25.7 MB gradient write
+      // (19 us vs 14 + 14 back to back; before the loader fixes the fused form
+      // had measured slower, 48 vs 38 us).
       d.S = g_fc1_dgrad_splits;
       auto launch_dgrad = [&]() {
         const dim3 g64(kFlat / 64, (B + 31) / 32, d.S);
@@ -323,7 +323,19 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       auto launch_wgrad = [&]() {
         return dz_launch_gemm<FcWg>(w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
       };
-      if (g_fc1_dgrad_first) {
+      if (g_fc1_dgrad_first == 2) {  // both in ONE launch (dgrad blocks first)
+        rc = dz_launch_gemm2<FcDgradOp<1, 2, 2, 1>, FcWg>(
+            d, dim3(kFlat / 64, (B + 31) / 32, d.S), w,
+            dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
+        if (rc) return rc;
+        DZ_PROF(s, "fc1_dgrad+wgrad");
+      } else if (g_fc1_dgrad_first == 3) {  // wgrad blocks first
+        rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1>>(
+            w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), d,
+            dim3(kFlat / 64, (B + 31) / 32, d.S), s);
+        if (rc) return rc;
+        DZ_PROF(s, "fc1_dgrad+wgrad");
+      } else if (g_fc1_dgrad_first) {
         if ((rc = launch_dgrad())) return rc;
         DZ_PROF(s, "fc1_dgrad");
         if ((rc = launch_wgrad())) return rc;

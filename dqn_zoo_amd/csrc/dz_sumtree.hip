@@ -152,8 +152,19 @@ __device__ __forceinline__ int64_t id_at_position(int64_t j, int64_t N, int64_t 
   return base + dz_mod(j - base, N - 1);
 }
 
+// RNG draws of a small batch passed BY VALUE in the kernel arguments (1.5 KB of
+// the 4 KB kernarg segment): no staging buffer, no H2D copy, no blit kernel in
+// front of the sample (that copy was a 4 us launch of its own per step).
+constexpr int kMaxHostDraws = 64;
+struct HostDraws {
+  int64_t pos[kMaxHostDraws];
+  double u_target[kMaxHostDraws];
+  double u_mix[kMaxHostDraws];
+};
+
+template <int HOST_DRAWS>
 __global__ __launch_bounds__(kMaxBatch) void prioritized_sample_kernel(
-    dz_prio_sample_args_t a, int n, int64_t* __restrict__ ids_out,
+    dz_prio_sample_args_t a, HostDraws hd, int n, int64_t* __restrict__ ids_out,
     int64_t* __restrict__ tree_idx_out, double* __restrict__ probs_out,
     double* __restrict__ weights_out, float* __restrict__ weights32_out,
     uint32_t* status) {
@@ -170,11 +181,14 @@ __global__ __launch_bounds__(kMaxBatch) void prioritized_sample_kernel(
   double w = 0.0;
   if (active) {
     // uniform candidate: replay.py:551-554
-    const int64_t uni_ti = tree_index_of_id(id_at_position(a.pos[i], N, a.t), N);
+    const int64_t pos_i = HOST_DRAWS ? hd.pos[i & (kMaxHostDraws - 1)] : a.pos[i];
+    const double ut_i = HOST_DRAWS ? hd.u_target[i & (kMaxHostDraws - 1)] : a.u_target[i];
+    const double um_i = HOST_DRAWS ? hd.u_mix[i & (kMaxHostDraws - 1)] : a.u_mix[i];
+    const int64_t uni_ti = tree_index_of_id(id_at_position(pos_i, N, a.t), N);
     // prioritized candidate: replay.py:556-560
     int64_t pri_ti = uni_ti;
     if (!zero_root) {
-      const double target = a.u_target[i] * root;
+      const double target = ut_i * root;
       if (!(0.0 <= target && target < root)) {
         raise(status, DZ_ST_BAD_TARGET);
       } else {
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(kMaxBatch) void prioritized_sample_kernel(
       }
     }
     // mix: replay.py:562-567
-    const int64_t ti = (a.u_mix[i] < a.usp) ? uni_ti : pri_ti;
+    const int64_t ti = (um_i < a.usp) ? uni_ti : pri_ti;
     // probabilities: replay.py:569-577 (separate mul, mul, add: no FMA)
     const double leaf = node[cap + ti];
     const double pp = zero_root ? a.uniform_prob : leaf / root;
@@ -424,10 +438,35 @@ extern "C" int dz_prioritized_sample(const dz_prio_sample_args_t* args, int batc
              args->t >= args->size);
   DZ_REQUIRE(args->pos && args->u_target && args->u_mix);
   dz_prof_pair(0, 0, dz_s(stream));
-  hipLaunchKernelGGL(prioritized_sample_kernel, dim3(1),
-                     dim3(round_up_64(batch)), 0, dz_s(stream), *args, batch,
+  hipLaunchKernelGGL(prioritized_sample_kernel<0>, dim3(1),
+                     dim3(round_up_64(batch)), 0, dz_s(stream), *args, HostDraws{}, batch,
                      ids_out, tree_idx_out, probs_out, weights_out,
                      weights32_out, status);
+  DZ_LAUNCH_CHECK();
+  dz_prof_pair(0, 1, dz_s(stream));
+  return DZ_OK;
+}
+
+extern "C" int dz_prioritized_sample_host_draws(
+    const dz_prio_sample_args_t* args, int batch, const int64_t* pos_h,
+    const double* u_target_h, const double* u_mix_h, int64_t* ids_out,
+    int64_t* tree_idx_out, double* probs_out, double* weights_out, float* weights32_out,
+    uint32_t* status, dz_stream_t stream) {
+  DZ_REQUIRE(args && ids_out && batch > 0 && batch <= kMaxHostDraws);
+  DZ_REQUIRE(args->node && dz_is_pow2(args->cap_pow2) && args->capacity > 0 &&
+             args->capacity <= args->cap_pow2);
+  DZ_REQUIRE(args->size > 0 && args->size <= args->capacity &&
+             args->t >= args->size);
+  DZ_REQUIRE(pos_h && u_target_h && u_mix_h);
+  HostDraws hd;
+  for (int i = 0; i < kMaxHostDraws; ++i) {
+    const int j = i < batch ? i : 0;
+    hd.pos[i] = pos_h[j]; hd.u_target[i] = u_target_h[j]; hd.u_mix[i] = u_mix_h[j];
+  }
+  dz_prof_pair(0, 0, dz_s(stream));
+  hipLaunchKernelGGL(prioritized_sample_kernel<1>, dim3(1), dim3(round_up_64(batch)), 0,
+                     dz_s(stream), *args, hd, batch, ids_out, tree_idx_out, probs_out,
+                     weights_out, weights32_out, status);
   DZ_LAUNCH_CHECK();
   dz_prof_pair(0, 1, dz_s(stream));
   return DZ_OK;

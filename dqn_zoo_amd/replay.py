@@ -714,18 +714,21 @@ class PrioritizedTransitionReplay(_ReplayBase):
       raise ValueError('Require 0 <= exponent <= 1.')
     slot = self._ring_slot(size)
     # host RNG draws in the reference's order (replay.py:551-566), written
-    # straight into the slot's pinned staging buffer.
-    if slot.copied is not None:
+    # into the slot's host buffer: for batches <= 64 they travel to the device
+    # inside the kernel arguments, otherwise through one pinned async copy.
+    via_args = size <= 64
+    if not via_args and slot.copied is not None:
       slot.copied.synchronize()  # the previous upload from this slot finished
     rs = self._random_state
     h = slot.host_np
     h[:size] = rs.randint(self._size, size=size)
     h[size:2 * size] = rs.uniform(size=size).view(np.int64)
     h[2 * size:] = rs.uniform(size=size).view(np.int64)
-    slot.draws.copy_(slot.host, non_blocking=True)
-    if slot.copied is None:
-      slot.copied = torch.cuda.Event()
-    slot.copied.record(torch.cuda.current_stream(self._device))
+    if not via_args:
+      slot.draws.copy_(slot.host, non_blocking=True)
+      if slot.copied is None:
+        slot.copied = torch.cuda.Event()
+      slot.copied.record(torch.cuda.current_stream(self._device))
     a = slot.args
     a.size = self._size
     a.t = self._t
@@ -735,10 +738,18 @@ class PrioritizedTransitionReplay(_ReplayBase):
     a.beta = beta
     lib = _lib.load()
     stream = self._stream()
-    _lib.check(lib.dz_prioritized_sample(
-        ctypes.byref(a), size, slot.ids.data_ptr(), None, slot.probs.data_ptr(),
-        slot.w64.data_ptr(), slot.w32.data_ptr(), self._status.word.data_ptr(),
-        stream), 'dz_prioritized_sample')
+    if via_args:
+      hp = slot.host.data_ptr()
+      _lib.check(lib.dz_prioritized_sample_host_draws(
+          ctypes.byref(a), size, hp, hp + 8 * size, hp + 16 * size,
+          slot.ids.data_ptr(), None, slot.probs.data_ptr(), slot.w64.data_ptr(),
+          slot.w32.data_ptr(), self._status.word.data_ptr(), stream),
+                 'dz_prioritized_sample_host_draws')
+    else:
+      _lib.check(lib.dz_prioritized_sample(
+          ctypes.byref(a), size, slot.ids.data_ptr(), None, slot.probs.data_ptr(),
+          slot.w64.data_ptr(), slot.w32.data_ptr(), self._status.word.data_ptr(),
+          stream), 'dz_prioritized_sample')
     _lib.check(lib.dz_replay_gather(slot.fields, len(self._ring.fields),
                                     slot.ids.data_ptr(), size, self._capacity,
                                     stream), 'dz_replay_gather')

@@ -175,6 +175,16 @@ int dz_prioritized_sample(const dz_prio_sample_args_t* args, int batch,
                           float* weights32_out, uint32_t* status,
                           dz_stream_t stream);
 
+/* The same for batch <= 64 with the three RNG draw arrays given as HOST
+ * pointers (args->pos/u_target/u_mix are ignored): the draws travel in the
+ * kernel arguments, so the per-step H2D copy of the draws and its blit launch
+ * disappear.  The arrays are read before the call returns.                   */
+int dz_prioritized_sample_host_draws(
+    const dz_prio_sample_args_t* args, int batch, const int64_t* pos_host,
+    const double* u_target_host, const double* u_mix_host, int64_t* ids_out,
+    int64_t* tree_idx_out, double* probs_out, double* weights_out,
+    float* weights32_out, uint32_t* status, dz_stream_t stream);
+
 /* leaf(id) = power_zero_safe(priority, exponent) for each id, then SumTree.set.
  * `prio_is_f32`: priorities are float32 and -- as NumPy does for an f32 array
  * raised to a Python-float exponent -- the power is evaluated in float32.

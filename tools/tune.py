@@ -44,13 +44,13 @@ def main():
   lib = _lib.load()
   names = {0: '<1,2,2,KT4>', 1: '<1,2,2,KT2>', 2: '<1,2,2,KT1>', 3: '<1,4,1,KT4>',
            4: '<1,4,1,KT2>', 5: '<1,1,4,KT2>', 6: '<1,1,4,KT1>', 7: '<1,4,1,KT1>'}
-  for weff in (0, 1):
-    lib.dz_set_tuning(12, weff)
-    for var, spl in ((2, 32), (1, 16), (2, 16), (0, 8), (1, 32)):
-      lib.dz_set_tuning(6, var); lib.dz_set_tuning(7, spl)
-      t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
-      print('weff %d fc1 dgrad var %d S=%2d: fc1_dgrad %.2f dfeat_reduce %.2f fc2 %.2f' % (
-          weff, var, spl, t['fc1_dgrad'], t['dfeat_reduce'], t['fc2_wgrad+dgrad']), flush=True)
+  for mode in (1, 2, 3):
+    lib.dz_set_tuning(5, mode)
+    t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
+    print('fc1 bwd mode %d: %s total %.1f' % (
+        mode, {k: round(v, 2) for k, v in t.items() if k.startswith('fc1_') and 'fwd' not in k and 'epi' not in k},
+        sum(t.values())), flush=True)
+  lib.dz_set_tuning(5, 1)
 
 
 if __name__ == '__main__':
