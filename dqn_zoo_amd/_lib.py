@@ -82,6 +82,9 @@ class RainbowArgs(ctypes.Structure):
       ('priorities', c_vp), ('lr', c_f32), ('b1', c_f32), ('b2', c_f32),
       ('eps', c_f32), ('max_norm', c_f32), ('resample_noise', c_i32),
       ('noise_seed', ctypes.c_uint64),
+      ('prio_node', c_vp), ('prio_cap_pow2', c_i64), ('prio_capacity', c_i64),
+      ('prio_ids', c_vp), ('prio_exponent', c_f64), ('prio_max_seen', c_vp),
+      ('prio_status', c_vp),
   ]
 
 

@@ -9,6 +9,7 @@
 //             wgrad/dgrad, conv1 wgrad, bias column sums
 //   update  : sum of squares -> global norm/clip scale -> Adam
 // Roofline notes per kernel are in DESIGN.md.
+#include "dz_sumtree_dev.h"
 #include "dz_torso.h"
 
 extern int g_iqn_variant;  // dz_iqn.hip (dz_set_tuning key 13)
@@ -379,9 +380,22 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     {  // conv1 weight+bias gradient partials straight from the uint8 states
       ConvWgradParams p;
       p.in = a->s_tm1; p.dy = ws + L.ws_dact1; p.part = part1; p.B = B; p.S = kS_cw1;
-      rc = dz_launch_gemm<Conv1Wg>(p, dim3(32 / Conv1Wg::BN, Conv1Wg::MT, kS_cw1), s);
+      const dim3 g1(32 / Conv1Wg::BN, Conv1Wg::MT, kS_cw1);
+      if (a->prio_node) {
+        // the sum-tree priority write-back rides in this launch as one extra block:
+        // it only needs the loss kernel's priorities and nothing here reads the tree
+        DZ_REQUIRE(a->prio_ids && a->prio_status && dz_is_pow2(a->prio_cap_pow2) &&
+                   a->prio_capacity > 0 && a->prio_capacity <= a->prio_cap_pow2 &&
+                   a->prio_exponent >= 0.0 && B <= 256);
+        const PrioUpdateParams q = {a->prio_node, a->prio_cap_pow2, a->prio_capacity, 0, 0,
+                                    a->prio_ids, a->priorities, 1, a->prio_exponent, B,
+                                    a->prio_max_seen, a->prio_status, 0};
+        rc = dz_launch_gemm_side<Conv1Wg, PrioUpdateSide>(p, g1, q, 1, s);
+      } else {
+        rc = dz_launch_gemm<Conv1Wg>(p, g1, s);
+      }
       if (rc) return rc;
-      DZ_PROF(s, "conv1_wgrad");
+      DZ_PROF(s, a->prio_node ? "conv1_wgrad+prio" : "conv1_wgrad");
     }
     {  // reduce the three conv partial slabs; linear-layer bias gradients
       FinalizeJobs J;

@@ -10,43 +10,9 @@
 // 32 touches 32*20*2*8 B = 10 KiB when sampling and 15 KiB when updating
 // (SURVEY.md 8d).  All batch-sized kernels run as ONE workgroup so that the
 // level-by-level recompute can use workgroup barriers.
-#include "dz_common.h"
+#include "dz_sumtree_dev.h"
 
 namespace {
-
-constexpr int kMaxBatch = 1024;
-
-__device__ __forceinline__ bool finite_nonneg(double v) {
-  return (v >= 0.0) && (v < __builtin_inf());  // false for NaN, -x, +inf
-}
-
-__device__ __forceinline__ void raise(uint32_t* status, uint32_t bit) {
-  if (status) atomicOr(status, bit);
-}
-
-// Shared body of SumTree.set for one workgroup.  `leaf[i]` are tree indices in
-// [0, cap), `val[i]` the new leaf values; n <= blockDim.x.
-// ref: replay.py:283-290.  After all leaves are assigned (last duplicate wins),
-// the sequential per-index root walks of the reference leave every touched node
-// equal to fl(left+right) of its final children; recomputing the touched nodes
-// level by level gives the identical final array.
-__device__ void set_leaves_and_ancestors(double* node, int64_t cap, int64_t my_leaf,
-                                         double my_val, bool active,
-                                         const int64_t* s_leaf, int n) {
-  const int i = threadIdx.x;
-  if (active) {
-    bool last = true;
-    for (int j = i + 1; j < n; ++j) last &= (s_leaf[j] != my_leaf);
-    if (last) node[cap + my_leaf] = my_val;
-  }
-  __syncthreads();
-  int64_t p = (cap + my_leaf) >> 1;
-  for (int64_t level = cap >> 1; level >= 1; level >>= 1) {
-    if (active) node[p] = node[2 * p] + node[2 * p + 1];
-    p >>= 1;
-    __syncthreads();
-  }
-}
 
 __global__ __launch_bounds__(kMaxBatch) void sumtree_set_kernel(
     double* node, int64_t cap, int64_t size, const int64_t* __restrict__ idx,
@@ -130,12 +96,6 @@ __global__ void sumtree_query_kernel(const double* __restrict__ node, int64_t ca
   out[i] = descend(node, cap, t);
 }
 
-// id -> tree index and back for the fixed-capacity distribution
-// (ref: replay.py:457,499,533: the free stack is popped from its END, and an
-// evicted index is pushed and popped straight back).
-__device__ __forceinline__ int64_t tree_index_of_id(int64_t id, int64_t N) {
-  return N - 1 - dz_mod(id, N);
-}
 // The live id whose slot is N-1-ti; live ids are [t-size, t).
 __device__ __forceinline__ int64_t id_of_tree_index(int64_t ti, int64_t N,
                                                     int64_t t, int64_t size) {
@@ -242,73 +202,10 @@ __global__ __launch_bounds__(kMaxBatch) void prioritized_sample_kernel(
   }
 }
 
-// power_zero_safe in the dtype NumPy would use (replay.py:203-208).
-__device__ __forceinline__ double leaf_from_priority_f64(double p, double e) {
-  if (p == 0.0) return 0.0;
-  if (e == 0.5) return sqrt(p);
-  if (e == 1.0) return p;
-  if (e == 2.0) return p * p;
-  if (e == 0.0) return 1.0;
-  return pow(p, e);
-}
-__device__ __forceinline__ double leaf_from_priority_f32(float p, double e) {
-  if (p == 0.0f) return 0.0;
-  if (e == 0.5) return (double)sqrtf(p);
-  if (e == 1.0) return (double)p;
-  if (e == 2.0) return (double)(p * p);
-  if (e == 0.0) return 1.0;
-  return (double)powf(p, (float)e);
-}
-
-__global__ __launch_bounds__(kMaxBatch) void prioritized_update_kernel(
-    double* node, int64_t cap, int64_t N, int64_t size, int64_t t,
-    const int64_t* __restrict__ ids, const void* __restrict__ prio, int is_f32,
-    double exponent, int n, double* max_seen, uint32_t* status) {
+__global__ __launch_bounds__(kMaxBatch) void prioritized_update_kernel(PrioUpdateParams p) {
   __shared__ int64_t s_leaf[kMaxBatch];
   __shared__ double s_red[kMaxBatch / 64];
-  const int i = threadIdx.x;
-  const bool active = i < n;
-  int64_t leaf = 0;
-  double v = 0.0, p64 = 0.0;
-  bool bad_id = false;
-  if (active) {
-    const int64_t id = ids[i];
-    bad_id = (id < t - size) || (id >= t);  // replay.py:541-543
-    leaf = tree_index_of_id(id, N);
-    if (is_f32) {
-      const float p = ((const float*)prio)[i];
-      p64 = (double)p;
-      v = leaf_from_priority_f32(p, exponent);
-    } else {
-      p64 = ((const double*)prio)[i];
-      v = leaf_from_priority_f64(p64, exponent);
-    }
-    s_leaf[i] = leaf;
-  }
-  const bool bad_v = active && !finite_nonneg(v);
-  const int any_bad_i = __syncthreads_or(bad_id);
-  const int any_bad_v = __syncthreads_or(bad_v);
-  if (any_bad_i || any_bad_v) {
-    if (i == 0) raise(status, (any_bad_v ? DZ_ST_BAD_VALUE : 0u) |
-                                  (any_bad_i ? DZ_ST_BAD_INDEX : 0u));
-    return;
-  }
-  if (max_seen) {  // rainbow/agent.py:196-197
-    double m = active ? p64 : -__builtin_inf();
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double o = __shfl_xor(m, off);
-      m = o > m ? o : m;
-    }
-    if ((i & 63) == 0) s_red[i >> 6] = m;
-    __syncthreads();
-    if (i == 0) {
-      double mm = *max_seen;
-      for (int k = 0; k < (int)((blockDim.x + 63) / 64); ++k)
-        mm = s_red[k] > mm ? s_red[k] : mm;
-      *max_seen = mm;
-    }
-  }
-  set_leaves_and_ancestors(node, cap, leaf, v, active, s_leaf, n);
+  prio_update_body(p, s_leaf, s_red);
 }
 
 __global__ __launch_bounds__(kMaxBatch) void prioritized_add_kernel(
@@ -484,9 +381,10 @@ extern "C" int dz_prioritized_update(double* node, int64_t cap_pow2,
   DZ_REQUIRE(n >= 0 && n <= kMaxBatch && exponent >= 0.0);
   if (n == 0) return DZ_OK;
   dz_prof_pair(2, 0, dz_s(stream));
+  const PrioUpdateParams q = {node, cap_pow2, capacity, size, t, ids, priorities, prio_is_f32,
+                              exponent, n, max_seen, status, 1};
   hipLaunchKernelGGL(prioritized_update_kernel, dim3(1), dim3(round_up_64(n)), 0,
-                     dz_s(stream), node, cap_pow2, capacity, size, t, ids,
-                     priorities, prio_is_f32, exponent, n, max_seen, status);
+                     dz_s(stream), q);
   DZ_LAUNCH_CHECK();
   dz_prof_pair(2, 1, dz_s(stream));
   return DZ_OK;

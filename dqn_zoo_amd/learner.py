@@ -170,11 +170,17 @@ class RainbowLearner:
 
   # -- the step -----------------------------------------------------------------
   def step(self, s_tm1, a_tm1, r_t, discount_t, s_t, weights,
-           phases: int = _lib.PHASE_ALL, resample_noise: bool = True) -> None:
+           phases: int = _lib.PHASE_ALL, resample_noise: bool = True,
+           priority_sink=None) -> None:
     """Enqueues one learner step.  Inputs are device tensors exactly as
     `PrioritizedTransitionReplay.sample_device` returns them: uint8 states
     [B,84,84,4], int64 actions, float64 rewards/discounts, float32 weights.
-    Results: `self.losses`, `self.priorities` (device), updated parameters."""
+    Results: `self.losses`, `self.priorities` (device), updated parameters.
+
+    `priority_sink` (from `PrioritizedTransitionReplay.priority_sink(ids)`):
+    the step writes the new priorities into that replay's sum tree itself,
+    inside its backward launches -- the caller then must NOT call
+    `update_priorities` for this batch.  Needs PHASE_BACKWARD in `phases`."""
     b = self.batch_size
     assert s_tm1.dtype == torch.uint8 and s_t.dtype == torch.uint8
     assert s_tm1.is_contiguous() and s_t.is_contiguous()
@@ -213,6 +219,14 @@ class RainbowLearner:
     # fresh noise for the 3 applies is generated by the step itself from
     # (seed, Adam step count): no per-step host argument, graph-replayable.
     a.resample_noise = int(bool(resample_noise) and bool(phases & _lib.PHASE_FORWARD))
+    if priority_sink is not None:
+      if not phases & _lib.PHASE_BACKWARD:
+        raise ValueError('priority_sink needs the backward phase in this call')
+      (a.prio_node, a.prio_cap_pow2, a.prio_capacity, a.prio_ids, a.prio_exponent,
+       a.prio_max_seen, a.prio_status) = priority_sink
+    else:
+      a.prio_node = None
+      a.prio_ids = None
     stream = torch.cuda.current_stream(self.device).cuda_stream
     if self.use_graphs:
       if not stream:
@@ -220,7 +234,7 @@ class RainbowLearner:
             'hipGraph capture needs a non-default stream: run the learner under '
             '`torch.cuda.stream(torch.cuda.Stream())` (bench.py does)')
       key = (a.s_tm1, a.s_t, a.a_tm1, a.r_t, a.discount_t, a.weights, phases,
-             a.resample_noise)
+             a.resample_noise, a.prio_node, a.prio_ids)
       g = self._graphs.get(key)
       if g is None:
         h = ctypes.c_void_p()

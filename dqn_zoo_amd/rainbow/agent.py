@@ -120,10 +120,11 @@ class Rainbow(parts.Agent):
     (ref: rainbow/agent.py:181-198)."""
     s = self._replay.sample_device(self._batch_size)
     t = s.transitions
-    self._learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32)
-    # priorities = clip(|losses|, 0, 100) were written by the loss kernel; the
-    # update kernel also folds their max into the running max priority.
-    self._replay.update_priorities(s.ids, self._learner.priorities)
+    # priorities = clip(|losses|, 0, 100) are written by the loss kernel and go
+    # straight into the sum tree (and the running max priority) inside the
+    # step's backward launches: no separate update_priorities kernel.
+    self._learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
+                       priority_sink=self._replay.priority_sink(s.ids))
 
   # -- properties ----------------------------------------------------------------
   @property

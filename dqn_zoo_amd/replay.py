@@ -865,6 +865,19 @@ class PrioritizedTransitionReplay(_ReplayBase):
     leaf = np.broadcast_to(np.asarray(leaf, dtype=np.float64), ids.shape)
     self._tree_set_host(tree_index_of_id(ids, self._capacity), leaf)
 
+  def priority_sink(self, ids: torch.Tensor):
+    """Descriptor that lets a learner step perform `update_priorities(ids, <its
+    float32 priorities>)` inside its own launches (RainbowLearner.step
+    `priority_sink=`): (tree, cap_pow2, capacity, ids, exponent, running-max
+    scalar, status word).  `ids` must be the device ids of the batch just
+    sampled from THIS replay; they are not re-validated."""
+    if not (isinstance(ids, torch.Tensor) and ids.dtype == torch.int64 and
+            ids.device == self._tree.device):
+      raise ValueError('priority_sink needs the int64 device ids of sample_device()')
+    return (self._tree.data_ptr(), self._cap_pow2, self._capacity, ids.data_ptr(),
+            float(self._priority_exponent), self.max_seen_priority_device.data_ptr(),
+            self._status.word.data_ptr())
+
   def check_status(self) -> None:
     """Synchronises and raises if any pipelined kernel flagged an error."""
     self._status.check()

@@ -286,6 +286,19 @@ typedef struct {
    * per-step host argument, so that the step can be replayed from a hipGraph  */
   int32_t resample_noise;
   uint64_t noise_seed;
+  /* Optional priority write-back inside the backward launch (prio_node != NULL
+   * and the call includes DZ_PHASE_BACKWARD): the step then performs
+   * dz_prioritized_update(prio_node, ..., prio_ids, priorities [float32],
+   * prio_exponent, batch, prio_max_seen, prio_status) itself, as one extra block
+   * of a weight-gradient launch, instead of a separate single-workgroup kernel
+   * after the step (ref: rainbow/agent.py:194-198).  The ids must be the ones the
+   * batch was sampled with (they are not re-validated against the live range).  */
+  double* prio_node;
+  int64_t prio_cap_pow2, prio_capacity;
+  const int64_t* prio_ids;
+  double prio_exponent;
+  double* prio_max_seen;
+  uint32_t* prio_status;
 } dz_rainbow_args_t;
 
 #define DZ_PHASE_FORWARD 1   /* 3 applies + loss (+ dlogits)                  */
