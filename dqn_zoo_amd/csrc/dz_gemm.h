@@ -464,6 +464,31 @@ static inline int dz_launch_gemm_side(const typename Op::Params& p, dim3 g,
   return DZ_OK;
 }
 
+// Two contractions plus a side job (see dz_mfma_gemm_side).
+template <class OpA, class OpB, class Side>
+__global__ __launch_bounds__(256) void dz_mfma_gemm2_side(typename OpA::Params pa, dim3 ga,
+                                                          typename OpB::Params pb, dim3 gb,
+                                                          typename Side::Params sp) {
+  constexpr int SM = DzGemmSmem<OpA>::ELEMS > DzGemmSmem<OpB>::ELEMS
+                         ? DzGemmSmem<OpA>::ELEMS : DzGemmSmem<OpB>::ELEMS;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  const unsigned na = ga.x * ga.y * ga.z, nb = gb.x * gb.y * gb.z;
+  if (blockIdx.x < na) dz_gemm_body<OpA>(pa, dz_unflatten(blockIdx.x, ga), smem);
+  else if (blockIdx.x < na + nb) dz_gemm_body<OpB>(pb, dz_unflatten(blockIdx.x - na, gb), smem);
+  else Side::run(sp, blockIdx.x - na - nb);
+}
+template <class OpA, class OpB, class Side>
+static inline int dz_launch_gemm2_side(const typename OpA::Params& pa, dim3 ga,
+                                       const typename OpB::Params& pb, dim3 gb,
+                                       const typename Side::Params& sp, unsigned side_blocks,
+                                       hipStream_t s) {
+  hipLaunchKernelGGL((dz_mfma_gemm2_side<OpA, OpB, Side>),
+                     dim3(dz_count(ga) + dz_count(gb) + side_blocks), dim3(256), 0, s, pa, ga,
+                     pb, gb, sp);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
 template <class OpA, class OpB>
 static inline int dz_launch_gemm2(const typename OpA::Params& pa, dim3 ga,
                                   const typename OpB::Params& pb, dim3 gb, hipStream_t s) {

@@ -270,6 +270,17 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     const int fc2_slots = ((NA + FcWg::BN - 1) / FcWg::BN) * (kHid / FcWg::BM) * 2 * 4;
     const int fc1_slots = (512 / FcWg::BN) * (kFlat / FcWg::BM) * 2 * 4;
     DZ_REQUIRE(fc2_slots + fc1_slots <= kNormSlots);
+    // optional priority write-back (dz_rainbow_args_t::prio_*), carried by the conv3
+    // backward launch
+    bool prio_pending = a->prio_node != nullptr;
+    PrioUpdateParams prio_q = {};
+    if (prio_pending) {
+      DZ_REQUIRE(a->prio_ids && a->prio_status && dz_is_pow2(a->prio_cap_pow2) &&
+                 a->prio_capacity > 0 && a->prio_capacity <= a->prio_cap_pow2 &&
+                 a->prio_exponent >= 0.0 && B <= 256);
+      prio_q = {a->prio_node, a->prio_cap_pow2, a->prio_capacity, 0, 0, a->prio_ids,
+                a->priorities, 1, a->prio_exponent, B, a->prio_max_seen, a->prio_status, 0};
+    }
     float* part1 = ws + L.ws_wgrad_part;
     float* part2 = part1 + (long)kS_cw1 * Conv1Wg::KROWS * 32;
     float* part3 = part2 + (long)kS_cw2 * Conv2Wg::KROWS * 64;
@@ -331,9 +342,8 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         if (rc) return rc;
         DZ_PROF(s, "fc1_dgrad+wgrad");
       } else if (g_fc1_dgrad_first == 3) {  // wgrad blocks first
-        rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1>>(
-            w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), d,
-            dim3(kFlat / 64, (B + 31) / 32, d.S), s);
+        const dim3 gw(512 / FcWg::BN, kFlat / FcWg::BM, 2), gd(kFlat / 64, (B + 31) / 32, d.S);
+        rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1>>(w, gw, d, gd, s);
         if (rc) return rc;
         DZ_PROF(s, "fc1_dgrad+wgrad");
       } else if (g_fc1_dgrad_first) {
@@ -359,9 +369,18 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       ConvDgradParams d;
       d.dy = ws + L.ws_dfeat; d.w = a->online + L.conv_w[2]; d.act = ws + L.ws_act2;
       d.dx = ws + L.ws_dact2; d.B = B;
-      rc = dz_launch_gemm2<Conv3Wg, Conv3Dg>(
-          w, dim3(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), d,
-          dim3(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1), s);
+      const dim3 gw(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), gd(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1);
+      if (prio_pending) {
+        // The sum-tree priority write-back rides in this launch as one extra block:
+        // it needs only the loss kernel's priorities and nothing here reads the tree.
+        // (Measured hosts: this launch hides it completely; inside the HBM-heavy fc1
+        // launch its dependent loads stretch to 18 us, inside conv1's 8.5 us launch
+        // it sticks out by 4 us.)
+        rc = dz_launch_gemm2_side<Conv3Wg, Conv3Dg, PrioUpdateSide>(w, gw, d, gd, prio_q, 1, s);
+        prio_pending = false;
+      } else {
+        rc = dz_launch_gemm2<Conv3Wg, Conv3Dg>(w, gw, d, gd, s);
+      }
       if (rc) return rc;
       DZ_PROF(s, "conv3_wgrad+dgrad");
     }
@@ -380,22 +399,9 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     {  // conv1 weight+bias gradient partials straight from the uint8 states
       ConvWgradParams p;
       p.in = a->s_tm1; p.dy = ws + L.ws_dact1; p.part = part1; p.B = B; p.S = kS_cw1;
-      const dim3 g1(32 / Conv1Wg::BN, Conv1Wg::MT, kS_cw1);
-      if (a->prio_node) {
-        // the sum-tree priority write-back rides in this launch as one extra block:
-        // it only needs the loss kernel's priorities and nothing here reads the tree
-        DZ_REQUIRE(a->prio_ids && a->prio_status && dz_is_pow2(a->prio_cap_pow2) &&
-                   a->prio_capacity > 0 && a->prio_capacity <= a->prio_cap_pow2 &&
-                   a->prio_exponent >= 0.0 && B <= 256);
-        const PrioUpdateParams q = {a->prio_node, a->prio_cap_pow2, a->prio_capacity, 0, 0,
-                                    a->prio_ids, a->priorities, 1, a->prio_exponent, B,
-                                    a->prio_max_seen, a->prio_status, 0};
-        rc = dz_launch_gemm_side<Conv1Wg, PrioUpdateSide>(p, g1, q, 1, s);
-      } else {
-        rc = dz_launch_gemm<Conv1Wg>(p, g1, s);
-      }
+      rc = dz_launch_gemm<Conv1Wg>(p, dim3(32 / Conv1Wg::BN, Conv1Wg::MT, kS_cw1), s);
       if (rc) return rc;
-      DZ_PROF(s, a->prio_node ? "conv1_wgrad+prio" : "conv1_wgrad");
+      DZ_PROF(s, "conv1_wgrad");
     }
     {  // reduce the three conv partial slabs; linear-layer bias gradients
       FinalizeJobs J;
@@ -417,6 +423,11 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       hipLaunchKernelGGL(finalize_grads_kernel, dim3((unsigned)n_final), dim3(256), 0, s, J);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "finalize_grads");
+    }
+    if (prio_pending) {  // no fused launch took it (non-default fc1 backward mode)
+      hipLaunchKernelGGL(prio_update_side_kernel, dim3(1), dim3(256), 0, s, prio_q);
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "prio_update");
     }
   }
 

@@ -139,4 +139,8 @@ struct PrioUpdateSide {
   }
 };
 
+__global__ __launch_bounds__(256) void prio_update_side_kernel(PrioUpdateParams q) {
+  PrioUpdateSide::run(q, 0);
+}
+
 }  // namespace
