@@ -239,6 +239,15 @@ __global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_head_loss_kernel(
   __shared__ float s_p[64];
   __shared__ float s_z[64];
   const int b = blockIdx.x, k = threadIdx.x;
+  // every per-sample scalar and the support are requested NOW, so that their
+  // trips to memory overlap the slab loads below instead of following them
+  const int kk = min(k, K - 1);
+  const float z_ld = support[kk];
+  const float zn_ld = support[min(kk + 1, K - 1)], zp_ld = support[max(kk - 1, 0)];
+  const float vmin = support[0], vmax = support[K - 1];
+  const float r = (float)r_t[b], g = (float)d_t[b];  // f64 -> f32 at the jit boundary
+  const int a0 = (int)a_tm1[b];
+  const float w_b = weights[b];
   if (PRE) {
     // All loads of a round are issued before any is consumed (the slabs were
     // written by the previous kernel: every load is a ~2 us trip past L2, so the
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_head_loss_kernel(
   }
   const bool on = k < K;
   const int NA = val_off;  // value-head columns start at the padded offset
-  const float z = on ? support[k] : 0.f;
+  const float z = on ? z_ld : 0.f;
   const float invA = 1.0f / (float)A;
 
   // logits of action a: dueling  v + adv_a - mean_a adv  (networks.py:254) or the
@@ -320,8 +329,6 @@ __global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_head_loss_kernel(
   const float e2 = on ? expf(lg2 - mx2) : 0.f;
   const float p_t = e2 / wave_sum(e2);
   // ---- Cramer projection of (r + g z, p_t) onto the support ----
-  const float r = (float)r_t[b], g = (float)d_t[b];  // f64 -> f32 at the jit boundary
-  const float vmin = support[0], vmax = support[K - 1];
   float zp = r + g * z;
   zp = fminf(fmaxf(zp, vmin), vmax);
   s_p[k] = on ? p_t : 0.f;
@@ -330,8 +337,8 @@ __global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_head_loss_kernel(
   float m = 0.f;
   if (on) {
     const float zq = z;
-    const float dpos = (k + 1 < K ? support[k + 1] : support[0]) - zq;
-    const float dneg = zq - (k > 0 ? support[k - 1] : support[K - 1]);
+    const float dpos = (k + 1 < K ? zn_ld : vmin) - zq;
+    const float dneg = zq - (k > 0 ? zp_ld : vmax);
     const float rpos = dpos > 0.f ? 1.0f / dpos : 0.f;
     const float rneg = dneg > 0.f ? 1.0f / dneg : 0.f;
     for (int j = 0; j < K; ++j) {
@@ -343,7 +350,6 @@ __global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_head_loss_kernel(
   }
   if (target_out && on) target_out[b * K + k] = m;
   // ---- group 0: cross-entropy with log_softmax(logits_tm1[a_tm1]) ----
-  const int a0 = (int)a_tm1[b];
   const float* o0 = PRE ? s_rows : fc2_out + (long)(0 * B + b) * ld;
   float mean0 = 0.f;
   if (dueling) {
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_head_loss_kernel(
   const float loss = -wave_sum(on ? m * lsm : 0.f);
   const float msum = wave_sum(m);
   // d loss / d logits_tm1[a0][k], scaled by w/B (loss = mean(losses*w))
-  const float gk = on ? ((e0 / se0) * msum - m) * (weights[b] / (float)B) : 0.f;
+  const float gk = on ? ((e0 / se0) * msum - m) * (w_b / (float)B) : 0.f;
   if (on) {
     float* d = dout2 + (long)b * ld;
     for (int a = 0; a < A; ++a)  // dueling: dadv[a][k] = G[a][k] - mean_a G[.][k]
