@@ -196,6 +196,8 @@ SIGNATURES = {
     'dz_prof_read_replay': (c_int, [c_vp]),
     'dz_replay_gather': (c_int, [ctypes.POINTER(FieldDesc), c_int, c_vp, c_int,
                                  c_i64, c_vp]),
+    'dz_replay_sample_uniform': (c_int, [ctypes.POINTER(FieldDesc), c_int, c_vp, c_int,
+                                         c_i64, c_i64, c_i64, c_vp, c_vp]),
     'dz_replay_insert': (c_int, [ctypes.POINTER(InsertField), c_int, c_i64, c_i64,
                                  c_vp, c_i64, c_f64, c_vp, c_f64, c_vp, c_vp]),
     'dz_uniform_pos_to_id': (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp,

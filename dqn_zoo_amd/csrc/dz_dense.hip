@@ -221,16 +221,16 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       w.x = ws + L.ws_feat; w.ldx = kFlat; w.dy = ws + L.ws_dh1; w.ldy = kHid; w.M = B;
       w.NH = 1; w.noisy = 0; w.noise = zeros; w.head[0] = h1; w.head[1] = h1;
       w.grad = grad;
-      rc = dz_launch_gemm<FcWg>(w, dim3(kHid / FcWg::BN, kFlat / FcWg::BM, 1), s);
-      if (rc) return rc;
-      DZ_PROF(s, "fc1_wgrad");
       FcDgradParams d;
       d.dy = ws + L.ws_dh1; d.ldy = kHid; d.M = B; d.NH = 1; d.S = kS_ddfeat; d.noisy = 0;
       d.params = a->online; d.noise = zeros; d.head[0] = h1; d.head[1] = h1;
       d.part = ws + L.ws_dfeat_part; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
-      rc = dz_launch_gemm<FcDgradOp<1, 2, 2, 1>>(d, dim3(kFlat / 64, (B + 31) / 32, kS_ddfeat), s);
+      // weight gradient and input gradient in ONE launch (as in dz_rainbow.hip)
+      rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1>>(
+          w, dim3(kHid / FcWg::BN, kFlat / FcWg::BM, 1), d,
+          dim3(kFlat / 64, (B + 31) / 32, kS_ddfeat), s);
       if (rc) return rc;
-      DZ_PROF(s, "fc1_dgrad");
+      DZ_PROF(s, "fc1_wgrad+dgrad");
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0, s,
                          ws + L.ws_dfeat_part, kS_ddfeat, (long)B * kFlat, ws + L.ws_feat,
                          ws + L.ws_dfeat);

@@ -343,11 +343,41 @@ class TransitionReplay(_ReplayBase):
         ids_d.data_ptr(), self._stream()), 'dz_uniform_pos_to_id')
     return ids_d
 
+  SAMPLE_RING_DEPTH = 4
+
   def sample_device(self, size: int):
-    """Pipelined sample: (structure of device tensors, ids tensor)."""
-    ids_d = self.sample_ids_device(size)
-    outs = self._ring.gather(ids_d, size, self._stream())
-    return type(self._structure)(*outs), ids_d
+    """Pipelined sample: (structure of device tensors, ids tensor).  For batches
+    <= 64 this is ONE launch: the `randint` draws travel in the kernel arguments,
+    the kernel maps positions to ids and gathers the rows (outputs live in a ring
+    of preallocated slots, valid for SAMPLE_RING_DEPTH further calls)."""
+    if size > 64:
+      ids_d = self.sample_ids_device(size)
+      outs = self._ring.gather(ids_d, size, self._stream())
+      return type(self._structure)(*outs), ids_d
+    if self._size == 0:
+      raise ValueError('low >= high')  # what randint(0) raises in NumPy.
+    ring = getattr(self, '_sample_ring', None)
+    if ring is None or ring[0][0] != size:
+      ring = []
+      for _ in range(self.SAMPLE_RING_DEPTH):
+        outs = [torch.empty((size,) + tuple(f.shape[1:]), dtype=f.dtype,
+                            device=self._device) for f in self._ring.fields]
+        arr = (_lib.FieldDesc * len(outs))()
+        for i, (f, o) in enumerate(zip(self._ring.fields, outs)):
+          arr[i].src = f.data_ptr()
+          arr[i].dst = o.data_ptr()
+          arr[i].row_bytes = f[0].numel() * f.element_size()
+        ids = torch.empty(size, dtype=torch.int64, device=self._device)
+        ring.append((size, arr, type(self._structure)(*outs), ids))
+      self._sample_ring, self._sample_ring_pos = ring, 0
+    _, arr, outs, ids = ring[self._sample_ring_pos % len(ring)]
+    self._sample_ring_pos += 1
+    pos = np.ascontiguousarray(self._random_state.randint(self._size, size=size),
+                               dtype=np.int64)
+    _lib.check(_lib.load().dz_replay_sample_uniform(
+        arr, len(self._ring.fields), pos.ctypes.data, size, self._t, self._size,
+        self._capacity, ids.data_ptr(), self._stream()), 'dz_replay_sample_uniform')
+    return outs, ids
 
   def sample(self, size: int) -> ReplayStructure:
     """Samples a batch uniformly with replacement (replay.py:157-163)."""

@@ -77,6 +77,16 @@ int dz_replay_gather(const dz_field_t* fields, int num_fields,
                      const int64_t* ids, int batch, int64_t capacity,
                      dz_stream_t stream);
 
+/* Uniform sample in ONE launch (batch <= 64): `pos_host[b]` are the host's
+ * `randint(size, size=batch)` draws (read before the call returns; they travel in
+ * the kernel arguments), ids_out[b] = _ids[pos[b]] by the closed form of
+ * dz_uniform_pos_to_id (may be NULL), dst[b] = src[ids[b] mod capacity].
+ * ref: replay.py:76-82 + 152-163 (TransitionReplay.sample).                  */
+int dz_replay_sample_uniform(const dz_field_t* fields, int num_fields,
+                             const int64_t* pos_host, int batch, int64_t t,
+                             int64_t size, int64_t capacity, int64_t* ids_out,
+                             dz_stream_t stream);
+
 /* One transition into the store, and (node != NULL) its sum-tree leaf, in ONE
  * launch: field i's row `t mod capacity` is written from `src_row` (a DEVICE
  * pointer to row_bytes bytes, e.g. the observation the actor just uploaded) or,

@@ -44,7 +44,24 @@ def main():
       lib.dz_set_tuning(int(k), int(v))
       print('set tuning', k, v)
       continue
-    if name == 'iqn':
+    if name == 'dqn_full':  # uniform replay sample + DQN update (BASELINE configs[1] shape)
+      from dqn_zoo_amd import replay as rl
+      cap = 100000
+      rep = rl.TransitionReplay(cap, rl.Transition(None, None, None, None, None),
+                                np.random.RandomState(1))
+      g = torch.Generator(device=dev); g.manual_seed(0)
+      pool = torch.randint(0, 256, (256, 84, 84, 4), dtype=torch.uint8, device=dev, generator=g)
+      for lo in range(0, cap, 4096):
+        n = min(4096, cap - lo)
+        i1 = torch.randint(0, 256, (n,), device=dev, generator=g)
+        rep.bulk_fill([pool[i1], torch.randint(0, A, (n,), device=dev, generator=g),
+                       torch.zeros(n, dtype=torch.float64, device=dev),
+                       torch.full((n,), 0.99, dtype=torch.float64, device=dev), pool[i1]])
+      ln = ll.DenseLearner(networks.DenseNetwork('dqn', A), 'q', rms, B)
+      def step():
+        t, _ = rep.sample_device(B)
+        ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, None)
+    elif name == 'iqn':
       ln = ll.IqnLearner(networks.IqnNetwork(A, 64), adam._replace(max_global_grad_norm=0.0), B)
       step = lambda: ln.step(s_tm1, a, r, d, s_t)
     else:
