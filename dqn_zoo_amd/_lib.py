@@ -112,6 +112,9 @@ class DenseArgs(ctypes.Structure):
       ('priorities', c_vp), ('lr', c_f32), ('decay_or_b1', c_f32), ('b2', c_f32),
       ('eps', c_f32), ('max_norm', c_f32), ('grad_error_bound', c_f32),
       ('huber', c_f32),
+      ('prio_node', c_vp), ('prio_cap_pow2', c_i64), ('prio_capacity', c_i64),
+      ('prio_ids', c_vp), ('prio_exponent', c_f64), ('prio_max_seen', c_vp),
+      ('prio_status', c_vp),
   ]
 
 

@@ -239,8 +239,17 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
     }
     ReduceJob conv_jobs[3];
     const TorsoBufs T = {L.conv_w, L.conv_b, ws + L.ws_act1, ws + L.ws_act2, ws + L.ws_feat};
+    PrioUpdateParams prio_q = {};
+    if (a->prio_node) {
+      DZ_REQUIRE(a->priorities && a->prio_ids && a->prio_status &&
+                 dz_is_pow2(a->prio_cap_pow2) && a->prio_capacity > 0 &&
+                 a->prio_capacity <= a->prio_cap_pow2 && a->prio_exponent >= 0.0 && B <= 256);
+      prio_q = {a->prio_node, a->prio_cap_pow2, a->prio_capacity, 0, 0, a->prio_ids,
+                a->priorities, 1, a->prio_exponent, B, a->prio_max_seen, a->prio_status, 0};
+    }
     rc = torso_backward(T, B, a->online, a->s_tm1, ws + L.ws_dfeat, ws + L.ws_dact2,
-                        ws + L.ws_dact1, ws + L.ws_wgrad_part, grad, conv_jobs, s);
+                        ws + L.ws_dact1, ws + L.ws_wgrad_part, grad, conv_jobs, s,
+                        a->prio_node ? &prio_q : nullptr);
     if (rc) return rc;
     {
       FinalizeJobs J;

@@ -4,6 +4,7 @@
 #pragma once
 
 #include "dz_qnet_kernels.h"
+#include "dz_sumtree_dev.h"
 
 extern int g_conv_fwd_variant[3];  // dz_core.hip; dz_set_tuning keys 9-11
 
@@ -109,10 +110,12 @@ inline int64_t torso_wgrad_part_elems() {
 // Backward of group 0 from dfeat (already masked by feat > 0): split-K partial
 // slabs of the three weight(+bias-row) gradients are left in `part`; the three
 // ReduceJobs that fold them into the gradient buffer are returned in `jobs`.
+// `prio`: optional sum-tree priority write-back carried by the conv3 launch as one
+// extra block (it depends only on the loss kernel's priorities).
 inline int torso_backward(const TorsoBufs& T, int B, const float* online,
                           const uint8_t* s_tm1, const float* dfeat, float* dact2,
                           float* dact1, float* part, float* grad, ReduceJob* jobs,
-                          hipStream_t s) {
+                          hipStream_t s, const PrioUpdateParams* prio = nullptr) {
   int rc;
   float* part1 = part;
   float* part2 = part1 + (long)kS_cw1 * Conv1Wg::KROWS * 32;
@@ -122,8 +125,11 @@ inline int torso_backward(const TorsoBufs& T, int B, const float* online,
     w.in = T.act2; w.dy = dfeat; w.part = part3; w.B = B; w.S = kS_cw3;
     ConvDgradParams d;
     d.dy = dfeat; d.w = online + T.conv_w[2]; d.act = T.act2; d.dx = dact2; d.B = B;
-    rc = dz_launch_gemm2<Conv3Wg, Conv3Dg>(w, dim3(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), d,
-                                          dim3(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1), s);
+    const dim3 gw(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), gd(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1);
+    if (prio)
+      rc = dz_launch_gemm2_side<Conv3Wg, Conv3Dg, PrioUpdateSide>(w, gw, d, gd, *prio, 1, s);
+    else
+      rc = dz_launch_gemm2<Conv3Wg, Conv3Dg>(w, gw, d, gd, s);
     if (rc) return rc;
     DZ_PROF(s, "conv3_wgrad+dgrad");
   }

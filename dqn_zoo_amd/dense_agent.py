@@ -130,9 +130,10 @@ class DenseAgent(parts.Agent):
     if self.PRIORITIZED:
       s = self._replay.sample_device(self._batch_size)
       t = s.transitions
-      ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32)
-      # priorities = |td| (prioritized/agent.py:202), max folded on the device
-      self._replay.update_priorities(s.ids, ln.priorities)
+      # priorities = |td| (prioritized/agent.py:202) go into the sum tree (and the
+      # running max) inside the step's backward launches
+      ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
+              priority_sink=self._replay.priority_sink(s.ids))
     else:
       t, _ = self._replay.sample_device(self._batch_size)
       ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, None)

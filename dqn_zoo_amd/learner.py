@@ -341,7 +341,9 @@ class DenseLearner:
     return self.ws[off:off + count]
 
   def step(self, s_tm1, a_tm1, r_t, discount_t, s_t, weights=None,
-           phases: int = _lib.PHASE_ALL) -> None:
+           phases: int = _lib.PHASE_ALL, priority_sink=None) -> None:
+    """`priority_sink`: see RainbowLearner.step (the |td| priorities go into the
+    replay's sum tree inside the backward launches)."""
     b = self.batch_size
     assert s_tm1.dtype == torch.uint8 and s_t.dtype == torch.uint8
     assert tuple(s_tm1.shape) == (b, 84, 84, 4) and s_tm1.is_contiguous()
@@ -385,6 +387,11 @@ class DenseLearner:
       a.eps, a.max_norm = self.opt.eps, 0.0
     a.grad_error_bound = self.grad_error_bound
     a.huber = self.huber_param
+    if priority_sink is not None:
+      if not phases & _lib.PHASE_BACKWARD:
+        raise ValueError('priority_sink needs the backward phase in this call')
+      (a.prio_node, a.prio_cap_pow2, a.prio_capacity, a.prio_ids, a.prio_exponent,
+       a.prio_max_seen, a.prio_status) = priority_sink
     _lib.check(self._lib.dz_dense_learn(
         ctypes.byref(a), phases,
         torch.cuda.current_stream(self.device).cuda_stream), 'dz_dense_learn')

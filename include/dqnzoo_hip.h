@@ -402,6 +402,14 @@ typedef struct {
   float lr, decay_or_b1, b2, eps, max_norm;
   float grad_error_bound;    /* Q / double-Q: clip of the td gradient           */
   float huber;               /* quantile: kappa                                 */
+  /* optional priority write-back inside the backward launch, as in
+   * dz_rainbow_args_t (prioritized/agent.py:202-206): needs `priorities`.      */
+  double* prio_node;
+  int64_t prio_cap_pow2, prio_capacity;
+  const int64_t* prio_ids;
+  double prio_exponent;
+  double* prio_max_seen;
+  uint32_t* prio_status;
 } dz_dense_args_t;
 
 int dz_dense_learn(const dz_dense_args_t* args, int phases, dz_stream_t stream);

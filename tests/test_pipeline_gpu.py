@@ -99,3 +99,43 @@ def test_priority_sink_equals_separate_update():
   with pytest.raises(ValueError):
     ln_b.step(tb.s_tm1, tb.a_tm1, tb.r_t, tb.discount_t, tb.s_t, sb.weights32,
               phases=1, priority_sink=rep_b.priority_sink(sb.ids))
+
+
+def test_dense_priority_sink_equals_separate_update():
+  """DenseLearner.step(priority_sink=...) for the prioritized double-Q agent:
+  same tree as step() + update_priorities(|td|) (prioritized/agent.py:202-206)."""
+  import torch
+  from dqn_zoo_amd import learner as ll, networks, parts
+  from dqn_zoo_amd import replay as rl
+  A, B, cap = 5, 12, 200
+  T = rl.Transition
+
+  def build():
+    rep = rl.PrioritizedTransitionReplay(
+        cap, T(None, None, None, None, None), 0.6,
+        parts.LinearSchedule(begin_t=0, end_t=1000, begin_value=0.4, end_value=1.0),
+        1e-3, True, np.random.RandomState(21))
+    rs = np.random.RandomState(6)
+    for i in range(cap + 15):
+      rep.add(T(rs.randint(0, 256, (84, 84, 4)).astype(np.uint8), int(rs.randint(A)),
+                float(rs.randint(-1, 2)), 0.99, rs.randint(0, 256, (84, 84, 4)).astype(np.uint8)),
+              1.0)
+    ln = ll.DenseLearner(networks.DenseNetwork('double_dqn', A), 'double_q',
+                         ll.RmsPropConfig(), B, seed=4)
+    return rep, ln
+
+  rep_a, ln_a = build()
+  rep_b, ln_b = build()
+  for _ in range(3):
+    sa = rep_a.sample_device(B); ta = sa.transitions
+    ln_a.step(ta.s_tm1, ta.a_tm1, ta.r_t, ta.discount_t, ta.s_t, sa.weights32)
+    rep_a.update_priorities(sa.ids, ln_a.priorities)
+    sb = rep_b.sample_device(B); tb = sb.transitions
+    ln_b.step(tb.s_tm1, tb.a_tm1, tb.r_t, tb.discount_t, tb.s_t, sb.weights32,
+              priority_sink=rep_b.priority_sink(sb.ids))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(sa.ids.cpu().numpy(), sb.ids.cpu().numpy())
+    np.testing.assert_array_equal(rep_a.tree_storage.cpu().numpy(),
+                                  rep_b.tree_storage.cpu().numpy())
+  rep_b.check_status()
+  assert rep_a.max_seen_priority_device.item() == rep_b.max_seen_priority_device.item()
