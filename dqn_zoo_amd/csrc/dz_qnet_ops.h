@@ -404,6 +404,9 @@ struct FcWgradParams {
   // tiles outside the problem write zeros, so the slot array is always complete.
   float* sumsq = nullptr;     // null: off
   int sq_nx = 0, sq_ny = 0;   // grid dimensions of this Op's launch
+  // noisy only: do not store the sigma-weight gradient (it still enters sumsq);
+  // the optimiser re-derives it as dWmu * eps_in (x) eps_out (adam_kernel DerivedGrad)
+  int skip_sig_store = 0;
 };
 
 template <int WM_, int WN_, int WK_, int KT_ = 1>
@@ -458,7 +461,7 @@ struct FcWgradOp {
         sq += v * v;
         if (p.noisy) {
           const float vs = v * (p.noise[hd.eps_in + k] * eo);
-          p.grad[hd.w_sig + (long)k * hd.ldw + col] = vs;
+          if (!p.skip_sig_store) p.grad[hd.w_sig + (long)k * hd.ldw + col] = vs;
           sq += vs * vs;
         }
       }

@@ -256,6 +256,10 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   }
 
   int n_final = 0;  // fused-norm partials left by this call's backward phase
+  // fc1 sigma-weight gradient: derived inside Adam instead of stored and re-read,
+  // when this one call both produces and consumes it
+  const bool derive_sig = (phases & DZ_PHASE_BACKWARD) && (phases & DZ_PHASE_OPTIMIZER) &&
+                          !a->keep_all_grads;
   if (phases & DZ_PHASE_BACKWARD) {
     DZ_REQUIRE(a->grad);
     float* grad = a->grad;
@@ -316,6 +320,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc1h[0]; w.head[1] = fc1h[1];
       w.grad = grad;
       w.sumsq = sq_slots + fc2_slots; w.sq_nx = 512 / FcWg::BN; w.sq_ny = kFlat / FcWg::BM;
+      w.skip_sig_store = derive_sig;
       FcDgradParams d;
       d.dy = ws + L.ws_dh1; d.ldy = 1024; d.M = B; d.NH = 2; d.S = kS_dfeat; d.noisy = g_dgrad_weff ? 2 : 1;
       d.params = a->online; d.noise = nz[0]; d.head[0] = fc1h[0]; d.head[1] = fc1h[1];
@@ -442,10 +447,18 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       DZ_PROF(s, "grad_sumsq");
       nparts = kNormBlocks;
     }
+    DerivedGrad dg = {};
+    if (derive_sig) {
+      dg.dst_off = L.fc1_sig_w; dg.src_off = L.fc1_mu_w; dg.rows = kFlat; dg.ld = L.fc1_ld;
+      dg.split_col = 512;
+      dg.eps_in0 = nz[0] + L.n_adv1_in; dg.eps_in1 = nz[0] + L.n_val1_in;
+      dg.eps_out = nz[0] + L.n_fc1_out;
+      dg.on = 1;
+    }
     hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
                        a->adam_m, a->adam_v, (long)(L.param_count >> 2),
                        ws + L.ws_norm_part, nparts, a->adam_count, a->losses,
-                       a->weights, B, sc, a->lr, a->b1, a->b2, a->eps, a->max_norm);
+                       a->weights, B, sc, a->lr, a->b1, a->b2, a->eps, a->max_norm, dg);
     DZ_LAUNCH_CHECK();
     DZ_PROF(s, "adam");
   }

@@ -71,6 +71,9 @@ class RainbowLearner:
     self._args = None
     self._graphs = {}        # (input pointers, phases, noise flag) -> hipGraphExec
     self.use_graphs = False  # replay each distinct call signature from a hipGraph
+    # False: a full step does not store the fc1 sigma-weight gradient (Adam derives it
+    # from the mu-weight gradient and the noise); True: `grad` holds every block
+    self.keep_all_grads = False
     # inference (acting) side: own workspace + one noise block, so that an
     # apply never aliases the buffers of an enqueued learner step.
     self._act_batch = 0
@@ -219,6 +222,7 @@ class RainbowLearner:
     # fresh noise for the 3 applies is generated by the step itself from
     # (seed, Adam step count): no per-step host argument, graph-replayable.
     a.resample_noise = int(bool(resample_noise) and bool(phases & _lib.PHASE_FORWARD))
+    a.keep_all_grads = int(self.keep_all_grads)
     if priority_sink is not None:
       if not phases & _lib.PHASE_BACKWARD:
         raise ValueError('priority_sink needs the backward phase in this call')
@@ -234,7 +238,7 @@ class RainbowLearner:
             'hipGraph capture needs a non-default stream: run the learner under '
             '`torch.cuda.stream(torch.cuda.Stream())` (bench.py does)')
       key = (a.s_tm1, a.s_t, a.a_tm1, a.r_t, a.discount_t, a.weights, phases,
-             a.resample_noise, a.prio_node, a.prio_ids)
+             a.resample_noise, a.prio_node, a.prio_ids, a.keep_all_grads)
       g = self._graphs.get(key)
       if g is None:
         h = ctypes.c_void_p()

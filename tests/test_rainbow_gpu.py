@@ -128,6 +128,7 @@ def test_clip_and_adam_vs_oracle(max_norm):
   A, B = 6, 32
   online, target, batch, w, noises = _problem(A, B, 5)
   ln = _learner(A, B, online, target, noises, max_norm=max_norm)
+  ln.keep_all_grads = True   # this test reads every gradient block after a full step
   dev = _dev_batch(batch, w)
   p = {k: v.copy() for k, v in online.items()}
   st = qo.adam_init(p)
@@ -188,6 +189,32 @@ def test_full_step_vs_oracle_update():
   t_dev = ln.get_params('target')
   for k in target:
     np.testing.assert_array_equal(t_dev[k], p_dev[k])
+
+
+@pytest.mark.parametrize('max_norm', [10.0, 1e-3])
+def test_derived_sigma_gradient_is_bit_identical(max_norm):
+  """Default full step (fc1 sigma-weight gradient derived inside Adam from the
+  mu-weight gradient and the noise, never stored) == step with every gradient
+  block materialised: parameters and both Adam moments bit for bit."""
+  A, B = 6, 32
+  online, target, batch, w, noises = _problem(A, B, 13)
+  dev = _dev_batch(batch, w)
+  lns = []
+  for keep in (False, True):
+    ln = _learner(A, B, online, target, noises, max_norm=max_norm)
+    ln.keep_all_grads = keep
+    for _ in range(3):
+      ln.step(*dev, resample_noise=False)
+    torch.cuda.synchronize()
+    lns.append(ln)
+  a, b = lns
+  assert torch.equal(a.online, b.online)
+  assert torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)
+  assert a.scalars()['gnorm'] == b.scalars()['gnorm']
+  ga = a.layout.unpack(a.grad.cpu().numpy())
+  gb = b.layout.unpack(b.grad.cpu().numpy())
+  np.testing.assert_array_equal(ga['adv1/mu/w'], gb['adv1/mu/w'])
+  assert np.abs(gb['adv1/sigma/w']).max() > 0
 
 
 def test_device_noise_distribution():
