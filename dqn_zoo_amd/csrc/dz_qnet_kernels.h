@@ -517,14 +517,49 @@ struct NoiseSide {
 // q_values[b][a] = sum_k softmax(v + adv_a - mean_a adv)[k] * support[k]
 // (ref: networks.py:254-258); also the greedy action and its value
 // (ref: rainbow/agent.py:125-131, first maximum).
-__global__ __launch_bounds__(64) void rainbow_q_values_kernel(
-    const float* __restrict__ fc2_out, int ld, int val_off, int A, int K,
+// PRE = 1: the fc2 split-K slabs are folded here (see rainbow_head_loss_kernel).
+template <int PRE>
+__global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_q_values_kernel(
+    float* __restrict__ fc2_out, int ld, int val_off, int A, int K,
     const float* __restrict__ support, float* __restrict__ q_out,
-    int32_t* __restrict__ greedy_out, float* __restrict__ vmax_out) {
+    int32_t* __restrict__ greedy_out, float* __restrict__ vmax_out, HeadPre pre) {
+  extern __shared__ float s_row[];  // PRE: [ld]
   const int b = blockIdx.x, k = threadIdx.x;
+  const float z_ld = support[min(k, K - 1)];
+  if (PRE) {
+    constexpr int E = 4, SMAX = 8;
+    for (int base = 0; base < ld; base += 256 * E) {
+      float v[E][SMAX];
+      float bs[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int c = min(base + (int)threadIdx.x + 256 * e, ld - 1);
+#pragma unroll
+        for (int sidx = 0; sidx < SMAX; ++sidx) {
+          const float t = pre.part[((long)min(sidx, pre.S - 1) * pre.rows + b) * ld + c];
+          v[e][sidx] = sidx < pre.S ? t : 0.f;
+        }
+        bs[e] = pre.prm[0][pre.b_sig + c] * pre.nz[0][pre.eps_out + c];
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int c = base + (int)threadIdx.x + 256 * e;
+        if (c < ld) {
+          float acc = 0.f;
+#pragma unroll
+          for (int sidx = 0; sidx < SMAX; ++sidx) acc += v[e][sidx];
+          acc += bs[e];
+          s_row[c] = acc;
+          fc2_out[(long)b * ld + c] = acc;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+  }
   const bool on = k < K;
-  const float z = on ? support[k] : 0.f;
-  const float* o = fc2_out + (long)b * ld;
+  const float z = on ? z_ld : 0.f;
+  const float* o = PRE ? s_row : fc2_out + (long)b * ld;
   float mean_adv = 0.f;
   for (int a = 0; a < A; ++a) mean_adv += on ? o[a * K + k] : 0.f;
   mean_adv /= (float)A;

@@ -27,6 +27,7 @@ int g_fc1_dgrad_variant = 2;  // FcDgradOp<1,2,2,KT=1>
 int g_fc1_dgrad_splits = 16;
 int g_dgrad_weff = 1;         // fc1 input gradient against W_eff (depth N, not 2N): 14.2 vs 17.2 us
 int g_fc2_splits = 8;         // 12 us (4 splits: 19 us)
+int g_adam_blocks = 2048;     // grid-stride Adam launch width
 
 }  // namespace
 
@@ -455,7 +456,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       dg.eps_out = nz[0] + L.n_fc1_out;
       dg.on = 1;
     }
-    hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_adam_blocks), dim3(256), 0, s, a->online, a->grad,
                        a->adam_m, a->adam_v, (long)(L.param_count >> 2),
                        ws + L.ws_norm_part, nparts, a->adam_count, a->losses,
                        a->weights, B, sc, a->lr, a->b1, a->b2, a->eps, a->max_norm, dg);
@@ -516,9 +517,52 @@ extern "C" int dz_rainbow_apply(int num_actions, int num_atoms, int batch,
   rc = rainbow_forward(L, H, 1, batch, prm, nz, in, ws, s);
   g_dz_prof_on = prof;
   if (rc) return rc;
-  hipLaunchKernelGGL(rainbow_q_values_kernel, dim3(batch), dim3(64), 0, s,
+  hipLaunchKernelGGL(rainbow_q_values_kernel<0>, dim3(batch), dim3(64), 0, s,
                      ws + L.ws_fc2_out, L.adv2_ld + L.val2_ld, L.adv2_ld, num_actions,
-                     num_atoms, support, q_values_out, greedy_out, vmax_out);
+                     num_atoms, support, q_values_out, greedy_out, vmax_out, HeadPre{});
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
+// The actor's apply (ref: rainbow/agent.py:125-131, 171-179): fresh noise from
+// (noise_seed, noise_counter) drawn as a side job of the conv1 launch, the fc2
+// split-K fold inside the q-value kernel: 8 launches instead of 10 at batch 1.
+extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const float* params,
+                              const uint8_t* states, float* noise, uint64_t noise_seed,
+                              uint64_t noise_counter, const float* support, float* ws,
+                              float* q_values_out, int32_t* greedy_out, float* vmax_out,
+                              dz_stream_t stream) {
+  DZ_REQUIRE(params && states && noise && support && ws && q_values_out);
+  dz_rainbow_layout_t L;
+  int rc = dz_rainbow_layout(num_actions, num_atoms, batch, &L);
+  if (rc != DZ_OK) return rc;
+  hipStream_t s = dz_s(stream);
+  FwdHeads H;
+  make_heads(L, H);
+  const float* prm[kG] = {params, params, params};
+  const float* nz[kG] = {noise, noise, noise};
+  const uint8_t* in[kG] = {states, states, states};
+  const int ld2 = L.adv2_ld + L.val2_ld;
+  const bool fuse = (size_t)ld2 * sizeof(float) <= 48 * 1024;
+  const NoiseParams nq = {noise, (long)L.noise_stride, noise_seed, noise_counter, nullptr};
+  const bool prof = g_dz_prof_on;
+  g_dz_prof_on = false;  // marks belong to dz_rainbow_learn
+  rc = rainbow_forward(L, H, 1, batch, prm, nz, in, ws, s, &nq, fuse);
+  g_dz_prof_on = prof;
+  if (rc) return rc;
+  if (fuse) {
+    HeadPre pre = {};
+    pre.part = ws + L.ws_fc2_part; pre.S = g_fc2_splits; pre.rows = batch;
+    for (int g = 0; g < kG; ++g) { pre.prm[g] = params; pre.nz[g] = noise; }
+    pre.b_sig = L.fc2_sig_b; pre.eps_out = (int)L.n_fc2_out;
+    hipLaunchKernelGGL(rainbow_q_values_kernel<1>, dim3(batch), dim3(256),
+                       (size_t)ld2 * sizeof(float), s, ws + L.ws_fc2_out, ld2, L.adv2_ld,
+                       num_actions, num_atoms, support, q_values_out, greedy_out, vmax_out, pre);
+  } else {
+    hipLaunchKernelGGL(rainbow_q_values_kernel<0>, dim3(batch), dim3(64), 0, s,
+                       ws + L.ws_fc2_out, ld2, L.adv2_ld, num_actions, num_atoms, support,
+                       q_values_out, greedy_out, vmax_out, HeadPre{});
+  }
   DZ_LAUNCH_CHECK();
   return DZ_OK;
 }
@@ -535,6 +579,7 @@ extern "C" int dz_set_tuning(int key, int value) {
     case 9: case 10: case 11: g_conv_fwd_variant[key - 9] = value; return DZ_OK;
     case 12: g_dgrad_weff = value; return DZ_OK;
     case 13: g_iqn_variant = value; return DZ_OK;
+    case 14: DZ_REQUIRE(value >= 64 && value <= 65536); g_adam_blocks = value; return DZ_OK;
     default: return DZ_ERR_INVALID_ARG;
   }
 }

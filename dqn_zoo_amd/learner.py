@@ -121,14 +121,6 @@ class RainbowLearner:
                                  dtype=torch.float32, device=self.device)
       self._act_batch = b
     stream = torch.cuda.current_stream(self.device).cuda_stream
-    if noise is not None:
-      self._act_noise.copy_(torch.from_numpy(self.layout.pack_noise(noise)))
-    elif resample_noise:
-      n = self._act_noise.numel()
-      _lib.check(self._lib.dz_noise_fill(
-          self._act_noise.data_ptr(), n, self._noise_seed ^ 0xA5A5A5A5,
-          self._noise_counter, stream), 'dz_noise_fill')
-      self._noise_counter += n
     a = self.network.num_actions
     q = torch.empty((b, a), dtype=torch.float32, device=self.device)
     # (greedy action, max q) packed in one 8-byte buffer per row so that the
@@ -136,6 +128,18 @@ class RainbowLearner:
     packed = torch.empty((2, b), dtype=torch.int32, device=self.device)
     greedy, vmax = packed[0], packed[1].view(torch.float32)
     params = self.online if which == 'online' else self.target
+    if noise is None and resample_noise:
+      # fresh noise drawn inside the apply's own launches (dz_rainbow_act)
+      n = self._act_noise.numel()
+      _lib.check(self._lib.dz_rainbow_act(
+          a, self.network.num_atoms, b, params.data_ptr(), states.data_ptr(),
+          self._act_noise.data_ptr(), self._noise_seed ^ 0xA5A5A5A5,
+          self._noise_counter, self.support.data_ptr(), self._act_ws.data_ptr(),
+          q.data_ptr(), greedy.data_ptr(), vmax.data_ptr(), stream), 'dz_rainbow_act')
+      self._noise_counter += n
+      return q, greedy, vmax
+    if noise is not None:
+      self._act_noise.copy_(torch.from_numpy(self.layout.pack_noise(noise)))
     _lib.check(self._lib.dz_rainbow_apply(
         a, self.network.num_atoms, b, params.data_ptr(), states.data_ptr(),
         self._act_noise.data_ptr(), self.support.data_ptr(),

@@ -335,6 +335,16 @@ int dz_rainbow_apply(int num_actions, int num_atoms, int batch, const float* par
                      float* ws, float* q_values_out, int32_t* greedy_out,
                      float* vmax_out, dz_stream_t stream);
 
+/* The actor's apply: dz_rainbow_apply with the noise block (noise_stride floats)
+ * first redrawn on the device from (noise_seed, noise_counter) -- inside the
+ * conv1 launch -- and the fc2 split-K fold inside the q-value kernel.
+ * ref: rainbow/agent.py:125-131, 171-179 (select_action with a fresh key).    */
+int dz_rainbow_act(int num_actions, int num_atoms, int batch, const float* params,
+                   const uint8_t* states, float* noise, uint64_t noise_seed,
+                   uint64_t noise_counter, const float* support, float* ws,
+                   float* q_values_out, int32_t* greedy_out, float* vmax_out,
+                   dz_stream_t stream);
+
 /* hipGraph form of dz_rainbow_learn: captures the launches of one call (same
  * args, same phases; every pointer in `args` is baked in) on `stream` and
  * returns an executable graph; dz_graph_launch replays it with one API call

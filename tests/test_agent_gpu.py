@@ -136,8 +136,17 @@ def test_apply_matches_oracle_forward():
   # fresh noise per apply (networks.py:169-170): same input, different output
   xs = torch.from_numpy(x).cuda()
   q1, _, _ = ln.apply(xs)
-  q2, _, _ = ln.apply(xs)
+  q2, g2, v2 = ln.apply(xs)
   assert not torch.equal(q1, q2)
+  # the fused actor path (dz_rainbow_act: noise drawn inside the conv1 launch,
+  # fc2 fold inside the q-value kernel) against the oracle with the SAME noise,
+  # read back from the device
+  nz_dev = ln.layout.unpack_noise(ln._act_noise.cpu().numpy())  # pylint: disable=protected-access
+  _, q_ref, _ = qo.rainbow_fwd(params, x, nz_dev, SUPPORT, A)
+  np.testing.assert_allclose(q2.cpu().numpy(), q_ref, rtol=2e-4, atol=2e-5)
+  np.testing.assert_array_equal(g2.cpu().numpy(), q_ref.argmax(axis=1))
+  a_t, v_t = ln.read_action(g2, v2)
+  assert a_t == int(q_ref[0].argmax()) and abs(v_t - q_ref[0].max()) < 1e-4
 
 
 def test_get_state_set_state_roundtrip():

@@ -44,13 +44,11 @@ def main():
   lib = _lib.load()
   names = {0: '<1,2,2,KT4>', 1: '<1,2,2,KT2>', 2: '<1,2,2,KT1>', 3: '<1,4,1,KT4>',
            4: '<1,4,1,KT2>', 5: '<1,1,4,KT2>', 6: '<1,1,4,KT1>', 7: '<1,4,1,KT1>'}
-  for mode in (1, 2, 3):
-    lib.dz_set_tuning(5, mode)
+  for nb in (512, 1024, 2048, 3072, 4096, 6712, 8192):
+    lib.dz_set_tuning(14, nb)
     t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
-    print('fc1 bwd mode %d: %s total %.1f' % (
-        mode, {k: round(v, 2) for k, v in t.items() if k.startswith('fc1_') and 'fwd' not in k and 'epi' not in k},
-        sum(t.values())), flush=True)
-  lib.dz_set_tuning(5, 1)
+    print('adam blocks %d: adam %.2f total %.1f' % (nb, t['adam'], sum(t.values())), flush=True)
+  lib.dz_set_tuning(14, 2048)
 
 
 if __name__ == '__main__':
