@@ -199,16 +199,12 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       d.dy = ws + L.ws_dout; d.ldy = ld2; d.M = M0; d.NH = 1; d.S = 1; d.noisy = 0;
       d.params = a->online; d.noise = zeros; d.head[0] = h2; d.head[1] = h2;
       d.part = ws + L.ws_dh1; d.ldo = kHid; d.K = kHid; d.x_off = 0;
+      d.relu_mask = ws + L.ws_h1;  // dh1 *= (h1 > 0) in the store (S == 1)
       rc = dz_launch_gemm2<IqnWg, IqnDg>(
           w, dim3((A + IqnWg::BN - 1) / IqnWg::BN, kHid / IqnWg::BM, kS_iqn_fc2w), d,
           dim3(kHid / IqnDg::BN, (M0 + IqnDg::BM - 1) / IqnDg::BM, 1), s);
       if (rc) return rc;
       DZ_PROF(s, "fc2_wgrad+dgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)(((long)M0 * kHid + 63) / 64)),
-                         dim3(256), 0, s, ws + L.ws_dh1, 1, (long)M0 * kHid, ws + L.ws_h1,
-                         ws + L.ws_dh1);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "dh1_mask");
     }
     {  // fc1: weight gradient (straight into grad) + input gradient
       IqnWgradParams w;

@@ -294,6 +294,9 @@ struct FcDgradParams {
   int ldo;
   int K;            // output columns (= heads' K)
   int x_off;        // output column offset
+  // S == 1 only: ReLU mask of the layer input fused into the store
+  // (out = mask[m][col] > 0 ? acc : 0), saving the separate masking pass
+  const float* relu_mask = nullptr;
 };
 
 template <int WM_, int WN_, int WK_, int KT_ = 1, int MI_ = 1, int NI_ = 1>
@@ -378,10 +381,15 @@ struct FcDgradOp {
     const int col = t.n0 + wn * 32 + (lane & 31);
     if (col >= p.K) return;
     float* base = p.part + (long)t.z * p.M * p.ldo + p.x_off + col;
+    const float* mk = p.relu_mask ? p.relu_mask + p.x_off + col : nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = t.m0 + wm * 32 + dz_acc_row(r, lane);
-      if (m < p.M) base[(long)m * p.ldo] = acc[r];
+      if (m < p.M) {
+        float v = acc[r];
+        if (mk) v = mk[(long)m * p.ldo] > 0.f ? v : 0.f;
+        base[(long)m * p.ldo] = v;
+      }
     }
   }
 };
