@@ -325,6 +325,9 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
           const float* src = red + (((k2 - 1) * PER + ((wm * WN + wn) * MI + mi) * NI + ni) * 16) * 64 + lane;
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[mi][ni][i] += src[i * 64];
+          // one accumulator block at a time: without this the compiler hoists all
+          // (WK-1)*MI*NI*16 LDS loads and pays for them in VGPRs (occupancy)
+          asm volatile("" ::: "memory");
         }
   }
 #pragma unroll

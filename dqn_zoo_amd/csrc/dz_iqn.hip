@@ -124,6 +124,9 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
       case 7: rc = dz_launch_gemm<IqnLinOp<1, 1, 4, 2, 2, 2>>(p, dim3(kHid / 64, my, ap.G), s); break;
       case 8: rc = dz_launch_gemm<IqnLinOp<2, 1, 2, 2, 1, 2>>(p, dim3(kHid / 64, my, ap.G), s); break;
       case 9: rc = dz_launch_gemm<IqnLinOp<2, 2, 1, 2, 2, 2>>(p, dim3(kHid / 128, (my + 1) / 2, ap.G), s); break;
+      case 12: rc = dz_launch_gemm<IqnLinOp<2, 1, 2, 1, 1, 2>>(p, dim3(kHid / 64, my, ap.G), s); break;
+      case 13: rc = dz_launch_gemm<IqnLinOp<1, 2, 2, 1, 2, 1>>(p, dim3(kHid / 64, my, ap.G), s); break;
+      case 14: rc = dz_launch_gemm_xcd<IqnLinOp<2, 1, 2, 1, 1, 2>>(p, dim3(kHid / 64, my, ap.G), s); break;
       case 5: rc = dz_launch_gemm_xcd<IqnLinOp<2, 2, 1, 4>>(p, dim3(kHid / 64, my, ap.G), s); break;
       case 2: rc = dz_launch_gemm<IqnLinOp<2, 2, 1, 1>>(p, dim3(kHid / 64, my, ap.G), s); break;
       case 3: rc = dz_launch_gemm<IqnLinOp<2, 2, 1, 3>>(p, dim3(kHid / 64, my, ap.G), s); break;

@@ -1,6 +1,6 @@
 ulimit -c 0
-for v in 6 7 8 9; do
-  timeout 200 python tools/agent_bench.py 13=$v iqn 2>&1 | grep -v amdgpu | cut -c1-150
+for v in "$@"; do
+  timeout 200 python tools/agent_bench.py 13=$v iqn 2>&1 | grep -v amdgpu | cut -c1-110
   timeout 200 python -c "
 from dqn_zoo_amd import _lib
 _lib.load().dz_set_tuning(13, $v)
