@@ -405,7 +405,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 //   g[dst_off + k*ld + n] = g[src_off + k*ld + n] * (eps_in_h[k] * eps_out[n])
 // (the sigma-weight gradient of a noisy layer is its mu-weight gradient times the
 // noise outer product, networks.py:168-176): the weight-gradient kernel then
-// writes, and this kernel reads, 12.85 MB less for Rainbow's fc1.
+// writes 12.85 MB less for Rainbow's fc1 (this kernel reads the mu block twice
+// instead of mu and sigma once each: same bytes).
 struct DerivedGrad {
   long dst_off, src_off;    // multiples of 4
   int rows, ld;             // ld multiple of 4

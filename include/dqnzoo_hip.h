@@ -311,7 +311,7 @@ typedef struct {
   uint32_t* prio_status;
   /* 0 (default): when a call runs backward AND optimiser, the fc1 sigma-weight
    * gradient (12.85 MB) is not written to `grad`: the optimiser re-derives it
-   * from the mu-weight gradient and the noise, bit-identically.  1: every
+   * from the mu-weight gradient and the noise, bit-identically (saves the write).  1: every
    * gradient block is materialised in `grad` (inspection, tests).             */
   int32_t keep_all_grads;
   int32_t pad_;
