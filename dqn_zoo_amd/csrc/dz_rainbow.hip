@@ -1,13 +1,17 @@
 // Rainbow learner step on one MI355X (ref: rainbow/agent.py:85-121).
 //
-// Launch sequence (all on the caller's stream, no host synchronisation):
-//   forward : conv1 conv2 conv3 (3 applies batched as groups) -> fc1 (noisy,
-//             adv1|val1 fused, split-K) -> epilogue -> fc2 (noisy adv2, val2)
-//             -> epilogue -> head/loss (dueling + softmax + double-Q selector +
-//             Cramer projection + cross-entropy + dlogits + priorities)
-//   backward: fc2 wgrad/dgrad, fc1 wgrad/dgrad, conv3 wgrad/dgrad, conv2
-//             wgrad/dgrad, conv1 wgrad, bias column sums
-//   update  : sum of squares -> global norm/clip scale -> Adam
+// Launch sequence (15 launches, all on the caller's stream, no host sync):
+//   forward : conv1 (+ the step's noise draw as a side job) conv2 conv3 (3 applies
+//             batched as groups) -> fc1 (noisy adv1|val1, one weight stream per
+//             parameter set, W_eff in registers, split-K) -> epilogue -> fc2 (noisy
+//             adv2, val2, split-K) -> head/loss (folds the fc2 slabs; dueling +
+//             softmax + double-Q selector + Cramer projection + cross-entropy +
+//             dlogits + priorities)
+//   backward: [fc2 wgrad | fc2 dgrad x2] -> reduce -> [fc1 wgrad | fc1 dgrad] ->
+//             reduce -> [conv3 wgrad | conv3 dgrad | sum-tree priority write-back]
+//             -> [conv2 wgrad | conv2 dgrad] -> conv1 wgrad -> finalize (conv
+//             partials, bias column sums, global-norm partials, step count)
+//   update  : Adam (folds the norm partials, clip, derives the fc1 sigma gradient)
 // Roofline notes per kernel are in DESIGN.md.
 #include "dz_sumtree_dev.h"
 #include "dz_torso.h"
