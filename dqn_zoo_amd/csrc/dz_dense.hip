@@ -88,6 +88,7 @@ static int dense_forward(const dz_dense_layout_t& L, int G, int B, const float* 
       q.part = ws + L.ws_fc1_part; q.ldo = kHid;
       q.rows_per_split = ((kFlat + kS_dfc1 - 1) / kS_dfc1 + 3) & ~3;
       DZ_REQUIRE(q.rows_per_split <= 100);
+      q.xcd_order = 0;
       hipLaunchKernelGGL((dz_fc_stream_fwd3<0, 50>), dim3(kHid / 128, kS_dfc1, ns), dim3(256),
                          (size_t)q.rows_per_split * (2 * 32 + 2) * sizeof(float), s, q);
       DZ_LAUNCH_CHECK();

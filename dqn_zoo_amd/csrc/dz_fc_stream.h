@@ -44,6 +44,7 @@ struct FcStreamFwd3Params {
   float* part;                         // [S][G*M][ldo]
   int ldo;
   int rows_per_split;                  // multiple of 4, <= 2*NL
+  int xcd_order;                       // 1: the strips of one (split, set) row block run on one XCD
 };
 
 // Groups the G applies by parameter pointer into at most 2 sets of at most 2
@@ -81,11 +82,20 @@ __global__ __launch_bounds__(256) void dz_fc_stream_fwd3(FcStreamFwd3Params p) {
   float* es = lds3 + 2 * R * 32;     // [2][R]      eps_in
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
+  // Workgroups go to the 8 XCDs round-robin by linear id; in XCD order all strips
+  // of one row block (one contiguous 4 KB weight row per k) are fetched through
+  // ONE XCD's L2 instead of eight.
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_order) {
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned j = L >> 3, yz = (j / gridDim.x) * 8 + (L & 7);
+    bx = j % gridDim.x; by = yz % gridDim.y; bz = yz / gridDim.y;
+  }
   const int strips0 = p.head[0].N / 128;
-  const int h_idx = blockIdx.x >= strips0 ? 1 : 0;
+  const int h_idx = (int)bx >= strips0 ? 1 : 0;
   const FcHead hd = dz_pick_head(p.head, h_idx);
-  const int n0 = (blockIdx.x - (h_idx ? strips0 : 0)) * 128 + 32 * wave;
-  const int split = blockIdx.y, set = blockIdx.z;
+  const int n0 = ((int)bx - (h_idx ? strips0 : 0)) * 128 + 32 * wave;
+  const int split = (int)by, set = (int)bz;
   const float* __restrict__ prm = set ? p.params[1] : p.params[0];
   const int ng = set ? p.ng[1] : p.ng[0];
   const int g0 = set ? p.grp[1][0] : p.grp[0][0];

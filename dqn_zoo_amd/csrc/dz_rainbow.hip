@@ -25,6 +25,7 @@ namespace {
 // measured best on MI355X at B = 32.
 int g_fc1_variant = 10;       // 10 = shared weight stream (dz_fc_stream_fwd3), 0 = tile GEMM
 int g_fc1_splits = 32;
+int g_fc1_xcd = 1;            // fc1 forward workgroups in XCD-aware order
 int g_fc1_dgrad_first = 3;    // fc1 backward: 3/2 = weight + input gradient in ONE launch (19 us;
                               // wgrad / dgrad blocks first), 1/0 = two launches (28 us)
 int g_fc1_dgrad_variant = 2;  // FcDgradOp<1,2,2,KT=1>
@@ -76,6 +77,7 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
         q.part = p.part; q.ldo = p.ldo;
         q.rows_per_split = ((kFlat + g_fc1_splits - 1) / g_fc1_splits + 3) & ~3;
         DZ_REQUIRE(q.rows_per_split <= 200);
+        q.xcd_order = g_fc1_xcd && ((g_fc1_splits * ns) % 8 == 0);
         const size_t lds = (size_t)q.rows_per_split * (2 * 32 + 2) * sizeof(float);
         if (q.rows_per_split <= 100)
           hipLaunchKernelGGL((dz_fc_stream_fwd3<1, 50>), dim3(8, g_fc1_splits, ns), dim3(256),
@@ -575,7 +577,8 @@ extern "C" int dz_set_tuning(int key, int value) {
   switch (key) {
     case 0: g_fc1_variant = value; return DZ_OK;
     case 1: DZ_REQUIRE(value >= 1 && value <= kMaxSplitFc1); g_fc1_splits = value; return DZ_OK;
-    case 2: case 3: case 4: return DZ_OK;  // retired experiments
+    case 2: g_fc1_xcd = value; return DZ_OK;
+    case 3: case 4: return DZ_OK;  // retired experiments
     case 5: g_fc1_dgrad_first = value; return DZ_OK;
     case 6: g_fc1_dgrad_variant = value; return DZ_OK;
     case 7: DZ_REQUIRE(value >= 1 && value <= kMaxS_dfeat); g_fc1_dgrad_splits = value; return DZ_OK;

@@ -44,11 +44,10 @@ def main():
   lib = _lib.load()
   names = {0: '<1,2,2,KT4>', 1: '<1,2,2,KT2>', 2: '<1,2,2,KT1>', 3: '<1,4,1,KT4>',
            4: '<1,4,1,KT2>', 5: '<1,1,4,KT2>', 6: '<1,1,4,KT1>', 7: '<1,4,1,KT1>'}
-  for nb in (512, 1024, 2048, 3072, 4096, 6712, 8192):
-    lib.dz_set_tuning(14, nb)
+  for x in (0, 1, 0, 1):
+    lib.dz_set_tuning(2, x)
     t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
-    print('adam blocks %d: adam %.2f total %.1f' % (nb, t['adam'], sum(t.values())), flush=True)
-  lib.dz_set_tuning(14, 2048)
+    print('fc1 fwd xcd order %d: fc1_fwd %.2f total %.1f' % (x, t['fc1_fwd'], sum(t.values())), flush=True)
 
 
 if __name__ == '__main__':
