@@ -353,6 +353,12 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
             dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
         if (rc) return rc;
         DZ_PROF(s, "fc1_dgrad+wgrad");
+      } else if (g_fc1_dgrad_first == 4) {  // as 3, tiles in XCD-aware order
+        rc = dz_launch_gemm2_xcd<FcWg, FcDgradOp<1, 2, 2, 1>>(
+            w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), d,
+            dim3(kFlat / 64, (B + 31) / 32, d.S), s);
+        if (rc) return rc;
+        DZ_PROF(s, "fc1_dgrad+wgrad");
       } else if (g_fc1_dgrad_first == 3) {  // wgrad blocks first
         const dim3 gw(512 / FcWg::BN, kFlat / FcWg::BM, 2), gd(kFlat / 64, (B + 31) / 32, d.S);
         rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1>>(w, gw, d, gd, s);
