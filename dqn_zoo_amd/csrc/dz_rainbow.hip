@@ -593,6 +593,7 @@ extern "C" int dz_set_tuning(int key, int value) {
     case 12: g_dgrad_weff = value; return DZ_OK;
     case 13: g_iqn_variant = value; return DZ_OK;
     case 14: DZ_REQUIRE(value >= 64 && value <= 65536); g_adam_blocks = value; return DZ_OK;
+    case 15: g_conv_xcd = value; return DZ_OK;
     default: return DZ_ERR_INVALID_ARG;
   }
 }

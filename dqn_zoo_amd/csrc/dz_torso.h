@@ -7,6 +7,7 @@
 #include "dz_sumtree_dev.h"
 
 extern int g_conv_fwd_variant[3];  // dz_core.hip; dz_set_tuning keys 9-11
+extern int g_conv_xcd;              // dz_core.hip; key 15
 
 namespace {
 
@@ -24,7 +25,10 @@ struct TorsoBufs {
 // 256 CUs; the variants trade tile size for workgroup count.
 template <class Op>
 inline int launch_conv_fwd(const ConvFwdParams& p, int CO, int G, int B, hipStream_t s) {
-  return dz_launch_gemm<Op>(p, dim3(CO / Op::BN, G * Op::tiles_per_group(B)), s);
+  const dim3 g(CO / Op::BN, G * Op::tiles_per_group(B), 1);
+  // column tiles of one pixel-row tile share the A operand: keep them on one XCD
+  if (g_conv_xcd && g.x > 1) return dz_launch_gemm_xcd<Op>(p, g, s);
+  return dz_launch_gemm<Op>(p, g, s);
 }
 template <class Op>
 inline int launch_conv1_fwd(const ConvFwdParams& p, int G, int B, const NoiseParams* side,

@@ -44,11 +44,11 @@ def main():
   lib = _lib.load()
   names = {0: '<1,2,2,KT4>', 1: '<1,2,2,KT2>', 2: '<1,2,2,KT1>', 3: '<1,4,1,KT4>',
            4: '<1,4,1,KT2>', 5: '<1,1,4,KT2>', 6: '<1,1,4,KT1>', 7: '<1,4,1,KT1>'}
-  for mode in (3, 4, 3, 4):
-    lib.dz_set_tuning(5, mode)
+  for x in (0, 1, 0, 1):
+    lib.dz_set_tuning(15, x)
     t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
-    print('fc1 bwd mode %d: %.2f total %.1f' % (mode, t['fc1_dgrad+wgrad'], sum(t.values())), flush=True)
-  lib.dz_set_tuning(5, 3)
+    print('conv xcd %d: conv2 %.2f conv3 %.2f total %.1f' % (x, t['conv2_fwd'], t['conv3_fwd'], sum(t.values())), flush=True)
+    print('   ', {k: round(v, 1) for k, v in t.items()}, flush=True)
 
 
 if __name__ == '__main__':
