@@ -139,7 +139,8 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
   const int G = a->loss == DZ_LOSS_DOUBLE_Q ? 3 : 2;
   const int B = a->batch, A = a->num_actions, N = a->num_outputs;
   if (a->loss == DZ_LOSS_CATEGORICAL)
-    DZ_REQUIRE(a->aux && a->num_atoms > 0 && a->num_atoms <= 64 && N == A * a->num_atoms);
+    DZ_REQUIRE(a->aux && a->num_atoms > 0 && a->num_atoms <= 64 && A <= 256 &&
+               N == A * a->num_atoms);
   else if (a->loss == DZ_LOSS_QUANTILE)
     DZ_REQUIRE(a->aux && a->num_atoms > 0 && a->num_atoms <= 256 && A <= 256 &&
                N == A * a->num_atoms);
@@ -175,7 +176,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
         DZ_REQUIRE(a->weights);  // c51 passes all-ones weights
         float* scratch = a->priorities ? a->priorities : ws + L.ws_scalars + 8;
         (void)scratch;
-        hipLaunchKernelGGL(rainbow_head_loss_kernel<0>, dim3(B), dim3(64), 0, s, out, ld2, 0,
+        hipLaunchKernelGGL(rainbow_head_loss_kernel<0>, dim3(B), dim3(256), 0, s, out, ld2, 0,
                            B, A, a->num_atoms, 0, 1, 1, a->a_tm1, a->r_t, a->discount_t,
                            a->weights, a->aux, dout, a->losses,
                            a->priorities ? a->priorities : (ws + L.ws_dfeat_part),

@@ -227,8 +227,10 @@ struct HeadPre {
   long b_sig;          // sigma-bias offset in the parameter vector
   int eps_out;         // its noise offset
 };
+// Launch with 256 threads: the 4 waves share the selector's per-action softmaxes
+// (A of them, 3 wave reductions each); wave 0 alone runs the rest.
 template <int PRE>
-__global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_head_loss_kernel(
+__global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
     float* __restrict__ fc2_out, int ld, int val_off, int B, int A, int K,
     int dueling, int sel_group, int tgt_group, const int64_t* __restrict__ a_tm1, const double* __restrict__ r_t,
     const double* __restrict__ d_t, const float* __restrict__ weights,
@@ -238,7 +240,9 @@ __global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_head_loss_kernel(
   extern __shared__ float s_rows[];  // PRE: [3][ld]
   __shared__ float s_p[64];
   __shared__ float s_z[64];
-  const int b = blockIdx.x, k = threadIdx.x;
+  __shared__ float s_q[256];         // selector q-values (A <= 256)
+  const int b = blockIdx.x, k = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   // every per-sample scalar and the support are requested NOW, so that their
   // trips to memory overlap the slab loads below instead of following them
   const int kk = min(k, K - 1);
@@ -286,7 +290,6 @@ __global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_head_loss_kernel(
       }
     }
     __syncthreads();
-    if (threadIdx.x >= 64) return;
   }
   const bool on = k < K;
   const int NA = val_off;  // value-head columns start at the padded offset
@@ -305,15 +308,23 @@ __global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_head_loss_kernel(
     mean_adv /= (float)A;
   }
   const float v1 = (on && dueling) ? o1[NA + k] : 0.f;
-  float best_q = -__builtin_inff();
-  int a_star = 0;
-  for (int a = 0; a < A; ++a) {
+  for (int a = wave; a < A; a += nwaves) {
     const float lg = on ? (v1 + o1[a * K + k] - mean_adv) : -__builtin_inff();
     const float mx = wave_max(lg);
     const float e = on ? expf(lg - mx) : 0.f;
     const float sm = wave_sum(e);
     const float q = wave_sum((e / sm) * z);
-    if (k == 0 && q_sel_out) q_sel_out[b * A + a] = q;
+    if (k == 0) {
+      s_q[a] = q;
+      if (q_sel_out) q_sel_out[b * A + a] = q;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  float best_q = -__builtin_inff();
+  int a_star = 0;
+  for (int a = 0; a < A; ++a) {
+    const float q = s_q[a];
     if (q > best_q) { best_q = q; a_star = a; }  // first maximum, as jnp.argmax
   }
   // ---- target distribution of the selected action ----

@@ -144,7 +144,7 @@ static void make_heads(const dz_rainbow_layout_t& L, FwdHeads& H) {
 
 // ---- layout -----------------------------------------------------------------
 extern "C" int dz_rainbow_layout(int A, int K, int B, dz_rainbow_layout_t* L) {
-  DZ_REQUIRE(L && A > 0 && K > 0 && K <= 64 && B > 0 && B <= 1024);
+  DZ_REQUIRE(L && A > 0 && A <= 256 && K > 0 && K <= 64 && B > 0 && B <= 1024);
   const int NA = A * K;
   L->num_actions = A; L->num_atoms = K; L->batch = B; L->groups = kG;
   int64_t o = 0;
@@ -252,7 +252,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
                            a->support, ws + L.ws_dout2, a->losses, a->priorities,
                            ws + L.ws_q_sel, ws + L.ws_target_probs, pre);
       } else {
-        hipLaunchKernelGGL(rainbow_head_loss_kernel<0>, dim3(B), dim3(64), 0, s,
+        hipLaunchKernelGGL(rainbow_head_loss_kernel<0>, dim3(B), dim3(256), 0, s,
                            ws + L.ws_fc2_out, ld2, NAp, B, A, K, 1, 1, 2, a->a_tm1, a->r_t,
                            a->discount_t, a->weights, a->support, ws + L.ws_dout2, a->losses,
                            a->priorities, ws + L.ws_q_sel, ws + L.ws_target_probs, pre);
