@@ -251,37 +251,38 @@ def measure_roofline(step, prof_steps, batch):
   return out
 
 
-def measure_replay(step, batch, n=100):
+def measure_replay(replay, learner, batch, n=100):
   """Device time of the replay kernels from HIP event pairs recorded INSIDE the
-  C entry points (dz_prof_read_replay), medians over n steps (SURVEY.md 8d:
+  C entry points (dz_prof_read_replay), medians over n rounds (SURVEY.md 8d:
   gather against HBM bandwidth; sum-tree sample / update as latency per query --
-  their bytes are trivial)."""
+  their bytes are trivial).  In the measured step sample+gather are ONE launch and
+  the write-back rides inside a backward launch; here each is also timed alone."""
   from dqn_zoo_amd import _lib
   lib = _lib.load()
   lib.dz_prof_enable(1)
   ms = (ctypes.c_float * 3)()
-  acc = [[], [], []]
+  stream = torch.cuda.current_stream(replay._device).cuda_stream  # pylint: disable=protected-access
+  fused, gather, update = [], [], []
   for _ in range(n):
-    step()
+    s = replay.sample_device(batch)                       # pair 0: sample + gather launch
+    replay._ring.gather(s.ids, batch, stream)             # pair 1: the gather alone  # pylint: disable=protected-access
+    replay.update_priorities(s.ids, learner.priorities)   # pair 2: the write-back alone
     torch.cuda.synchronize()
     lib.dz_prof_read_replay(ctypes.addressof(ms))
-    for i in range(3):
-      if ms[i] >= 0:
-        acc[i].append(ms[i] * 1e3)
+    fused.append(ms[0] * 1e3); gather.append(ms[1] * 1e3); update.append(ms[2] * 1e3)
   lib.dz_prof_enable(0)
-  t_sample, t_gather, t_update = (float(np.median(a)) if a else None for a in acc)
-  if t_update is None:
-    t_update = float('nan')
+  t_fused, t_gather, t_update = (float(np.median(a)) for a in (fused, gather, update))
   gather_bytes = 2 * batch * (2 * 28224 + 4 + 8 + 8)  # read + written
   return {
-      'sumtree_sample_us': round(t_sample, 2), 'gather_us': round(t_gather, 2),
+      'sample_plus_gather_us': round(t_fused, 2), 'gather_alone_us': round(t_gather, 2),
       'sumtree_update_us': round(t_update, 2),
-      'sumtree_sample_ns_per_query': round(1e3 * t_sample / batch, 1),
+      'sumtree_sample_ns_per_query': round(1e3 * t_fused / batch, 1),
       'sumtree_update_ns_per_leaf': round(1e3 * t_update / batch, 1),
       'gather_GBps': round(gather_bytes / t_gather / 1e3, 1),
       'gather_frac_of_hbm_peak': round(gather_bytes / (t_gather * 1e-6) / PEAK_HBM, 4),
-      'note': 'event pairs include ~2-3 us of event overhead each; one workgroup '
-              'walks 20 tree levels (capacity 1e6): dependent-load latency, not bytes'}
+      'note': 'event pairs include ~2-3 us of event overhead each; sample+gather is one '
+              'launch whose gather blocks re-derive their tree index (20 dependent loads, '
+              'capacity 1e6): dependent-load latency, not bytes'}
 
 
 def usable_cpus():
@@ -456,8 +457,7 @@ def main():
       out['roofline'] = measure_roofline(seq_step, args.prof_steps, args.batch)
       # the write-back timed as its own kernel (in the measured step it rides
       # inside a backward launch)
-      out['replay'] = measure_replay(make_step(replay, learner, args.batch,
-                                               fused_write_back=False), args.batch)
+      out['replay'] = measure_replay(replay, learner, args.batch)
     if world == 1 and args.cpu_seconds > 0:
       out['cpu_baseline'] = cpu_baseline(args, args.seed, args.cpu_seconds)
       out['speedup_vs_cpu_baseline'] = round(

@@ -219,6 +219,9 @@ SIGNATURES = {
     'dz_prioritized_sample_host_draws': (c_int, [ctypes.POINTER(PrioSampleArgs), c_int,
                                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                  c_vp, c_vp, c_vp, c_vp]),
+    'dz_prioritized_sample_gather': (c_int, [ctypes.POINTER(PrioSampleArgs), c_int, c_vp, c_vp,
+                                             c_vp, ctypes.POINTER(FieldDesc), c_int, c_vp,
+                                             c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dz_prioritized_update': (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp,
                                       c_vp, c_int, c_f64, c_int, c_vp, c_vp,
                                       c_vp]),

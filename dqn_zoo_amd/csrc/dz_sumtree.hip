@@ -122,14 +122,33 @@ struct HostDraws {
   double u_mix[kMaxHostDraws];
 };
 
+// Tree index drawn for batch element i (replay.py:551-567): uniform candidate,
+// prioritized candidate (descent), mix.  `bad` reports a target outside [0, root).
 template <int HOST_DRAWS>
-__global__ __launch_bounds__(kMaxBatch) void prioritized_sample_kernel(
-    dz_prio_sample_args_t a, HostDraws hd, int n, int64_t* __restrict__ ids_out,
+__device__ __forceinline__ int64_t sample_tree_index(const dz_prio_sample_args_t& a,
+                                                     const HostDraws& hd, int i, double root,
+                                                     bool zero_root, bool& bad) {
+  const int64_t N = a.capacity;
+  const int64_t pos_i = HOST_DRAWS ? hd.pos[i & (kMaxHostDraws - 1)] : a.pos[i];
+  const double ut_i = HOST_DRAWS ? hd.u_target[i & (kMaxHostDraws - 1)] : a.u_target[i];
+  const double um_i = HOST_DRAWS ? hd.u_mix[i & (kMaxHostDraws - 1)] : a.u_mix[i];
+  const int64_t uni_ti = tree_index_of_id(id_at_position(pos_i, N, a.t), N);
+  int64_t pri_ti = uni_ti;
+  bad = false;
+  if (!zero_root) {
+    const double target = ut_i * root;
+    if (!(0.0 <= target && target < root)) bad = true;
+    else pri_ti = descend(a.node, a.cap_pow2, target);
+  }
+  return (um_i < a.usp) ? uni_ti : pri_ti;
+}
+
+template <int HOST_DRAWS>
+__device__ __forceinline__ void prioritized_sample_body(
+    const dz_prio_sample_args_t& a, const HostDraws& hd, int n, int64_t* __restrict__ ids_out,
     int64_t* __restrict__ tree_idx_out, double* __restrict__ probs_out,
     double* __restrict__ weights_out, float* __restrict__ weights32_out,
-    uint32_t* status) {
-  __shared__ double s_red[kMaxBatch / 64];
-  __shared__ double s_max;
+    uint32_t* status, double* s_red, double& s_max) {
   const int i = threadIdx.x;
   const bool active = i < n;
   const double* __restrict__ node = a.node;
@@ -140,23 +159,9 @@ __global__ __launch_bounds__(kMaxBatch) void prioritized_sample_kernel(
 
   double w = 0.0;
   if (active) {
-    // uniform candidate: replay.py:551-554
-    const int64_t pos_i = HOST_DRAWS ? hd.pos[i & (kMaxHostDraws - 1)] : a.pos[i];
-    const double ut_i = HOST_DRAWS ? hd.u_target[i & (kMaxHostDraws - 1)] : a.u_target[i];
-    const double um_i = HOST_DRAWS ? hd.u_mix[i & (kMaxHostDraws - 1)] : a.u_mix[i];
-    const int64_t uni_ti = tree_index_of_id(id_at_position(pos_i, N, a.t), N);
-    // prioritized candidate: replay.py:556-560
-    int64_t pri_ti = uni_ti;
-    if (!zero_root) {
-      const double target = ut_i * root;
-      if (!(0.0 <= target && target < root)) {
-        raise(status, DZ_ST_BAD_TARGET);
-      } else {
-        pri_ti = descend(node, cap, target);
-      }
-    }
-    // mix: replay.py:562-567
-    const int64_t ti = (um_i < a.usp) ? uni_ti : pri_ti;
+    bool bad;
+    const int64_t ti = sample_tree_index<HOST_DRAWS>(a, hd, i, root, zero_root, bad);
+    if (bad) raise(status, DZ_ST_BAD_TARGET);
     // probabilities: replay.py:569-577 (separate mul, mul, add: no FMA)
     const double leaf = node[cap + ti];
     const double pp = zero_root ? a.uniform_prob : leaf / root;
@@ -199,6 +204,63 @@ __global__ __launch_bounds__(kMaxBatch) void prioritized_sample_kernel(
     if (!(w - w == 0.0)) raise(status, DZ_ST_NONFINITE_WEIGHT);  // replay.py:241
     if (weights_out) weights_out[i] = w;
     if (weights32_out) weights32_out[i] = (float)w;  // the jit-boundary cast
+  }
+}
+
+template <int HOST_DRAWS>
+__global__ __launch_bounds__(kMaxBatch) void prioritized_sample_kernel(
+    dz_prio_sample_args_t a, HostDraws hd, int n, int64_t* __restrict__ ids_out,
+    int64_t* __restrict__ tree_idx_out, double* __restrict__ probs_out,
+    double* __restrict__ weights_out, float* __restrict__ weights32_out,
+    uint32_t* status) {
+  __shared__ double s_red[kMaxBatch / 64];
+  __shared__ double s_max;
+  prioritized_sample_body<HOST_DRAWS>(a, hd, n, ids_out, tree_idx_out, probs_out, weights_out,
+                                      weights32_out, status, s_red, s_max);
+}
+
+// Sample AND gather in one launch (batch <= 64, draws in the kernel arguments).
+// Block row y == n is the sampler proper (ids, probabilities, IS weights: exactly
+// prioritized_sample_body); every gather block (x = chunk, y = batch element,
+// z = field) re-derives ITS element's tree index with the same arithmetic (one
+// thread, ~20 dependent loads that hit L2 after the first block) instead of
+// waiting for a second launch to read ids[]: the descent and the copy overlap.
+struct SampleGatherFields { dz_field_t f[DZ_MAX_FIELDS]; int num_fields; };
+__global__ __launch_bounds__(256) void prioritized_sample_gather_kernel(
+    dz_prio_sample_args_t a, HostDraws hd, int n, SampleGatherFields gf,
+    int64_t* __restrict__ ids_out, double* __restrict__ probs_out,
+    double* __restrict__ weights_out, float* __restrict__ weights32_out, uint32_t* status) {
+  __shared__ double s_red[4];
+  __shared__ double s_max;
+  __shared__ int64_t s_slot;
+  if ((int)blockIdx.y == n) {
+    if (blockIdx.x == 0 && blockIdx.z == 0)
+      prioritized_sample_body<1>(a, hd, n, ids_out, nullptr, probs_out, weights_out,
+                                 weights32_out, status, s_red, s_max);
+    return;
+  }
+  const int b = blockIdx.y;
+  if (threadIdx.x == 0) {
+    const double root = a.node[1];
+    bool bad;
+    const int64_t ti = sample_tree_index<1>(a, hd, b, root, root == 0.0, bad);
+    s_slot = dz_mod(id_of_tree_index(ti, a.capacity, a.t, a.size), a.capacity);
+  }
+  __syncthreads();
+  const dz_field_t fd = gf.f[blockIdx.z];
+  const int64_t rb = fd.row_bytes;
+  const char* src = (const char*)fd.src + s_slot * rb;
+  char* dst = (char*)fd.dst + (int64_t)b * rb;
+  const bool vec_ok = ((rb & 15) == 0) && ((((uintptr_t)fd.src) & 15) == 0) &&
+                      ((((uintptr_t)fd.dst) & 15) == 0);
+  if (vec_ok) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int64_t nvec = rb >> 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256)
+      ((u32x4*)dst)[i] = __builtin_nontemporal_load((const u32x4*)src + i);
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rb; i += (int64_t)gridDim.x * 256)
+      dst[i] = src[i];
   }
 }
 
@@ -364,6 +426,43 @@ extern "C" int dz_prioritized_sample_host_draws(
   hipLaunchKernelGGL(prioritized_sample_kernel<1>, dim3(1), dim3(round_up_64(batch)), 0,
                      dz_s(stream), *args, hd, batch, ids_out, tree_idx_out, probs_out,
                      weights_out, weights32_out, status);
+  DZ_LAUNCH_CHECK();
+  dz_prof_pair(0, 1, dz_s(stream));
+  return DZ_OK;
+}
+
+extern "C" int dz_prioritized_sample_gather(
+    const dz_prio_sample_args_t* args, int batch, const int64_t* pos_h,
+    const double* u_target_h, const double* u_mix_h, const dz_field_t* fields,
+    int num_fields, int64_t* ids_out, double* probs_out, double* weights_out,
+    float* weights32_out, uint32_t* status, dz_stream_t stream) {
+  DZ_REQUIRE(args && ids_out && batch > 0 && batch <= kMaxHostDraws);
+  DZ_REQUIRE(args->node && dz_is_pow2(args->cap_pow2) && args->capacity > 0 &&
+             args->capacity <= args->cap_pow2);
+  DZ_REQUIRE(args->size > 0 && args->size <= args->capacity && args->t >= args->size);
+  DZ_REQUIRE(pos_h && u_target_h && u_mix_h && fields && num_fields > 0 &&
+             num_fields <= DZ_MAX_FIELDS);
+  HostDraws hd;
+  for (int i = 0; i < kMaxHostDraws; ++i) {
+    const int j = i < batch ? i : 0;
+    hd.pos[i] = pos_h[j]; hd.u_target[i] = u_target_h[j]; hd.u_mix[i] = u_mix_h[j];
+  }
+  SampleGatherFields gf;
+  gf.num_fields = num_fields;
+  int64_t max_rb = 0;
+  for (int i = 0; i < num_fields; ++i) {
+    DZ_REQUIRE(fields[i].src && fields[i].dst && fields[i].row_bytes > 0);
+    gf.f[i] = fields[i];
+    if (fields[i].row_bytes > max_rb) max_rb = fields[i].row_bytes;
+  }
+  int64_t chunks = ((max_rb >> 4) + 255) / 256;
+  if (chunks < 1) chunks = 1;
+  if (chunks > 64) chunks = 64;
+  dz_prof_pair(0, 0, dz_s(stream));
+  hipLaunchKernelGGL(prioritized_sample_gather_kernel,
+                     dim3((unsigned)chunks, (unsigned)batch + 1, (unsigned)num_fields), dim3(256),
+                     0, dz_s(stream), *args, hd, batch, gf, ids_out, probs_out, weights_out,
+                     weights32_out, status);
   DZ_LAUNCH_CHECK();
   dz_prof_pair(0, 1, dz_s(stream));
   return DZ_OK;

@@ -768,18 +768,18 @@ class PrioritizedTransitionReplay(_ReplayBase):
     a.beta = beta
     lib = _lib.load()
     stream = self._stream()
-    if via_args:
+    if via_args:  # ONE launch: sample (draws in the kernel arguments) + gather
       hp = slot.host.data_ptr()
-      _lib.check(lib.dz_prioritized_sample_host_draws(
-          ctypes.byref(a), size, hp, hp + 8 * size, hp + 16 * size,
-          slot.ids.data_ptr(), None, slot.probs.data_ptr(), slot.w64.data_ptr(),
-          slot.w32.data_ptr(), self._status.word.data_ptr(), stream),
-                 'dz_prioritized_sample_host_draws')
-    else:
-      _lib.check(lib.dz_prioritized_sample(
-          ctypes.byref(a), size, slot.ids.data_ptr(), None, slot.probs.data_ptr(),
+      _lib.check(lib.dz_prioritized_sample_gather(
+          ctypes.byref(a), size, hp, hp + 8 * size, hp + 16 * size, slot.fields,
+          len(self._ring.fields), slot.ids.data_ptr(), slot.probs.data_ptr(),
           slot.w64.data_ptr(), slot.w32.data_ptr(), self._status.word.data_ptr(),
-          stream), 'dz_prioritized_sample')
+          stream), 'dz_prioritized_sample_gather')
+      return slot.sample
+    _lib.check(lib.dz_prioritized_sample(
+        ctypes.byref(a), size, slot.ids.data_ptr(), None, slot.probs.data_ptr(),
+        slot.w64.data_ptr(), slot.w32.data_ptr(), self._status.word.data_ptr(),
+        stream), 'dz_prioritized_sample')
     _lib.check(lib.dz_replay_gather(slot.fields, len(self._ring.fields),
                                     slot.ids.data_ptr(), size, self._capacity,
                                     stream), 'dz_replay_gather')

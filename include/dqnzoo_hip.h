@@ -195,6 +195,16 @@ int dz_prioritized_sample_host_draws(
     int64_t* tree_idx_out, double* probs_out, double* weights_out,
     float* weights32_out, uint32_t* status, dz_stream_t stream);
 
+/* dz_prioritized_sample_host_draws AND dz_replay_gather in ONE launch: the
+ * gather blocks re-derive their element's tree index with the sampler's own
+ * arithmetic instead of waiting for ids[] from a previous launch.
+ * ref: replay.py:706-723 (PrioritizedTransitionReplay.sample).                */
+int dz_prioritized_sample_gather(
+    const dz_prio_sample_args_t* args, int batch, const int64_t* pos_host,
+    const double* u_target_host, const double* u_mix_host, const dz_field_t* fields,
+    int num_fields, int64_t* ids_out, double* probs_out, double* weights_out,
+    float* weights32_out, uint32_t* status, dz_stream_t stream);
+
 /* leaf(id) = power_zero_safe(priority, exponent) for each id, then SumTree.set.
  * `prio_is_f32`: priorities are float32 and -- as NumPy does for an f32 array
  * raised to a Python-float exponent -- the power is evaluated in float32.
