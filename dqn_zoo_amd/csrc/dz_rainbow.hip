@@ -33,6 +33,7 @@ int g_fc1_dgrad_splits = 16;
 int g_dgrad_weff = 1;         // fc1 input gradient against W_eff (depth N, not 2N): 14.2 vs 17.2 us
 int g_fc2_splits = 8;         // 12 us (4 splits: 19 us)
 int g_adam_blocks = 2048;     // grid-stride Adam launch width
+int g_fc2_dgrad_splits = kS_dh1;  // 1: unsplit, no reduce launch
 
 }  // namespace
 
@@ -302,24 +303,31 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       w.grad = grad;
       w.sumsq = sq_slots; w.sq_nx = (NA + FcWg::BN - 1) / FcWg::BN; w.sq_ny = kHid / FcWg::BM;
       FcDgradParams d[2];
+      const int s_dh1 = g_fc2_dgrad_splits;
       for (int h = 0; h < 2; ++h) {
         d[h].dy = ws + L.ws_dout2; d[h].ldy = ld2; d[h].M = B; d[h].NH = 1;
         // (the W_eff form of this small input gradient measured slower: 16.4 vs 14.1 us)
-        d[h].S = kS_dh1; d[h].noisy = 1; d[h].params = a->online; d[h].noise = nz[0];
+        d[h].S = s_dh1; d[h].noisy = 1; d[h].params = a->online; d[h].noise = nz[0];
         d[h].head[0] = fc2h[h]; d[h].head[1] = fc2h[h];
-        d[h].part = ws + L.ws_dfeat_part; d[h].ldo = 1024; d[h].K = kHid;
-        d[h].x_off = 512 * h;
+        d[h].ldo = 1024; d[h].K = kHid; d[h].x_off = 512 * h;
+        if (s_dh1 == 1) {  // unsplit: straight into dh1 with the ReLU mask in the store
+          d[h].part = ws + L.ws_dh1; d[h].relu_mask = ws + L.ws_h1;
+        } else {
+          d[h].part = ws + L.ws_dfeat_part;
+        }
       }
-      const dim3 gd(kHid / FcDg::BN, (B + 31) / 32, kS_dh1);
+      const dim3 gd(kHid / FcDg::BN, (B + 31) / 32, s_dh1);
       rc = dz_launch_gemm3<FcWg, FcDg, FcDg>(
           w, dim3((NA + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 2), d[0], gd, d[1], gd, s);
       if (rc) return rc;
       DZ_PROF(s, "fc2_wgrad+dgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * 1024 + 63) / 64), dim3(256), 0,
-                         s, ws + L.ws_dfeat_part, kS_dh1, (long)B * 1024, ws + L.ws_h1,
-                         ws + L.ws_dh1);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "dh1_reduce");
+      if (s_dh1 > 1) {
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * 1024 + 63) / 64), dim3(256), 0,
+                           s, ws + L.ws_dfeat_part, s_dh1, (long)B * 1024, ws + L.ws_h1,
+                           ws + L.ws_dh1);
+        DZ_LAUNCH_CHECK();
+        DZ_PROF(s, "dh1_reduce");
+      }
     }
     {  // fc1: weight gradients + input gradient (adv1 + val1 paths) -> dfeat
       FcWgradParams w;
@@ -594,6 +602,7 @@ extern "C" int dz_set_tuning(int key, int value) {
     case 13: g_iqn_variant = value; return DZ_OK;
     case 14: DZ_REQUIRE(value >= 64 && value <= 65536); g_adam_blocks = value; return DZ_OK;
     case 15: g_conv_xcd = value; return DZ_OK;
+    case 16: DZ_REQUIRE(value >= 1 && value <= kS_dh1); g_fc2_dgrad_splits = value; return DZ_OK;
     default: return DZ_ERR_INVALID_ARG;
   }
 }

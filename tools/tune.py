@@ -44,11 +44,11 @@ def main():
   lib = _lib.load()
   names = {0: '<1,2,2,KT4>', 1: '<1,2,2,KT2>', 2: '<1,2,2,KT1>', 3: '<1,4,1,KT4>',
            4: '<1,4,1,KT2>', 5: '<1,1,4,KT2>', 6: '<1,1,4,KT1>', 7: '<1,4,1,KT1>'}
-  for x in (0, 1, 0, 1):
-    lib.dz_set_tuning(15, x)
+  for sp in (5, 1, 2, 5, 1):
+    lib.dz_set_tuning(16, sp)
     t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
-    print('conv xcd %d: conv2 %.2f conv3 %.2f total %.1f' % (x, t['conv2_fwd'], t['conv3_fwd'], sum(t.values())), flush=True)
-    print('   ', {k: round(v, 1) for k, v in t.items()}, flush=True)
+    print('fc2 dgrad splits %d: fc2 bwd %.2f reduce %.2f total %.1f' % (
+        sp, t['fc2_wgrad+dgrad'], t.get('dh1_reduce', 0.0), sum(t.values())), flush=True)
 
 
 if __name__ == '__main__':
