@@ -388,6 +388,10 @@ def main():
   if world > 1:
     import torch.distributed as dist  # RCCL (backend "nccl" on ROCm)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    # NCCL_DEBUG=VERSION (set in this image) makes RCCL print a version banner on
+    # STDOUT; stdout carries the one JSON line only
+    if os.environ.get('NCCL_DEBUG', '').upper() == 'VERSION':
+      os.environ['NCCL_DEBUG'] = 'NONE'
     dist.init_process_group('nccl', rank=rank, world_size=world,
                             device_id=device)
 
@@ -462,6 +466,10 @@ def main():
       out['cpu_baseline'] = cpu_baseline(args, args.seed, args.cpu_seconds)
       out['speedup_vs_cpu_baseline'] = round(
           value / out['cpu_baseline']['value'], 1)
+    try:  # anything a C library buffered on stdout goes out BEFORE the JSON line
+      ctypes.CDLL(None).fflush(None)
+    except OSError:
+      pass
     print(json.dumps(out), flush=True)
   if dist is not None:
     dist.barrier()
