@@ -225,7 +225,9 @@ struct FcFwdOp {
     t.z = g; t.z2 = h | (split << 8);
     t.m0 = bid.y * BM;
     t.n0 = bid.x * BN;
-    const int chunks = (hd.K / 16) * (p.noisy ? 2 : 1);
+    // noisy == 1: depth 2K over [x | x.eps_in] [Wmu ; Wsig.eps_out];
+    // noisy == 2: depth K against W_eff = Wmu + Wsig (eps_in (x) eps_out), built in load_b
+    const int chunks = (hd.K / 16) * (p.noisy == 1 ? 2 : 1);
     const int stages = (chunks + CPS - 1) / CPS;
     const int per = (stages + p.S - 1) / p.S;
     t.st_begin = split * per;
@@ -235,7 +237,7 @@ struct FcFwdOp {
   __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {
     const FcHead& hd = t.hd;
-    const int kc = hd.K / 16, total = kc * (p.noisy ? 2 : 1);
+    const int kc = hd.K / 16, total = kc * (p.noisy == 1 ? 2 : 1);
     const int gc = st * CPS + c;
     const int m = t.m0 + row;
     const bool ok = (m < p.M) & (gc < total);
@@ -249,7 +251,7 @@ struct FcFwdOp {
   __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
     const FcHead& hd = t.hd;
-    const int kc = hd.K / 16, total = kc * (p.noisy ? 2 : 1);
+    const int kc = hd.K / 16, total = kc * (p.noisy == 1 ? 2 : 1);
     const int gc = st * CPS + c;
     const bool ok = gc < total;
     const int gcc = min(gc, total - 1);
@@ -258,6 +260,12 @@ struct FcFwdOp {
     const int n = min(t.n0 + 4 * rq, hd.ldw - 4);
     const float4 v = dz_ld4(t.prm + (sig ? hd.w_sig : hd.w_mu) + (long)k * hd.ldw + n);
     const float4 e = dz_ld4(t.nz + hd.eps_out + n);
+    if (p.noisy == 2) {
+      const float4 sg = dz_ld4(t.prm + hd.w_sig + (long)k * hd.ldw + n);
+      const float ei = t.nz[hd.eps_in + k];
+      return dz_sel4(ok, dz_f4(__builtin_fmaf(sg.x, ei * e.x, v.x), __builtin_fmaf(sg.y, ei * e.y, v.y),
+                               __builtin_fmaf(sg.z, ei * e.z, v.z), __builtin_fmaf(sg.w, ei * e.w, v.w)));
+    }
     return dz_sel4(ok, sig ? dz_mul4(v, e) : v);
   }
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,

@@ -32,6 +32,7 @@ int g_fc1_dgrad_variant = 2;  // FcDgradOp<1,2,2,KT=1>
 int g_fc1_dgrad_splits = 16;
 int g_dgrad_weff = 1;         // fc1 input gradient against W_eff (depth N, not 2N): 14.2 vs 17.2 us
 int g_fc2_splits = 8;         // 12 us (4 splits: 19 us)
+int g_fc2_weff = 1;           // fc2 forward against W_eff (depth K): 11.2 vs 12.1 us
 int g_adam_blocks = 2048;     // grid-stride Adam launch width
 int g_fc2_dgrad_splits = kS_dh1;  // 1: unsplit, no reduce launch
 
@@ -102,7 +103,7 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
   {  // fc2: noisy adv2 (no mu bias) and val2 (no mu bias)
     FcFwdParams p;
     p.x = ws + L.ws_h1; p.ldx = 1024; p.M = B; p.G = G; p.NH = 2; p.S = g_fc2_splits;
-    p.noisy = 1;
+    p.noisy = g_fc2_weff ? 2 : 1;
     for (int g = 0; g < G; ++g) { p.params[g] = prm[g]; p.noise[g] = nz[g]; }
     p.head[0] = fc2h[0]; p.head[1] = fc2h[1];
     p.part = ws + L.ws_fc2_part; p.ldo = ld2;
@@ -603,6 +604,7 @@ extern "C" int dz_set_tuning(int key, int value) {
     case 14: DZ_REQUIRE(value >= 64 && value <= 65536); g_adam_blocks = value; return DZ_OK;
     case 15: g_conv_xcd = value; return DZ_OK;
     case 16: DZ_REQUIRE(value >= 1 && value <= kS_dh1); g_fc2_dgrad_splits = value; return DZ_OK;
+    case 17: g_fc2_weff = value; return DZ_OK;
     default: return DZ_ERR_INVALID_ARG;
   }
 }

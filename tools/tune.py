@@ -44,11 +44,12 @@ def main():
   lib = _lib.load()
   names = {0: '<1,2,2,KT4>', 1: '<1,2,2,KT2>', 2: '<1,2,2,KT1>', 3: '<1,4,1,KT4>',
            4: '<1,4,1,KT2>', 5: '<1,1,4,KT2>', 6: '<1,1,4,KT1>', 7: '<1,4,1,KT1>'}
-  for sp in (5, 1, 2, 5, 1):
-    lib.dz_set_tuning(16, sp)
+  for weff, spl in ((0, 8), (1, 8), (1, 4), (0, 8), (1, 8), (1, 4)):
+    lib.dz_set_tuning(17, weff); lib.dz_set_tuning(8, spl)
     t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
-    print('fc2 dgrad splits %d: fc2 bwd %.2f reduce %.2f total %.1f' % (
-        sp, t['fc2_wgrad+dgrad'], t.get('dh1_reduce', 0.0), sum(t.values())), flush=True)
+    print('fc2 fwd weff %d S=%d: fc2_fwd %.2f head_loss %.2f total %.1f' % (
+        weff, spl, t['fc2_fwd'], t['head_loss'], sum(t.values())), flush=True)
+  lib.dz_set_tuning(17, 1); lib.dz_set_tuning(8, 8)
 
 
 if __name__ == '__main__':
