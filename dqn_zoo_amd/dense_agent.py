@@ -15,14 +15,12 @@ no host synchronisation.
 from typing import Any, Mapping
 
 import numpy as np
-import torch
 
 from dqn_zoo_amd import device_obs
 from dqn_zoo_amd import learner as learner_lib
 from dqn_zoo_amd import networks
 from dqn_zoo_amd import parts
 from dqn_zoo_amd import processors
-from dqn_zoo_amd import replay as replay_lib
 
 
 def epsilon_greedy_sample(q_values: np.ndarray, epsilon: float,

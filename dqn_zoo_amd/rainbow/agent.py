@@ -18,7 +18,6 @@ round trips per learner step, rainbow/agent.py:184-198).
 from typing import Any, Mapping
 
 import numpy as np
-import torch
 
 from dqn_zoo_amd import device_obs
 from dqn_zoo_amd import learner as learner_lib
