@@ -531,13 +531,16 @@ int dz_prof_read_replay(float* ms_out);
 
 /* Tuning knobs for tools/tune.py (kernel variant / split-K sweeps in one GPU
  * session).  key: 0 = fc1 forward variant (10 = shared weight stream [default],
- * 8/9 = per-apply streams, 0-7 = tile GEMMs), 1 = fc1 forward k-splits (<= 32),
- * 2 = fc1 input-gradient streaming kernel on/off, 5 = fused fc1 launch runs the
- * input gradient's blocks first, 6 = fc1 input-gradient tile variant, 7 = its
- * split factor (<= 32), 8 = fc2 forward k-splits (<= 8), 9/10/11 = conv1/2/3
- * forward tile variant (dz_torso.h), 12 = fc1 input gradient against W_eff
- * (depth N) instead of the two-GEMM form (depth 2N).  Keys 3 and 4 are retired
- * experiments (accepted, ignored).  Defaults are the measured best.            */
+ * else the tile GEMM), 1 = fc1 forward k-splits (<= 32), 2 = fc1 forward blocks
+ * in XCD-aware order, 5 = fc1 backward launch form (3/2 = weight + input gradient
+ * in one launch, wgrad / dgrad blocks first; 4 = same in XCD order; 1/0 = two
+ * launches), 6 = fc1 input-gradient tile variant, 7 = its split factor (<= 32),
+ * 8 = fc2 forward k-splits (<= 8), 9/10/11 = conv1/2/3 forward tile variant
+ * (dz_torso.h), 12 = fc1 input gradient against W_eff (depth N) instead of the
+ * two-GEMM form (depth 2N), 13 = IQN value-head GEMM tiling (dz_iqn.hip),
+ * 14 = Adam launch width (blocks), 15 = conv forward tiles in XCD-aware order,
+ * 16 = fc2 input-gradient k-splits (<= 5), 17 = fc2 forward against W_eff.
+ * Keys 3 and 4 are retired (accepted, ignored).  Defaults are the measured best. */
 int dz_set_tuning(int key, int value);
 
 /* dst = src for a parameter buffer (target network sync,
