@@ -130,8 +130,12 @@ class DenseAgent(parts.Agent):
       t = s.transitions
       # priorities = |td| (prioritized/agent.py:202) go into the sum tree (and the
       # running max) inside the step's backward launches
-      ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
-              priority_sink=self._replay.priority_sink(s.ids))
+      if self._batch_size <= 256:
+        ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
+                priority_sink=self._replay.priority_sink(s.ids))
+      else:  # the side block handles up to 256 leaves
+        ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32)
+        self._replay.update_priorities(s.ids, ln.priorities)
     else:
       t, _ = self._replay.sample_device(self._batch_size)
       ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, None)

@@ -122,8 +122,12 @@ class Rainbow(parts.Agent):
     # priorities = clip(|losses|, 0, 100) are written by the loss kernel and go
     # straight into the sum tree (and the running max priority) inside the
     # step's backward launches: no separate update_priorities kernel.
-    self._learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
-                       priority_sink=self._replay.priority_sink(s.ids))
+    if self._batch_size <= 256:
+      self._learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
+                         priority_sink=self._replay.priority_sink(s.ids))
+    else:  # the side block handles up to 256 leaves
+      self._learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32)
+      self._replay.update_priorities(s.ids, self._learner.priorities)
 
   # -- properties ----------------------------------------------------------------
   @property
