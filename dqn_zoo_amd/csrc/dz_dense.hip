@@ -99,7 +99,7 @@ static int dense_forward(const dz_dense_layout_t& L, int G, int B, const float* 
       for (int g = 0; g < 3; ++g) { p.params[g] = p3[g]; p.noise[g] = zeros; }
       p.head[0] = h1; p.head[1] = h1;
       p.part = ws + L.ws_fc1_part; p.ldo = kHid;
-      rc = dz_launch_gemm<FcFwd>(p, dim3(kHid / FcFwd::BN, (B + 31) / 32, G * kS_dfc1), s);
+      rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4, 0>>(p, dim3(kHid / FcFwd::BN, (B + 31) / 32, G * kS_dfc1), s);
       if (rc) return rc;
     }
     DZ_PROF(s, "fc1_fwd");
@@ -118,7 +118,7 @@ static int dense_forward(const dz_dense_layout_t& L, int G, int B, const float* 
     for (int g = 0; g < 3; ++g) { p.params[g] = p3[g]; p.noise[g] = zeros; }
     p.head[0] = h2; p.head[1] = h2;
     p.part = ws + L.ws_fc2_part; p.ldo = ld2;
-    rc = dz_launch_gemm<FcFwd>(p, dim3((N + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32,
+    rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4, 0>>(p, dim3((N + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32,
                                       G * kS_fc2), s);
     if (rc) return rc;
     DZ_PROF(s, "fc2_fwd");
@@ -207,7 +207,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       d.dy = ws + L.ws_dout; d.ldy = ld2; d.M = B; d.NH = 1; d.S = s_dh1; d.noisy = 0;
       d.params = a->online; d.noise = zeros; d.head[0] = h2; d.head[1] = h2;
       d.part = ws + L.ws_dfeat_part; d.ldo = kHid; d.K = kHid; d.x_off = 0;
-      rc = dz_launch_gemm2<FcWg, FcDg>(
+      rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 4, 1, 1, 0>>(
           w, dim3((N + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 1), d,
           dim3(kHid / FcDg::BN, (B + 31) / 32, s_dh1), s);
       if (rc) return rc;
@@ -228,7 +228,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       d.params = a->online; d.noise = zeros; d.head[0] = h1; d.head[1] = h1;
       d.part = ws + L.ws_dfeat_part; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
       // weight gradient and input gradient in ONE launch (as in dz_rainbow.hip)
-      rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1>>(
+      rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 0>>(
           w, dim3(kHid / FcWg::BN, kFlat / FcWg::BM, 1), d,
           dim3(kFlat / 64, (B + 31) / 32, kS_ddfeat), s);
       if (rc) return rc;
@@ -283,7 +283,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
                          (long)L.param_count, ws + L.ws_norm_part, a->opt_count);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "grad_sumsq");
-      hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
+      hipLaunchKernelGGL(adam_kernel<0>, dim3(2048), dim3(256), 0, s, a->online, a->grad,
                          a->opt_m, a->opt_v, (long)(L.param_count >> 2),
                          ws + L.ws_norm_part, kNormBlocks, a->opt_count, a->losses, wts, B,
                          sc, a->lr, a->decay_or_b1, a->b2, a->eps, a->max_norm);

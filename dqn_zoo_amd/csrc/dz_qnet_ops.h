@@ -29,6 +29,14 @@ __device__ __forceinline__ float4 dz_ld4(const float* p) { return *(const float4
 __device__ __forceinline__ float4 dz_sel4(bool ok, float4 v) {
   return dz_f4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
+// c ? e : (1,1,1,1): a divergent `c ? v * e : v` becomes an exec-masked block with
+// its own vmcnt(0) wait; v * (c ? e : 1) is branch-free and exact (x * 1 == x)
+__device__ __forceinline__ float4 dz_one_or4(bool c, float4 e) {
+  return dz_f4(c ? e.x : 1.f, c ? e.y : 1.f, c ? e.z : 1.f, c ? e.w : 1.f);
+}
+// c ? a : b on VALUES (see FcDgradOp::locate)
+template <class T>
+__device__ __forceinline__ T dz_val(bool c, T a, T b) { return c ? a : b; }
 // keep v[j] iff i+j < n
 __device__ __forceinline__ float4 dz_mask4(float4 v, int i, int n) {
   return dz_f4(i < n ? v.x : 0.f, i + 1 < n ? v.y : 0.f, i + 2 < n ? v.z : 0.f,
@@ -206,8 +214,13 @@ struct FcFwdParams {
   int ldo;
 };
 
-template <int WM_, int WN_, int WK_, int KT_ = 1>
+// NZ_ >= 0 fixes Params::noisy at compile time: the run-time `noisy == 2` test in
+// the loader splits it into basic blocks, and each block waits for its own loads
+// before the next block issues any (one round trip per block instead of one per
+// stage).
+template <int WM_, int WN_, int WK_, int KT_ = 1, int NZ_ = -1>
 struct FcFwdOp {
+  __device__ static int nzy(const FcFwdParams& p) { return NZ_ >= 0 ? NZ_ : p.noisy; }
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_RC, A_MAP = DZ_MAP_QUAD;
   static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
@@ -227,7 +240,7 @@ struct FcFwdOp {
     t.n0 = bid.x * BN;
     // noisy == 1: depth 2K over [x | x.eps_in] [Wmu ; Wsig.eps_out];
     // noisy == 2: depth K against W_eff = Wmu + Wsig (eps_in (x) eps_out), built in load_b
-    const int chunks = (hd.K / 16) * (p.noisy == 1 ? 2 : 1);
+    const int chunks = (hd.K / 16) * (nzy(p) == 1 ? 2 : 1);
     const int stages = (chunks + CPS - 1) / CPS;
     const int per = (stages + p.S - 1) / p.S;
     t.st_begin = split * per;
@@ -237,7 +250,7 @@ struct FcFwdOp {
   __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {
     const FcHead& hd = t.hd;
-    const int kc = hd.K / 16, total = kc * (p.noisy == 1 ? 2 : 1);
+    const int kc = hd.K / 16, total = kc * (nzy(p) == 1 ? 2 : 1);
     const int gc = st * CPS + c;
     const int m = t.m0 + row;
     const bool ok = (m < p.M) & (gc < total);
@@ -246,12 +259,12 @@ struct FcFwdOp {
     const int k = (gcc - (sig ? kc : 0)) * 16 + 4 * q;
     const float4 v = dz_ld4(p.x + (long)(t.z * p.M + min(m, p.M - 1)) * p.ldx + hd.x_off + k);
     const float4 e = dz_ld4(t.nz + hd.eps_in + k);  // L2-resident, tiny
-    return dz_sel4(ok, sig ? dz_mul4(v, e) : v);
+    return dz_sel4(ok, dz_mul4(v, dz_one_or4(sig, e)));
   }
   __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
     const FcHead& hd = t.hd;
-    const int kc = hd.K / 16, total = kc * (p.noisy == 1 ? 2 : 1);
+    const int kc = hd.K / 16, total = kc * (nzy(p) == 1 ? 2 : 1);
     const int gc = st * CPS + c;
     const bool ok = gc < total;
     const int gcc = min(gc, total - 1);
@@ -260,13 +273,13 @@ struct FcFwdOp {
     const int n = min(t.n0 + 4 * rq, hd.ldw - 4);
     const float4 v = dz_ld4(t.prm + (sig ? hd.w_sig : hd.w_mu) + (long)k * hd.ldw + n);
     const float4 e = dz_ld4(t.nz + hd.eps_out + n);
-    if (p.noisy == 2) {
+    if (nzy(p) == 2) {
       const float4 sg = dz_ld4(t.prm + hd.w_sig + (long)k * hd.ldw + n);
       const float ei = t.nz[hd.eps_in + k];
       return dz_sel4(ok, dz_f4(__builtin_fmaf(sg.x, ei * e.x, v.x), __builtin_fmaf(sg.y, ei * e.y, v.y),
                                __builtin_fmaf(sg.z, ei * e.z, v.z), __builtin_fmaf(sg.w, ei * e.w, v.w)));
     }
-    return dz_sel4(ok, sig ? dz_mul4(v, e) : v);
+    return dz_sel4(ok, dz_mul4(v, dz_one_or4(sig, e)));
   }
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
@@ -307,14 +320,23 @@ struct FcDgradParams {
   const float* relu_mask = nullptr;
 };
 
-template <int WM_, int WN_, int WK_, int KT_ = 1, int MI_ = 1, int NI_ = 1>
+template <int WM_, int WN_, int WK_, int KT_ = 1, int MI_ = 1, int NI_ = 1, int NZ_ = -1>
 struct FcDgradOp {
+  __device__ __forceinline__ static int nzy(const FcDgradParams& p) { return NZ_ >= 0 ? NZ_ : p.noisy; }  // see FcFwdOp
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int MI = MI_, NI = NI_;
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_KC, A_MAP = DZ_MAP_QUAD;
   static constexpr int BM = 32 * WM * MI, BN = 32 * WN * NI, BK = 16 * CPS;
   typedef FcDgradParams Params;
-  typedef DzTile Tile;
+  // both heads' descriptors copied into registers once: a per-thread select between
+  // two KERNEL-ARGUMENT fields is compiled as a select of their addresses and a
+  // vector load from the kernarg segment + vmcnt(0) in front of every operand load
+  // (second loader rule; seen in the fc1 backward ISA)
+  // (every member function is __forceinline__: inlined before the optimiser runs,
+  // the Tile is split into SSA values first; otherwise `h1 ? t.hb.N : t.ha.N` is
+  // canonicalised inside the not-yet-inlined helper to a load through a selected
+  // ADDRESS, and the Tile then lives in scratch memory)
+  struct Tile : DzTile { FcHead ha, hb; int tot0, tot1; };
 
   struct Loc { int N, ldw, eps_in, eps_out, out_off, n0; long w, w2; bool sig, ok; };
 
@@ -322,32 +344,37 @@ struct FcDgradOp {
   // noisy == 2: ONE pass of depth N over the effective weight
   //   W_eff[k][n] = Wmu[k][n] + Wsig[k][n] * (eps_in[k] * eps_out[n])
   // built in the B loader (two loads + 2 VALU per element, half the MFMAs).
-  __device__ static int chunks_of(const Params& p, int h) {
-    return (((h ? p.head[1].N : p.head[0].N) + 15) / 16) * (p.noisy == 1 ? 2 : 1);
+  __device__ __forceinline__ static int chunks_of(const Params& p, int h) {
+    return (((h ? p.head[1].N : p.head[0].N) + 15) / 16) * (nzy(p) == 1 ? 2 : 1);
   }
   // global chunk -> (head, mu|sigma, first n), arithmetic only (NH <= 2).
-  __device__ static Loc locate(const Params& p, int gc) {
-    const int tot0 = chunks_of(p, 0);
-    const int tot1 = p.NH > 1 ? chunks_of(p, 1) : 0;
+  __device__ __forceinline__ static Loc locate(const Tile& t, int gc) {
+    const int tot0 = t.tot0, tot1 = t.tot1;
     Loc L;
     L.ok = gc < tot0 + tot1;
     gc = min(gc, tot0 + tot1 - 1);
     const bool h1 = gc >= tot0;
-    const FcHead& a = p.head[0];
-    const FcHead& b = p.head[1];  // == head[0] when NH == 1 (callers fill both)
-    L.N = h1 ? b.N : a.N; L.ldw = h1 ? b.ldw : a.ldw;
-    L.eps_in = h1 ? b.eps_in : a.eps_in; L.eps_out = h1 ? b.eps_out : a.eps_out;
-    L.out_off = h1 ? b.out_off : a.out_off;
+    const FcHead& a = t.ha;
+    const FcHead& b = t.hb;  // == head[0] when NH == 1 (callers fill both)
+    // dz_val: by-value arguments.  `h1 ? b.N : a.N` on two lvalues is itself an
+    // LVALUE in C++ -- a selected address and a load through it, which pins the
+    // descriptors in memory (scratch, or the kernarg segment) behind a vmcnt(0).
+    L.N = dz_val(h1, b.N, a.N); L.ldw = dz_val(h1, b.ldw, a.ldw);
+    L.eps_in = dz_val(h1, b.eps_in, a.eps_in); L.eps_out = dz_val(h1, b.eps_out, a.eps_out);
+    L.out_off = dz_val(h1, b.out_off, a.out_off);
     const int gl = gc - (h1 ? tot0 : 0);
     const int cp = (L.N + 15) / 16;
     L.sig = gl >= cp;
     L.n0 = (gl - (L.sig ? cp : 0)) * 16;
-    L.w = L.sig ? (h1 ? b.w_sig : a.w_sig) : (h1 ? b.w_mu : a.w_mu);
-    L.w2 = h1 ? b.w_sig : a.w_sig;
+    const long w_sig = dz_val(h1, b.w_sig, a.w_sig), w_mu = dz_val(h1, b.w_mu, a.w_mu);
+    L.w = L.sig ? w_sig : w_mu;
+    L.w2 = w_sig;
     return L;
   }
-  __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
-    const int chunks = chunks_of(p, 0) + (p.NH > 1 ? chunks_of(p, 1) : 0);
+  __device__ __forceinline__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
+    t.ha = p.head[0]; t.hb = p.head[1];
+    t.tot0 = chunks_of(p, 0); t.tot1 = p.NH > 1 ? chunks_of(p, 1) : 0;
+    const int chunks = t.tot0 + t.tot1;
     const int stages = (chunks + CPS - 1) / CPS;
     const int per = (stages + p.S - 1) / p.S;
     t.z = bid.z;  // split
@@ -357,47 +384,55 @@ struct FcDgradOp {
     t.st_end = min(stages, t.st_begin + per);
     return t.n0 < p.K && t.m0 < p.M;
   }
-  __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
+  __device__ __forceinline__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {
-    const Loc L = locate(p, st * CPS + c);
+    const Loc L = locate(t, st * CPS + c);
     const int m = t.m0 + row;
     const int n = L.n0 + 4 * q;
     const int nc = min(n, L.ldw - 4);  // dY columns share the weights' padded pitch
     float4 v = dz_ld4(p.dy + (long)min(m, p.M - 1) * p.ldy + L.out_off + nc);
     const float4 e = dz_ld4(p.noise + L.eps_out + nc);
-    v = L.sig ? dz_mul4(v, e) : v;
+    v = dz_mul4(v, dz_one_or4(L.sig, e));
     return dz_mask4(dz_sel4(L.ok & (m < p.M), v), n, L.N);
   }
   // B tile row = output column k; 4 consecutive reduction indices n.
-  __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
+  __device__ __forceinline__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {
-    const Loc L = locate(p, st * CPS + c);
+    const Loc L = locate(t, st * CPS + c);
     const int k = min(t.n0 + row, p.K - 1);
     const int nc = min(L.n0 + 4 * q, L.ldw - 4);
     const float4 v = dz_ld4(p.params + L.w + (long)k * L.ldw + nc);
     const float e = p.noise[L.eps_in + k];
-    if (p.noisy == 2) {
+    if (nzy(p) == 2) {
       const float4 sg = dz_ld4(p.params + L.w2 + (long)k * L.ldw + nc);
       const float4 eo = dz_ld4(p.noise + L.eps_out + nc);
       return dz_f4(__builtin_fmaf(sg.x, e * eo.x, v.x), __builtin_fmaf(sg.y, e * eo.y, v.y),
                    __builtin_fmaf(sg.z, e * eo.z, v.z), __builtin_fmaf(sg.w, e * eo.w, v.w));
     }
-    return L.sig ? dz_scale4(v, e) : v;
+    return dz_scale4(v, L.sig ? e : 1.f);
   }
-  __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
+  __device__ __forceinline__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
     const int col = t.n0 + wn * 32 + (lane & 31);
     if (col >= p.K) return;
     float* base = p.part + (long)t.z * p.M * p.ldo + p.x_off + col;
-    const float* mk = p.relu_mask ? p.relu_mask + p.x_off + col : nullptr;
+    if (p.relu_mask) {  // (uniform) all 16 mask values first, then the stores
+      const float* mk = p.relu_mask + p.x_off + col;
+      float mv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        mv[r] = mk[(long)min(t.m0 + wm * 32 + dz_acc_row(r, lane), p.M - 1) * p.ldo];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = t.m0 + wm * 32 + dz_acc_row(r, lane);
+        if (m < p.M) base[(long)m * p.ldo] = mv[r] > 0.f ? acc[r] : 0.f;
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = t.m0 + wm * 32 + dz_acc_row(r, lane);
-      if (m < p.M) {
-        float v = acc[r];
-        if (mk) v = mk[(long)m * p.ldo] > 0.f ? v : 0.f;
-        base[(long)m * p.ldo] = v;
-      }
+      if (m < p.M) base[(long)m * p.ldo] = acc[r];
     }
   }
 };
@@ -423,6 +458,9 @@ struct FcWgradParams {
   // noisy only: do not store the sigma-weight gradient (it still enters sumsq);
   // the optimiser re-derives it as dWmu * eps_in (x) eps_out (adam_kernel DerivedGrad)
   int skip_sig_store = 0;
+  // store nothing, only the norm partials: the optimiser launch recomputes the
+  // (one-stage) contraction and applies the update tile by tile (FcWgradAdamOp)
+  int skip_mu_store = 0;
 };
 
 template <int WM_, int WN_, int WK_, int KT_ = 1>
@@ -467,16 +505,24 @@ struct FcWgradOp {
     const int col = t.n0 + wn * 32 + (lane & 31);
     const bool colok = col < hd.N;
     const float eo = (p.noisy && colok) ? p.noise[hd.eps_out + col] : 0.f;
+    // all 16 eps_in values up front (clamped, unconditional): loaded inside the
+    // row loop they are 16 serial load -> wait -> multiply -> store round trips
+    // (not noisy: p.noise may be null -> any valid K floats, values unused)
+    const float* eip = p.noisy ? p.noise + hd.eps_in : p.x;
+    float ei[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      ei[r] = eip[min(t.m0 + wm * 32 + dz_acc_row(r, lane), hd.K - 1)];
     float sq = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = t.m0 + wm * 32 + dz_acc_row(r, lane);
       if (colok && k < hd.K) {
         const float v = acc[r];
-        p.grad[hd.w_mu + (long)k * hd.ldw + col] = v;
+        if (!p.skip_mu_store) p.grad[hd.w_mu + (long)k * hd.ldw + col] = v;
         sq += v * v;
         if (p.noisy) {
-          const float vs = v * (p.noise[hd.eps_in + k] * eo);
+          const float vs = v * (ei[r] * eo);
           if (!p.skip_sig_store) p.grad[hd.w_sig + (long)k * hd.ldw + col] = vs;
           sq += vs * vs;
         }
@@ -639,13 +685,20 @@ struct ConvDgradOp {
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
     const int ci = t.n0 + wn * 32 + (lane & 31);
+    // all 16 mask values first (pixel() clamps, so every address is valid): loaded
+    // inside the store loop they are 16 serial load -> wait -> store round trips
+    unsigned o[16];
+    float mk[16];
+    bool ok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int img, h, w;
-      if (pixel(p, t, wm * 32 + dz_acc_row(r, lane), img, h, w)) {
-        const long o = (((long)img * H + h) * W + w) * C + ci;
-        p.dx[o] = p.act[o] > 0.f ? acc[r] : 0.f;
-      }
+      ok[r] = pixel(p, t, wm * 32 + dz_acc_row(r, lane), img, h, w);
+      o[r] = (unsigned)(((img * H + h) * W + w) * C + ci);
+      mk[r] = p.act[o[r]];
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok[r]) p.dx[o[r]] = mk[r] > 0.f ? acc[r] : 0.f;
   }
 };

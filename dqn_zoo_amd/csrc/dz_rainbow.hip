@@ -1,6 +1,6 @@
 // Rainbow learner step on one MI355X (ref: rainbow/agent.py:85-121).
 //
-// Launch sequence (15 launches, all on the caller's stream, no host sync):
+// Launch sequence (16 launches, all on the caller's stream, no host sync):
 //   forward : conv1 (+ the step's noise draw as a side job) conv2 conv3 (3 applies
 //             batched as groups) -> fc1 (noisy adv1|val1, one weight stream per
 //             parameter set, W_eff in registers, split-K) -> epilogue -> fc2 (noisy
@@ -35,6 +35,9 @@ int g_fc2_splits = 8;         // 12 us (4 splits: 19 us)
 int g_fc2_weff = 1;           // fc2 forward against W_eff (depth K): 11.2 vs 12.1 us
 int g_adam_blocks = 2048;     // grid-stride Adam launch width
 int g_fc2_dgrad_splits = kS_dh1;  // 1: unsplit, no reduce launch
+int g_adam_pipe = 1;          // flat Adam: branch-free, software-pipelined loads
+int g_adam_fused = 0;         // fc1 weight gradient recomputed inside the optimiser launch
+                              // (FcWgradAdamOp): never stored, never re-read
 
 }  // namespace
 
@@ -107,8 +110,9 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
     for (int g = 0; g < G; ++g) { p.params[g] = prm[g]; p.noise[g] = nz[g]; }
     p.head[0] = fc2h[0]; p.head[1] = fc2h[1];
     p.part = ws + L.ws_fc2_part; p.ldo = ld2;
-    rc = dz_launch_gemm<FcFwd>(p, dim3((NA + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32,
-                                      G * 2 * g_fc2_splits), s);
+    const dim3 g2((NA + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32, G * 2 * g_fc2_splits);
+    rc = g_fc2_weff ? dz_launch_gemm<FcFwdOp<1, 2, 2, 4, 2>>(p, g2, s)
+                    : dz_launch_gemm<FcFwdOp<1, 2, 2, 4, 1>>(p, g2, s);
     if (rc) return rc;
     DZ_PROF(s, "fc2_fwd");
     if (skip_fc2_epilogue) return rc;  // the loss kernel folds the partial slabs itself
@@ -269,6 +273,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   // when this one call both produces and consumes it
   const bool derive_sig = (phases & DZ_PHASE_BACKWARD) && (phases & DZ_PHASE_OPTIMIZER) &&
                           !a->keep_all_grads;
+  // ... and the whole fc1 weight gradient recomputed inside the optimiser launch
+  const bool fuse_adam = derive_sig && g_adam_fused && kFlat % FcWg::BM == 0 &&
+                         512 % FcWg::BN == 0;
+  auto fc1_wgrad_params = [&](FcWgradParams& w) {
+    w.x = ws + L.ws_feat; w.ldx = kFlat; w.dy = ws + L.ws_dh1; w.ldy = 1024; w.M = B;
+    w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc1h[0]; w.head[1] = fc1h[1];
+    w.grad = a->grad;
+  };
   if (phases & DZ_PHASE_BACKWARD) {
     DZ_REQUIRE(a->grad);
     float* grad = a->grad;
@@ -318,7 +330,8 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         }
       }
       const dim3 gd(kHid / FcDg::BN, (B + 31) / 32, s_dh1);
-      rc = dz_launch_gemm3<FcWg, FcDg, FcDg>(
+      typedef FcDgradOp<1, 2, 2, 4, 1, 1, 1> FcDg1;  // noisy == 1 at compile time
+      rc = dz_launch_gemm3<FcWg, FcDg1, FcDg1>(
           w, dim3((NA + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 2), d[0], gd, d[1], gd, s);
       if (rc) return rc;
       DZ_PROF(s, "fc2_wgrad+dgrad");
@@ -332,11 +345,10 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     }
     {  // fc1: weight gradients + input gradient (adv1 + val1 paths) -> dfeat
       FcWgradParams w;
-      w.x = ws + L.ws_feat; w.ldx = kFlat; w.dy = ws + L.ws_dh1; w.ldy = 1024; w.M = B;
-      w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc1h[0]; w.head[1] = fc1h[1];
-      w.grad = grad;
+      fc1_wgrad_params(w);
       w.sumsq = sq_slots + fc2_slots; w.sq_nx = 512 / FcWg::BN; w.sq_ny = kFlat / FcWg::BM;
       w.skip_sig_store = derive_sig;
+      w.skip_mu_store = fuse_adam;
       FcDgradParams d;
       d.dy = ws + L.ws_dh1; d.ldy = 1024; d.M = B; d.NH = 2; d.S = kS_dfeat; d.noisy = g_dgrad_weff ? 2 : 1;
       d.params = a->online; d.noise = nz[0]; d.head[0] = fc1h[0]; d.head[1] = fc1h[1];
@@ -370,7 +382,9 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         DZ_PROF(s, "fc1_dgrad+wgrad");
       } else if (g_fc1_dgrad_first == 3) {  // wgrad blocks first
         const dim3 gw(512 / FcWg::BN, kFlat / FcWg::BM, 2), gd(kFlat / 64, (B + 31) / 32, d.S);
-        rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1>>(w, gw, d, gd, s);
+        rc = g_dgrad_weff
+                 ? dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 2>>(w, gw, d, gd, s)
+                 : dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 1>>(w, gw, d, gd, s);
         if (rc) return rc;
         DZ_PROF(s, "fc1_dgrad+wgrad");
       } else if (g_fc1_dgrad_first) {
@@ -469,6 +483,47 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       DZ_PROF(s, "grad_sumsq");
       nparts = kNormBlocks;
     }
+    if (fuse_adam) {
+      FcWgradAdamParams w;
+      fc1_wgrad_params(w);
+      w.prm = a->online; w.m = a->adam_m; w.v = a->adam_v;
+      w.part = ws + L.ws_norm_part; w.nparts = nparts; w.count = a->adam_count;
+      w.h = {a->lr, a->b1, a->b2, a->eps, a->max_norm};
+      AdamFlatParams q;
+      q.p = a->online; q.g = a->grad; q.m = a->adam_m; q.v = a->adam_v;
+      // the parameter vector minus the two fc1 weight blocks (whose 32 pad columns
+      // per row hold zeros and would receive zero updates: nobody touches them)
+      const long mu_end = L.fc1_mu_w + (long)kFlat * L.fc1_ld;
+      q.seg_begin[0] = 0; q.seg_len[0] = L.fc1_mu_w >> 2;
+      q.seg_begin[1] = mu_end >> 2; q.seg_len[1] = (L.fc1_sig_w - mu_end) >> 2;
+      q.seg_begin[2] = (L.fc1_sig_w + (long)kFlat * L.fc1_ld) >> 2;
+      q.seg_len[2] = (L.param_count >> 2) - q.seg_begin[2];
+      DZ_REQUIRE((L.fc1_mu_w & 3) == 0 && (L.fc1_sig_w & 3) == 0 && (L.fc1_ld & 3) == 0);
+      q.part = w.part; q.nparts = nparts; q.count = a->adam_count;
+      q.losses = a->losses; q.weights = a->weights; q.B = B; q.sc = sc; q.h = w.h;
+      const long flat4 = q.seg_len[0] + q.seg_len[1] + q.seg_len[2];
+      const dim3 gw(512 / FcWg::BN, kFlat / FcWg::BM, 2);
+      const unsigned nside = (unsigned)((flat4 + 255) / 256);
+      switch (g_adam_fused) {  // rows per round / next round's loads issued early
+        case 2: rc = dz_launch_gemm_side<FcWgradAdamOp<FcWg, 2, 1>, AdamFlatSide>(w, gw, q, nside, s); break;
+        case 3: rc = dz_launch_gemm_side<FcWgradAdamOp<FcWg, 4, 1>, AdamFlatSide>(w, gw, q, nside, s); break;
+        case 4: rc = dz_launch_gemm_side<FcWgradAdamOp<FcWg, 8, 0>, AdamFlatSide>(w, gw, q, nside, s); break;
+        case 5: rc = dz_launch_gemm_side<FcWgradAdamOp<FcWg, 2, 0>, AdamFlatSide>(w, gw, q, nside, s); break;
+        case 6: case 7: {  // 32 x 128 tiles: 512 contiguous bytes per row and workgroup
+          typedef FcWgradOp<1, 4, 1, 2> Wide;
+          const dim3 g2(512 / Wide::BN, kFlat / Wide::BM, 2);
+          if (g_adam_fused == 6)
+            rc = dz_launch_gemm_side<FcWgradAdamOp<Wide, 2, 1>, AdamFlatSide>(w, g2, q, nside, s);
+          else
+            rc = dz_launch_gemm_side<FcWgradAdamOp<Wide, 4, 0>, AdamFlatSide>(w, g2, q, nside, s);
+          break;
+        }
+        default: rc = dz_launch_gemm_side<FcWgradAdamOp<FcWg, 4, 0>, AdamFlatSide>(w, gw, q, nside, s); break;
+      }
+      if (rc) return rc;
+      DZ_PROF(s, "adam");
+      return DZ_OK;
+    }
     DerivedGrad dg = {};
     if (derive_sig) {
       dg.dst_off = L.fc1_sig_w; dg.src_off = L.fc1_mu_w; dg.rows = kFlat; dg.ld = L.fc1_ld;
@@ -477,10 +532,16 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       dg.eps_out = nz[0] + L.n_fc1_out;
       dg.on = 1;
     }
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_adam_blocks), dim3(256), 0, s, a->online, a->grad,
-                       a->adam_m, a->adam_v, (long)(L.param_count >> 2),
-                       ws + L.ws_norm_part, nparts, a->adam_count, a->losses,
-                       a->weights, B, sc, a->lr, a->b1, a->b2, a->eps, a->max_norm, dg);
+    if (g_adam_pipe)
+      hipLaunchKernelGGL(adam_kernel<1>, dim3((unsigned)g_adam_blocks), dim3(256), 0, s, a->online,
+                         a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
+                         ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,
+                         a->lr, a->b1, a->b2, a->eps, a->max_norm, dg);
+    else
+      hipLaunchKernelGGL(adam_kernel<0>, dim3((unsigned)g_adam_blocks), dim3(256), 0, s, a->online,
+                         a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
+                         ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,
+                         a->lr, a->b1, a->b2, a->eps, a->max_norm, dg);
     DZ_LAUNCH_CHECK();
     DZ_PROF(s, "adam");
   }
@@ -605,6 +666,8 @@ extern "C" int dz_set_tuning(int key, int value) {
     case 15: g_conv_xcd = value; return DZ_OK;
     case 16: DZ_REQUIRE(value >= 1 && value <= kS_dh1); g_fc2_dgrad_splits = value; return DZ_OK;
     case 17: g_fc2_weff = value; return DZ_OK;
+    case 18: g_adam_fused = value; return DZ_OK;
+    case 19: g_adam_pipe = value; return DZ_OK;
     default: return DZ_ERR_INVALID_ARG;
   }
 }

@@ -42,14 +42,13 @@ def main():
          torch.rand(B, dtype=torch.float32, device='cuda', generator=g))
   ln.resample_noise()
   lib = _lib.load()
-  names = {0: '<1,2,2,KT4>', 1: '<1,2,2,KT2>', 2: '<1,2,2,KT1>', 3: '<1,4,1,KT4>',
-           4: '<1,4,1,KT2>', 5: '<1,1,4,KT2>', 6: '<1,1,4,KT1>', 7: '<1,4,1,KT1>'}
-  for weff, spl in ((0, 8), (1, 8), (1, 4), (0, 8), (1, 8), (1, 4)):
-    lib.dz_set_tuning(17, weff); lib.dz_set_tuning(8, spl)
+  sweep = [a.split('=') for a in sys.argv[1:]] or [('18', '0'), ('18', '1')] * 3
+  for key, val in sweep:  # e.g. `tune.py 18=0 18=1`: one timing table per setting
+    lib.dz_set_tuning(int(key), int(val))
     t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
-    print('fc2 fwd weff %d S=%d: fc2_fwd %.2f head_loss %.2f total %.1f' % (
-        weff, spl, t['fc2_fwd'], t['head_loss'], sum(t.values())), flush=True)
-  lib.dz_set_tuning(17, 1); lib.dz_set_tuning(8, 8)
+    top = sorted(t.items(), key=lambda kv: -kv[1])[:(4 if len(sweep) > 2 else 99)]
+    print('key %s = %s: total %.1f us  %s' % (
+        key, val, sum(t.values()), '  '.join('%s %.2f' % kv for kv in top)), flush=True)
 
 
 if __name__ == '__main__':
