@@ -78,6 +78,15 @@ template <class Op> struct DzMI<Op, decltype((void)Op::MI)> { static constexpr i
 template <class Op, class = void> struct DzNI { static constexpr int v = 1; };
 template <class Op> struct DzNI<Op, decltype((void)Op::NI)> { static constexpr int v = Op::NI; };
 
+// Optional deferred operand conversion (KC+ROW16 A operands): an Op with
+// A_RAW16 = 1 provides  uint4 load_a16_raw(p, t, st, c, row)  and
+// void cook16(uint4, float4 (&v)[4]).  The raw 16 bytes stay in 4 registers while
+// the MFMAs of the current stage run and are converted when they are written to
+// LDS; converting in the loader makes the compiler wait for the prefetch right
+// after issuing it (vmcnt(0) + v_cvt in the middle of the MFMA block: conv1 ISA).
+template <class Op, class = void> struct DzRaw16 { static constexpr int v = 0; };
+template <class Op> struct DzRaw16<Op, decltype((void)Op::A_RAW16)> { static constexpr int v = Op::A_RAW16; };
+
 template <int ROWS, int CPS, int LAYOUT>
 struct DzLdsTile {
   static constexpr int LD = (LAYOUT == DZ_KC) ? 20 : ROWS;
@@ -150,8 +159,17 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
   constexpr bool A_FULL = A_ROW16 ? ((BM * CPS) % 256 == 0) : (AT::SLOTS % 256 == 0);
   constexpr bool B_FULL = BT::SLOTS % 256 == 0;
 
+  constexpr bool A_RAW = A_ROW16 && DzRaw16<Op>::v;
   auto load_stage = [&](int st) {
-    if constexpr (A_ROW16) {
+    if constexpr (A_RAW) {
+#pragma unroll
+      for (int j = 0; j < NA / 4; ++j) {
+        const int idx = tid + j * 256;
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (A_FULL || idx < BM * CPS) raw = Op::load_a16_raw(p, t, st, idx % CPS, idx / CPS);
+        ra[4 * j] = __builtin_bit_cast(float4, raw);  // the other three stay unused
+      }
+    } else if constexpr (A_ROW16) {
 #pragma unroll
       for (int j = 0; j < NA / 4; ++j) {
         const int idx = tid + j * 256;
@@ -196,7 +214,19 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
   };
 
   auto store_stage = [&]() {
-    if constexpr (A_ROW16) {
+    if constexpr (A_RAW) {
+#pragma unroll
+      for (int j = 0; j < NA / 4; ++j) {
+        const int idx = tid + j * 256;
+        if (A_FULL || idx < BM * CPS) {
+          float4 v[4];
+          Op::cook16(__builtin_bit_cast(uint4, ra[4 * j]), v);
+          float* dst = As + (idx % CPS) * AT::CHUNK + (idx / CPS) * 20;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *(float4*)(dst + 4 * q) = v[q];
+        }
+      }
+    } else if constexpr (A_ROW16) {
 #pragma unroll
       for (int j = 0; j < NA / 4; ++j) {
         const int idx = tid + j * 256;

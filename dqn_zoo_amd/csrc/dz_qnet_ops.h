@@ -132,6 +132,20 @@ struct ConvFwdOp {
     const int kh = tap / KS, kw = tap % KS;
     return dz_sel4(ok, dz_ld4((const float*)t.in + off + ((long)kh * W + kw) * C + ci));
   }
+  // deferred conversion (dz_gemm.h DzRaw16): the loader keeps the 16 raw bytes
+  static constexpr int A_RAW16 = IN_U8;
+  __device__ static uint4 load_a16_raw(const Params& p, const Tile& t, int st, int c, int row) {
+    long off;
+    const bool ok = pixel_base(p, t, row, off);
+    const int k0 = st * BK + c * 16;  // KS*C == 32 bytes per kernel row
+    const int kh = k0 / 32, o = k0 % 32;
+    const uint4 raw = *(const uint4*)((const uint8_t*)t.in + off + (long)kh * W * C + o);
+    return make_uint4(ok ? raw.x : 0u, ok ? raw.y : 0u, ok ? raw.z : 0u, ok ? raw.w : 0u);
+  }
+  __device__ static void cook16(uint4 raw, float4 (&v)[4]) {  // byte 0 -> 0/255 == 0.0f
+    v[0] = dz_u8x4_to_unit(raw.x); v[1] = dz_u8x4_to_unit(raw.y);
+    v[2] = dz_u8x4_to_unit(raw.z); v[3] = dz_u8x4_to_unit(raw.w);
+  }
   __device__ static void load_a16(const Params& p, const Tile& t, int st, int c,
                                   int row, float4 (&v)[4]) {
     long off;

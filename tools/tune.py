@@ -46,7 +46,11 @@ def main():
   for key, val in sweep:  # e.g. `tune.py 18=0 18=1`: one timing table per setting
     lib.dz_set_tuning(int(key), int(val))
     t = timings(ln, dev, steps=20, phases=_lib.PHASE_ALL)
-    top = sorted(t.items(), key=lambda kv: -kv[1])[:(4 if len(sweep) > 2 else 99)]
+    top = sorted(t.items(), key=lambda kv: -kv[1])
+    if os.environ.get('TUNE_ONLY'):
+      top = [kv for kv in top if os.environ['TUNE_ONLY'] in kv[0]]
+    elif len(sweep) > 2:
+      top = top[:4]
     print('key %s = %s: total %.1f us  %s' % (
         key, val, sum(t.values()), '  '.join('%s %.2f' % kv for kv in top)), flush=True)
 
