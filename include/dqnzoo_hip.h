@@ -539,7 +539,10 @@ int dz_prof_read_replay(float* ms_out);
  * (dz_torso.h), 12 = fc1 input gradient against W_eff (depth N) instead of the
  * two-GEMM form (depth 2N), 13 = IQN value-head GEMM tiling (dz_iqn.hip),
  * 14 = Adam launch width (blocks), 15 = conv forward tiles in XCD-aware order,
- * 16 = fc2 input-gradient k-splits (<= 5), 17 = fc2 forward against W_eff.
+ * 16 = fc2 input-gradient k-splits (<= 5), 17 = fc2 forward against W_eff,
+ * 18 = fc1 weight gradient recomputed inside the optimiser launch instead of
+ * stored (0 = off [default]; 1..7 = tile / rows-per-round variants), 19 = flat
+ * Adam with branch-free software-pipelined loads (1 [default]) or the plain loop.
  * Keys 3 and 4 are retired (accepted, ignored).  Defaults are the measured best. */
 int dz_set_tuning(int key, int value);
 
