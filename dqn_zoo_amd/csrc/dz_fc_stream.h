@@ -107,7 +107,34 @@ __global__ __launch_bounds__(256) void dz_fc_stream_fwd3(FcStreamFwd3Params p) {
   const int nrows = max(min(K, r0 + R) - r0, 0);
   const int ncol = n0 + l31;
 
-  // (1) every weight load of the wave first: they fly during the LDS staging.
+  // Issue order matters: vector loads return in order, so whatever is issued last
+  // gates everything before it.  (1) the small operands first -- x, eps_in, eps_out;
+  // (2) then every weight load of the wave; (3) the LDS staging waits only for (1)
+  // (vmcnt = the weight loads still in flight) and the MFMA chain then consumes the
+  // weights as they arrive.  With the weights issued first, x arrived last and the
+  // first MFMA waited for the whole stream (vmcnt(0) in front of 150 MFMAs).
+  const float eo0 = NOISY ? nz0[hd.eps_out + ncol] : 0.f;
+  const float eo1 = NOISY ? nz1[hd.eps_out + ncol] : 0.f;
+  const int mm = threadIdx.x & 31, q0 = threadIdx.x >> 5;
+  constexpr int NP = (2 * NL / 4 + 7) / 8;
+  float4 v[2][NP];
+  float e0 = 0.f, e1 = 0.f;
+  const float ok = mm < p.M ? 1.f : 0.f;  // applied at the LDS write, not here (no use of a
+  {                                        // loaded value before the weight loads are issued)
+    const int mc = min(mm, p.M - 1);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int k = min(r0 + 4 * (q0 + 8 * j), K - 4);  // r0, K multiples of 4
+      v[0][j] = dz_ld4(p.x + (long)(g0 * p.M + mc) * p.ldx + hd.x_off + k);
+      v[1][j] = dz_ld4(p.x + (long)(g1 * p.M + mc) * p.ldx + hd.x_off + k);
+    }
+    if (NOISY) {
+      const int k = min(r0 + (int)threadIdx.x, K - 1);
+      e0 = nz0[hd.eps_in + k]; e1 = nz1[hd.eps_in + k];
+    }
+  }
+
+  __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks (1) below (2)
   float wm[NL], wg[NOISY ? NL : 1];
 #pragma unroll
   for (int u = 0; u < NL; ++u) {
@@ -116,41 +143,25 @@ __global__ __launch_bounds__(256) void dz_fc_stream_fwd3(FcStreamFwd3Params p) {
     wm[u] = prm[hd.w_mu + off];
     if (NOISY) wg[u] = prm[hd.w_sig + off];
   }
+  __builtin_amdgcn_sched_barrier(0);
 
-  // (2) stage x[g][k] (k-major, 32 batch rows minor) and eps_in[g][k].
+  // stage x[g][k] (k-major, 32 batch rows minor) and eps_in[g][k]
   {
-    const int mm = threadIdx.x & 31, q0 = threadIdx.x >> 5;
-    const int mc = min(mm, p.M - 1);
-    const float ok = mm < p.M ? 1.f : 0.f;
-    constexpr int NP = (2 * NL / 4 + 7) / 8;
-    float4 v[2][NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int k = min(r0 + 4 * (q0 + 8 * j), K - 4);  // r0, K multiples of 4
-      v[0][j] = dz_scale4(dz_ld4(p.x + (long)(g0 * p.M + mc) * p.ldx + hd.x_off + k), ok);
-      v[1][j] = dz_scale4(dz_ld4(p.x + (long)(g1 * p.M + mc) * p.ldx + hd.x_off + k), ok);
-    }
-    float e0 = 0.f, e1 = 0.f;
-    if (NOISY) {
-      const int k = min(r0 + (int)threadIdx.x, K - 1);
-      e0 = nz0[hd.eps_in + k]; e1 = nz1[hd.eps_in + k];
-    }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int q = q0 + 8 * j;
       if (4 * q < nrows) {
         float* d0 = xs + (4 * q) * 32 + mm;
-        d0[0] = v[0][j].x; d0[32] = v[0][j].y; d0[64] = v[0][j].z; d0[96] = v[0][j].w;
+        const float4 a = dz_scale4(v[0][j], ok), b = dz_scale4(v[1][j], ok);
+        d0[0] = a.x; d0[32] = a.y; d0[64] = a.z; d0[96] = a.w;
         float* d1 = d0 + R * 32;
-        d1[0] = v[1][j].x; d1[32] = v[1][j].y; d1[64] = v[1][j].z; d1[96] = v[1][j].w;
+        d1[0] = b.x; d1[32] = b.y; d1[64] = b.z; d1[96] = b.w;
       }
     }
     if (NOISY && (int)threadIdx.x < R) { es[threadIdx.x] = e0; es[R + threadIdx.x] = e1; }
   }
   __syncthreads();
 
-  const float eo0 = NOISY ? nz0[hd.eps_out + ncol] : 0.f;
-  const float eo1 = NOISY ? nz1[hd.eps_out + ncol] : 0.f;
   f32x16 acc0, acc1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
