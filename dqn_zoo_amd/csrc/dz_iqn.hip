@@ -290,7 +290,7 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
                        (long)L.param_count, ws + L.ws_norm_part, a->opt_count);
     DZ_LAUNCH_CHECK();
     DZ_PROF(s, "grad_sumsq");
-    hipLaunchKernelGGL(adam_kernel<0>, dim3(2048), dim3(256), 0, s, a->online, a->grad, a->opt_m,
+    hipLaunchKernelGGL(adam_kernel<1>, dim3(2048), dim3(256), 0, s, a->online, a->grad, a->opt_m,
                        a->opt_v, (long)(L.param_count >> 2), ws + L.ws_norm_part, kNormBlocks,
                        a->opt_count, a->losses, zeros, B, sc, a->lr, a->b1, a->b2, a->eps,
                        a->max_norm);

@@ -79,6 +79,16 @@ struct IqnLinOp {
     if (col >= p.N) return;
     const int g = t.z;
     const float b = t.prm[p.b_off + col];
+    // the 16 feature factors of the MIX epilogue up front (clamped rows): loaded in
+    // the row loop they are 16 serial load -> wait -> store round trips
+    float fm[16];
+    if (p.epi == IQN_EPI_MIX) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mc = min(t.m0 + wm * 32 + dz_acc_row(r, lane), t.rows - 1);
+        fm[r] = p.feat[(long)(t.feat_row0 + mc / t.samples) * p.N + col];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = t.m0 + wm * 32 + dz_acc_row(r, lane);
@@ -87,7 +97,7 @@ struct IqnLinOp {
       if (p.epi != IQN_EPI_BIAS) v = v > 0.f ? v : 0.f;
       if (p.epi == IQN_EPI_MIX) {
         if (g == 0 && p.temb) p.temb[(long)m * p.N + col] = v;
-        v = v * p.feat[(long)(t.feat_row0 + m / t.samples) * p.N + col];
+        v = v * fm[r];
       }
       p.out[(long)(t.row0 + m) * p.ldo + col] = v;
     }
@@ -178,6 +188,25 @@ __global__ void uniform_fill_kernel(float* __restrict__ out, long n, uint64_t se
   out[i] = (float)(h >> 41) * (1.0f / 8388608.0f);
 }
 
+// mean over the n rows of column a, one wave: lane i sums rows i, i+64, ... in
+// that order (8 clamped loads in flight per round), then the wave folds.
+__device__ __forceinline__ float iqn_col_mean(const float* __restrict__ o, int ld, int n, int a,
+                                              int lane) {
+  float sum = 0.f;
+  for (int base = 0; base < n; base += 8 * 64) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = base + 64 * j + lane;
+      const float y = o[(long)min(r, n - 1) * ld + a];
+      x[j] = r < n ? y : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += x[j];
+  }
+  return wave_sum(sum) / (float)n;
+}
+
 // vmap(rlax.quantile_q_learning) over the batch (iqn/agent.py:199-209).  One block
 // per batch element; rows of `out` are (batch element, sample) pairs.
 //   a* = argmax_a mean_n out_sel[b][n][a];  target_j = r + g * out_t[b][j][a*]
@@ -199,9 +228,7 @@ __global__ __launch_bounds__(256) void iqn_loss_kernel(
     float best = -__builtin_inff();
     int arg = 0;
     for (int a = 0; a < A; ++a) {
-      float sum = 0.f;
-      for (int n = i; n < n1; n += 64) sum += o1[(long)n * ld + a];
-      sum = wave_sum(sum) / (float)n1;
+      const float sum = iqn_col_mean(o1, ld, n1, a, i);
       if (sum > best) { best = sum; arg = a; }
     }
     if (i == 0) s_astar = arg;
@@ -256,12 +283,23 @@ __global__ __launch_bounds__(256) void iqn_mix_bwd_kernel(float* __restrict__ dh
   if (c >= F) return;
   const float f = feat[(long)b * F + c];
   float acc = 0.f;
-  long o = (long)b * samples * F + c;
-#pragma unroll 4
-  for (int n = 0; n < samples; ++n, o += F) {
-    const float d = dhin[o], e = temb[o];
-    acc += d * e;
-    dhin[o] = e > 0.f ? d * f : 0.f;
+  const long o0 = (long)b * samples * F + c;
+  // 8 rows per round, all 16 loads first: dhin is updated in place, so the compiler
+  // cannot move a later row's load above an earlier row's store by itself
+  for (int n0 = 0; n0 < samples; n0 += 8) {
+    float d[8], e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long o = o0 + (long)min(n0 + j, samples - 1) * F;
+      d[j] = dhin[o]; e[j] = temb[o];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (n0 + j < samples) {
+        acc += d[j] * e[j];
+        dhin[o0 + (long)(n0 + j) * F] = e[j] > 0.f ? d[j] * f : 0.f;
+      }
+    }
   }
   dfeat[(long)b * F + c] = f > 0.f ? acc : 0.f;
 }
@@ -279,11 +317,8 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(ColPartJobs jobs, int 
   if (blockIdx.x * 64 >= jb.cols) return;
   const int rps = (jb.rows + S - 1) / S;
   const int r0 = blockIdx.y * rps, r1 = min(jb.rows, r0 + rps);
-  float v = 0.f;
-  if (c < jb.cols) {
-#pragma unroll 4
-    for (int r = r0 + w; r < r1; r += 4) v += jb.m[(long)r * jb.ld + c];
-  }
+  const float v = r1 > r0 ? dz_slab_sum(jb.m + (long)r0 * jb.ld, r1 - r0, jb.ld,
+                                        min(c, jb.cols - 1), w) : 0.f;
   red[w][l] = v;
   __syncthreads();
   if (w == 0 && c < jb.cols)
@@ -300,9 +335,7 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceJobs8 J) {
   while (j < J.n - 1 && b >= J.r_end[j]) ++j;
   const ReduceJob jb = J.r[j];
   const long i = (long)(b - (j ? J.r_end[j - 1] : 0)) * 64 + l;
-  float v = 0.f;
-  if (i < jb.n)
-    for (int s = w; s < jb.S; s += 4) v += jb.part[(long)s * jb.n + i];
+  const float v = dz_slab_sum(jb.part, jb.S, jb.n, i < jb.n ? i : jb.n - 1, w);
   red[w][l] = v;
   __syncthreads();
   if (w == 0 && i < jb.n) jb.out[i] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
@@ -320,9 +353,7 @@ __global__ __launch_bounds__(64) void iqn_q_values_kernel(const float* __restric
   float best = -__builtin_inff();
   int arg = 0;
   for (int a = 0; a < A; ++a) {
-    float sum = 0.f;
-    for (int n = i; n < samples; n += 64) sum += o[(long)n * ld + a];
-    sum = wave_sum(sum) / (float)samples;
+    const float sum = iqn_col_mean(o, ld, samples, a, i);
     if (i == 0 && q_out) q_out[b * A + a] = sum;
     if (sum > best) { best = sum; arg = a; }
   }

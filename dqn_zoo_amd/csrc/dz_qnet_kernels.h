@@ -988,9 +988,18 @@ __global__ __launch_bounds__(1024) void quantile_loss_kernel(
 __global__ __launch_bounds__(256) void rmsprop_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
     float* __restrict__ nu, long n4, float lr, float decay, float eps) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    float4 gv = ((const float4*)g)[i];
-    float4 mv = ((float4*)mu)[i], vv = ((float4*)nu)[i], pv = ((float4*)p)[i];
+  // software-pipelined like adam_kernel<1>: the next element's loads (clamped,
+  // unconditional) are issued before the current element's arithmetic
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  long ic = min(i, n4 - 1);
+  float4 gv = ((const float4*)g)[ic], mv = ((const float4*)mu)[ic];
+  float4 vv = ((const float4*)nu)[ic], pv = ((const float4*)p)[ic];
+  while (i < n4) {
+    const long inext = i + stride;
+    ic = min(inext, n4 - 1);
+    const float4 gn = ((const float4*)g)[ic], mn = ((const float4*)mu)[ic];
+    const float4 vn = ((const float4*)nu)[ic], pn = ((const float4*)p)[ic];
     float* G = (float*)&gv; float* M = (float*)&mv; float* V = (float*)&vv;
     float* P = (float*)&pv;
 #pragma unroll
@@ -1001,6 +1010,7 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(
       P[j] = P[j] + (-lr) * upd;
     }
     ((float4*)mu)[i] = mv; ((float4*)nu)[i] = vv; ((float4*)p)[i] = pv;
+    gv = gn; mv = mn; vv = vn; pv = pn; i = inext;
   }
 }
 
