@@ -267,6 +267,12 @@ def load():
           'ABI mismatch: struct %s is %d bytes in the library, %d in _lib.py' %
           (cls.__name__, lib.dz_struct_size(which), ctypes.sizeof(cls)))
   _check_single_hip_runtime()
+  # DZ_TUNING="key=value,key=value": kernel-variant knobs (dz_set_tuning) for A/B
+  # measurements of an unmodified program, e.g. DZ_TUNING=20=0 python bench.py
+  for kv in filter(None, os.environ.get('DZ_TUNING', '').split(',')):
+    key, value = kv.split('=')
+    if lib.dz_set_tuning(int(key), int(value)) != DZ_OK:
+      raise HipLibraryError('DZ_TUNING: dz_set_tuning(%s) refused' % kv)
   _lib = lib
   return lib
 

@@ -5,6 +5,7 @@
 #pragma once
 
 #include "dz_fc_stream.h"
+#include "dz_sumtree_dev.h"
 
 namespace {
 
@@ -469,7 +470,18 @@ __global__ __launch_bounds__(256) void adam_kernel(
     float* __restrict__ v, long n4, const float* __restrict__ part, int nparts,
     const int32_t* __restrict__ count, const float* __restrict__ losses,
     const float* __restrict__ weights, int B, float* __restrict__ sc, float lr, float b1,
-    float b2, float eps, float max_norm, DerivedGrad dg = DerivedGrad{}) {
+    float b2, float eps, float max_norm, DerivedGrad dg = DerivedGrad{},
+    PrioUpdateParams prio = PrioUpdateParams{}) {
+  // Optional side job (prio.node != null): block 0 is the sum-tree priority
+  // write-back (a ~10 us chain of dependent loads on one workgroup that needs only
+  // the loss kernel's priorities); this launch is the longest of the step and does
+  // not touch the tree, so the chain disappears inside it.  The optimiser blocks
+  // are [1, gridDim.x).
+  unsigned bid = blockIdx.x, nblk = gridDim.x;
+  if (prio.node) {
+    if (bid == 0) { PrioUpdateSide::run(prio, 0); return; }
+    bid -= 1; nblk -= 1;
+  }
   __shared__ float red[4];
   // PIPE: branch-free loads (derived block or not: clamped pointers, the noise
   // factors select to 1, x * (1 * 1) == x), the first element's loads issued before
@@ -488,8 +500,8 @@ __global__ __launch_bounds__(256) void adam_kernel(
     e.p = ((const float4*)p)[i];
     e.ei = *eip; e.eo = *eop; e.der = der;  // no use of a loaded value here: nothing waits
   };
-  const long stride = (long)gridDim.x * 256;
-  long ip = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stride = (long)nblk * 256;
+  long ip = (long)bid * 256 + threadIdx.x;
   Elem cur;
   if (PIPE) load(min(ip, n4 - 1), cur);  // clamped, unconditional (no exec-mask block)
   // thread t sums part[t], part[t+256], ... in that order; 8 clamped loads are in
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(256) void adam_kernel(
   const int c = *count;  // already incremented (sumsq_kernel)
   const float bc1 = 1.0f - powf(b1, (float)c), bc2 = 1.0f - powf(b2, (float)c);
   const bool pass = !(max_norm > 0.f && !(gn < max_norm));
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (bid == 0 && threadIdx.x == 0) {
     sc[DZ_SC_GNORM] = gn; sc[DZ_SC_BC1] = bc1; sc[DZ_SC_BC2] = bc2;
     sc[DZ_SC_CLIP] = pass ? 1.f : 0.f;
     float l = 0.f;
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(256) void adam_kernel(
     }
     return;
   }
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+  for (long i = (long)bid * 256 + threadIdx.x; i < n4; i += (long)nblk * 256) {
     float4 gv;
     if (i >= d0 && i < d1) {  // derived block: mu-gradient times the noise outer product
       const unsigned rel = (unsigned)(i - d0) << 2;  // < 2^31 (block of at most 8 GB)

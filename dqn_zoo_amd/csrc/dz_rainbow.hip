@@ -35,6 +35,7 @@ int g_fc2_splits = 8;         // 12 us (4 splits: 19 us)
 int g_fc2_weff = 1;           // fc2 forward against W_eff (depth K): 11.2 vs 12.1 us
 int g_adam_blocks = 2048;     // grid-stride Adam launch width
 int g_fc2_dgrad_splits = kS_dh1;  // 1: unsplit, no reduce launch
+int g_prio_host = 1;          // priority write-back side block: 1 = in the Adam launch, 0 = conv3 backward
 int g_adam_pipe = 1;          // flat Adam: branch-free, software-pipelined loads
 int g_adam_fused = 0;         // fc1 weight gradient recomputed inside the optimiser launch
                               // (FcWgradAdamOp): never stored, never re-read
@@ -281,6 +282,17 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc1h[0]; w.head[1] = fc1h[1];
     w.grad = a->grad;
   };
+  // optional priority write-back (dz_rainbow_args_t::prio_*), carried by one of this
+  // call's launches as an extra block
+  bool prio_pending = a->prio_node != nullptr;
+  PrioUpdateParams prio_q = {};
+  if (prio_pending) {
+    DZ_REQUIRE(a->prio_ids && a->prio_status && dz_is_pow2(a->prio_cap_pow2) &&
+               a->prio_capacity > 0 && a->prio_capacity <= a->prio_cap_pow2 &&
+               a->prio_exponent >= 0.0 && B <= 256);
+    prio_q = {a->prio_node, a->prio_cap_pow2, a->prio_capacity, 0, 0, a->prio_ids,
+              a->priorities, 1, a->prio_exponent, B, a->prio_max_seen, a->prio_status, 0};
+  }
   if (phases & DZ_PHASE_BACKWARD) {
     DZ_REQUIRE(a->grad);
     float* grad = a->grad;
@@ -297,15 +309,6 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     DZ_REQUIRE(fc2_slots + fc1_slots <= kNormSlots);
     // optional priority write-back (dz_rainbow_args_t::prio_*), carried by the conv3
     // backward launch
-    bool prio_pending = a->prio_node != nullptr;
-    PrioUpdateParams prio_q = {};
-    if (prio_pending) {
-      DZ_REQUIRE(a->prio_ids && a->prio_status && dz_is_pow2(a->prio_cap_pow2) &&
-                 a->prio_capacity > 0 && a->prio_capacity <= a->prio_cap_pow2 &&
-                 a->prio_exponent >= 0.0 && B <= 256);
-      prio_q = {a->prio_node, a->prio_cap_pow2, a->prio_capacity, 0, 0, a->prio_ids,
-                a->priorities, 1, a->prio_exponent, B, a->prio_max_seen, a->prio_status, 0};
-    }
     float* part1 = ws + L.ws_wgrad_part;
     float* part2 = part1 + (long)kS_cw1 * Conv1Wg::KROWS * 32;
     float* part3 = part2 + (long)kS_cw2 * Conv2Wg::KROWS * 64;
@@ -411,7 +414,8 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       d.dy = ws + L.ws_dfeat; d.w = a->online + L.conv_w[2]; d.act = ws + L.ws_act2;
       d.dx = ws + L.ws_dact2; d.B = B;
       const dim3 gw(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), gd(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1);
-      if (prio_pending) {
+      const bool prio_in_adam = g_prio_host == 1 && (phases & DZ_PHASE_OPTIMIZER) && !fuse_adam;
+      if (prio_pending && !prio_in_adam) {
         // The sum-tree priority write-back rides in this launch as one extra block:
         // it needs only the loss kernel's priorities and nothing here reads the tree.
         // (Measured hosts: this launch hides it completely; inside the HBM-heavy fc1
@@ -464,11 +468,6 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       hipLaunchKernelGGL(finalize_grads_kernel, dim3((unsigned)n_final), dim3(256), 0, s, J);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "finalize_grads");
-    }
-    if (prio_pending) {  // no fused launch took it (non-default fc1 backward mode)
-      hipLaunchKernelGGL(prio_update_side_kernel, dim3(1), dim3(256), 0, s, prio_q);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "prio_update");
     }
   }
 
@@ -532,11 +531,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       dg.eps_out = nz[0] + L.n_fc1_out;
       dg.on = 1;
     }
+    // with the write-back as block 0 the grid stays g_adam_blocks wide (all blocks
+    // co-resident at 8 per CU): one optimiser block fewer
     if (g_adam_pipe)
       hipLaunchKernelGGL(adam_kernel<1>, dim3((unsigned)g_adam_blocks), dim3(256), 0, s, a->online,
                          a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
                          ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,
-                         a->lr, a->b1, a->b2, a->eps, a->max_norm, dg);
+                         a->lr, a->b1, a->b2, a->eps, a->max_norm, dg,
+                         prio_pending ? prio_q : PrioUpdateParams{});
     else
       hipLaunchKernelGGL(adam_kernel<0>, dim3((unsigned)g_adam_blocks), dim3(256), 0, s, a->online,
                          a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
@@ -544,6 +546,12 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
                          a->lr, a->b1, a->b2, a->eps, a->max_norm, dg);
     DZ_LAUNCH_CHECK();
     DZ_PROF(s, "adam");
+    if (g_adam_pipe) prio_pending = false;
+  }
+  if (prio_pending) {  // no launch of this call carried it
+    hipLaunchKernelGGL(prio_update_side_kernel, dim3(1), dim3(256), 0, s, prio_q);
+    DZ_LAUNCH_CHECK();
+    DZ_PROF(s, "prio_update");
   }
   return DZ_OK;
 }
@@ -668,6 +676,7 @@ extern "C" int dz_set_tuning(int key, int value) {
     case 17: g_fc2_weff = value; return DZ_OK;
     case 18: g_adam_fused = value; return DZ_OK;
     case 19: g_adam_pipe = value; return DZ_OK;
+    case 20: g_prio_host = value; return DZ_OK;
     default: return DZ_ERR_INVALID_ARG;
   }
 }

@@ -119,5 +119,5 @@ def test_tuning_keys_host_only(lib):
   assert lib.dz_set_tuning(1, 33) == _lib.DZ_ERR_INVALID_ARG      # <= 32
   assert lib.dz_set_tuning(8, 9) == _lib.DZ_ERR_INVALID_ARG       # fc2 splits <= 8
   for key, default in ((0, 10), (1, 32), (5, 3), (6, 2), (7, 16), (8, 8), (9, 1), (10, 1),
-                       (11, 1), (12, 1), (13, 5), (14, 2048), (15, 0), (16, 5), (17, 1), (18, 0), (19, 1)):
+                       (11, 1), (12, 1), (13, 5), (14, 2048), (15, 0), (16, 5), (17, 1), (18, 0), (19, 1), (20, 1)):
     assert lib.dz_set_tuning(key, default) == _lib.DZ_OK, key
