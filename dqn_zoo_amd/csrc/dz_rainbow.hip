@@ -385,9 +385,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         DZ_PROF(s, "fc1_dgrad+wgrad");
       } else if (g_fc1_dgrad_first == 3) {  // wgrad blocks first
         const dim3 gw(512 / FcWg::BN, kFlat / FcWg::BM, 2), gd(kFlat / 64, (B + 31) / 32, d.S);
-        rc = g_dgrad_weff
-                 ? dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 2>>(w, gw, d, gd, s)
-                 : dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 1>>(w, gw, d, gd, s);
+        if (!g_dgrad_weff)
+          rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 1>>(w, gw, d, gd, s);
+        else if (g_fc1_dgrad_variant == 0)  // 64-deep stages: one per workgroup at 16 splits
+          rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 4, 1, 1, 2>>(w, gw, d, gd, s);
+        else if (g_fc1_dgrad_variant == 1)
+          rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 2, 1, 1, 2>>(w, gw, d, gd, s);
+        else
+          rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 2>>(w, gw, d, gd, s);
         if (rc) return rc;
         DZ_PROF(s, "fc1_dgrad+wgrad");
       } else if (g_fc1_dgrad_first) {
