@@ -508,22 +508,9 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       const long flat4 = q.seg_len[0] + q.seg_len[1] + q.seg_len[2];
       const dim3 gw(512 / FcWg::BN, kFlat / FcWg::BM, 2);
       const unsigned nside = (unsigned)((flat4 + 255) / 256);
-      switch (g_adam_fused) {  // rows per round / next round's loads issued early
-        case 2: rc = dz_launch_gemm_side<FcWgradAdamOp<FcWg, 2, 1>, AdamFlatSide>(w, gw, q, nside, s); break;
-        case 3: rc = dz_launch_gemm_side<FcWgradAdamOp<FcWg, 4, 1>, AdamFlatSide>(w, gw, q, nside, s); break;
-        case 4: rc = dz_launch_gemm_side<FcWgradAdamOp<FcWg, 8, 0>, AdamFlatSide>(w, gw, q, nside, s); break;
-        case 5: rc = dz_launch_gemm_side<FcWgradAdamOp<FcWg, 2, 0>, AdamFlatSide>(w, gw, q, nside, s); break;
-        case 6: case 7: {  // 32 x 128 tiles: 512 contiguous bytes per row and workgroup
-          typedef FcWgradOp<1, 4, 1, 2> Wide;
-          const dim3 g2(512 / Wide::BN, kFlat / Wide::BM, 2);
-          if (g_adam_fused == 6)
-            rc = dz_launch_gemm_side<FcWgradAdamOp<Wide, 2, 1>, AdamFlatSide>(w, g2, q, nside, s);
-          else
-            rc = dz_launch_gemm_side<FcWgradAdamOp<Wide, 4, 0>, AdamFlatSide>(w, g2, q, nside, s);
-          break;
-        }
-        default: rc = dz_launch_gemm_side<FcWgradAdamOp<FcWg, 4, 0>, AdamFlatSide>(w, gw, q, nside, s); break;
-      }
+      // 2 accumulator rows per round, the next round's loads issued early: the best of
+      // the measured forms (rows per round 2/4/8, plain / pipelined, 64x64 / 32x128 tiles)
+      rc = dz_launch_gemm_side<FcWgradAdamOp<FcWg, 2, 1>, AdamFlatSide>(w, gw, q, nside, s);
       if (rc) return rc;
       DZ_PROF(s, "adam");
       return DZ_OK;

@@ -541,7 +541,7 @@ int dz_prof_read_replay(float* ms_out);
  * 14 = Adam launch width (blocks), 15 = conv forward tiles in XCD-aware order,
  * 16 = fc2 input-gradient k-splits (<= 5), 17 = fc2 forward against W_eff,
  * 18 = fc1 weight gradient recomputed inside the optimiser launch instead of
- * stored (0 = off [default]; 1..7 = tile / rows-per-round variants), 19 = flat
+ * stored (0 = off [default], 1 = on: same time, 20 % less traffic), 19 = flat
  * Adam with branch-free software-pipelined loads (1 [default]) or the plain loop,
  * 20 = launch that carries the priority write-back block (1 = Adam [default],
  * 0 = conv3 backward).
