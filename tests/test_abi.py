@@ -121,3 +121,13 @@ def test_tuning_keys_host_only(lib):
   for key, default in ((0, 10), (1, 32), (5, 3), (6, 2), (7, 16), (8, 8), (9, 1), (10, 1),
                        (11, 1), (12, 1), (13, 5), (14, 2048), (15, 0), (16, 5), (17, 1), (18, 0), (19, 1), (20, 1)):
     assert lib.dz_set_tuning(key, default) == _lib.DZ_OK, key
+
+
+def test_env_tuning_spec(lib):
+  """DZ_TUNING entries are applied through dz_set_tuning; bad ones raise."""
+  _lib.apply_env_tuning(lib, '')
+  _lib.apply_env_tuning(lib, '20=1, 19=1')
+  with pytest.raises(_lib.HipLibraryError):
+    _lib.apply_env_tuning(lib, '99=0')
+  with pytest.raises(_lib.HipLibraryError):
+    _lib.apply_env_tuning(lib, 'fast')
