@@ -81,6 +81,41 @@ __device__ __forceinline__ int64_t descend(const double* __restrict__ node,
   return i - cap;
 }
 
+// The same descent by 8 consecutive lanes (sub = lane & 7, all with the same
+// target), THREE levels per memory round trip: lane sub loads the left-child sum
+// of one of the 7 nodes that can be the current node within the next 3 steps
+//   sub 1: 2i     sub 2, 3: 4i, 4i+2     sub 4..7: 8i, 8i+2, 8i+4, 8i+6
+// and the group then takes the 3 decisions from registers (shuffles).  Same
+// comparisons and subtractions on the same node values as descend(): the result is
+// identical; the chain is ceil(levels/3) dependent loads instead of `levels`.
+__device__ __forceinline__ int64_t descend8(const double* __restrict__ node, int64_t cap,
+                                            double target, int sub) {
+  const int base = (int)(threadIdx.x & 63) & ~7;  // first lane of this group in the wave
+  int64_t i = 1;
+  while (i < cap) {
+    int64_t idx = sub < 2 ? 2 * i : (sub < 4 ? 4 * i + 2 * (sub - 2) : 8 * i + 2 * (sub - 4));
+    idx = idx < 2 * cap ? idx : 2 * cap - 1;  // past the leaves: unused
+    const double v = node[idx];
+    int pick = 1;
+#pragma unroll
+    for (int step = 0; step < 3; ++step) {
+      const double left = __shfl(v, base + pick);
+      if (i < cap) {  // group-uniform
+        int d = 0;
+        if (target < left) {
+          i = 2 * i;
+        } else {
+          target -= left;
+          i = 2 * i + 1;
+          d = 1;
+        }
+        pick = 2 * pick + d;  // 1 -> 2|3 -> 4..7
+      }
+    }
+  }
+  return i - cap;
+}
+
 __global__ void sumtree_query_kernel(const double* __restrict__ node, int64_t cap,
                                      const double* __restrict__ targets, int n,
                                      int64_t* __restrict__ out, uint32_t* status) {
@@ -124,10 +159,11 @@ struct HostDraws {
 
 // Tree index drawn for batch element i (replay.py:551-567): uniform candidate,
 // prioritized candidate (descent), mix.  `bad` reports a target outside [0, root).
-template <int HOST_DRAWS>
+// COOP: called by 8 consecutive lanes with the same i; `sub` = lane & 7 (descend8).
+template <int HOST_DRAWS, int COOP = 0>
 __device__ __forceinline__ int64_t sample_tree_index(const dz_prio_sample_args_t& a,
                                                      const HostDraws& hd, int i, double root,
-                                                     bool zero_root, bool& bad) {
+                                                     bool zero_root, bool& bad, int sub = 0) {
   const int64_t N = a.capacity;
   const int64_t pos_i = HOST_DRAWS ? hd.pos[i & (kMaxHostDraws - 1)] : a.pos[i];
   const double ut_i = HOST_DRAWS ? hd.u_target[i & (kMaxHostDraws - 1)] : a.u_target[i];
@@ -138,17 +174,20 @@ __device__ __forceinline__ int64_t sample_tree_index(const dz_prio_sample_args_t
   if (!zero_root) {
     const double target = ut_i * root;
     if (!(0.0 <= target && target < root)) bad = true;
-    else pri_ti = descend(a.node, a.cap_pow2, target);
+    else pri_ti = COOP ? descend8(a.node, a.cap_pow2, target, sub)
+                       : descend(a.node, a.cap_pow2, target);
   }
   return (um_i < a.usp) ? uni_ti : pri_ti;
 }
 
+// s_ti != null (256-thread block, n <= 64): the descents are done first, 8 lanes per
+// batch element (descend8), and parked in s_ti[]; otherwise one thread per element.
 template <int HOST_DRAWS>
 __device__ __forceinline__ void prioritized_sample_body(
     const dz_prio_sample_args_t& a, const HostDraws& hd, int n, int64_t* __restrict__ ids_out,
     int64_t* __restrict__ tree_idx_out, double* __restrict__ probs_out,
     double* __restrict__ weights_out, float* __restrict__ weights32_out,
-    uint32_t* status, double* s_red, double& s_max) {
+    uint32_t* status, double* s_red, double& s_max, int64_t* s_ti = nullptr) {
   const int i = threadIdx.x;
   const bool active = i < n;
   const double* __restrict__ node = a.node;
@@ -156,11 +195,23 @@ __device__ __forceinline__ void prioritized_sample_body(
   const double root = node[1];
   const bool zero_root = (root == 0.0);
   if (zero_root && a.assume_nonzero_root && i == 0) raise(status, DZ_ST_ZERO_ROOT);
+  if (s_ti) {
+    for (int q = i >> 3; q < n; q += (int)blockDim.x >> 3) {
+      bool bad;
+      const int64_t ti = sample_tree_index<HOST_DRAWS, 1>(a, hd, q, root, zero_root, bad, i & 7);
+      if ((i & 7) == 0) {
+        if (bad) raise(status, DZ_ST_BAD_TARGET);
+        s_ti[q] = ti;
+      }
+    }
+    __syncthreads();
+  }
 
   double w = 0.0;
   if (active) {
-    bool bad;
-    const int64_t ti = sample_tree_index<HOST_DRAWS>(a, hd, i, root, zero_root, bad);
+    bool bad = false;
+    const int64_t ti = s_ti ? s_ti[i]
+                            : sample_tree_index<HOST_DRAWS>(a, hd, i, root, zero_root, bad);
     if (bad) raise(status, DZ_ST_BAD_TARGET);
     // probabilities: replay.py:569-577 (separate mul, mul, add: no FMA)
     const double leaf = node[cap + ti];
@@ -222,8 +273,8 @@ __global__ __launch_bounds__(kMaxBatch) void prioritized_sample_kernel(
 // Sample AND gather in one launch (batch <= 64, draws in the kernel arguments).
 // Block row y == n is the sampler proper (ids, probabilities, IS weights: exactly
 // prioritized_sample_body); every gather block (x = chunk, y = batch element,
-// z = field) re-derives ITS element's tree index with the same arithmetic (one
-// thread, ~20 dependent loads that hit L2 after the first block) instead of
+// z = field) re-derives ITS element's tree index with the same arithmetic (8
+// lanes, 7 dependent round trips for 20 levels: descend8) instead of
 // waiting for a second launch to read ids[]: the descent and the copy overlap.
 struct SampleGatherFields { dz_field_t f[DZ_MAX_FIELDS]; int num_fields; };
 __global__ __launch_bounds__(256) void prioritized_sample_gather_kernel(
@@ -233,18 +284,20 @@ __global__ __launch_bounds__(256) void prioritized_sample_gather_kernel(
   __shared__ double s_red[4];
   __shared__ double s_max;
   __shared__ int64_t s_slot;
+  __shared__ int64_t s_ti[kMaxHostDraws];
   if ((int)blockIdx.y == n) {
     if (blockIdx.x == 0 && blockIdx.z == 0)
       prioritized_sample_body<1>(a, hd, n, ids_out, nullptr, probs_out, weights_out,
-                                 weights32_out, status, s_red, s_max);
+                                 weights32_out, status, s_red, s_max, s_ti);
     return;
   }
   const int b = blockIdx.y;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 8) {  // 8 lanes walk the element's descent, 3 levels per round trip
     const double root = a.node[1];
     bool bad;
-    const int64_t ti = sample_tree_index<1>(a, hd, b, root, root == 0.0, bad);
-    s_slot = dz_mod(id_of_tree_index(ti, a.capacity, a.t, a.size), a.capacity);
+    const int64_t ti = sample_tree_index<1, 1>(a, hd, b, root, root == 0.0, bad, threadIdx.x);
+    if (threadIdx.x == 0)
+      s_slot = dz_mod(id_of_tree_index(ti, a.capacity, a.t, a.size), a.capacity);
   }
   __syncthreads();
   const dz_field_t fd = gf.f[blockIdx.z];
