@@ -52,6 +52,9 @@ def parse_args():
   ap.add_argument('--cpu-seconds', type=float, default=15.0,
                   help='CPU-baseline time budget (0 disables)')
   ap.add_argument('--prof-steps', type=int, default=100)
+  ap.add_argument('--other-configs', type=int, default=1,
+                  help='also measure BASELINE configs 2 and 3 (DQN + uniform replay; '
+                       'double-Q + prioritized) after the headline (0 disables)')
   ap.add_argument('--no-graphs', action='store_true',
                   help='launch the learner kernels eagerly instead of hipGraph replay')
   ap.add_argument('--pipelined', action='store_true',
@@ -408,26 +411,44 @@ def main():
     step = make_step_pipelined(replay, learner, args.batch, device)
   seq_step = make_step(replay, learner, args.batch)
 
+  # ---- setup that is NOT a step, all of it before the clock starts ----------
+  # (round 1 had these inside the timed window: at the driver's --steps 20 the
+  # first-use costs of torch.distributed / ReplicaStats / the .cpu() reads were
+  # 75 % of the measurement)
+  from dqn_zoo_amd import distributed as dz_dist
+  # one hipGraph per slot of the replay's sample ring: capture them all now so
+  # that no --warmup value can leave a capture inside the timed region
+  prime = 0 if args.no_graphs else replay.SAMPLE_RING_DEPTH
+  for _ in range(prime):
+    step()
+  # the statistics path once, end to end (allocations, first-use kernels, the
+  # all-reduce's communicator set-up, the two device->host reads)
+  dry = dz_dist.ReplicaStats(device)
+  dry.add(grad_steps=0, loss_sum=learner.losses.double().sum())
+  dry.all_reduce()
+  stats = dz_dist.ReplicaStats(device)
+  torch.cuda.synchronize()
+
   for _ in range(args.warmup):
     step()
   torch.cuda.synchronize()
   if dist is not None:
     dist.barrier()
   torch.cuda.synchronize()
+  # ---- the timed region: EXACTLY args.steps steps ---------------------------
   t0 = time.perf_counter()
   for _ in range(args.steps):
     step()
-  # statistics boundary: one RCCL all-reduce of packed sums over xGMI
-  # (keys of EpisodeTracker/StepRateTracker, parts.py:239-284)
-  from dqn_zoo_amd import distributed as dz_dist
-  stats = dz_dist.ReplicaStats(device)
-  stats.add(grad_steps=args.steps, loss_sum=learner.losses.double().sum())
-  totals = stats.all_reduce()
   torch.cuda.synchronize()
   if dist is not None:
     dist.barrier()
-  torch.cuda.synchronize()
+    torch.cuda.synchronize()
   dt = time.perf_counter() - t0
+  # statistics boundary (not a gradient step, outside the clock): one RCCL
+  # all-reduce of packed sums over xGMI (keys of
+  # EpisodeTracker/StepRateTracker, parts.py:239-284)
+  stats.add(grad_steps=args.steps, loss_sum=learner.losses.double().sum())
+  totals = stats.all_reduce()
   if dist is not None:
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -453,6 +474,7 @@ def main():
             'state': '84x84x4 uint8', 'num_actions': NUM_ACTIONS,
             'num_atoms': NUM_ATOMS, 'parallelism': 'replicas x%d' % world,
             'launch': 'eager' if args.no_graphs else 'hipGraph replay',
+            'untimed_setup_steps': prime,
             'streams': 'sequential' if args.sequential else
                        'replay ops overlapped on a side stream'},
     }
