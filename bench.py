@@ -64,6 +64,32 @@ def parse_args():
   return ap.parse_args()
 
 
+def fill_synthetic(replay, cap, device, seed, discount, priority=None):
+  """Synthetic transitions: states from a pool of 256 seeded random
+  84x84x4 uint8 frames, a ~ U{0..A-1}, r in {-1,0,1}, discount in {0, `discount`};
+  written straight into the HBM store (equivalent to `cap` add() calls)."""
+  g = torch.Generator(device=device)
+  g.manual_seed(seed)
+  pool = torch.randint(0, 256, (256, 84, 84, 4), dtype=torch.uint8,
+                       device=device, generator=g)
+  chunk = 4096
+  done = 0
+  while done < cap:
+    n = min(chunk, cap - done)
+    i1 = torch.randint(0, 256, (n,), device=device, generator=g)
+    i2 = torch.randint(0, 256, (n,), device=device, generator=g)
+    a = torch.randint(0, NUM_ACTIONS, (n,), device=device, generator=g)
+    r = (torch.randint(0, 3, (n,), device=device, generator=g) - 1).double()
+    d = torch.randint(0, 2, (n,), device=device, generator=g).double() * discount
+    fields = [pool[i1], a, r, d, pool[i2]]
+    if priority is None:
+      replay.bulk_fill(fields)
+    else:
+      replay.bulk_fill(fields, priority=priority)
+    done += n
+  return pool
+
+
 def build_workload(args, device, seed):
   from dqn_zoo_amd import learner as learner_lib
   from dqn_zoo_amd import networks
@@ -81,29 +107,13 @@ def build_workload(args, device, seed):
       priority_exponent=0.5, importance_sampling_exponent=beta,
       uniform_sample_probability=1e-3, normalize_weights=True,
       random_state=rs, device=device)
-  # synthetic transitions: pool of 256 seeded random frames
-  g = torch.Generator(device=device)
-  g.manual_seed(seed)
-  pool = torch.randint(0, 256, (256, 84, 84, 4), dtype=torch.uint8,
-                       device=device, generator=g)
-  chunk = 4096
-  done = 0
-  while done < cap:
-    n = min(chunk, cap - done)
-    i1 = torch.randint(0, 256, (n,), device=device, generator=g)
-    i2 = torch.randint(0, 256, (n,), device=device, generator=g)
-    a = torch.randint(0, NUM_ACTIONS, (n,), device=device, generator=g)
-    r = (torch.randint(0, 3, (n,), device=device, generator=g) - 1).double()
-    d = torch.randint(0, 2, (n,), device=device, generator=g).double() * \
-        N_STEP_DISCOUNT
-    replay.bulk_fill([pool[i1], a, r, d, pool[i2]], priority=1.0)
-    done += n
+  fill_synthetic(replay, cap, device, seed, N_STEP_DISCOUNT, priority=1.0)
   support = np.linspace(-VMAX, VMAX, NUM_ATOMS).astype(np.float32)
   net = networks.RainbowNetwork(NUM_ACTIONS, support, 0.1)
   learner = learner_lib.RainbowLearner(net, learner_lib.AdamConfig(), b,
                                        seed=seed, device=device)
   torch.cuda.synchronize(device)
-  return replay, learner, pool
+  return replay, learner, None
 
 
 def make_step(replay, learner, batch, fused_write_back=True):
@@ -193,6 +203,157 @@ def kernel_work(b, a=NUM_ACTIONS, k=NUM_ATOMS):
   w['adam'] = (0.0, 7.0 * p_ref * 4)           # read g,p,m,v; write p,m,v
   w['grad_sumsq'] = (0.0, 1.0 * p_ref * 4)
   return w
+
+
+def dense_kernel_work(b, g, a=NUM_ACTIONS):
+  """name -> (flops, bytes) of ONE launch of the dense-head (NatureDQN) learner
+  at batch b with g network applies per step (2: DQN; 3: double-Q)."""
+  p_ref = 77984 + (3136 * 512 + 512) + (512 * a + a)
+  f = lambda m, n, kk: 2.0 * m * n * kk
+  sets = 2  # online + target weights are each streamed once
+  w = {}
+  w['conv1_fwd'] = (f(g * b * 400, 32, 256), g * b * 28224 + g * b * 400 * 32 * 4)
+  w['conv2_fwd'] = (f(g * b * 81, 64, 512), g * b * (12800 + 5184) * 4)
+  w['conv3_fwd'] = (f(g * b * 49, 64, 576), g * b * (5184 + 3136) * 4)
+  w['fc1_fwd'] = (f(g * b, 512, 3136), sets * 3136 * 512 * 4)
+  w['fc2_fwd'] = (f(g * b, a, 512), sets * 512 * a * 4)
+  w['fc1_wgrad+dgrad'] = (f(3136, 512, b) + f(b, 3136, 512), 2 * 3136 * 512 * 4)
+  w['fc2_wgrad+dgrad'] = (f(512, a, b) + f(b, 512, a), 2 * 512 * a * 4)
+  w['conv3_wgrad+dgrad'] = (f(576, 64, b * 49) + f(b * 81, 64, 576),
+                            2 * b * (5184 + 3136) * 4)
+  w['conv2_wgrad+dgrad'] = (f(512, 64, b * 81) + f(b * 400, 32, 256),
+                            2 * b * (12800 + 5184) * 4)
+  w['conv1_wgrad'] = (f(256, 32, b * 400), b * 28224 + b * 12800 * 4)
+  w['rmsprop'] = (0.0, 7.0 * p_ref * 4)  # read g,p,mu,nu; write p,mu,nu
+  return w
+
+
+def profile_kernels(step, n):
+  """Average per-kernel durations (s) of `step` from the library's HIP events."""
+  from dqn_zoo_amd import _lib
+  lib = _lib.load()
+  lib.dz_prof_enable(1)
+  ms = (ctypes.c_float * 96)()
+  names = ctypes.create_string_buffer(96 * 32)
+  acc = {}
+  for _ in range(n):
+    step()
+    torch.cuda.synchronize()
+    k = lib.dz_prof_read(96, ctypes.addressof(ms), ctypes.addressof(names))
+    for i in range(k):
+      nm = names.raw[32 * i:32 * i + 32].split(b'\0')[0].decode()
+      acc.setdefault(nm, []).append(ms[i] * 1e-3)
+  lib.dz_prof_enable(0)
+  return {k: float(np.mean(v)) for k, v in acc.items()}
+
+
+def roofline_of(avg, work):
+  """Dominant kernel of a step and its roofline fraction (as `roofline`)."""
+  dom = max(avg, key=avg.get)
+  out = {'kernel': dom, 'avg_us': round(avg[dom] * 1e6, 2), 'traffic': None}
+  if dom in work:
+    flops, nbytes = work[dom]
+    if flops / PEAK_F32_MFMA > nbytes / PEAK_HBM:
+      out.update(bound='mfma', achieved=round(flops / avg[dom] / 1e12, 3),
+                 peak=PEAK_F32_MFMA / 1e12, unit='TFLOP/s')
+    else:
+      out.update(bound='hbm', achieved=round(nbytes / avg[dom] / 1e9, 3),
+                 peak=PEAK_HBM / 1e9, unit='GB/s')
+    out['frac'] = round(out['achieved'] / out['peak'], 4)
+  out['learn_kernels_us'] = round(sum(avg.values()) * 1e6, 1)
+  return out
+
+
+def measure_other_configs(args, device, steps, warmup, prof_steps):
+  """BASELINE.json configs[1] and configs[2] at full size (1M-transition store in
+  HBM, batch 32): the whole sample -> update (-> priority write-back) step, as
+  `Dqn._learn` / `PrioritizedDqn._learn` enqueue it (ref: dqn/agent.py:179-189,
+  dqn/run_atari.py:201-219; prioritized/agent.py:187-206,
+  prioritized/run_atari.py:104-113,234-250).  One store is alive at a time."""
+  from dqn_zoo_amd import learner as learner_lib
+  from dqn_zoo_amd import networks
+  from dqn_zoo_amd import parts
+  from dqn_zoo_amd import replay as replay_lib
+
+  cap, b = args.capacity, args.batch
+  T = replay_lib.Transition(None, None, None, None, None)
+  out = {}
+
+  def run(name, replay, learner, step, work, desc):
+    learner.use_graphs = not args.no_graphs
+    for _ in range(max(warmup, replay.SAMPLE_RING_DEPTH)):
+      step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    replay.check_status()
+    e = {'metric': 'gradient-steps/sec (%s, batch %d)' % (name, b),
+         'value': round(steps / dt, 2), 'unit': 'steps/s', 'steps': steps,
+         'ms_per_step': round(1e3 * dt / steps, 4),
+         'replay_samples_per_sec': round(steps / dt * b, 1), 'dtype': 'f32',
+         'config': dict(desc, replay_capacity=cap, global_batch=b,
+                        num_actions=NUM_ACTIONS,
+                        launch='eager' if args.no_graphs else
+                               'hipGraph replay (learner) + 1 eager sample launch')}
+    if prof_steps > 0:
+      learner.use_graphs = False
+      e['roofline'] = roofline_of(profile_kernels(step, prof_steps), work)
+    return e
+
+  # ---- configs[1]: DQN, NatureDQN net, uniform replay ------------------------
+  rep = replay_lib.TransitionReplay(cap, T, np.random.RandomState(args.seed),
+                                    device=device)
+  fill_synthetic(rep, cap, device, args.seed, 0.99)
+  ln = learner_lib.DenseLearner(
+      networks.DenseNetwork('dqn', NUM_ACTIONS), 'q',
+      learner_lib.RmsPropConfig(learning_rate=0.00025, decay=0.95,
+                                eps=0.01 / 32 ** 2), b, seed=args.seed,
+      device=device)
+
+  def step_dqn():
+    t, _ = rep.sample_device(b)
+    ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, None)
+
+  out['dqn_uniform_1m'] = run(
+      'DQN + uniform replay', rep, ln, step_dqn, dense_kernel_work(b, 2),
+      {'workload': 'dqn learner step: uniform sample (positions -> ids -> gather, '
+                   'one launch) + 2x NatureDQN apply + Q-learning loss + backward '
+                   '+ centred RMSProp', 'baseline_config': 1})
+  del rep, ln, step_dqn
+  torch.cuda.empty_cache()
+
+  # ---- configs[2]: double-Q + prioritized replay (exponent 0.6) ---------------
+  beta = parts.LinearSchedule(begin_t=int(0.05 * cap), end_t=200 * 250000,
+                              begin_value=0.4, end_value=1.0)
+  rep = replay_lib.PrioritizedTransitionReplay(
+      cap, T, priority_exponent=0.6, importance_sampling_exponent=beta,
+      uniform_sample_probability=1e-3, normalize_weights=True,
+      random_state=np.random.RandomState(args.seed), device=device)
+  fill_synthetic(rep, cap, device, args.seed, 0.99, priority=1.0)
+  ln = learner_lib.DenseLearner(
+      networks.DenseNetwork('double_dqn', NUM_ACTIONS), 'double_q',
+      learner_lib.RmsPropConfig(learning_rate=0.00025 / 4, decay=0.95,
+                                eps=(0.01 / 32 ** 2) * (1.0 / 4) ** 2), b,
+      seed=args.seed, device=device)
+
+  def step_prio():
+    sm = rep.sample_device(b)
+    t = sm.transitions
+    ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, sm.weights32,
+            priority_sink=rep.priority_sink(sm.ids))
+
+  out['double_q_prioritized_1m'] = run(
+      'double-Q + prioritized replay', rep, ln, step_prio, dense_kernel_work(b, 3),
+      {'workload': 'prioritized-DQN learner step: sum-tree sample (exponent 0.6) + '
+                   'IS weights + gather (one launch) + 3x NatureDQN apply (shared '
+                   'bias) + double-Q loss + backward (+ |td| priority write-back as '
+                   'a side block) + centred RMSProp', 'baseline_config': 2})
+  del rep, ln
+  torch.cuda.empty_cache()
+  return out
 
 
 def pmc_traffic(kernel):
@@ -387,8 +548,30 @@ def main():
     raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
+  # `bench.py --gpus N` started by hand (not under torchrun): spawn the ranks
+  # ourselves, degrading to the GPUs this box has (gpurun boxes have one)
+  if args.gpus > 1 and 'RANK' not in os.environ:
+    have = torch.cuda.device_count()
+    n = min(args.gpus, have)
+    if n < args.gpus:
+      print('bench.py: --gpus %d requested, %d visible: running %d replica(s)' %
+            (args.gpus, have, n), file=sys.stderr)
+    if n > 1:
+      import socket
+      sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+      argv = [a for a in sys.argv[1:]]
+      for i, a in enumerate(argv):
+        if a == '--gpus':
+          argv[i + 1] = str(n)
+        elif a.startswith('--gpus='):
+          argv[i] = '--gpus=%d' % n
+      os.execv(sys.executable, [
+          sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+          '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+          '--master-port', str(port), os.path.abspath(__file__)] + argv)
+    args.gpus = n
   dist = None
-  if world > 1:
+  if 'RANK' in os.environ:  # under torchrun, world 1 included: RCCL is exercised
     import torch.distributed as dist  # RCCL (backend "nccl" on ROCm)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     # NCCL_DEBUG=VERSION (set in this image) makes RCCL print a version banner on
@@ -474,6 +657,7 @@ def main():
             'state': '84x84x4 uint8', 'num_actions': NUM_ACTIONS,
             'num_atoms': NUM_ATOMS, 'parallelism': 'replicas x%d' % world,
             'launch': 'eager' if args.no_graphs else 'hipGraph replay',
+            'collective': 'rccl' if dist is not None else 'none (single process)',
             'untimed_setup_steps': prime,
             'streams': 'sequential' if args.sequential else
                        'replay ops overlapped on a side stream'},
@@ -484,6 +668,13 @@ def main():
       # the write-back timed as its own kernel (in the measured step it rides
       # inside a backward launch)
       out['replay'] = measure_replay(replay, learner, args.batch)
+    if world == 1 and args.other_configs:
+      # BASELINE configs 2 and 3 (the headline's store is released first)
+      del step, seq_step, replay, learner
+      torch.cuda.empty_cache()
+      out['other_configs'] = measure_other_configs(
+          args, device, steps=max(args.steps, 200), warmup=max(args.warmup, 20),
+          prof_steps=min(args.prof_steps, 20))
     if world == 1 and args.cpu_seconds > 0:
       out['cpu_baseline'] = cpu_baseline(args, args.seed, args.cpu_seconds)
       out['speedup_vs_cpu_baseline'] = round(

@@ -178,6 +178,8 @@ SIGNATURES = {
                                ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dz_rainbow_graph_capture': (c_int, [ctypes.POINTER(RainbowArgs), c_int, c_vp,
                                          ctypes.POINTER(c_vp)]),
+    'dz_graph_capture_begin': (c_int, [c_vp]),
+    'dz_graph_capture_end': (c_int, [c_vp, c_int, ctypes.POINTER(c_vp)]),
     'dz_graph_launch': (c_int, [c_vp, c_vp]),
     'dz_graph_destroy': (c_int, [c_vp]),
     'dz_dense_layout': (c_int, [c_int, c_int, c_int, c_int,
@@ -309,6 +311,24 @@ def check(code, what):
   if code == DZ_ERR_UNSUPPORTED:
     raise NotImplementedError('%s: unsupported configuration' % what)
   raise HipLibraryError('%s: unknown error code %d' % (what, code))
+
+
+def capture_graph(stream, enqueue):
+  """Runs `enqueue()` (calls into this library on `stream`) under hipGraph
+  capture and returns the executable graph handle."""
+  lib = load()
+  if not stream:
+    raise RuntimeError('hipGraph capture needs a non-default stream: run under '
+                       '`torch.cuda.stream(torch.cuda.Stream())`')
+  check(lib.dz_graph_capture_begin(stream), 'dz_graph_capture_begin')
+  h = ctypes.c_void_p()
+  try:
+    enqueue()
+  except BaseException:
+    lib.dz_graph_capture_end(stream, 1, ctypes.byref(h))
+    raise
+  check(lib.dz_graph_capture_end(stream, 0, ctypes.byref(h)), 'dz_graph_capture_end')
+  return h
 
 
 def ptr(t):

@@ -567,6 +567,31 @@ extern "C" int dz_rainbow_graph_capture(const dz_rainbow_args_t* args, int phase
   return DZ_OK;
 }
 
+extern "C" int dz_graph_capture_begin(dz_stream_t stream) {
+  DZ_REQUIRE(stream && !g_dz_prof_on);
+  DZ_HIP_CHECK(hipStreamBeginCapture(dz_s(stream), hipStreamCaptureModeThreadLocal));
+  return DZ_OK;
+}
+
+extern "C" int dz_graph_capture_end(dz_stream_t stream, int discard, void** graph_exec_out) {
+  DZ_REQUIRE(stream && graph_exec_out);
+  *graph_exec_out = nullptr;
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(dz_s(stream), &graph);
+  if (discard) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    return DZ_OK;
+  }
+  DZ_HIP_CHECK(e);
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  DZ_HIP_CHECK(e);
+  *graph_exec_out = (void*)exec;
+  return DZ_OK;
+}
+
 extern "C" int dz_graph_launch(void* graph_exec, dz_stream_t stream) {
   DZ_REQUIRE(graph_exec);
   DZ_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, dz_s(stream)));

@@ -88,6 +88,10 @@ class DenseAgent(parts.Agent):
       self._learn()
     if self._frame_t % self._target_network_update_period == 0:
       self._learner.sync_target()
+      # the reference raises at the offending call when a priority or weight
+      # goes NaN/inf/negative (replay.py:233-242,281-282); here those land in a
+      # sticky device word, polled once per target period (one host sync)
+      self._replay.check_status()
     return action
 
   def reset(self) -> None:

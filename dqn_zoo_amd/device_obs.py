@@ -13,6 +13,17 @@ import numpy as np
 import torch
 
 
+def canonical_scalars(transition):
+  """Scalar fields in the dtypes the reference's `np.stack` of Python scalars
+  yields (replay.py:157-163: int -> int64, float -> float64).  An environment or
+  processor that emits np.float32 rewards / np.int32 actions would otherwise
+  freeze the store's dtype to that of the first item, and the learner kernels
+  read int64 / float64."""
+  return transition._replace(a_tm1=np.int64(transition.a_tm1),
+                             r_t=np.float64(transition.r_t),
+                             discount_t=np.float64(transition.discount_t))
+
+
 class ObservationCache:
 
   def __init__(self, device, depth: int = 8, shape=(84, 84, 4)):
@@ -46,10 +57,9 @@ class ObservationCache:
     """The transition with `s_tm1` / `s_t` replaced by their device copies
     where the cache holds them."""
     a, b = self.lookup(transition.s_tm1), self.lookup(transition.s_t)
-    if a is None and b is None:
-      return transition
-    return transition._replace(s_tm1=transition.s_tm1 if a is None else a,
-                               s_t=transition.s_t if b is None else b)
+    return canonical_scalars(transition)._replace(
+        s_tm1=transition.s_tm1 if a is None else a,
+        s_t=transition.s_t if b is None else b)
 
   def clear(self) -> None:
     self._host = [None] * self._depth

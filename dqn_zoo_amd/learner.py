@@ -28,6 +28,25 @@ def read_packed_action(greedy: torch.Tensor, vmax: torch.Tensor):
   return int(h[0, 0]), float(h[1].view(torch.float32)[0])
 
 
+def check_batch(b, s_tm1, a_tm1, r_t, discount_t, s_t, weights=None):
+  """Validates a device batch (survives `python -O`, unlike assert): the
+  kernels reinterpret raw pointers, so a wrong dtype would be silent garbage."""
+  for name, x, dt, shape in (
+      ('s_tm1', s_tm1, torch.uint8, (b, 84, 84, 4)),
+      ('s_t', s_t, torch.uint8, (b, 84, 84, 4)),
+      ('a_tm1', a_tm1, torch.int64, (b,)), ('r_t', r_t, torch.float64, (b,)),
+      ('discount_t', discount_t, torch.float64, (b,)),
+      ('weights', weights, torch.float32, (b,))):
+    if x is None and name == 'weights':
+      continue
+    if not isinstance(x, torch.Tensor) or x.dtype != dt:
+      raise TypeError('%s must be a %s device tensor, got %s' % (
+          name, dt, getattr(x, 'dtype', type(x))))
+    if tuple(x.shape) != shape or not x.is_contiguous():
+      raise ValueError('%s must be contiguous with shape %s, got %s' % (
+          name, shape, tuple(x.shape)))
+
+
 class AdamConfig(typing.NamedTuple):
   """optax.chain(clip_by_global_norm(max_norm), adam(lr, eps=eps))
   (ref: rainbow/run_atari.py:77-81, 229-235).  max_norm <= 0 disables the clip."""
@@ -99,6 +118,19 @@ class RainbowLearner:
     """Explicit noise for the 3 applies (parity runs)."""
     blocks = [self.layout.pack_noise(n) for n in noises]
     self.noise.copy_(torch.from_numpy(np.concatenate(blocks)))
+
+  def set_noise_state(self, seed: int, counter: int) -> None:
+    """Restores the noise stream position (agent `set_state`).  The cached
+    argument block and every captured hipGraph bake the old seed in: drop them."""
+    self._noise_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    self._noise_counter = int(counter)
+    self._args = None
+    self.drop_graphs()
+
+  def drop_graphs(self) -> None:
+    graphs, self._graphs = self._graphs, {}
+    for g in graphs.values():
+      self._lib.dz_graph_destroy(g)
 
   def resample_noise(self) -> None:
     """Fresh factorised noise for the 3 applies, generated on the device."""
@@ -189,11 +221,9 @@ class RainbowLearner:
     inside its backward launches -- the caller then must NOT call
     `update_priorities` for this batch.  Needs PHASE_BACKWARD in `phases`."""
     b = self.batch_size
-    assert s_tm1.dtype == torch.uint8 and s_t.dtype == torch.uint8
-    assert s_tm1.is_contiguous() and s_t.is_contiguous()
-    assert tuple(s_tm1.shape) == (b, 84, 84, 4) and tuple(s_t.shape) == (b, 84, 84, 4)
-    assert a_tm1.dtype == torch.int64 and r_t.dtype == torch.float64
-    assert discount_t.dtype == torch.float64 and weights.dtype == torch.float32
+    check_batch(b, s_tm1, a_tm1, r_t, discount_t, s_t, weights)
+    if weights is None:
+      raise TypeError('weights must be a float32 device tensor')
     a = self._args
     if a is None:  # everything that never changes is filled once
       a = self._args = _lib.RainbowArgs()
@@ -320,6 +350,8 @@ class DenseLearner:
     self.huber_param = float(huber_param)
     self._act_ws = None
     self._act_batch = 0
+    self._graphs = {}        # (input pointers, phases, sink) -> hipGraphExec
+    self.use_graphs = False  # replay each distinct call signature from a hipGraph
 
   def get_params(self, which='online') -> dict:
     t = self.online if which == 'online' else self.target
@@ -353,10 +385,7 @@ class DenseLearner:
     """`priority_sink`: see RainbowLearner.step (the |td| priorities go into the
     replay's sum tree inside the backward launches)."""
     b = self.batch_size
-    assert s_tm1.dtype == torch.uint8 and s_t.dtype == torch.uint8
-    assert tuple(s_tm1.shape) == (b, 84, 84, 4) and s_tm1.is_contiguous()
-    assert a_tm1.dtype == torch.int64 and r_t.dtype == torch.float64
-    assert discount_t.dtype == torch.float64
+    check_batch(b, s_tm1, a_tm1, r_t, discount_t, s_t, weights)
     a = _lib.DenseArgs()
     net = self.network
     a.loss = self.loss_id
@@ -381,7 +410,6 @@ class DenseLearner:
     if weights is None and self.loss == 'categorical':
       weights = self.ones   # the categorical head kernel always takes weights
     if weights is not None:
-      assert weights.dtype == torch.float32
       a.weights = weights.data_ptr()
     a.aux = None if self.aux is None else self.aux.data_ptr()
     a.ws = self.ws.data_ptr()
@@ -400,9 +428,31 @@ class DenseLearner:
         raise ValueError('priority_sink needs the backward phase in this call')
       (a.prio_node, a.prio_cap_pow2, a.prio_capacity, a.prio_ids, a.prio_exponent,
        a.prio_max_seen, a.prio_status) = priority_sink
-    _lib.check(self._lib.dz_dense_learn(
-        ctypes.byref(a), phases,
-        torch.cuda.current_stream(self.device).cuda_stream), 'dz_dense_learn')
+    stream = torch.cuda.current_stream(self.device).cuda_stream
+    enqueue = lambda: _lib.check(self._lib.dz_dense_learn(
+        ctypes.byref(a), phases, stream), 'dz_dense_learn')
+    if not self.use_graphs:
+      enqueue()
+      return
+    # every argument is a pointer or a constant of this object: the launches of
+    # one call signature are captured once and replayed (as jax.jit does)
+    key = (a.s_tm1, a.s_t, a.a_tm1, a.r_t, a.discount_t, a.weights, phases,
+           a.prio_node, a.prio_ids)
+    g = self._graphs.get(key)
+    if g is None:
+      g = self._graphs[key] = _lib.capture_graph(stream, enqueue)
+    _lib.check(self._lib.dz_graph_launch(g, stream), 'dz_graph_launch')
+
+  def drop_graphs(self) -> None:
+    graphs, self._graphs = self._graphs, {}
+    for g in graphs.values():
+      self._lib.dz_graph_destroy(g)
+
+  def __del__(self):
+    try:
+      self.drop_graphs()
+    except Exception:  # pylint: disable=broad-except
+      pass
 
   def apply(self, states: torch.Tensor, which: str = 'online'):
     """Head outputs [B, num_outputs] for uint8 states; for Q heads also
@@ -494,10 +544,7 @@ class IqnLearner:
     """taus: optional (tau_tm1 [B,N0], tau_sel [B,N1], tau_t [B,N2]) float32
     device tensors; default: drawn on the device."""
     b = self.batch_size
-    assert s_tm1.dtype == torch.uint8 and s_t.dtype == torch.uint8
-    assert tuple(s_tm1.shape) == (b, 84, 84, 4) and s_tm1.is_contiguous()
-    assert a_tm1.dtype == torch.int64 and r_t.dtype == torch.float64
-    assert discount_t.dtype == torch.float64
+    check_batch(b, s_tm1, a_tm1, r_t, discount_t, s_t)
     if taus is None:
       self.sample_taus()
     else:

@@ -95,6 +95,10 @@ class Rainbow(parts.Agent):
 
     if self._frame_t % self._target_network_update_period == 0:
       self._learner.sync_target()
+      # the reference raises at the offending call when a priority or weight
+      # goes NaN/inf/negative (replay.py:233-242,281-282); here those land in a
+      # sticky device word, polled once per target period (one host sync)
+      self._replay.check_status()
 
     return action
 
@@ -166,7 +170,7 @@ class Rainbow(parts.Agent):
 
   def set_state(self, state: Mapping[str, Any]) -> None:
     ln = self._learner
-    ln._noise_seed, ln._noise_counter = state['rng_key']  # pylint: disable=protected-access
+    ln.set_noise_state(*state['rng_key'])
     self._frame_t = state['frame_t']
     ln.set_opt_state(state['opt_state'])
     ln.set_params(state['online_params'], 'online')

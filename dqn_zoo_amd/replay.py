@@ -41,6 +41,7 @@ import torch
 from dqn_zoo_amd import _lib
 
 ReplayStructure = TypeVar('ReplayStructure', bound=Tuple[Any, ...])
+COMPACT_FORMAT = 'dqn_zoo_amd.replay.compact.v1'
 
 
 class Transition(typing.NamedTuple):
@@ -112,6 +113,62 @@ def position_to_id(pos, t, capacity):
 def tree_index_of_id(ids, capacity):
   """Sum-tree index of an id (free stack popped from the end, replay.py:499)."""
   return capacity - 1 - np.mod(np.asarray(ids, dtype=np.int64), capacity)
+
+
+def uniform_distribution_state(t, size, capacity):
+  """`UniformDistribution.get_state()` of the reference (replay.py:95-100) for a
+  replay that has seen `t` adds: {'ids': swap-remove list, 'id_to_index': dict},
+  materialised from the closed form."""
+  ids = position_to_id(np.arange(size, dtype=np.int64), t, capacity)
+  return {'ids': [int(i) for i in ids],
+          'id_to_index': {int(i): j for j, i in enumerate(ids)}}
+
+
+def prioritized_distribution_state(t, size, capacity, cap_pow2, tree_storage):
+  """`PrioritizedDistribution.get_state()` of the reference (replay.py:606-615)
+  materialised from the closed forms: tree index of id i
+  is N-1-(i mod N); the free stack `list(range(N))` is popped from the end, so
+  while filling it still holds [0, N-size); `_active_indices` is the swap-remove
+  list of R1 holding tree indices."""
+  ids = np.arange(t - size, t, dtype=np.int64)
+  idx = tree_index_of_id(ids, capacity)
+  active_ids = position_to_id(np.arange(size, dtype=np.int64), t, capacity)
+  active = tree_index_of_id(active_ids, capacity)
+  return {
+      'sum_tree': {'size': int(capacity), 'storage': tree_storage,
+                   'first_leaf': int(cap_pow2)},
+      'id_to_index': {int(i): int(j) for i, j in zip(ids, idx)},
+      'index_to_id': {int(j): int(i) for i, j in zip(ids, idx)},
+      'inactive_indices': list(range(capacity - size)),
+      'active_indices': [int(j) for j in active],
+      'active_indices_location': {int(j): k for k, j in enumerate(active)},
+  }
+
+
+def _check_storage_ids(storage, t, capacity):
+  """A reference `storage` list must be the FIFO window [t-size, t) in order
+  (replay.py:141-150 adds at the end and evicts from the front)."""
+  size = len(storage)
+  if size > capacity or size > t:
+    raise ValueError('storage holds %d items: more than capacity or t' % size)
+  ids = [int(k) for k, _ in storage]
+  if ids != list(range(t - size, t)):
+    raise ValueError(
+        'storage ids are not the FIFO window [t - size, t): this replay only '
+        'supports states produced by add() (one item at a time, oldest evicted)')
+  return size
+
+
+def _same_table(got, want, name):
+  if isinstance(want, dict):
+    ok = isinstance(got, dict) and {int(k): int(v) for k, v in got.items()} == want
+  else:
+    ok = [int(x) for x in got] == want
+  if not ok:
+    raise ValueError(
+        "state['distribution'][%r] does not match the add-one/evict-oldest "
+        'bookkeeping this replay implements in closed form (replay.py:475-534); '
+        'states built through other usage patterns are not supported' % name)
 
 
 # --------------------------------------------------------------------------- #
@@ -290,6 +347,95 @@ class _ReplayBase(Generic[ReplayStructure]):
   def _to_host(self, tensors):
     return type(self._structure)(*[x.cpu().numpy() for x in tensors])
 
+  def _live_rows_host(self):
+    """Host arrays [size, *shape] per field, oldest item first."""
+    if self._ring.fields is None or self._size == 0:
+      return None
+    lo = (self._t - self._size) % self._capacity
+    first = min(self._size, self._capacity - lo)
+    out = []
+    for f in self._ring.fields:
+      a = f[lo:lo + first].cpu().numpy()
+      if first < self._size:
+        a = np.concatenate([a, f[:self._size - first].cpu().numpy()], axis=0)
+      out.append(a)
+    return out
+
+  def _reference_storage(self):
+    """`list(self._storage.items())` of the reference (replay.py:182,751):
+    [(id, item)] oldest first, scalar fields as Python scalars."""
+    rows = self._live_rows_host()
+    if rows is None:
+      return []
+    make = type(self._structure)
+    t0 = self._t - self._size
+    return [(t0 + k, make(*[(a[k].item() if a.ndim == 1 else a[k]) for a in rows]))
+            for k in range(self._size)]
+
+  def _load_rows(self, rows, t, size):
+    """Host arrays [size, *shape] per field (oldest first) into the ring."""
+    self._t, self._size = int(t), int(size)
+    if rows is None or size == 0:
+      return
+    self._allocate_fields([a.shape[1:] for a in rows], [a.dtype for a in rows])
+    lo = (self._t - self._size) % self._capacity
+    first = min(self._size, self._capacity - lo)
+    for dst, a in zip(self._ring.fields, rows):
+      a = np.ascontiguousarray(a)
+      dst[lo:lo + first].copy_(torch.from_numpy(a[:first]))
+      if first < self._size:
+        dst[:self._size - first].copy_(torch.from_numpy(a[first:]))
+
+  def _load_reference_storage(self, storage, t):
+    size = _check_storage_ids(storage, int(t), self._capacity)
+    rows = None
+    if size:
+      nf = len(storage[0][1])
+      rows = [np.stack([np.asarray(item[i]) for _, item in storage])
+              for i in range(nf)]
+    self._load_rows(rows, t, size)
+
+  def _compact_state(self, where):
+    """Native state: only the live rows; `where` = 'host' (NumPy) or 'device'
+    (clones in HBM: a 1M-transition store snapshots in tens of ms, and 288 GB
+    holds the store plus a snapshot)."""
+    if where == 'device':
+      fields = None if self._ring.fields is None else [
+          f.clone() for f in self._ring.fields]
+      return {'format': COMPACT_FORMAT, 't': self._t, 'size': self._size,
+              'layout': 'ring', 'fields': fields}
+    return {'format': COMPACT_FORMAT, 't': self._t, 'size': self._size,
+            'layout': 'oldest_first', 'fields': self._live_rows_host()}
+
+  def _load_compact(self, state):
+    if state.get('layout', 'ring') == 'ring':   # full [capacity, ...] arrays
+      self._t, self._size = int(state['t']), int(state['size'])
+      if state['fields'] is not None:
+        fs = [f if isinstance(f, torch.Tensor) else torch.from_numpy(np.asarray(f))
+              for f in state['fields']]
+        self._allocate_fields(
+            [tuple(f.shape[1:]) for f in fs],
+            [np.dtype(str(f.dtype).replace('torch.', '')) for f in fs])
+        for dst, src in zip(self._ring.fields, fs):
+          dst.copy_(src)
+    else:
+      self._load_rows(state['fields'], state['t'], state['size'])
+
+  def check_status(self) -> None:
+    """Synchronises and raises what the reference would have raised at the
+    offending call (ValueError for NaN/inf/negative priorities or non-finite
+    importance weights, replay.py:233-242,281-282) if any pipelined kernel
+    flagged it in the sticky device status word since the last check.  The
+    agents poll this at every target-network sync, so a diverged run stops
+    within one target period instead of training on NaNs."""
+    self._status.check()
+
+  def _allocate_fields(self, shapes, np_dtypes):
+    """(Re-)allocates the field arrays; cached sample slots hold raw pointers
+    into the old arrays and must go with them."""
+    self._ring.allocate(shapes, np_dtypes)
+    self._sample_ring = None
+
   def bulk_fill(self, fields: Sequence[torch.Tensor]) -> int:
     """Appends `n` items given as device tensors `[n, *shape]` per field
     (synthetic-benchmark fill; equivalent to n add() calls on the storage)."""
@@ -384,22 +530,38 @@ class TransitionReplay(_ReplayBase):
     outs, _ = self.sample_device(size)
     return self._to_host(outs)
 
-  def get_state(self) -> Mapping[str, Any]:
+  def get_state(self, compact=False) -> Mapping[str, Any]:
+    """Replay state.  Default: the REFERENCE's dictionary (replay.py:178-185):
+    {'storage': [(id, item)...], 't', 'distribution': {'ids', 'id_to_index'}},
+    loadable by `dqn_zoo.replay.TransitionReplay.set_state`.  `compact=True`
+    ('host') / 'device': native format with the live rows as arrays (no
+    per-item Python objects; 'device' keeps them in HBM)."""
+    if compact:
+      return self._compact_state('device' if compact == 'device' else 'host')
     return {
+        'storage': self._reference_storage(),
         't': self._t,
-        'size': self._size,
-        'fields': None if self._ring.fields is None else
-                  [f.cpu().numpy() for f in self._ring.fields],
+        'distribution': uniform_distribution_state(self._t, self._size,
+                                                   self._capacity),
     }
 
   def set_state(self, state: Mapping[str, Any]) -> None:
-    self._t = state['t']
-    self._size = state['size']
-    if state['fields'] is not None:
-      self._ring.allocate([f.shape[1:] for f in state['fields']],
-                          [f.dtype for f in state['fields']])
-      for dst, src in zip(self._ring.fields, state['fields']):
-        dst.copy_(torch.from_numpy(src))
+    """Accepts the reference's dictionary (replay.py:187-191) or the native
+    compact one.  The reference's distribution tables are validated against the
+    closed forms this class implements; `t` and the FIFO window carry the rest."""
+    if state.get('format') == COMPACT_FORMAT:
+      self._load_compact(state)
+      return
+    if 'storage' not in state:  # round-1 native format
+      self._load_compact({'t': state['t'], 'size': state['size'],
+                          'fields': state['fields'], 'layout': 'ring'})
+      return
+    size = _check_storage_ids(state['storage'], int(state['t']), self._capacity)
+    want = uniform_distribution_state(int(state['t']), size, self._capacity)
+    _same_table(state['distribution']['ids'], want['ids'], 'ids')
+    _same_table(state['distribution']['id_to_index'], want['id_to_index'],
+                'id_to_index')
+    self._load_reference_storage(state['storage'], state['t'])
 
   def check_valid(self) -> Tuple[bool, str]:
     if self._t < self._size:
@@ -908,10 +1070,6 @@ class PrioritizedTransitionReplay(_ReplayBase):
             float(self._priority_exponent), self.max_seen_priority_device.data_ptr(),
             self._status.word.data_ptr())
 
-  def check_status(self) -> None:
-    """Synchronises and raises if any pipelined kernel flagged an error."""
-    self._status.check()
-
   @property
   def importance_sampling_exponent(self):
     """Importance sampling exponent at current step (replay.py:742-745)."""
@@ -922,27 +1080,61 @@ class PrioritizedTransitionReplay(_ReplayBase):
     """The float64[2*cap_pow2] heap array in HBM (root at [1])."""
     return self._tree
 
-  def get_state(self) -> Mapping[str, Any]:
+  def get_state(self, compact=False) -> Mapping[str, Any]:
+    """Replay state.  Default: the REFERENCE's dictionary (replay.py:747-754):
+    {'storage': [(id, item)...], 't', 'distribution': {'sum_tree': {'size',
+    'storage', 'first_leaf'}, 'id_to_index', 'index_to_id', 'inactive_indices',
+    'active_indices', 'active_indices_location'}} with the tables materialised
+    from the closed forms -- `dqn_zoo.replay.PrioritizedTransitionReplay
+    .set_state` loads it.  `compact=True` ('host') / 'device': native format
+    (live rows + the float64 tree + the running max priority)."""
+    if compact:
+      where = 'device' if compact == 'device' else 'host'
+      st = dict(self._compact_state(where))
+      st['sum_tree_storage'] = self._tree.clone() if where == 'device' \
+          else self._tree.cpu().numpy()
+      st['max_seen_priority'] = float(self.max_seen_priority_device.item())
+      return st
     return {
+        'storage': self._reference_storage(),
         't': self._t,
-        'size': self._size,
-        'fields': None if self._ring.fields is None else
-                  [f.cpu().numpy() for f in self._ring.fields],
-        'sum_tree_storage': self._tree.cpu().numpy(),
-        'max_seen_priority': float(self.max_seen_priority_device.item()),
+        'distribution': prioritized_distribution_state(
+            self._t, self._size, self._capacity, self._cap_pow2,
+            self._tree.cpu().numpy()),
     }
 
   def set_state(self, state: Mapping[str, Any]) -> None:
-    self._t = state['t']
-    self._size = state['size']
-    if state['fields'] is not None:
-      self._ring.allocate([f.shape[1:] for f in state['fields']],
-                          [f.dtype for f in state['fields']])
-      for dst, src in zip(self._ring.fields, state['fields']):
-        dst.copy_(torch.from_numpy(src))
-    self._tree.copy_(torch.from_numpy(state['sum_tree_storage']))
-    self.max_seen_priority_device.fill_(state['max_seen_priority'])
-    self._sample_ring = None  # field arrays may have been re-allocated
+    """Accepts the reference's dictionary (replay.py:756-760) or the native
+    compact one.  The reference format does not carry the agent's
+    max_seen_priority (rainbow/agent.py:231,245 keeps it in the agent state):
+    the agents restore `max_seen_priority_device` themselves."""
+    if state.get('format') == COMPACT_FORMAT or 'storage' not in state:
+      st = dict(state)
+      st.setdefault('layout', 'ring')   # round-1 native dictionaries
+      self._load_compact(st)
+      tree = st['sum_tree_storage']
+      self._tree.copy_(tree if isinstance(tree, torch.Tensor)
+                       else torch.from_numpy(np.asarray(tree, np.float64)))
+      self.max_seen_priority_device.fill_(st['max_seen_priority'])
+      return
+    t = int(state['t'])
+    size = _check_storage_ids(state['storage'], t, self._capacity)
+    dist = state['distribution']
+    tree = dist['sum_tree']
+    storage = np.asarray(tree['storage'], dtype=np.float64)
+    if (int(tree['size']) != self._capacity or
+        int(tree['first_leaf']) != self._cap_pow2 or
+        storage.shape != (2 * self._cap_pow2,)):
+      raise ValueError(
+          'sum tree of size %s / first_leaf %s does not fit a replay of '
+          'capacity %d' % (tree['size'], tree['first_leaf'], self._capacity))
+    want = prioritized_distribution_state(t, size, self._capacity,
+                                          self._cap_pow2, None)
+    for name in ('id_to_index', 'index_to_id', 'inactive_indices',
+                 'active_indices', 'active_indices_location'):
+      _same_table(dist[name], want[name], name)
+    self._load_reference_storage(state['storage'], t)
+    self._tree.copy_(torch.from_numpy(storage))
 
   def check_valid(self) -> Tuple[bool, str]:
     if self._t < self._size:

@@ -366,6 +366,16 @@ int dz_rainbow_graph_capture(const dz_rainbow_args_t* args, int phases,
 int dz_graph_launch(void* graph_exec, dz_stream_t stream);
 int dz_graph_destroy(void* graph_exec);
 
+/* Generic capture for the other learners (dz_dense_learn, dz_iqn_learn) and
+ * any fixed sequence of this library's launches: everything enqueued on
+ * `stream` (non-default) between begin and end becomes ONE executable graph.
+ * dz_graph_capture_end must be called even if a call in between failed (it
+ * then discards the partial graph and returns that the capture was aborted).
+ * The reference's counterpart is jax.jit tracing `update` once and replaying
+ * the compiled executable (dqn/agent.py:109-117).                           */
+int dz_graph_capture_begin(dz_stream_t stream);
+int dz_graph_capture_end(dz_stream_t stream, int discard, void** graph_exec_out);
+
 /* Fills n noise blocks with f(x)=sign(x)sqrt|x|, x ~ truncated normal on
  * [-2,2] (ref: networks.py:142-144), from a counter-based generator keyed by
  * (seed, counter).  Distribution-equivalent to the reference, not bit-equal

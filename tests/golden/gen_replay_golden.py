@@ -9,6 +9,7 @@ patterns, and at the end the sha256 of the whole sum-tree storage plus the
 private id<->index tables the closed forms are checked against.
 """
 
+import copy
 import hashlib
 import os
 import sys
@@ -47,8 +48,34 @@ def gen_prioritized(ref, case):
     w_log.append(weights.astype(np.float64))
     root_log.append(tree.root())
 
+  snap_at = protocol.STATE_SNAPSHOTS.get(name)
+
+  def on_snapshot(rep, t, max_seen):
+    # the reference's own get_state(), frozen (it returns live references)
+    st = copy.deepcopy(rep.get_state())
+    packed = protocol.pack_state(st, prioritized=True)
+    packed['snapshot_step'] = np.int64(snap_at)
+    packed['max_seen'] = np.float64(max_seen)
+    key = rs.get_state()
+    packed['rng_key'] = np.asarray(key[1], dtype=np.uint32)
+    packed['rng_pos'] = np.int64(key[2])
+    np.savez_compressed(os.path.join(HERE, 'state_prio_%s.npz' % name), **packed)
+    # round trip through the reference itself: a fresh object restored from the
+    # unpacked fixture must continue identically (checked by the trace below
+    # being recorded on the restored object)
+    fresh = ref.PrioritizedTransitionReplay(
+        capacity=cap, structure=protocol.Item(None, None), priority_exponent=expo,
+        importance_sampling_exponent=protocol.beta_schedule(cap),
+        uniform_sample_probability=usp, normalize_weights=norm, random_state=rs)
+    fresh.set_state(protocol.unpack_state(packed, prioritized=True))
+    nonlocal tree, replay
+    replay = fresh
+    tree = fresh._distribution._sum_tree  # pylint: disable=protected-access
+    return fresh
+
   try:
-    protocol.drive_prioritized(replay, cap, fill, batch, steps, seed, on_sample)
+    protocol.drive_prioritized(replay, cap, fill, batch, steps, seed, on_sample,
+                               snapshot_at=snap_at, on_snapshot=on_snapshot)
   finally:
     ref.importance_sampling_weights = orig
 
@@ -83,7 +110,24 @@ def gen_uniform(ref, case):
   def on_sample(k, s):
     ids_log.append(np.asarray(s.a, dtype=np.int64))
 
-  protocol.drive_uniform(replay, cap, fill, batch, steps, seed, on_sample)
+  snap_at = protocol.UNIFORM_STATE_SNAPSHOTS.get(name)
+
+  def on_snapshot(rep, t):
+    st = copy.deepcopy(rep.get_state())
+    packed = protocol.pack_state(st, prioritized=False)
+    packed['snapshot_step'] = np.int64(snap_at)
+    key = rs.get_state()
+    packed['rng_key'] = np.asarray(key[1], dtype=np.uint32)
+    packed['rng_pos'] = np.int64(key[2])
+    np.savez_compressed(os.path.join(HERE, 'state_uni_%s.npz' % name), **packed)
+    fresh = ref.TransitionReplay(cap, protocol.Item(None, None), rs)
+    fresh.set_state(protocol.unpack_state(packed, prioritized=False))
+    nonlocal replay
+    replay = fresh
+    return fresh
+
+  protocol.drive_uniform(replay, cap, fill, batch, steps, seed, on_sample,
+                         snapshot_at=snap_at, on_snapshot=on_snapshot)
   out = dict(ids=np.stack(ids_log))
   if cap <= 1000:
     out['pos_to_id'] = np.array(

@@ -169,6 +169,17 @@ def test_get_state_set_state_roundtrip():
                                   state['online_params'][k])
     np.testing.assert_array_equal(s2['opt_state']['nu'][k],
                                   state['opt_state']['nu'][k])
-  np.testing.assert_array_equal(s2['replay']['sum_tree_storage'],
-                                state['replay']['sum_tree_storage'])
+  # the replay part is the REFERENCE's dictionary (replay.py:747-754)
+  assert set(state['replay']) == {'storage', 't', 'distribution'}
+  assert set(state['replay']['distribution']) == {
+      'sum_tree', 'id_to_index', 'index_to_id', 'inactive_indices',
+      'active_indices', 'active_indices_location'}
+  np.testing.assert_array_equal(
+      s2['replay']['distribution']['sum_tree']['storage'],
+      state['replay']['distribution']['sum_tree']['storage'])
+  assert s2['replay']['distribution']['active_indices'] == \
+      state['replay']['distribution']['active_indices']
+  for (i, a), (j, b) in zip(s2['replay']['storage'], state['replay']['storage']):
+    assert i == j and a.a_tm1 == b.a_tm1 and a.r_t == b.r_t
+    np.testing.assert_array_equal(a.s_t, b.s_t)
   assert rep2.size == rep.size and list(rep2.ids()) == list(rep.ids())

@@ -36,3 +36,37 @@ def test_driver_command_measures_the_step():
     assert key in out
   r = out['roofline']
   assert r['bound'] in ('hbm', 'mfma') and 0 < r['frac'] <= 1
+
+
+@pytest.mark.gpu
+def test_gpus_flag_degrades_to_visible_devices():
+  """`bench.py --gpus 8` by hand on a smaller box runs what is there (the
+  driver launches N > 1 through torchrun itself)."""
+  import torch
+  have = torch.cuda.device_count()
+  out = _run('--gpus', '8', '--steps', '20', '--warmup', '5', '--cpu-seconds', '0',
+             '--prof-steps', '0', '--other-configs', '0', '--capacity', '8192')
+  assert out['n_gpus'] == min(8, have)
+  assert out['config']['parallelism'] == 'replicas x%d' % min(8, have)
+
+
+@pytest.mark.gpu
+def test_rccl_statistics_all_reduce_under_torchrun_world1():
+  """The N > 1 code path (process group on RCCL, barrier, the packed float64
+  all-reduce of ReplicaStats, MAX of durations) with one rank: what the driver's
+  scaling run executes, minus the peers."""
+  import socket
+  sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+  r = subprocess.run(
+      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+       '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port',
+       str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '20',
+       '--warmup', '5', '--cpu-seconds', '0', '--prof-steps', '0',
+       '--other-configs', '0', '--capacity', '8192'],
+      capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, r.stdout[-2000:]
+  out = json.loads(lines[0])
+  assert out['n_gpus'] == 1 and out['value'] > 0
+  assert out['config']['collective'] == 'rccl'

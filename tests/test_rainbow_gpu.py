@@ -177,11 +177,10 @@ def test_full_step_vs_oracle_update():
   lr = ln.opt.learning_rate
   for k in newp:
     diff = np.abs(p_dev[k] - newp[k])
-    # Adam's first step moves every weight by ~lr*g/(|g|+eps); entries whose
-    # gradient is ~eps are ill-conditioned, so bound the bulk tightly and the
-    # tail by the step size itself.
-    assert np.percentile(diff, 99) <= 0.02 * lr, k
-    assert diff.max() <= 1.01 * lr, k
+    # Adam's first step moves every weight by lr*g/(|g|+eps): a flipped sign
+    # would be a 2*lr discrepancy, a missed update 1*lr.  Both excluded by 20x
+    # (the 10-step trajectory is in tests/test_trajectory_gpu.py).
+    assert diff.max() <= 0.05 * lr, (k, diff.max() / lr)
   # target untouched, then synced
   t_dev = ln.get_params('target')
   for k in target:

@@ -149,15 +149,28 @@ def _run_prio(rl, case, bulk):
   rep = rl.PrioritizedTransitionReplay(
       cap, protocol.Item(None, None), expo, protocol.beta_schedule(cap), usp,
       norm, np.random.RandomState(seed))
-  ids_log, w_log, root_log = [], [], []
+  ids_log, w_log, root_log, probs_log = [], [], [], []
 
   def on_sample(k, ids, w):
     ids_log.append(ids)
     w_log.append(w)
     root_log.append(float(rep.tree_storage[1].item()))
 
-  protocol.drive_prioritized(rep, cap, fill, batch, steps, seed, on_sample,
-                             bulk_fill=_device_bulk if bulk else None)
+  # the device's sampling probabilities, as `sample()` hands them to the host
+  # weight computation (same tap point as the golden generator's spy)
+  orig = rl.importance_sampling_weights
+
+  def spy(probabilities, **kw):
+    probs_log.append(np.array(probabilities, dtype=np.float64))
+    return orig(probabilities, **kw)
+
+  rl.importance_sampling_weights = spy
+  try:
+    protocol.drive_prioritized(rep, cap, fill, batch, steps, seed, on_sample,
+                               bulk_fill=_device_bulk if bulk else None)
+  finally:
+    rl.importance_sampling_weights = orig
+  rep.golden_probs = np.stack(probs_log)
   return rep, np.stack(ids_log), np.stack(w_log), np.array(root_log)
 
 
@@ -168,6 +181,10 @@ def test_prioritized_golden(rl, case):
   rep, ids, w, roots = _run_prio(rl, case, bulk=False)
   np.testing.assert_array_equal(ids, g['ids'])
   np.testing.assert_array_equal(_bits(roots), g['root_bits'])
+  # sampling probabilities: BITWISE equal to the reference's
+  np.testing.assert_array_equal(_bits(rep.golden_probs), g['probs_bits'])
+  # weights = NumPy `**beta` of those probabilities on this host: the last bit of
+  # NumPy's SIMD pow may differ from the machine that generated the fixture
   np.testing.assert_allclose(w, g['weights_bits'].view(np.float64), rtol=4e-16)
   np.testing.assert_array_equal(_bits(rep.tree_storage.cpu().numpy()),
                                 g['tree_storage_bits'])
@@ -183,6 +200,7 @@ def test_prioritized_golden_1m(rl):
   rep, ids, w, roots = _run_prio(rl, case, bulk=True)
   np.testing.assert_array_equal(ids, g['ids'])
   np.testing.assert_array_equal(_bits(roots), g['root_bits'])
+  np.testing.assert_array_equal(_bits(rep.golden_probs), g['probs_bits'])
   np.testing.assert_allclose(w, g['weights_bits'].view(np.float64), rtol=4e-16)
   sha = hashlib.sha256(rep.tree_storage.cpu().numpy().tobytes()).digest()
   assert sha == g['tree_sha256'].tobytes()
