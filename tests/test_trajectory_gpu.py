@@ -1,17 +1,27 @@
 """Multi-step END-TO-END parity: 10 consecutive learner steps on the device vs
-10 steps of the CPU oracle, each side using ITS OWN gradients and its own
-optimiser state throughout (nothing is re-synchronised between steps), fresh
-batch / weights / noise every step, at the BASELINE shape (A = 6, B = 32) and
-with the reference's optimiser settings.
+10 steps of the float64 CPU oracle, each side using ITS OWN gradients and its
+own optimiser state (fresh batch / weights / noise every step), at the BASELINE
+shape (A = 6, B = 32) with the reference's optimiser settings.
 
-Bounds (stated, and chosen to exclude sign flips of the normalised updates):
+Stated bounds:
   * per-sample losses / TD errors of EVERY step: rtol 1e-5 (+ 2e-6 abs for TD
-    errors that cancel to ~0) -- the north-star tolerance holds along the
+    errors that cancel to ~0): the north-star tolerance holds along the
     trajectory, not just on the first step;
-  * after k steps, max |p_device - p_oracle| <= 0.05 * k * lr per tensor.
-    Adam and centred RMSProp move a weight by ~lr * sign(g) per step when
-    |g| >> eps: one flipped sign is a 2 * lr discrepancy at step 1, i.e. 40x the
-    bound; a whole-step error (the round-1 bound of 1.01 * lr) is 20x over it.
+  * after k un-resynchronised steps, max |p_device - p_oracle| <= 0.01 * k * lr
+    per tensor.  Adam and centred RMSProp move a weight by ~lr * sign(g) per step
+    when |g| >> eps: one flipped sign is a 2 * lr discrepancy at step 1, 200x the
+    bound; the round-1 bound (1.01 * lr, a whole missed step) is 100x over it.
+
+ReLU ties.  The step has ~7e5 ReLU units; float32 summed in a different order
+than the oracle's lands a pre-activation that is ~0 (|z| of a few 1e-6, measured:
+about one unit every few steps) on the other side of zero.  That is a legitimate
+float32 outcome, but it switches a whole gradient path on or off, and RMSProp's
+lr / sqrt(eps) gain then separates the two trajectories for good.  The test
+therefore compares the device's stored activations with the oracle's float64
+pre-activations every step; a mismatch is accepted ONLY where |z64| <= AMBIG,
+after which the oracle adopts the device's parameters and optimiser state and
+the comparison restarts (at most MAX_TIES times).  Everything else stays
+un-resynchronised: the oracle is never fed the device's gradients.
 """
 
 import numpy as np
@@ -24,6 +34,8 @@ pytestmark = pytest.mark.gpu
 
 A, B, STEPS = 6, 32, 10
 SUPPORT = np.linspace(-10.0, 10.0, 51).astype(np.float32)
+AMBIG = 2e-5      # |float64 pre-activation| below which a ReLU side may differ
+MAX_TIES = 4
 
 
 def _batch(rs, n_step):
@@ -40,13 +52,52 @@ def _dev(xs):
           for x in xs]
 
 
-def _check_params(p_dev, p_orc, k, lr, what):
-  worst = 0.0
-  for name in p_orc:
-    diff = np.abs(p_dev[name] - p_orc[name]).max()
-    worst = max(worst, diff / lr)
-    assert diff <= 0.05 * k * lr, (what, name, 'step', k, diff / lr)
-  return worst
+def _f64(t):
+  return {k: np.asarray(v, np.float64) for k, v in t.items()}
+
+
+def _relu_ties(ln, pre64):
+  """Units whose ReLU side differs between the device's stored activations of
+  the differentiated apply (group 0) and the oracle's float64 pre-activations
+  `pre64` = dict(act1, act2, feat, h1).  Returns (count, max |z64| among them)."""
+  hid = pre64['h1'].shape[1]
+  dev = {
+      'act1': ln.ws_view('act1', B * 400 * 32).cpu().numpy().reshape(B, 20, 20, 32),
+      'act2': ln.ws_view('act2', B * 81 * 64).cpu().numpy().reshape(B, 9, 9, 64),
+      'feat': ln.ws_view('feat', B * 3136).cpu().numpy().reshape(B, 7, 7, 64),
+      'h1': ln.ws_view('h1', B * hid).cpu().numpy().reshape(B, hid),
+  }
+  n, worst = 0, 0.0
+  for k, z in pre64.items():
+    bad = (dev[k] > 0) != (z.reshape(dev[k].shape) > 0)
+    if bad.any():
+      n += int(bad.sum())
+      worst = max(worst, float(np.abs(z.reshape(dev[k].shape)[bad]).max()))
+  return n, worst
+
+
+class _Tracker:
+  """Parameter bound between resynchronisations + the tie budget."""
+
+  def __init__(self, lr, what):
+    self.lr, self.what = lr, what
+    self.since, self.ties, self.worst = 0, 0, 0.0
+
+  def step(self, k, ties, p_dev, p_orc):
+    n, z = ties
+    if n:
+      assert z <= AMBIG, (self.what, 'step', k, 'ReLU side differs at |z64| =', z)
+      self.ties += 1
+      assert self.ties <= MAX_TIES, (self.what, 'too many ReLU ties', self.ties)
+      self.since = 0
+      return True     # caller resynchronises the oracle to the device
+    self.since += 1
+    for name in p_orc:
+      diff = np.abs(p_dev[name] - p_orc[name]).max()
+      self.worst = max(self.worst, diff / self.lr)
+      assert diff <= 0.01 * self.since * self.lr, (
+          self.what, name, 'step', k, 'since sync', self.since, diff / self.lr)
+    return False
 
 
 def test_rainbow_trajectory_vs_oracle():
@@ -61,8 +112,9 @@ def test_rainbow_trajectory_vs_oracle():
   opt = ll.AdamConfig()   # rainbow/run_atari.py: lr 6.25e-5, eps 1.5625e-4, clip 10
   ln = ll.RainbowLearner(networks.RainbowNetwork(A, SUPPORT), opt, B, params=online)
   ln.set_params(target, 'target')
-  p, st = dict(online), qo.adam_init(online)
-  worst = 0.0
+  p, st, tgt = _f64(online), qo.adam_init(_f64(online)), _f64(target)
+  sup64 = SUPPORT.astype(np.float64)
+  tr = _Tracker(opt.learning_rate, 'rainbow')
   for k in range(1, STEPS + 1):
     batch = _batch(rs, 3)
     w = rs.uniform(0.1, 1.0, size=B).astype(np.float32)
@@ -70,24 +122,30 @@ def test_rainbow_trajectory_vs_oracle():
     ln.set_noise(noises)
     ln.step(*_dev(batch), torch.from_numpy(w).cuda(), resample_noise=False)
     torch.cuda.synchronize()
-    p, st, out = qo.rainbow_update(p, target, st, batch, w, noises, SUPPORT, A,
+    n64 = [_f64(n) for n in noises]
+    _, _, c = qo.rainbow_fwd(p, batch[0], n64[0], sup64, A, np.float64)
+    tc = c['torso']
+    ties = _relu_ties(ln, dict(
+        act1=tc['conv1'][2], act2=tc['conv2'][2], feat=tc['conv3'][2],
+        h1=np.concatenate([c['a1'], c['v1']], axis=1)))
+    p, st, out = qo.rainbow_update(p, tgt, st, batch, w, n64, sup64, A,
                                    lr=opt.learning_rate, eps=opt.eps,
-                                   max_norm=opt.max_global_grad_norm)
+                                   max_norm=opt.max_global_grad_norm, dt=np.float64)
     np.testing.assert_allclose(ln.losses.cpu().numpy(), out['losses'], rtol=1e-5,
                                err_msg='step %d' % k)
     np.testing.assert_allclose(ln.priorities.cpu().numpy(), out['priorities'],
                                rtol=1e-5)
     sc = ln.scalars()
     np.testing.assert_allclose(sc['loss'], out['loss'], rtol=1e-5)
-    np.testing.assert_allclose(sc['gnorm'], out['gnorm'], rtol=1e-4)
-    worst = max(worst, _check_params(ln.get_params(), p, k, opt.learning_rate,
-                                     'rainbow'))
+    if tr.step(k, ties, ln.get_params(), p):
+      p = _f64(ln.get_params())
+      o = ln.get_opt_state()
+      st = dict(count=o['count'], mu=_f64(o['mu']), nu=_f64(o['nu']))
+    else:
+      np.testing.assert_allclose(sc['gnorm'], out['gnorm'], rtol=1e-4)
   assert int(ln.adam_count.item()) == STEPS
-  m_dev = ln.layout.unpack(ln.adam_m.cpu().numpy())
-  for name in st['mu']:
-    scale = np.abs(st['mu'][name]).max()
-    assert np.abs(m_dev[name] - st['mu'][name]).max() <= 2e-4 * scale, name
-  print('rainbow: worst |dp| / lr over %d steps = %.4f' % (STEPS, worst))
+  print('rainbow: worst |dp|/lr = %.4f, ReLU ties %d in %d steps' % (
+      tr.worst, tr.ties, STEPS))
 
 
 @pytest.mark.parametrize('kind', ['dqn', 'prioritized'])
@@ -108,20 +166,30 @@ def test_dqn_rmsprop_trajectory_vs_oracle(kind):
                        'q' if kind == 'dqn' else 'double_q', opt, B,
                        grad_error_bound=1.0 / 32, params=online)
   ln.set_params(target, 'target')
-  p, st = dict(online), qo.rmsprop_init(online)
-  worst = 0.0
+  p, st, tgt = _f64(online), qo.rmsprop_init(_f64(online)), _f64(target)
+  tr = _Tracker(opt.learning_rate, kind)
   for k in range(1, STEPS + 1):
     batch = _batch(rs, 1)
     w = rs.uniform(0.1, 1.0, size=B).astype(np.float32) if kind != 'dqn' else None
     ln.step(*_dev(batch), None if w is None else torch.from_numpy(w).cuda())
     torch.cuda.synchronize()
-    _, td, grads, _ = qo.dqn_family_loss_and_grads(kind, p, target, batch, w, 1.0 / 32)
+    _, c = qo.mlp_head_fwd(p, batch[0], np.float64)
+    tc = c['torso']
+    ties = _relu_ties(ln, dict(act1=tc['conv1'][2], act2=tc['conv2'][2],
+                               feat=tc['conv3'][2], h1=c['z1']))
+    _, td, grads, _ = qo.dqn_family_loss_and_grads(kind, p, tgt, batch, w, 1.0 / 32,
+                                                   np.float64)
     p, st = qo.rmsprop_centered_update(p, grads, st, opt.learning_rate, opt.decay,
                                        opt.eps)
-    np.testing.assert_allclose(ln.losses.cpu().numpy(), td, rtol=1e-5, atol=2e-6,
+    td_dev = ln.losses.cpu().numpy()
+    np.testing.assert_allclose(td_dev, td, rtol=1e-5, atol=2e-6,
                                err_msg='step %d' % k)
-    np.testing.assert_allclose(ln.priorities.cpu().numpy(), np.abs(td), rtol=1e-5,
-                               atol=2e-6)
+    np.testing.assert_allclose(ln.priorities.cpu().numpy(), np.abs(td_dev),
+                               rtol=1e-6, atol=1e-7)
     assert (np.abs(td) > 1.0).any() and (np.abs(td) < 1.0).any()
-    worst = max(worst, _check_params(ln.get_params(), p, k, opt.learning_rate, kind))
-  print('%s: worst |dp| / lr over %d steps = %.4f' % (kind, STEPS, worst))
+    if tr.step(k, ties, ln.get_params(), p):
+      p = _f64(ln.get_params())
+      o = ln.get_opt_state()
+      st = dict(mu=_f64(o['mu']), nu=_f64(o['nu']))
+  print('%s: worst |dp|/lr = %.4f, ReLU ties %d in %d steps' % (
+      kind, tr.worst, tr.ties, STEPS))
