@@ -197,7 +197,6 @@ SIGNATURES = {
     'dz_noise_fill': (c_int, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64,
                               c_vp]),
     'dz_param_copy': (c_int, [c_vp, c_vp, c_i64, c_vp]),
-    'dz_set_tuning': (c_int, [c_int, c_int]),
     'dz_prof_enable': (c_int, [c_int]),
     'dz_prof_read': (c_int, [c_int, c_vp, c_vp]),
     'dz_prof_read_replay': (c_int, [c_vp]),
@@ -239,19 +238,6 @@ class HipLibraryError(RuntimeError):
 _lib = None
 
 
-def apply_env_tuning(lib, spec):
-  """DZ_TUNING="key=value,key=value": kernel-variant knobs (dz_set_tuning) for A/B
-  measurements of an unmodified program, e.g. `DZ_TUNING=20=0 python bench.py`.
-  A malformed or refused entry is an error, never silently ignored."""
-  for kv in filter(None, (x.strip() for x in spec.split(','))):
-    try:
-      key, value = (int(x) for x in kv.split('='))
-    except ValueError as e:
-      raise HipLibraryError('DZ_TUNING: cannot parse %r' % kv) from e
-    if lib.dz_set_tuning(key, value) != DZ_OK:
-      raise HipLibraryError('DZ_TUNING: dz_set_tuning(%s) refused' % kv)
-
-
 def load():
   """Loads the library once; raises HipLibraryError if it is unusable."""
   global _lib
@@ -282,7 +268,6 @@ def load():
           'ABI mismatch: struct %s is %d bytes in the library, %d in _lib.py' %
           (cls.__name__, lib.dz_struct_size(which), ctypes.sizeof(cls)))
   _check_single_hip_runtime()
-  apply_env_tuning(lib, os.environ.get('DZ_TUNING', ''))
   _lib = lib
   return lib
 

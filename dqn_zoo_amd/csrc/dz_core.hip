@@ -22,9 +22,6 @@ extern "C" int dz_struct_size(int which) {
   }
 }
 
-int g_conv_xcd = 0;  // XCD-ordered conv tiles: measured no gain (tools/tune.py)
-int g_conv_fwd_variant[3] = {1, 1, 1};  // measured best of the shapes in dz_torso.h (tools/tune.py)
-
 // ---- event profiler ----------------------------------------------------------
 #include <string.h>
 bool g_dz_prof_on = false;

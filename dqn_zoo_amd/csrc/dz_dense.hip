@@ -283,7 +283,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
                          (long)L.param_count, ws + L.ws_norm_part, a->opt_count);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "grad_sumsq");
-      hipLaunchKernelGGL(adam_kernel<1>, dim3(2048), dim3(256), 0, s, a->online, a->grad,
+      hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
                          a->opt_m, a->opt_v, (long)(L.param_count >> 2),
                          ws + L.ws_norm_part, kNormBlocks, a->opt_count, a->losses, wts, B,
                          sc, a->lr, a->decay_or_b1, a->b2, a->eps, a->max_norm);

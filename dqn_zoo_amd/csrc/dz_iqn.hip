@@ -13,12 +13,6 @@ constexpr int kS_iqn_fc2w = 32;   // row splits of the fc2 weight gradient
 constexpr int kS_iqn_embw = 8;    // row splits of the embedding weight gradient
 constexpr int kS_iqn_bias = 32;   // row splits of the bias column sums
 }
-// dz_set_tuning key 13: tiling of the value-head GEMMs.  Measured (fc1 forward /
-// fc1 backward, us): 0 = 64x64 KT2 207/159, 1 = KT4 196/161, 5 = forward KT4 in
-// XCD-aware tile order 192/159 [default], 6-9 = 2-4 accumulators per wave
-// 258-325/170-307 (the compiler spends 141-256 VGPRs on them: occupancy 1-2).
-int g_iqn_variant = 5;
-
 extern "C" int dz_iqn_layout(int A, int latent, int B, int n0, int n1, int n2,
                              dz_iqn_layout_t* L) {
   DZ_REQUIRE(L && A > 0 && B > 0 && B <= 1024 && latent >= 16 && latent % 16 == 0);
@@ -116,21 +110,11 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
     p.x = ws + L.ws_hin; p.ldx = kFlat; p.w_off = L.fc1_w; p.b_off = L.fc1_b;
     p.ldw = L.fc1_ld; p.K = kFlat; p.N = kHid; p.epi = IQN_EPI_BIAS_RELU;
     p.out = ws + L.ws_h1; p.ldo = kHid; p.feat = nullptr; p.temb = nullptr;
-    switch (g_iqn_variant) {  // all variants have 64x64 tiles
-      default: rc = dz_launch_gemm<IqnLin>(p, dim3(kHid / IqnLin::BN, my, ap.G), s); break;
-      case 1: rc = dz_launch_gemm<IqnLinOp<2, 2, 1, 4>>(p, dim3(kHid / 64, my, ap.G), s); break;
-      case 4: rc = dz_launch_gemm_xcd<IqnLin>(p, dim3(kHid / 64, my, ap.G), s); break;
-      case 6: rc = dz_launch_gemm<IqnLinOp<1, 1, 4, 1, 2, 2>>(p, dim3(kHid / 64, my, ap.G), s); break;
-      case 7: rc = dz_launch_gemm<IqnLinOp<1, 1, 4, 2, 2, 2>>(p, dim3(kHid / 64, my, ap.G), s); break;
-      case 8: rc = dz_launch_gemm<IqnLinOp<2, 1, 2, 2, 1, 2>>(p, dim3(kHid / 64, my, ap.G), s); break;
-      case 9: rc = dz_launch_gemm<IqnLinOp<2, 2, 1, 2, 2, 2>>(p, dim3(kHid / 128, (my + 1) / 2, ap.G), s); break;
-      case 12: rc = dz_launch_gemm<IqnLinOp<2, 1, 2, 1, 1, 2>>(p, dim3(kHid / 64, my, ap.G), s); break;
-      case 13: rc = dz_launch_gemm<IqnLinOp<1, 2, 2, 1, 2, 1>>(p, dim3(kHid / 64, my, ap.G), s); break;
-      case 14: rc = dz_launch_gemm_xcd<IqnLinOp<2, 1, 2, 1, 1, 2>>(p, dim3(kHid / 64, my, ap.G), s); break;
-      case 5: rc = dz_launch_gemm_xcd<IqnLinOp<2, 2, 1, 4>>(p, dim3(kHid / 64, my, ap.G), s); break;
-      case 2: rc = dz_launch_gemm<IqnLinOp<2, 2, 1, 1>>(p, dim3(kHid / 64, my, ap.G), s); break;
-      case 3: rc = dz_launch_gemm<IqnLinOp<2, 2, 1, 3>>(p, dim3(kHid / 64, my, ap.G), s); break;
-    }
+    // 64x64 tiles, KT4, tiles in XCD-aware order (all column tiles of one A-row slab on
+    // one XCD: the 77 MB activation crosses the fabric once instead of 8 times, +4 %).
+    // Measured alternatives (removed): KT2 207 us vs 192; 2-4 accumulators per wave
+    // 258-325 us (141-256 VGPRs, occupancy 1-2): DESIGN.md 6b.
+    rc = dz_launch_gemm_xcd<IqnLinOp<2, 2, 1, 4>>(p, dim3(kHid / 64, my, ap.G), s);
     if (rc) return rc;
     DZ_PROF(s, "fc1_fwd");
   }
@@ -218,18 +202,7 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       d.params = a->online; d.noise = zeros; d.head[0] = h1; d.head[1] = h1;
       d.part = ws + L.ws_dhin; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
       const dim3 gw(kHid / 64, kFlat / 64, 1), gd(kFlat / 64, (M0 + 63) / 64, 1);
-      switch (g_iqn_variant) {
-        default: rc = dz_launch_gemm2<IqnWg, IqnDg>(w, gw, d, gd, s); break;
-        case 1: rc = dz_launch_gemm2<IqnWgradOp<2, 2, 1, 4>, FcDgradOp<2, 2, 1, 4>>(w, gw, d, gd, s); break;
-        case 4: rc = dz_launch_gemm2_xcd<IqnWg, IqnDg>(w, gw, d, gd, s); break;
-        case 6: rc = dz_launch_gemm2<IqnWgradOp<1, 1, 4, 1, 2, 2>, FcDgradOp<1, 1, 4, 1, 2, 2>>(w, gw, d, gd, s); break;
-        case 7: rc = dz_launch_gemm2<IqnWgradOp<1, 1, 4, 2, 2, 2>, FcDgradOp<1, 1, 4, 2, 2, 2>>(w, gw, d, gd, s); break;
-        case 8: rc = dz_launch_gemm2<IqnWgradOp<2, 1, 2, 2, 1, 2>, FcDgradOp<2, 1, 2, 2, 1, 2>>(w, gw, d, gd, s); break;
-        case 9: rc = dz_launch_gemm2<IqnWgradOp<2, 2, 1, 2, 2, 2>, FcDgradOp<2, 2, 1, 2, 2, 2>>(
-            w, dim3(kHid / 128, (kFlat + 127) / 128, 1), d, dim3((kFlat + 127) / 128, (M0 + 127) / 128, 1), s); break;
-        case 2: rc = dz_launch_gemm2<IqnWgradOp<2, 2, 1, 1>, FcDgradOp<2, 2, 1, 1>>(w, gw, d, gd, s); break;
-        case 3: rc = dz_launch_gemm2<IqnWgradOp<2, 2, 1, 3>, FcDgradOp<2, 2, 1, 3>>(w, gw, d, gd, s); break;
-      }
+      rc = dz_launch_gemm2<IqnWg, IqnDg>(w, gw, d, gd, s);
       if (rc) return rc;
       DZ_PROF(s, "fc1_wgrad+dgrad");
     }
@@ -290,7 +263,7 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
                        (long)L.param_count, ws + L.ws_norm_part, a->opt_count);
     DZ_LAUNCH_CHECK();
     DZ_PROF(s, "grad_sumsq");
-    hipLaunchKernelGGL(adam_kernel<1>, dim3(2048), dim3(256), 0, s, a->online, a->grad, a->opt_m,
+    hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad, a->opt_m,
                        a->opt_v, (long)(L.param_count >> 2), ws + L.ws_norm_part, kNormBlocks,
                        a->opt_count, a->losses, zeros, B, sc, a->lr, a->b1, a->b2, a->eps,
                        a->max_norm);

@@ -29,9 +29,9 @@ constexpr int kMaxSplitFc1 = 32;
 // conv geometries (networks.py:194-198)
 //                      U8  H   W   C  KS S  OH  OW  CO
 //                                                       WM WN WK KT
-using Conv1Fwd = ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 4, 1, 1, 4>;
-using Conv2Fwd = ConvFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 1, 2, 2, 4>;
-using Conv3Fwd = ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 2, 2, 3>;
+using Conv1Fwd = ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 2, 1, 2, 2>;
+using Conv2Fwd = ConvFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4, 2>;
+using Conv3Fwd = ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4, 3>;
 using Conv1Wg = ConvWgradOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 2, 1, 2, 2>;
 using Conv2Wg = ConvWgradOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 2, 2, 1, 2>;
 using Conv3Wg = ConvWgradOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 2, 2, 1, 2>;
@@ -464,7 +464,6 @@ __device__ __forceinline__ void adam_elem(float& P, float G, float& M, float& V,
 // scalars in all blocks) instead of waiting on a one-block "scalars" launch
 // (that launch cost ~5 us + a ~2 us gap for 2 KB of work); block 0 publishes
 // the scalars (global norm, bias corrections, clip flag, mean weighted loss).
-template <int PIPE = 0>
 __global__ __launch_bounds__(256) void adam_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
     float* __restrict__ v, long n4, const float* __restrict__ part, int nparts,
@@ -483,9 +482,9 @@ __global__ __launch_bounds__(256) void adam_kernel(
     bid -= 1; nblk -= 1;
   }
   __shared__ float red[4];
-  // PIPE: branch-free loads (derived block or not: clamped pointers, the noise
-  // factors select to 1, x * (1 * 1) == x), the first element's loads issued before
-  // the scalar prelude and each next element's before the current arithmetic.
+  // Branch-free loads (derived block or not: clamped pointers, the noise factors
+  // select to 1, x * (1 * 1) == x), the first element's loads issued before the
+  // scalar prelude and each next element's before the current arithmetic.
   struct Elem { float4 g, m, v, p, eo; float ei; bool der; };
   const long d0 = dg.on ? (dg.dst_off >> 2) : 0, d1 = dg.on ? d0 + (((long)dg.rows * dg.ld) >> 2) : 0;
   auto load = [&](long i, Elem& e) {
@@ -503,7 +502,7 @@ __global__ __launch_bounds__(256) void adam_kernel(
   const long stride = (long)nblk * 256;
   long ip = (long)bid * 256 + threadIdx.x;
   Elem cur;
-  if (PIPE) load(min(ip, n4 - 1), cur);  // clamped, unconditional (no exec-mask block)
+  load(min(ip, n4 - 1), cur);  // clamped, unconditional (no exec-mask block)
   // thread t sums part[t], part[t+256], ... in that order; 8 clamped loads are in
   // flight per round (a plain loop serialises one L2 round trip per partial, and
   // every block of this one-wave launch pays that chain before its first byte);
@@ -534,232 +533,23 @@ __global__ __launch_bounds__(256) void adam_kernel(
     for (int i = 0; i < B; ++i) l += losses[i] * weights[i];
     sc[DZ_SC_LOSS] = l / (float)B;
   }
-  if (PIPE) {
-    while (ip < n4) {
-      const long inext = ip + stride;
-      Elem nxt;
-      load(min(inext, n4 - 1), nxt);
-      float* G = (float*)&cur.g; float* M = (float*)&cur.m; float* V = (float*)&cur.v;
-      float* P = (float*)&cur.p; const float* EO = (const float*)&cur.eo;
-      const float ei = cur.der ? cur.ei : 1.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float gj = G[j] * (ei * (cur.der ? EO[j] : 1.f));
-        asm volatile("" : "+v"(gj));  // a rounded product (never contracted into the update)
-        adam_elem(P[j], gj, M[j], V[j], pass, gn, bc1, bc2, lr, b1, b2, eps, max_norm);
-      }
-      ((float4*)m)[ip] = cur.m; ((float4*)v)[ip] = cur.v; ((float4*)p)[ip] = cur.p;
-      cur = nxt; ip = inext;
-    }
-    return;
-  }
-  for (long i = (long)bid * 256 + threadIdx.x; i < n4; i += (long)nblk * 256) {
-    float4 gv;
-    if (i >= d0 && i < d1) {  // derived block: mu-gradient times the noise outer product
-      const unsigned rel = (unsigned)(i - d0) << 2;  // < 2^31 (block of at most 8 GB)
-      const unsigned k = rel / (unsigned)dg.ld, n = rel - k * (unsigned)dg.ld;
-      gv = ((const float4*)(g + dg.src_off))[i - d0];
-      const float ei = ((int)n < dg.split_col ? dg.eps_in0 : dg.eps_in1)[k];
-      const float4 eo = *(const float4*)(dg.eps_out + n);
-      gv.x = gv.x * (ei * eo.x); gv.y = gv.y * (ei * eo.y);
-      gv.z = gv.z * (ei * eo.z); gv.w = gv.w * (ei * eo.w);
-    } else {
-      gv = ((const float4*)g)[i];
-    }
-    float4 mv = ((float4*)m)[i], vv = ((float4*)v)[i], pv = ((float4*)p)[i];
-    float* G = (float*)&gv; float* M = (float*)&mv; float* V = (float*)&vv;
-    float* P = (float*)&pv;
+  while (ip < n4) {
+    const long inext = ip + stride;
+    Elem nxt;
+    load(min(inext, n4 - 1), nxt);
+    float* G = (float*)&cur.g; float* M = (float*)&cur.m; float* V = (float*)&cur.v;
+    float* P = (float*)&cur.p; const float* EO = (const float*)&cur.eo;
+    const float ei = cur.der ? cur.ei : 1.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      adam_elem(P[j], G[j], M[j], V[j], pass, gn, bc1, bc2, lr, b1, b2, eps, max_norm);
+      float gj = G[j] * (ei * (cur.der ? EO[j] : 1.f));
+      asm volatile("" : "+v"(gj));  // a rounded product (never contracted into the update)
+      adam_elem(P[j], gj, M[j], V[j], pass, gn, bc1, bc2, lr, b1, b2, eps, max_norm);
     }
-    ((float4*)m)[i] = mv; ((float4*)v)[i] = vv; ((float4*)p)[i] = pv;
+    ((float4*)m)[ip] = cur.m; ((float4*)v)[ip] = cur.v; ((float4*)p)[ip] = cur.p;
+    cur = nxt; ip = inext;
   }
 }
-
-// --------------------------------------------------------------------------- //
-//  Optimiser launch that never reads a stored gradient for the big noisy layer.
-//  Rainbow's fc1 weight gradient is a ONE-stage contraction (depth = batch 32)
-//  over two L2-resident operands (feat 400 KB, dh1 128 KB), while storing it and
-//  reading it back is 80 MB of HBM traffic per step.  So the backward pass only
-//  leaves its norm partials (FcWgradParams::skip_mu_store) and this launch
-//  recomputes each 64x64 tile with the SAME Op (identical MFMA order => identical
-//  values) and applies clip + Adam to the tile's mu and sigma parameters straight
-//  from the accumulators.  Everything outside those two blocks is updated by the
-//  flat side job (AdamFlatSide) in the same launch.
-// --------------------------------------------------------------------------- //
-struct AdamHyper { float lr, b1, b2, eps, max_norm; };
-struct AdamScalars { float gn, bc1, bc2; bool pass; };
-
-// The scalars of adam_kernel, computed by ONE wave with the same summation tree:
-// adam_kernel's thread t sums part[t], part[t+256], ...; its wave w folds threads
-// [64w, 64w+64); the block adds (r0+r1)+(r2+r3).  Here every wave plays all four.
-__device__ __forceinline__ AdamScalars adam_scalars_wave(const float* __restrict__ part,
-                                                         int nparts,
-                                                         const int32_t* __restrict__ count,
-                                                         const AdamHyper& h) {
-  const int lane = threadIdx.x & 63;
-  // 16 clamped loads in flight per round (a plain loop serialises one L2 round trip
-  // per partial); out-of-range slots add +0 to a non-negative sum: no change
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int base = 0; base < nparts; base += 1024) {
-    float x[4][4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i = base + j * 256 + w * 64 + lane;
-        const float y = part[min(i, nparts - 1)];
-        x[w][j] = i < nparts ? y : 0.f;
-      }
-#pragma unroll
-    for (int w = 0; w < 4; ++w)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[w] += x[w][j];
-  }
-  float r[4];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) r[w] = wave_sum(s[w]);
-  AdamScalars sc;
-  // the same value in every lane: move it to a scalar register so that `pass`
-  // becomes a uniform branch (the clip division is skipped, not computed and
-  // discarded per element)
-  sc.gn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
-      int, sqrtf((r[0] + r[1]) + (r[2] + r[3])))));
-  const int c = *count;
-  sc.bc1 = 1.0f - powf(h.b1, (float)c);
-  sc.bc2 = 1.0f - powf(h.b2, (float)c);
-  sc.pass = !(h.max_norm > 0.f && !(sc.gn < h.max_norm));
-  return sc;
-}
-
-struct FcWgradAdamParams : FcWgradParams {
-  float* prm;   // parameters, first moment, second moment (parameter layout)
-  float* m;
-  float* v;
-  const float* part;  // global-norm partials
-  int nparts;
-  const int32_t* count;  // already incremented
-  AdamHyper h;
-};
-
-template <class Base, int R, int PIPE>
-struct FcWgradAdamOp : Base {
-  typedef FcWgradAdamParams Params;
-  struct Tile : Base::Tile { AdamScalars sc; };
-
-  __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
-    const bool ok = Base::tile(p, bid, t);
-    t.sc = adam_scalars_wave(p.part, p.nparts, p.count, p.h);
-    return ok;
-  }
-  // R accumulator rows (x mu and sigma) per round; PIPE: the next round's loads
-  // are issued before this round's arithmetic.
-  struct Round {
-    unsigned o[R];
-    float pm[R], mm[R], vm[R], ps[R], ms[R], vs[R], ei[R];
-  };
-  __device__ static float& at(float* b, unsigned byte_off) {
-    return *(float*)((char*)b + byte_off);
-  }
-  // full tiles only (host checks K % BM == 0 and N % BN == 0): no bounds tests, so
-  // all loads of a round are in flight before the first use.  32-bit BYTE offsets
-  // from the buffer bases: global_load v, voff, s[base] (one VGPR per address).
-  __device__ static void load(const Params& p, const Tile& t, int row0, int col, int lane,
-                              int r0, unsigned sig, Round& x) {
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const int k = row0 + dz_acc_row(r0 + q, lane);
-      x.o[q] = ((unsigned)t.hd.w_mu + (unsigned)k * (unsigned)t.hd.ldw + (unsigned)col) * 4u;
-      x.ei[q] = p.noise[t.hd.eps_in + k];
-      x.pm[q] = at(p.prm, x.o[q]); x.mm[q] = at(p.m, x.o[q]); x.vm[q] = at(p.v, x.o[q]);
-      x.ps[q] = at(p.prm, x.o[q] + sig); x.ms[q] = at(p.m, x.o[q] + sig);
-      x.vs[q] = at(p.v, x.o[q] + sig);
-    }
-  }
-  __device__ static void update(const Params& p, const AdamScalars& sc, const f32x16& acc,
-                                int r0, float eo, unsigned sig, Round& x) {
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const float g = acc[r0 + q];
-      float gs = g * (x.ei[q] * eo);
-      asm volatile("" : "+v"(gs));  // a rounded product, as if stored and re-read
-      adam_elem(x.pm[q], g, x.mm[q], x.vm[q], sc.pass, sc.gn, sc.bc1, sc.bc2, p.h.lr, p.h.b1,
-                p.h.b2, p.h.eps, p.h.max_norm);
-      adam_elem(x.ps[q], gs, x.ms[q], x.vs[q], sc.pass, sc.gn, sc.bc1, sc.bc2, p.h.lr, p.h.b1,
-                p.h.b2, p.h.eps, p.h.max_norm);
-    }
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      at(p.prm, x.o[q]) = x.pm[q]; at(p.m, x.o[q]) = x.mm[q]; at(p.v, x.o[q]) = x.vm[q];
-      at(p.prm, x.o[q] + sig) = x.ps[q]; at(p.m, x.o[q] + sig) = x.ms[q];
-      at(p.v, x.o[q] + sig) = x.vs[q];
-    }
-  }
-  __device__ static void store(const Params& p, const Tile& t, int wm, int wn, int lane,
-                               const f32x16& acc) {
-    const int col = t.n0 + wn * 32 + (lane & 31);
-    const int row0 = t.m0 + wm * 32;
-    const float eo = p.noise[t.hd.eps_out + col];
-    const unsigned sig = (unsigned)(t.hd.w_sig - t.hd.w_mu) * 4u;
-    if constexpr (PIPE) {
-      Round x[2];
-      load(p, t, row0, col, lane, 0, sig, x[0]);
-#pragma unroll
-      for (int i = 0; i < 16 / R; ++i) {
-        if (i + 1 < 16 / R) load(p, t, row0, col, lane, (i + 1) * R, sig, x[(i + 1) & 1]);
-        update(p, t.sc, acc, i * R, eo, sig, x[i & 1]);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16 / R; ++i) {
-        Round x;
-        load(p, t, row0, col, lane, i * R, sig, x);
-        update(p, t.sc, acc, i * R, eo, sig, x);
-      }
-    }
-  }
-};
-
-// The rest of the parameter vector: up to 3 segments (float4 units) around the
-// blocks the tiles own; block 0 publishes the scalars like adam_kernel.
-struct AdamFlatParams {
-  float* p; const float* g; float* m; float* v;
-  long seg_begin[3], seg_len[3];  // float4 units
-  const float* part; int nparts; const int32_t* count;
-  const float* losses; const float* weights; int B; float* sc;
-  AdamHyper h;
-};
-struct AdamFlatSide {
-  typedef AdamFlatParams Params;
-  __device__ static void run(const Params& q, unsigned block) {
-    const AdamScalars sc = adam_scalars_wave(q.part, q.nparts, q.count, q.h);
-    if (block == 0 && threadIdx.x == 0) {
-      q.sc[DZ_SC_GNORM] = sc.gn; q.sc[DZ_SC_BC1] = sc.bc1; q.sc[DZ_SC_BC2] = sc.bc2;
-      q.sc[DZ_SC_CLIP] = sc.pass ? 1.f : 0.f;
-      float l = 0.f;
-      for (int i = 0; i < q.B; ++i) l += q.losses[i] * q.weights[i];
-      q.sc[DZ_SC_LOSS] = l / (float)q.B;
-    }
-    long j = (long)block * 256 + threadIdx.x;
-    long i = -1;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      if (i < 0 && j < q.seg_len[s]) i = q.seg_begin[s] + j;
-      j -= q.seg_len[s];
-    }
-    if (i < 0) return;
-    float4 gv = ((const float4*)q.g)[i];
-    float4 mv = ((float4*)q.m)[i], vv = ((float4*)q.v)[i], pv = ((float4*)q.p)[i];
-    float* G = (float*)&gv; float* M = (float*)&mv; float* V = (float*)&vv;
-    float* P = (float*)&pv;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      adam_elem(P[e], G[e], M[e], V[e], sc.pass, sc.gn, sc.bc1, sc.bc2, q.h.lr, q.h.b1, q.h.b2,
-                q.h.eps, q.h.max_norm);
-    ((float4*)q.m)[i] = mv; ((float4*)q.v)[i] = vv; ((float4*)q.p)[i] = pv;
-  }
-};
 
 __global__ void copy_kernel(float* __restrict__ dst, const float* __restrict__ src,
                             long n4) {

@@ -472,9 +472,6 @@ struct FcWgradParams {
   // noisy only: do not store the sigma-weight gradient (it still enters sumsq);
   // the optimiser re-derives it as dWmu * eps_in (x) eps_out (adam_kernel DerivedGrad)
   int skip_sig_store = 0;
-  // store nothing, only the norm partials: the optimiser launch recomputes the
-  // (one-stage) contraction and applies the update tile by tile (FcWgradAdamOp)
-  int skip_mu_store = 0;
 };
 
 template <int WM_, int WN_, int WK_, int KT_ = 1>
@@ -533,7 +530,7 @@ struct FcWgradOp {
       const int k = t.m0 + wm * 32 + dz_acc_row(r, lane);
       if (colok && k < hd.K) {
         const float v = acc[r];
-        if (!p.skip_mu_store) p.grad[hd.w_mu + (long)k * hd.ldw + col] = v;
+        p.grad[hd.w_mu + (long)k * hd.ldw + col] = v;
         sq += v * v;
         if (p.noisy) {
           const float vs = v * (ei[r] * eo);

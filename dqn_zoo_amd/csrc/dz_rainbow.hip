@@ -16,29 +16,14 @@
 #include "dz_sumtree_dev.h"
 #include "dz_torso.h"
 
-extern int g_iqn_variant;  // dz_iqn.hip (dz_set_tuning key 13)
-
 namespace {
 
-// Run-time tuning knobs (dz_set_tuning): kernel variant and split factors, used
-// by tools/tune.py to sweep configurations in ONE GPU session.  Defaults are the
-// measured best on MI355X at B = 32.
-int g_fc1_variant = 10;       // 10 = shared weight stream (dz_fc_stream_fwd3), 0 = tile GEMM
-int g_fc1_splits = 32;
-int g_fc1_xcd = 1;            // fc1 forward workgroups in XCD-aware order
-int g_fc1_dgrad_first = 3;    // fc1 backward: 3/2 = weight + input gradient in ONE launch (19 us;
-                              // wgrad / dgrad blocks first), 1/0 = two launches (28 us)
-int g_fc1_dgrad_variant = 2;  // FcDgradOp<1,2,2,KT=1>
-int g_fc1_dgrad_splits = 16;
-int g_dgrad_weff = 1;         // fc1 input gradient against W_eff (depth N, not 2N): 14.2 vs 17.2 us
-int g_fc2_splits = 8;         // 12 us (4 splits: 19 us)
-int g_fc2_weff = 1;           // fc2 forward against W_eff (depth K): 11.2 vs 12.1 us
-int g_adam_blocks = 2048;     // grid-stride Adam launch width
-int g_fc2_dgrad_splits = kS_dh1;  // 1: unsplit, no reduce launch
-int g_prio_host = 1;          // priority write-back side block: 1 = in the Adam launch, 0 = conv3 backward
-int g_adam_pipe = 1;          // flat Adam: branch-free, software-pipelined loads
-int g_adam_fused = 0;         // fc1 weight gradient recomputed inside the optimiser launch
-                              // (FcWgradAdamOp): never stored, never re-read
+// Launch constants: the measured best on MI355X at B = 32 (the sweeps and the
+// alternatives that lost are in DESIGN.md 6b; the code that implemented them is gone).
+constexpr int kFc1Splits = 32;       // fc1 forward k-splits (98 rows each)
+constexpr int kFc1DgradSplits = 16;  // fc1 input-gradient k-splits
+constexpr int kFc2Splits = 8;        // fc2 forward k-splits
+constexpr int kAdamBlocks = 2048;    // grid-stride Adam launch width (8 blocks per CU)
 
 }  // namespace
 
@@ -68,37 +53,31 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
     for (int g = 0; g < G; ++g) { p.params[g] = prm[g]; p.noise[g] = nz[g]; }
     p.head[0] = fc1h[0]; p.head[1] = fc1h[1];
     p.part = ws + L.ws_fc1_part; p.ldo = 1024;
-    p.S = g_fc1_splits;
-    const dim3 gz(1, (B + 31) / 32, G * 2 * g_fc1_splits);
-    if (g_fc1_variant != 10 || B > 32) {
-      // tile GEMM over the depth-2K form [x | x.eps_in] [Wmu ; Wsig.eps_out]
-      rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4>>(p, dim3(8, gz.y, gz.z), s);
+    p.S = kFc1Splits;
+    if (B > 32) {
+      // more than one batch tile: tile GEMM over the depth-2K form [x | x.eps_in] [Wmu ; Wsig.eps_out]
+      rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4>>(p, dim3(8, (B + 31) / 32, G * 2 * kFc1Splits), s);
     } else {
-      {  // one weight stream per parameter set, W_eff built in registers
-        FcStreamFwd3Params q;
-        q.x = p.x; q.ldx = p.ldx; q.M = B; q.noisy = 1; q.G = G;
-        const int ns = dz_fc3_assign_sets(q, G, prm, nz);
-        DZ_REQUIRE(ns > 0);
-        q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
-        q.part = p.part; q.ldo = p.ldo;
-        q.rows_per_split = ((kFlat + g_fc1_splits - 1) / g_fc1_splits + 3) & ~3;
-        DZ_REQUIRE(q.rows_per_split <= 200);
-        q.xcd_order = g_fc1_xcd && ((g_fc1_splits * ns) % 8 == 0);
-        const size_t lds = (size_t)q.rows_per_split * (2 * 32 + 2) * sizeof(float);
-        if (q.rows_per_split <= 100)
-          hipLaunchKernelGGL((dz_fc_stream_fwd3<1, 50>), dim3(8, g_fc1_splits, ns), dim3(256),
-                             lds, s, q);
-        else
-          hipLaunchKernelGGL((dz_fc_stream_fwd3<1, 100>), dim3(8, g_fc1_splits, ns), dim3(256),
-                             lds, s, q);
-        DZ_LAUNCH_CHECK();
-        rc = DZ_OK;
-      }
+      // one weight stream per parameter set, W_eff built in registers; workgroups in
+      // XCD-aware order (+3 %)
+      FcStreamFwd3Params q;
+      q.x = p.x; q.ldx = p.ldx; q.M = B; q.noisy = 1; q.G = G;
+      const int ns = dz_fc3_assign_sets(q, G, prm, nz);
+      DZ_REQUIRE(ns > 0);
+      q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
+      q.part = p.part; q.ldo = p.ldo;
+      q.rows_per_split = ((kFlat + kFc1Splits - 1) / kFc1Splits + 3) & ~3;
+      static_assert((((kFlat + kFc1Splits - 1) / kFc1Splits + 3) & ~3) <= 100, "NL = 50 k-pairs per lane");
+      q.xcd_order = (kFc1Splits * ns) % 8 == 0;
+      const size_t lds = (size_t)q.rows_per_split * (2 * 32 + 2) * sizeof(float);
+      hipLaunchKernelGGL((dz_fc_stream_fwd3<1, 50>), dim3(8, kFc1Splits, ns), dim3(256), lds, s, q);
+      DZ_LAUNCH_CHECK();
+      rc = DZ_OK;
     }
     if (rc) return rc;
     DZ_PROF(s, "fc1_fwd");
     hipLaunchKernelGGL(fc_epilogue_kernel, dim3(16, G * B), dim3(256), 0, s,
-                       ws + L.ws_fc1_part, g_fc1_splits, G * B, 1024, 1024, B,
+                       ws + L.ws_fc1_part, kFc1Splits, G * B, 1024, 1024, B,
                        prm[0], prm[1], prm[2], (long)L.fc1_mu_b, (long)L.fc1_sig_b,
                        nz[0], nz[1], nz[2], (int)L.n_fc1_out, 1, ws + L.ws_h1);
     DZ_LAUNCH_CHECK();
@@ -106,19 +85,18 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
   }
   {  // fc2: noisy adv2 (no mu bias) and val2 (no mu bias)
     FcFwdParams p;
-    p.x = ws + L.ws_h1; p.ldx = 1024; p.M = B; p.G = G; p.NH = 2; p.S = g_fc2_splits;
-    p.noisy = g_fc2_weff ? 2 : 1;
+    p.x = ws + L.ws_h1; p.ldx = 1024; p.M = B; p.G = G; p.NH = 2; p.S = kFc2Splits;
+    p.noisy = 2;  // against W_eff (depth K): 11.2 vs 12.1 us for the two-GEMM form
     for (int g = 0; g < G; ++g) { p.params[g] = prm[g]; p.noise[g] = nz[g]; }
     p.head[0] = fc2h[0]; p.head[1] = fc2h[1];
     p.part = ws + L.ws_fc2_part; p.ldo = ld2;
-    const dim3 g2((NA + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32, G * 2 * g_fc2_splits);
-    rc = g_fc2_weff ? dz_launch_gemm<FcFwdOp<1, 2, 2, 4, 2>>(p, g2, s)
-                    : dz_launch_gemm<FcFwdOp<1, 2, 2, 4, 1>>(p, g2, s);
+    const dim3 g2((NA + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32, G * 2 * kFc2Splits);
+    rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4, 2>>(p, g2, s);
     if (rc) return rc;
     DZ_PROF(s, "fc2_fwd");
     if (skip_fc2_epilogue) return rc;  // the loss kernel folds the partial slabs itself
     hipLaunchKernelGGL(fc_epilogue_kernel, dim3((ld2 + 63) / 64, G * B), dim3(256),
-                       0, s, ws + L.ws_fc2_part, g_fc2_splits, G * B, ld2, ld2, B,
+                       0, s, ws + L.ws_fc2_part, kFc2Splits, G * B, ld2, ld2, B,
                        prm[0], prm[1], prm[2], (long)-1, (long)L.fc2_sig_b, nz[0],
                        nz[1], nz[2], (int)L.n_fc2_out, 0, ws + L.ws_fc2_out);
     DZ_LAUNCH_CHECK();
@@ -250,7 +228,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       if (rc) return rc;
       HeadPre pre = {};
       if (fuse) {
-        pre.part = ws + L.ws_fc2_part; pre.S = g_fc2_splits; pre.rows = kG * B;
+        pre.part = ws + L.ws_fc2_part; pre.S = kFc2Splits; pre.rows = kG * B;
         for (int g = 0; g < kG; ++g) { pre.prm[g] = prm[g]; pre.nz[g] = nz[g]; }
         pre.b_sig = L.fc2_sig_b; pre.eps_out = (int)L.n_fc2_out;
         hipLaunchKernelGGL(rainbow_head_loss_kernel<1>, dim3(B), dim3(256),
@@ -274,9 +252,6 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   // when this one call both produces and consumes it
   const bool derive_sig = (phases & DZ_PHASE_BACKWARD) && (phases & DZ_PHASE_OPTIMIZER) &&
                           !a->keep_all_grads;
-  // ... and the whole fc1 weight gradient recomputed inside the optimiser launch
-  const bool fuse_adam = derive_sig && g_adam_fused && kFlat % FcWg::BM == 0 &&
-                         512 % FcWg::BN == 0;
   auto fc1_wgrad_params = [&](FcWgradParams& w) {
     w.x = ws + L.ws_feat; w.ldx = kFlat; w.dy = ws + L.ws_dh1; w.ldy = 1024; w.M = B;
     w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc1h[0]; w.head[1] = fc1h[1];
@@ -319,18 +294,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       w.grad = grad;
       w.sumsq = sq_slots; w.sq_nx = (NA + FcWg::BN - 1) / FcWg::BN; w.sq_ny = kHid / FcWg::BM;
       FcDgradParams d[2];
-      const int s_dh1 = g_fc2_dgrad_splits;
+      constexpr int s_dh1 = kS_dh1;
       for (int h = 0; h < 2; ++h) {
         d[h].dy = ws + L.ws_dout2; d[h].ldy = ld2; d[h].M = B; d[h].NH = 1;
         // (the W_eff form of this small input gradient measured slower: 16.4 vs 14.1 us)
         d[h].S = s_dh1; d[h].noisy = 1; d[h].params = a->online; d[h].noise = nz[0];
         d[h].head[0] = fc2h[h]; d[h].head[1] = fc2h[h];
         d[h].ldo = 1024; d[h].K = kHid; d[h].x_off = 512 * h;
-        if (s_dh1 == 1) {  // unsplit: straight into dh1 with the ReLU mask in the store
-          d[h].part = ws + L.ws_dh1; d[h].relu_mask = ws + L.ws_h1;
-        } else {
-          d[h].part = ws + L.ws_dfeat_part;
-        }
+        d[h].part = ws + L.ws_dfeat_part;
       }
       const dim3 gd(kHid / FcDg::BN, (B + 31) / 32, s_dh1);
       typedef FcDgradOp<1, 2, 2, 4, 1, 1, 1> FcDg1;  // noisy == 1 at compile time
@@ -338,76 +309,32 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
           w, dim3((NA + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 2), d[0], gd, d[1], gd, s);
       if (rc) return rc;
       DZ_PROF(s, "fc2_wgrad+dgrad");
-      if (s_dh1 > 1) {
-        hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * 1024 + 63) / 64), dim3(256), 0,
-                           s, ws + L.ws_dfeat_part, s_dh1, (long)B * 1024, ws + L.ws_h1,
-                           ws + L.ws_dh1);
-        DZ_LAUNCH_CHECK();
-        DZ_PROF(s, "dh1_reduce");
-      }
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * 1024 + 63) / 64), dim3(256), 0,
+                         s, ws + L.ws_dfeat_part, s_dh1, (long)B * 1024, ws + L.ws_h1,
+                         ws + L.ws_dh1);
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "dh1_reduce");
     }
     {  // fc1: weight gradients + input gradient (adv1 + val1 paths) -> dfeat
       FcWgradParams w;
       fc1_wgrad_params(w);
       w.sumsq = sq_slots + fc2_slots; w.sq_nx = 512 / FcWg::BN; w.sq_ny = kFlat / FcWg::BM;
       w.skip_sig_store = derive_sig;
-      w.skip_mu_store = fuse_adam;
+      // input gradient against W_eff (built in the B loader: depth N instead of the
+      // two-GEMM form's 2N, 14.2 vs 17.2 us), single-chunk stages
       FcDgradParams d;
-      d.dy = ws + L.ws_dh1; d.ldy = 1024; d.M = B; d.NH = 2; d.S = kS_dfeat; d.noisy = g_dgrad_weff ? 2 : 1;
+      d.dy = ws + L.ws_dh1; d.ldy = 1024; d.M = B; d.NH = 2; d.S = kFc1DgradSplits; d.noisy = 2;
       d.params = a->online; d.noise = nz[0]; d.head[0] = fc1h[0]; d.head[1] = fc1h[1];
       d.part = ws + L.ws_dfeat_part; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
-      // One launch for the 25.7 MB weight read and the 25.7 MB gradient write
-      // (19 us vs 14 + 14 back to back; before the loader fixes the fused form
-      // had measured slower, 48 vs 38 us).
-      d.S = g_fc1_dgrad_splits;
-      auto launch_dgrad = [&]() {
-        const dim3 g64(kFlat / 64, (B + 31) / 32, d.S);
-        switch (g_fc1_dgrad_variant) {
-          case 0: return dz_launch_gemm<FcDgradOp<1, 2, 2, 4>>(d, g64, s);
-          case 1: return dz_launch_gemm<FcDgradOp<1, 2, 2, 2>>(d, g64, s);
-          default: return dz_launch_gemm<FcDgradOp<1, 2, 2, 1>>(d, g64, s);
-        }
-      };
-      auto launch_wgrad = [&]() {
-        return dz_launch_gemm<FcWg>(w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
-      };
-      if (g_fc1_dgrad_first == 2) {  // both in ONE launch (dgrad blocks first)
-        rc = dz_launch_gemm2<FcDgradOp<1, 2, 2, 1>, FcWg>(
-            d, dim3(kFlat / 64, (B + 31) / 32, d.S), w,
-            dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), s);
-        if (rc) return rc;
-        DZ_PROF(s, "fc1_dgrad+wgrad");
-      } else if (g_fc1_dgrad_first == 4) {  // as 3, tiles in XCD-aware order
-        rc = dz_launch_gemm2_xcd<FcWg, FcDgradOp<1, 2, 2, 1>>(
-            w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), d,
-            dim3(kFlat / 64, (B + 31) / 32, d.S), s);
-        if (rc) return rc;
-        DZ_PROF(s, "fc1_dgrad+wgrad");
-      } else if (g_fc1_dgrad_first == 3) {  // wgrad blocks first
-        const dim3 gw(512 / FcWg::BN, kFlat / FcWg::BM, 2), gd(kFlat / 64, (B + 31) / 32, d.S);
-        if (!g_dgrad_weff)
-          rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 1>>(w, gw, d, gd, s);
-        else if (g_fc1_dgrad_variant == 0)  // 64-deep stages: one per workgroup at 16 splits
-          rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 4, 1, 1, 2>>(w, gw, d, gd, s);
-        else if (g_fc1_dgrad_variant == 1)
-          rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 2, 1, 1, 2>>(w, gw, d, gd, s);
-        else
-          rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 2>>(w, gw, d, gd, s);
-        if (rc) return rc;
-        DZ_PROF(s, "fc1_dgrad+wgrad");
-      } else if (g_fc1_dgrad_first) {
-        if ((rc = launch_dgrad())) return rc;
-        DZ_PROF(s, "fc1_dgrad");
-        if ((rc = launch_wgrad())) return rc;
-        DZ_PROF(s, "fc1_wgrad");
-      } else {
-        if ((rc = launch_wgrad())) return rc;
-        DZ_PROF(s, "fc1_wgrad");
-        if ((rc = launch_dgrad())) return rc;
-        DZ_PROF(s, "fc1_dgrad");
-      }
+      // ONE launch for the 25.7 MB weight read and the 12.9 MB gradient write, the
+      // weight-gradient blocks first (15 us vs 14 + 14 back to back)
+      rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 2>>(
+          w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), d,
+          dim3(kFlat / 64, (B + 31) / 32, kFc1DgradSplits), s);
+      if (rc) return rc;
+      DZ_PROF(s, "fc1_dgrad+wgrad");
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0,
-                         s, ws + L.ws_dfeat_part, g_fc1_dgrad_splits, (long)B * kFlat,
+                         s, ws + L.ws_dfeat_part, kFc1DgradSplits, (long)B * kFlat,
                          ws + L.ws_feat, ws + L.ws_dfeat);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "dfeat_reduce");
@@ -419,7 +346,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       d.dy = ws + L.ws_dfeat; d.w = a->online + L.conv_w[2]; d.act = ws + L.ws_act2;
       d.dx = ws + L.ws_dact2; d.B = B;
       const dim3 gw(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), gd(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1);
-      const bool prio_in_adam = g_prio_host == 1 && (phases & DZ_PHASE_OPTIMIZER) && !fuse_adam;
+      const bool prio_in_adam = (phases & DZ_PHASE_OPTIMIZER) != 0;
       if (prio_pending && !prio_in_adam) {
         // The sum-tree priority write-back rides in this launch as one extra block:
         // it needs only the loss kernel's priorities and nothing here reads the tree.
@@ -487,34 +414,6 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       DZ_PROF(s, "grad_sumsq");
       nparts = kNormBlocks;
     }
-    if (fuse_adam) {
-      FcWgradAdamParams w;
-      fc1_wgrad_params(w);
-      w.prm = a->online; w.m = a->adam_m; w.v = a->adam_v;
-      w.part = ws + L.ws_norm_part; w.nparts = nparts; w.count = a->adam_count;
-      w.h = {a->lr, a->b1, a->b2, a->eps, a->max_norm};
-      AdamFlatParams q;
-      q.p = a->online; q.g = a->grad; q.m = a->adam_m; q.v = a->adam_v;
-      // the parameter vector minus the two fc1 weight blocks (whose 32 pad columns
-      // per row hold zeros and would receive zero updates: nobody touches them)
-      const long mu_end = L.fc1_mu_w + (long)kFlat * L.fc1_ld;
-      q.seg_begin[0] = 0; q.seg_len[0] = L.fc1_mu_w >> 2;
-      q.seg_begin[1] = mu_end >> 2; q.seg_len[1] = (L.fc1_sig_w - mu_end) >> 2;
-      q.seg_begin[2] = (L.fc1_sig_w + (long)kFlat * L.fc1_ld) >> 2;
-      q.seg_len[2] = (L.param_count >> 2) - q.seg_begin[2];
-      DZ_REQUIRE((L.fc1_mu_w & 3) == 0 && (L.fc1_sig_w & 3) == 0 && (L.fc1_ld & 3) == 0);
-      q.part = w.part; q.nparts = nparts; q.count = a->adam_count;
-      q.losses = a->losses; q.weights = a->weights; q.B = B; q.sc = sc; q.h = w.h;
-      const long flat4 = q.seg_len[0] + q.seg_len[1] + q.seg_len[2];
-      const dim3 gw(512 / FcWg::BN, kFlat / FcWg::BM, 2);
-      const unsigned nside = (unsigned)((flat4 + 255) / 256);
-      // 2 accumulator rows per round, the next round's loads issued early: the best of
-      // the measured forms (rows per round 2/4/8, plain / pipelined, 64x64 / 32x128 tiles)
-      rc = dz_launch_gemm_side<FcWgradAdamOp<FcWg, 2, 1>, AdamFlatSide>(w, gw, q, nside, s);
-      if (rc) return rc;
-      DZ_PROF(s, "adam");
-      return DZ_OK;
-    }
     DerivedGrad dg = {};
     if (derive_sig) {
       dg.dst_off = L.fc1_sig_w; dg.src_off = L.fc1_mu_w; dg.rows = kFlat; dg.ld = L.fc1_ld;
@@ -525,20 +424,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     }
     // with the write-back as block 0 the grid stays g_adam_blocks wide (all blocks
     // co-resident at 8 per CU): one optimiser block fewer
-    if (g_adam_pipe)
-      hipLaunchKernelGGL(adam_kernel<1>, dim3((unsigned)g_adam_blocks), dim3(256), 0, s, a->online,
-                         a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
-                         ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,
-                         a->lr, a->b1, a->b2, a->eps, a->max_norm, dg,
-                         prio_pending ? prio_q : PrioUpdateParams{});
-    else
-      hipLaunchKernelGGL(adam_kernel<0>, dim3((unsigned)g_adam_blocks), dim3(256), 0, s, a->online,
-                         a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
-                         ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,
-                         a->lr, a->b1, a->b2, a->eps, a->max_norm, dg);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)kAdamBlocks), dim3(256), 0, s, a->online,
+                       a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
+                       ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,
+                       a->lr, a->b1, a->b2, a->eps, a->max_norm, dg,
+                       prio_pending ? prio_q : PrioUpdateParams{});
     DZ_LAUNCH_CHECK();
     DZ_PROF(s, "adam");
-    if (g_adam_pipe) prio_pending = false;
+    prio_pending = false;
   }
   if (prio_pending) {  // no launch of this call carried it
     hipLaunchKernelGGL(prio_update_side_kernel, dim3(1), dim3(256), 0, s, prio_q);
@@ -659,7 +552,7 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
   if (rc) return rc;
   if (fuse) {
     HeadPre pre = {};
-    pre.part = ws + L.ws_fc2_part; pre.S = g_fc2_splits; pre.rows = batch;
+    pre.part = ws + L.ws_fc2_part; pre.S = kFc2Splits; pre.rows = batch;
     for (int g = 0; g < kG; ++g) { pre.prm[g] = params; pre.nz[g] = noise; }
     pre.b_sig = L.fc2_sig_b; pre.eps_out = (int)L.n_fc2_out;
     hipLaunchKernelGGL(rainbow_q_values_kernel<1>, dim3(batch), dim3(256),
@@ -672,30 +565,6 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
   }
   DZ_LAUNCH_CHECK();
   return DZ_OK;
-}
-
-extern "C" int dz_set_tuning(int key, int value) {
-  switch (key) {
-    case 0: g_fc1_variant = value; return DZ_OK;
-    case 1: DZ_REQUIRE(value >= 1 && value <= kMaxSplitFc1); g_fc1_splits = value; return DZ_OK;
-    case 2: g_fc1_xcd = value; return DZ_OK;
-    case 3: case 4: return DZ_OK;  // retired experiments
-    case 5: g_fc1_dgrad_first = value; return DZ_OK;
-    case 6: g_fc1_dgrad_variant = value; return DZ_OK;
-    case 7: DZ_REQUIRE(value >= 1 && value <= kMaxS_dfeat); g_fc1_dgrad_splits = value; return DZ_OK;
-    case 8: DZ_REQUIRE(value >= 1 && value <= kMaxS_fc2); g_fc2_splits = value; return DZ_OK;
-    case 9: case 10: case 11: g_conv_fwd_variant[key - 9] = value; return DZ_OK;
-    case 12: g_dgrad_weff = value; return DZ_OK;
-    case 13: g_iqn_variant = value; return DZ_OK;
-    case 14: DZ_REQUIRE(value >= 64 && value <= 65536); g_adam_blocks = value; return DZ_OK;
-    case 15: g_conv_xcd = value; return DZ_OK;
-    case 16: DZ_REQUIRE(value >= 1 && value <= kS_dh1); g_fc2_dgrad_splits = value; return DZ_OK;
-    case 17: g_fc2_weff = value; return DZ_OK;
-    case 18: g_adam_fused = value; return DZ_OK;
-    case 19: g_adam_pipe = value; return DZ_OK;
-    case 20: g_prio_host = value; return DZ_OK;
-    default: return DZ_ERR_INVALID_ARG;
-  }
 }
 
 extern "C" int dz_noise_fill(float* noise, int64_t count, uint64_t seed,

@@ -6,9 +6,6 @@
 #include "dz_qnet_kernels.h"
 #include "dz_sumtree_dev.h"
 
-extern int g_conv_fwd_variant[3];  // dz_core.hip; dz_set_tuning keys 9-11
-extern int g_conv_xcd;              // dz_core.hip; key 15
-
 namespace {
 
 struct TorsoBufs {
@@ -19,16 +16,13 @@ struct TorsoBufs {
   float* feat;             // [G*B][3136]
 };
 
-// Tile-shape variants of the three forward convolutions (dz_set_tuning keys
-// 9-11; index 0 = the aliases of dz_qnet_kernels.h).  The M dimension (3 applies
-// x 32 images x output pixels) gives 147-300 workgroups of the default shapes on
-// 256 CUs; the variants trade tile size for workgroup count.
+// Forward launch shapes: the M dimension (3 applies x 32 images x output pixels)
+// gives 300-600 workgroups of the shapes in dz_qnet_kernels.h on 256 CUs (the
+// measured best of a sweep over 4-6 tile shapes per layer; XCD-ordered tiles made
+// no difference for these: DESIGN.md 6b).
 template <class Op>
 inline int launch_conv_fwd(const ConvFwdParams& p, int CO, int G, int B, hipStream_t s) {
-  const dim3 g(CO / Op::BN, G * Op::tiles_per_group(B), 1);
-  // column tiles of one pixel-row tile share the A operand: keep them on one XCD
-  if (g_conv_xcd && g.x > 1) return dz_launch_gemm_xcd<Op>(p, g, s);
-  return dz_launch_gemm<Op>(p, g, s);
+  return dz_launch_gemm<Op>(p, dim3(CO / Op::BN, G * Op::tiles_per_group(B), 1), s);
 }
 template <class Op>
 inline int launch_conv1_fwd(const ConvFwdParams& p, int G, int B, const NoiseParams* side,
@@ -38,10 +32,6 @@ inline int launch_conv1_fwd(const ConvFwdParams& p, int G, int B, const NoisePar
     return dz_launch_gemm_side<Op, NoiseSide>(p, g, *side, (unsigned)((side->n + 255) / 256), s);
   return dz_launch_gemm<Op>(p, g, s);
 }
-//                             U8  H   W   C  KS S  OH  OW  CO
-#define DZ_C1(...) ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, __VA_ARGS__>
-#define DZ_C2(...) ConvFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, __VA_ARGS__>
-#define DZ_C3(...) ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, __VA_ARGS__>
 
 // relu(conv3(relu(conv2(relu(conv1(u8/255)))))) for G groups; group g reads
 // images in[g] with parameters prm[g].  `side`: optional noise draw fused into
@@ -57,14 +47,7 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
       p.w[g] = prm[g] + T.conv_w[0]; p.bias[g] = prm[g] + T.conv_b[0];
     }
     p.out = T.act1; p.B = B; p.G = G;
-    switch (g_conv_fwd_variant[0]) {
-      default: rc = launch_conv1_fwd<Conv1Fwd>(p, G, B, side, s); break;
-      case 1: rc = launch_conv1_fwd<DZ_C1(2, 1, 2, 2)>(p, G, B, side, s); break;
-      case 2: rc = launch_conv1_fwd<DZ_C1(2, 1, 2, 4)>(p, G, B, side, s); break;
-      case 3: rc = launch_conv1_fwd<DZ_C1(4, 1, 1, 2)>(p, G, B, side, s); break;
-      case 4: rc = launch_conv1_fwd<DZ_C1(1, 1, 4, 2)>(p, G, B, side, s); break;
-      case 5: rc = launch_conv1_fwd<DZ_C1(2, 1, 2, 1)>(p, G, B, side, s); break;
-    }
+    rc = launch_conv1_fwd<Conv1Fwd>(p, G, B, side, s);
     if (rc) return rc;
     DZ_PROF(s, side ? "conv1_fwd+noise" : "conv1_fwd");
   }
@@ -75,14 +58,7 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
       p.w[g] = prm[g] + T.conv_w[1]; p.bias[g] = prm[g] + T.conv_b[1];
     }
     p.out = T.act2; p.B = B; p.G = G;
-    switch (g_conv_fwd_variant[1]) {
-      default: rc = launch_conv_fwd<Conv2Fwd>(p, 64, G, B, s); break;
-      case 1: rc = launch_conv_fwd<DZ_C2(1, 1, 4, 2)>(p, 64, G, B, s); break;
-      case 2: rc = launch_conv_fwd<DZ_C2(1, 1, 4, 4)>(p, 64, G, B, s); break;
-      case 3: rc = launch_conv_fwd<DZ_C2(2, 1, 2, 4)>(p, 64, G, B, s); break;
-      case 4: rc = launch_conv_fwd<DZ_C2(1, 2, 2, 2)>(p, 64, G, B, s); break;
-      case 5: rc = launch_conv_fwd<DZ_C2(1, 1, 4, 1)>(p, 64, G, B, s); break;
-    }
+    rc = launch_conv_fwd<Conv2Fwd>(p, 64, G, B, s);
     if (rc) return rc;
     DZ_PROF(s, "conv2_fwd");
   }
@@ -93,13 +69,7 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
       p.w[g] = prm[g] + T.conv_w[2]; p.bias[g] = prm[g] + T.conv_b[2];
     }
     p.out = T.feat; p.B = B; p.G = G;
-    switch (g_conv_fwd_variant[2]) {
-      default: rc = launch_conv_fwd<Conv3Fwd>(p, 64, G, B, s); break;
-      case 1: rc = launch_conv_fwd<DZ_C3(1, 1, 4, 3)>(p, 64, G, B, s); break;
-      case 2: rc = launch_conv_fwd<DZ_C3(1, 1, 4, 1)>(p, 64, G, B, s); break;
-      case 3: rc = launch_conv_fwd<DZ_C3(2, 1, 2, 3)>(p, 64, G, B, s); break;
-      case 4: rc = launch_conv_fwd<DZ_C3(1, 2, 2, 1)>(p, 64, G, B, s); break;
-    }
+    rc = launch_conv_fwd<Conv3Fwd>(p, 64, G, B, s);
     if (rc) return rc;
     DZ_PROF(s, "conv3_fwd");
   }

@@ -539,24 +539,19 @@ int dz_prof_read(int max_marks, float* ms_out, char* names_out);
  * Call after synchronising the stream.                                       */
 int dz_prof_read_replay(float* ms_out);
 
-/* Tuning knobs for tools/tune.py (kernel variant / split-K sweeps in one GPU
- * session).  key: 0 = fc1 forward variant (10 = shared weight stream [default],
- * else the tile GEMM), 1 = fc1 forward k-splits (<= 32), 2 = fc1 forward blocks
- * in XCD-aware order, 5 = fc1 backward launch form (3/2 = weight + input gradient
- * in one launch, wgrad / dgrad blocks first; 4 = same in XCD order; 1/0 = two
- * launches), 6 = fc1 input-gradient tile variant, 7 = its split factor (<= 32),
- * 8 = fc2 forward k-splits (<= 8), 9/10/11 = conv1/2/3 forward tile variant
- * (dz_torso.h), 12 = fc1 input gradient against W_eff (depth N) instead of the
- * two-GEMM form (depth 2N), 13 = IQN value-head GEMM tiling (dz_iqn.hip),
- * 14 = Adam launch width (blocks), 15 = conv forward tiles in XCD-aware order,
- * 16 = fc2 input-gradient k-splits (<= 5), 17 = fc2 forward against W_eff,
- * 18 = fc1 weight gradient recomputed inside the optimiser launch instead of
- * stored (0 = off [default], 1 = on: same time, 20 % less traffic), 19 = flat
- * Adam with branch-free software-pipelined loads (1 [default]) or the plain loop,
- * 20 = launch that carries the priority write-back block (1 = Adam [default],
- * 0 = conv3 backward).
- * Keys 3 and 4 are retired (accepted, ignored).  Defaults are the measured best. */
-int dz_set_tuning(int key, int value);
+/* STRUCTURAL LIMITS (each returns DZ_ERR_INVALID_ARG when exceeded):
+ *  - categorical heads (Rainbow, C51): num_atoms <= 64 (one wavefront lane per
+ *    atom in the loss kernel), num_actions <= 256; quantile heads: <= 256
+ *    quantiles per action, num_actions <= 256;
+ *  - the priority write-back carried inside a learner launch (`prio_*` fields of
+ *    dz_rainbow_args_t / dz_dense_args_t): batch <= 256 (one workgroup walks all
+ *    leaves); larger batches call dz_prioritized_update as its own launch;
+ *  - the one-launch sample entry points (dz_replay_sample_uniform,
+ *    dz_prioritized_sample_gather): batch <= 64 (the RNG draws travel in the
+ *    kernel arguments); larger batches use dz_prioritized_sample + dz_replay_gather;
+ *  - dz_rainbow_layout: batch <= 1024.
+ * There are no run-time tuning knobs: launch shapes are compile-time constants
+ * (csrc/dz_rainbow.hip, csrc/dz_qnet_kernels.h), chosen by measurement.       */
 
 /* dst = src for a parameter buffer (target network sync,
  * ref: rainbow/agent.py:157-158).                                           */

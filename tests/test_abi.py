@@ -109,25 +109,3 @@ def test_div255_identity():
   y2 = (r.astype(np.float64) * np.float64(rc) + y.astype(np.float64)).astype(np.float32)
   assert (y != true).any()          # the plain reciprocal multiply is NOT exact
   np.testing.assert_array_equal(y2, true)
-
-
-def test_tuning_keys_host_only(lib):
-  """dz_set_tuning is host-side state (no device call): unknown keys are refused,
-  range-checked keys reject out-of-range values, documented keys are accepted."""
-  assert lib.dz_set_tuning(99, 0) == _lib.DZ_ERR_INVALID_ARG
-  assert lib.dz_set_tuning(1, 0) == _lib.DZ_ERR_INVALID_ARG       # fc1 splits >= 1
-  assert lib.dz_set_tuning(1, 33) == _lib.DZ_ERR_INVALID_ARG      # <= 32
-  assert lib.dz_set_tuning(8, 9) == _lib.DZ_ERR_INVALID_ARG       # fc2 splits <= 8
-  for key, default in ((0, 10), (1, 32), (5, 3), (6, 2), (7, 16), (8, 8), (9, 1), (10, 1),
-                       (11, 1), (12, 1), (13, 5), (14, 2048), (15, 0), (16, 5), (17, 1), (18, 0), (19, 1), (20, 1)):
-    assert lib.dz_set_tuning(key, default) == _lib.DZ_OK, key
-
-
-def test_env_tuning_spec(lib):
-  """DZ_TUNING entries are applied through dz_set_tuning; bad ones raise."""
-  _lib.apply_env_tuning(lib, '')
-  _lib.apply_env_tuning(lib, '20=1, 19=1')
-  with pytest.raises(_lib.HipLibraryError):
-    _lib.apply_env_tuning(lib, '99=0')
-  with pytest.raises(_lib.HipLibraryError):
-    _lib.apply_env_tuning(lib, 'fast')

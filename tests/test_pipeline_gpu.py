@@ -1,6 +1,6 @@
-"""The multi-stream forms of the step (weight gradients on the auxiliary
-stream inside dz_rainbow_learn; replay write-back/sample prefetch on a side
-stream in bench.make_step_pipelined) must be BIT-IDENTICAL to the sequential
+"""The multi-stream form of the step (replay write-back/sample prefetch on a
+side stream in bench.make_step_pipelined) and the hipGraph form must be
+BIT-IDENTICAL to the sequential
 single-stream step: same sampled ids, same losses, same parameters."""
 
 import types
@@ -12,11 +12,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(pipelined, overlap, steps=12, graphs=False):
+def _run(pipelined, steps=12, graphs=False):
   import bench
-  from dqn_zoo_amd import _lib
-  lib = _lib.load()
-  lib.dz_set_tuning(4, int(overlap))
   args = types.SimpleNamespace(capacity=2048, batch=32)
   dev = torch.device('cuda', 0)
   replay, learner, _ = bench.build_workload(args, dev, seed=3)
@@ -32,7 +29,6 @@ def _run(pipelined, overlap, steps=12, graphs=False):
     torch.cuda.synchronize()
     losses.append(learner.losses.cpu().numpy().copy())
   replay.check_status()
-  lib.dz_set_tuning(4, 1)
   torch.cuda.synchronize()
   torch.cuda.set_stream(prev)
   return (np.stack(losses), learner.online.cpu().numpy(),
@@ -41,10 +37,9 @@ def _run(pipelined, overlap, steps=12, graphs=False):
 
 
 def test_overlapped_steps_are_bit_identical_to_sequential():
-  ref = _run(pipelined=False, overlap=False)
-  for pipelined, overlap, graphs in ((False, True, False), (True, True, False),
-                                     (False, False, True), (True, True, True)):
-    got = _run(pipelined, overlap, graphs=graphs)
+  ref = _run(pipelined=False)
+  for pipelined, graphs in ((True, False), (False, True), (True, True)):
+    got = _run(pipelined, graphs=graphs)
     np.testing.assert_array_equal(got[0], ref[0])
     np.testing.assert_array_equal(got[1], ref[1])
     # the pipelined loop has prefetched one extra sample but the tree only

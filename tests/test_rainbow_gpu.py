@@ -191,15 +191,12 @@ def test_full_step_vs_oracle_update():
     np.testing.assert_array_equal(t_dev[k], p_dev[k])
 
 
-@pytest.mark.parametrize('fused', [0, 1])
 @pytest.mark.parametrize('max_norm', [10.0, 1e-3])
-def test_derived_sigma_gradient_is_bit_identical(max_norm, fused):
-  """Default full step (fc1 weight gradients never stored: the optimiser launch
-  recomputes each tile and derives the sigma part from the noise) == step with
-  every gradient block materialised and the flat Adam kernel: parameters and both
-  Adam moments bit for bit.  fused = 1: the tile-recomputing optimiser launch
-  (dz_set_tuning key 18), off by default."""
-  _lib.load().dz_set_tuning(18, fused)
+def test_derived_sigma_gradient_is_bit_identical(max_norm):
+  """Default full step (the fc1 sigma-weight gradient is never stored: the
+  optimiser derives it from the mu-weight gradient and the noise) == step with
+  every gradient block materialised: parameters and both Adam moments bit for
+  bit."""
   A, B = 6, 32
   online, target, batch, w, noises = _problem(A, B, 13)
   dev = _dev_batch(batch, w)
@@ -211,7 +208,6 @@ def test_derived_sigma_gradient_is_bit_identical(max_norm, fused):
       ln.step(*dev, resample_noise=False)
     torch.cuda.synchronize()
     lns.append(ln)
-  _lib.load().dz_set_tuning(18, 0)
   a, b = lns
   assert torch.equal(a.online, b.online)
   assert torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)

@@ -3,7 +3,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   tag=$(echo $set | cut -d' ' -f1)
-  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pr_$tag -- python $R/tools/run_fwd.py 10 32 > $OUT/pr_$tag.log 2>&1 < /dev/null
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pr_$tag -- python $R/tools/run_fwd.py > $OUT/pr_$tag.log 2>&1 < /dev/null
   f=$(find $OUT/pr_$tag -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" <<'PY'
 import csv, sys

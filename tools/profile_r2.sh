@@ -3,15 +3,16 @@
 # two PMC passes (FETCH_SIZE, WRITE_SIZE; counters only, with --kernel-trace) on
 # the learner step.  Outputs under gpurun_out/ (copied into profiles/ by hand).
 ulimit -c 0
+TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-timeout 400 python $R/bench.py > $OUT/bench_final.json 2> $OUT/bench_final.err < /dev/null
+timeout 600 python $R/bench.py --steps 20 --warmup 5 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err < /dev/null
 echo "bench rc=$?"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py --steps 300 --warmup 50 --cpu-seconds 0 --prof-steps 0 --no-graphs > $OUT/kt.log 2>&1 < /dev/null
-f=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py --steps 300 --warmup 50 --cpu-seconds 0 --prof-steps 0 --other-configs 0 --no-graphs > $OUT/kt.log 2>&1 < /dev/null
+f=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${TAG}_kernel_stats.csv
 t=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
-if [ -n "$t" ]; then python - "$t" > $OUT/kernel_step_summary.txt <<'PY'
+if [ -n "$t" ]; then python - "$t" > $OUT/${TAG}_kernel_step_summary.txt <<'PY'
 import csv, sys
 from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -34,9 +35,9 @@ PY
 fi
 rm -rf $OUT/kt
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python $R/tools/run_fwd.py 10 32 > $OUT/pmc_$c.log 2>&1 < /dev/null
+  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python $R/tools/run_fwd.py > $OUT/pmc_$c.log 2>&1 < /dev/null
   f=$(find $OUT/pmc_$c -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then python - "$f" $c > $OUT/pmc_$c.csv <<'PY'
+  if [ -n "$f" ]; then python - "$f" $c > $OUT/${TAG}_pmc_$c.csv <<'PY'
 import csv, sys
 from collections import defaultdict
 d = defaultdict(list)
@@ -51,5 +52,6 @@ PY
   fi
   rm -rf $OUT/pmc_$c
 done
+bash $R/tools/pmc_rainbow.sh > $OUT/${TAG}_pmc_sq_rainbow.txt 2>&1
 ls -la $OUT | tail -12
-head -3 $OUT/kernel_step_summary.txt
+head -3 $OUT/${TAG}_kernel_step_summary.txt

@@ -18,11 +18,7 @@ dev = (torch.randint(0, 256, (B, 84, 84, 4), dtype=torch.uint8, device='cuda', g
        torch.rand(B, dtype=torch.float32, device='cuda', generator=g))
 ln.resample_noise()
 lib = _lib.load()
-var = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-spl = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-phases = int(sys.argv[3]) if len(sys.argv) > 3 else _lib.PHASE_ALL
-lib.dz_set_tuning(0, var)
-lib.dz_set_tuning(1, spl)
+phases = int(sys.argv[1]) if len(sys.argv) > 1 else _lib.PHASE_ALL
 for _ in range(12):
   ln.step(*dev, phases=phases, resample_noise=False)
 torch.cuda.synchronize()
