@@ -178,6 +178,9 @@ SIGNATURES = {
                                ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dz_rainbow_graph_capture': (c_int, [ctypes.POINTER(RainbowArgs), c_int, c_vp,
                                          ctypes.POINTER(c_vp)]),
+    'dz_atari_observation': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int,
+                                     c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int,
+                                     c_int, c_vp, c_vp]),
     'dz_graph_capture_begin': (c_int, [c_vp]),
     'dz_graph_capture_end': (c_int, [c_vp, c_int, ctypes.POINTER(c_vp)]),
     'dz_graph_launch': (c_int, [c_vp, c_vp]),

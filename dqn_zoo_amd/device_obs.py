@@ -33,6 +33,7 @@ class ObservationCache:
     self._dev = torch.empty((depth,) + tuple(shape), dtype=torch.uint8,
                             device=device)
     self._host = [None] * depth
+    self._ext = [None] * depth   # device tensors handed in as observations
     self._pos = 0
 
   def upload(self, observation) -> torch.Tensor:
@@ -41,6 +42,15 @@ class ObservationCache:
     selected action), which is what makes that safe."""
     k = self._pos % self._depth
     self._pos += 1
+    if isinstance(observation, torch.Tensor):
+      # already in HBM (processors.atari(device_observations=True)): no copy at
+      # all; remembered by identity so that the replay insert finds it too
+      if observation.dtype != torch.uint8 or not observation.is_cuda:
+        raise TypeError('device observations must be uint8 CUDA tensors')
+      self._host[k] = observation
+      self._ext[k] = observation.contiguous()
+      return self._ext[k][None]
+    self._ext[k] = None
     a = np.ascontiguousarray(observation, dtype=np.uint8)
     self._pin[k].copy_(torch.from_numpy(a))
     self._dev[k].copy_(self._pin[k], non_blocking=True)
@@ -50,7 +60,7 @@ class ObservationCache:
   def lookup(self, observation):
     for k in range(self._depth):
       if self._host[k] is observation:
-        return self._dev[k]
+        return self._dev[k] if self._ext[k] is None else self._ext[k]
     return None
 
   def on_device(self, transition):
@@ -63,3 +73,4 @@ class ObservationCache:
 
   def clear(self) -> None:
     self._host = [None] * self._depth
+    self._ext = [None] * self._depth

@@ -539,6 +539,31 @@ int dz_prof_read(int max_marks, float* ms_out, char* names_out);
  * Call after synchronising the stream.                                       */
 int dz_prof_read_replay(float* ms_out);
 
+/* ------------------------------------------------------------------------- *
+ *  Atari observation preprocessing (next row f4)
+ *  ref: dqn_zoo/processors.py:367-371 (rgb2y), 374-387 (resize: PIL BILINEAR),
+ *       486-505 (observation branch of atari(): pool, grayscale, resize, stack)
+ * ------------------------------------------------------------------------- */
+
+/* One preprocessed observation in ONE launch:
+ *   frame = resize(rgb2y(max(frames[0..n_frames))))  -> ring[slot]
+ *   obs[y][x][j] = j-th oldest of the `count` newest ring frames, zeros after
+ * frames[f]: device uint8 [height][width][channels] (host array of n_frames <= 4
+ *   device pointers; n_frames = 0 pools nothing: a black frame); channels 3 = RGB (grayscaled with the reference's float64
+ *   weights, un-fused, truncated) or 1 = already gray.
+ * xbounds/xcoeffs, ybounds/ycoeffs: Pillow's 8-bit resample tables for each axis,
+ *   device int32 [out][2] = (first input index, taps) and [out][ksize] 22-bit
+ *   fixed-point weights (ksize <= 64); the horizontal pass runs first with a
+ *   uint8 intermediate, exactly as PIL.Image.resize does.
+ * ring: device uint8 [stack][out_h][out_w] frame stack (stack <= 8); the new
+ *   frame is written to `slot`, `count` = frames held including it.
+ * obs: device uint8 [out_h][out_w][stack] (np.stack(..., axis=-1) order).     */
+int dz_atari_observation(const uint8_t* const* frames, int n_frames, int height, int width,
+                         int channels, const int32_t* xbounds, const int32_t* xcoeffs,
+                         int xksize, const int32_t* ybounds, const int32_t* ycoeffs,
+                         int yksize, int out_h, int out_w, uint8_t* ring, int stack,
+                         int slot, int count, uint8_t* obs, dz_stream_t stream);
+
 /* STRUCTURAL LIMITS (each returns DZ_ERR_INVALID_ARG when exceeded):
  *  - categorical heads (Rainbow, C51): num_atoms <= 64 (one wavefront lane per
  *    atom in the loss kernel), num_actions <= 256; quantile heads: <= 256
