@@ -7,9 +7,9 @@
 // flight per workgroup and measured 1.2 TB/s.  Here every wave streams its slice
 // of W from HBM straight into MFMA operand registers: lane l loads the single
 // float W[k + (l>>5)][n0 + (l&31)], which IS its B operand of
-// v_mfma_f32_32x32x2_f32, ALL of the wave's loads are issued up front (50 k-pairs
-// = 100 VGPRs when noisy) and the MFMAs drain them in order behind counted vmcnt
-// waits -- no LDS for weights, no barrier in the loop.  The A operand (x) is
+// v_mfma_f32_32x32x2_f32; the loads run as a software pipeline of small chunks
+// (3 x 5 k-pairs in flight per wave) that the MFMAs drain in order behind counted
+// vmcnt waits -- no LDS for weights, no barrier in the loop.  The A operand (x) is
 // staged once per workgroup in LDS, k-major, so the per-MFMA ds_read_b32 is
 // conflict-free.  (Measured alternatives, removed: 16-byte loads feeding 4
 // column-interleaved accumulators, 26 -> 31 us; per-apply streams at depth 2K,
@@ -73,10 +73,25 @@ static inline int dz_fc3_assign_sets(FcStreamFwd3Params& q, int G, const float* 
   return ns;
 }
 
-// NL = k-pairs per lane (x2 dword loads when noisy): 50 with 32 k-splits, 100 with 16.
-template <int NOISY, int NL>
+// NL = k-pairs per lane; CH = k-pairs per pipeline chunk; DEPTH chunks in flight.
+//
+// Software pipeline (round 2; measured with tools/micro/fc1_micro.hip, 51 MB of
+// weights, back to back):  all 100 loads of a wave issued up front 18.2 us;
+// chunks of 5 k-pairs with 3 chunks in flight and the LDS operands of a chunk
+// fetched one chunk ahead 14.6 us, bit-identical slabs (the bare load stream takes
+// 8.6 us, the 12.6 MB of slab stores 2.3 us).  Two things were wrong with the
+// up-front form:
+//   * a CU's memory pipeline serves its waves' load instructions in issue order, so
+//     with 100 loads queued per wave the data arrives wave by wave and the last wave
+//     starts its 100-150 MFMA chain when the stream ends; with 20-30 loads in
+//     flight per wave all waves advance together (60 in flight: 16.2 us, 20: 14.5);
+//   * x and eps_in were read from LDS right in front of each MFMA: an
+//     `s_waitcnt lgkmcnt(0)` (~100 cycles) before every one of the 64-cycle MFMAs.
+template <int NOISY, int NL, int CH = 5, int DEPTH = 3>
 __global__ __launch_bounds__(256) void dz_fc_stream_fwd3(FcStreamFwd3Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds3[];
+  constexpr int NCH = NL / CH;
+  static_assert(NL % CH == 0 && NCH >= DEPTH, "chunking");
   const int R = p.rows_per_split;
   float* xs = lds3;                  // [2][R][32]  x (batch-row minor)
   float* es = lds3 + 2 * R * 32;     // [2][R]      eps_in
@@ -107,12 +122,9 @@ __global__ __launch_bounds__(256) void dz_fc_stream_fwd3(FcStreamFwd3Params p) {
   const int nrows = max(min(K, r0 + R) - r0, 0);
   const int ncol = n0 + l31;
 
-  // Issue order matters: vector loads return in order, so whatever is issued last
-  // gates everything before it.  (1) the small operands first -- x, eps_in, eps_out;
-  // (2) then every weight load of the wave; (3) the LDS staging waits only for (1)
-  // (vmcnt = the weight loads still in flight) and the MFMA chain then consumes the
-  // weights as they arrive.  With the weights issued first, x arrived last and the
-  // first MFMA waited for the whole stream (vmcnt(0) in front of 150 MFMAs).
+  // Issue order matters: vector loads return in order.  (1) the small operands
+  // first -- x, eps_in, eps_out; (2) the first DEPTH weight chunks; (3) the LDS
+  // staging waits only for (1) and runs while (2) is in flight.
   const float eo0 = NOISY ? nz0[hd.eps_out + ncol] : 0.f;
   const float eo1 = NOISY ? nz1[hd.eps_out + ncol] : 0.f;
   const int mm = threadIdx.x & 31, q0 = threadIdx.x >> 5;
@@ -133,16 +145,22 @@ __global__ __launch_bounds__(256) void dz_fc_stream_fwd3(FcStreamFwd3Params p) {
       e0 = nz0[hd.eps_in + k]; e1 = nz1[hd.eps_in + k];
     }
   }
-
   __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks (1) below (2)
-  float wm[NL], wg[NOISY ? NL : 1];
+  float wm[DEPTH][CH], wg[DEPTH][NOISY ? CH : 1];
+  const float* wmu = prm + hd.w_mu + ncol;
+  const float* wsg = prm + hd.w_sig + ncol;
+  // chunk c: lane l holds W[r0 + 2u + (l>>5)][n0 + (l&31)] for its CH k-pairs u,
+  // which IS its B operand of v_mfma_f32_32x32x2_f32
+  auto issue = [&](int c, float (&m)[CH], float (&g)[NOISY ? CH : 1]) {
 #pragma unroll
-  for (int u = 0; u < NL; ++u) {
-    const int k = min(r0 + 2 * u + half, K - 1);
-    const long off = (long)k * hd.ldw + ncol;
-    wm[u] = prm[hd.w_mu + off];
-    if (NOISY) wg[u] = prm[hd.w_sig + off];
-  }
+    for (int j = 0; j < CH; ++j) {
+      const int k = min(r0 + 2 * (c * CH + j) + half, K - 1);
+      m[j] = wmu[(long)k * hd.ldw];
+      if (NOISY) g[j] = wsg[(long)k * hd.ldw];
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < DEPTH; ++c) issue(c, wm[c], wg[c]);
   __builtin_amdgcn_sched_barrier(0);
 
   // stage x[g][k] (k-major, 32 batch rows minor) and eps_in[g][k]
@@ -165,40 +183,68 @@ __global__ __launch_bounds__(256) void dz_fc_stream_fwd3(FcStreamFwd3Params p) {
   f32x16 acc0, acc1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-  if (ng > 1) {
+  // the LDS operands of a chunk: x of both applies, and the per-element noise factor
+  // eps_in[k] * eps_out[n] of W_eff = Wmu + Wsig * (eps_in (x) eps_out)
+  struct Ops { float a0[CH], a1[CH], f0[CH], f1[CH]; };
+  auto fetch = [&](int c, Ops& o, bool two) {
 #pragma unroll
-    for (int u = 0; u < NL; ++u) {
-      const int rl = 2 * u + half;
+    for (int j = 0; j < CH; ++j) {
+      const int rl = 2 * (c * CH + j) + half;
       const int rc = min(rl, R - 1);
       const bool live = rl < nrows;
-      const float a0 = live ? xs[rc * 32 + l31] : 0.f;
-      const float a1 = live ? xs[(R + rc) * 32 + l31] : 0.f;
-      float w0 = wm[u], w1 = wm[u];
-      if (NOISY) {
-        w0 = __builtin_fmaf(wg[u], es[rc] * eo0, wm[u]);
-        w1 = __builtin_fmaf(wg[u], es[R + rc] * eo1, wm[u]);
+      o.a0[j] = live ? xs[rc * 32 + l31] : 0.f;
+      o.f0[j] = NOISY ? es[rc] * eo0 : 0.f;
+      if (two) {
+        o.a1[j] = live ? xs[(R + rc) * 32 + l31] : 0.f;
+        o.f1[j] = NOISY ? es[R + rc] * eo1 : 0.f;
       }
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w1, acc1, 0, 0, 0);
+    }
+  };
+  Ops ops[2];
+  if (ng > 1) {
+    fetch(0, ops[0], true);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float (&m)[CH] = wm[c % DEPTH];
+      float (&g)[NOISY ? CH : 1] = wg[c % DEPTH];
+      if (c + 1 < NCH) fetch(c + 1, ops[(c + 1) & 1], true);
+      const Ops& o = ops[c & 1];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const float w0 = NOISY ? __builtin_fmaf(g[j], o.f0[j], m[j]) : m[j];
+        const float w1 = NOISY ? __builtin_fmaf(g[j], o.f1[j], m[j]) : m[j];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a0[j], w0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1[j], w1, acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + DEPTH < NCH) issue(c + DEPTH, m, g);  // refill the registers just consumed
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else {
+    fetch(0, ops[0], false);
 #pragma unroll
-    for (int u = 0; u < NL; ++u) {
-      const int rl = 2 * u + half;
-      const int rc = min(rl, R - 1);
-      const float a0 = rl < nrows ? xs[rc * 32 + l31] : 0.f;
-      float w0 = wm[u];
-      if (NOISY) w0 = __builtin_fmaf(wg[u], es[rc] * eo0, wm[u]);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w0, acc0, 0, 0, 0);
+    for (int c = 0; c < NCH; ++c) {
+      float (&m)[CH] = wm[c % DEPTH];
+      float (&g)[NOISY ? CH : 1] = wg[c % DEPTH];
+      if (c + 1 < NCH) fetch(c + 1, ops[(c + 1) & 1], false);
+      const Ops& o = ops[c & 1];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const float w0 = NOISY ? __builtin_fmaf(g[j], o.f0[j], m[j]) : m[j];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a0[j], w0, acc0, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + DEPTH < NCH) issue(c + DEPTH, m, g);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   float* base = p.part + (long)split * p.G * p.M * p.ldo + hd.out_off + ncol;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int mm = dz_acc_row(r, lane);
-    if (mm < p.M) {
-      base[(long)(g0 * p.M + mm) * p.ldo] = acc0[r];
-      if (ng > 1) base[(long)(g1 * p.M + mm) * p.ldo] = acc1[r];
+    const int mrow = dz_acc_row(r, lane);
+    if (mrow < p.M) {
+      base[(long)(g0 * p.M + mrow) * p.ldo] = acc0[r];
+      if (ng > 1) base[(long)(g1 * p.M + mrow) * p.ldo] = acc1[r];
     }
   }
 }

@@ -90,7 +90,12 @@ template <class Op> struct DzRaw16<Op, decltype((void)Op::A_RAW16)> { static con
 template <int ROWS, int CPS, int LAYOUT>
 struct DzLdsTile {
   static constexpr int LD = (LAYOUT == DZ_KC) ? 20 : ROWS;
-  static constexpr int CHUNK = (LAYOUT == DZ_KC) ? ROWS * 20 : 16 * ROWS;
+  // KC chunk pitch: ROWS*20 floats is a multiple of 64 banks for ROWS = 64, 128, so
+  // the ROW16 loader's 4 lanes that write the same row of 4 different chunks all hit
+  // one bank (conv1 forward: 921 600 conflict cycles per launch); 16 floats of
+  // skew put the chunks of a row 16 banks apart
+  static constexpr int CHUNK = (LAYOUT == DZ_KC)
+      ? ROWS * 20 + (((ROWS * 20) % 64 == 0 && CPS > 1) ? 16 : 0) : 16 * ROWS;
   static constexpr int ELEMS = CPS * CHUNK;
   // number of float4 "load slots" per stage and per thread
   static constexpr int SLOTS = ROWS * 16 * CPS / 4;

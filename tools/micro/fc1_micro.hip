@@ -1,0 +1,391 @@
+// Where do the 18.7 us of dz_fc_stream_fwd3 go?  The shipped kernel with pieces
+// switched off by a template mask (tools only).
+//   bit0: skip the partial-slab stores      bit1: skip the MFMAs (consume weights with adds)
+//   bit2: skip x staging/LDS (A operand = constant)
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include "dz_qnet_kernels.h"
+int g_dz_last_hip_error = 0;
+bool g_dz_prof_on = false;
+void dz_prof_begin(hipStream_t) {}
+void dz_prof_pair(int, int, hipStream_t) {}
+void dz_prof_mark(hipStream_t, const char*) {}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %d line %d\n", (int)e, __LINE__); exit(1); } } while (0)
+
+template <int NOISY, int NL, int MASK>
+__global__ __launch_bounds__(256) void fwd3_var(FcStreamFwd3Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds3[];
+  const int R = p.rows_per_split;
+  float* xs = lds3;
+  float* es = lds3 + 2 * R * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_order) {
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned j = L >> 3, yz = (j / gridDim.x) * 8 + (L & 7);
+    bx = j % gridDim.x; by = yz % gridDim.y; bz = yz / gridDim.y;
+  }
+  const int strips0 = p.head[0].N / 128;
+  const int h_idx = (int)bx >= strips0 ? 1 : 0;
+  const FcHead hd = dz_pick_head(p.head, h_idx);
+  const int n0 = ((int)bx - (h_idx ? strips0 : 0)) * 128 + 32 * wave;
+  const int split = (int)by, set = (int)bz;
+  const float* __restrict__ prm = set ? p.params[1] : p.params[0];
+  const int ng = set ? p.ng[1] : p.ng[0];
+  const int g0 = set ? p.grp[1][0] : p.grp[0][0];
+  const int g1 = set ? p.grp[1][1] : p.grp[0][1];
+  const float* __restrict__ nz0 = dz_pick3(p.noise, g0);
+  const float* __restrict__ nz1 = dz_pick3(p.noise, g1);
+  const int K = hd.K;
+  const int r0 = split * R;
+  const int nrows = max(min(K, r0 + R) - r0, 0);
+  const int ncol = n0 + l31;
+  const float eo0 = NOISY ? nz0[hd.eps_out + ncol] : 0.f;
+  const float eo1 = NOISY ? nz1[hd.eps_out + ncol] : 0.f;
+  const int mm = threadIdx.x & 31, q0 = threadIdx.x >> 5;
+  constexpr int NP = (2 * NL / 4 + 7) / 8;
+  float4 v[2][NP];
+  float e0 = 0.f, e1 = 0.f;
+  const float ok = mm < p.M ? 1.f : 0.f;
+  if (!(MASK & 4)) {
+    const int mc = min(mm, p.M - 1);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int k = min(r0 + 4 * (q0 + 8 * j), K - 4);
+      v[0][j] = dz_ld4(p.x + (long)(g0 * p.M + mc) * p.ldx + hd.x_off + k);
+      v[1][j] = dz_ld4(p.x + (long)(g1 * p.M + mc) * p.ldx + hd.x_off + k);
+    }
+    if (NOISY) {
+      const int k = min(r0 + (int)threadIdx.x, K - 1);
+      e0 = nz0[hd.eps_in + k]; e1 = nz1[hd.eps_in + k];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float wm[NL], wg[NOISY ? NL : 1];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int k = min(r0 + 2 * u + half, K - 1);
+    const long off = (long)k * hd.ldw + ncol;
+    wm[u] = prm[hd.w_mu + off];
+    if (NOISY) wg[u] = prm[hd.w_sig + off];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (!(MASK & 4)) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int q = q0 + 8 * j;
+      if (4 * q < nrows) {
+        float* d0 = xs + (4 * q) * 32 + mm;
+        const float4 a = dz_scale4(v[0][j], ok), b = dz_scale4(v[1][j], ok);
+        d0[0] = a.x; d0[32] = a.y; d0[64] = a.z; d0[96] = a.w;
+        float* d1 = d0 + R * 32;
+        d1[0] = b.x; d1[32] = b.y; d1[64] = b.z; d1[96] = b.w;
+      }
+    }
+    if (NOISY && (int)threadIdx.x < R) { es[threadIdx.x] = e0; es[R + threadIdx.x] = e1; }
+    __syncthreads();
+  }
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  if (ng > 1) {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int rl = 2 * u + half;
+      const int rc = min(rl, R - 1);
+      const bool live = rl < nrows;
+      float a0 = 1.f, a1 = 1.f, ei0 = 1.f, ei1 = 1.f;
+      if (!(MASK & 4)) {
+        a0 = live ? xs[rc * 32 + l31] : 0.f; a1 = live ? xs[(R + rc) * 32 + l31] : 0.f;
+        ei0 = es[rc]; ei1 = es[R + rc];
+      }
+      float w0 = wm[u], w1 = wm[u];
+      if (NOISY) { w0 = __builtin_fmaf(wg[u], ei0 * eo0, wm[u]); w1 = __builtin_fmaf(wg[u], ei1 * eo1, wm[u]); }
+      if (MASK & 2) { acc0[u & 15] += a0 * w0; acc1[u & 15] += a1 * w1; }
+      else {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w1, acc1, 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int rl = 2 * u + half;
+      const int rc = min(rl, R - 1);
+      float a0 = 1.f, ei0 = 1.f;
+      if (!(MASK & 4)) { a0 = rl < nrows ? xs[rc * 32 + l31] : 0.f; ei0 = es[rc]; }
+      float w0 = wm[u];
+      if (NOISY) w0 = __builtin_fmaf(wg[u], ei0 * eo0, wm[u]);
+      if (MASK & 2) acc0[u & 15] += a0 * w0;
+      else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w0, acc0, 0, 0, 0);
+    }
+  }
+  float* base = p.part + (long)split * p.G * p.M * p.ldo + hd.out_off + ncol;
+  if (MASK & 1) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+    if (s == 123.456f) base[0] = s;
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mrow = dz_acc_row(r, lane);
+    if (mrow < p.M) {
+      base[(long)(g0 * p.M + mrow) * p.ldo] = acc0[r];
+      if (ng > 1) base[(long)(g1 * p.M + mrow) * p.ldo] = acc1[r];
+    }
+  }
+}
+
+
+// ---- chunked software pipeline: CH k-pairs per chunk, 3 chunks in flight ----
+template <int NOISY, int NL, int CH, int DEPTH = 3, int NOSTORE = 0>
+__global__ __launch_bounds__(256) void fwd3_pipe(FcStreamFwd3Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds3[];
+  constexpr int NCH = NL / CH;
+  static_assert(NL % CH == 0 && NCH >= DEPTH, "chunks");
+  const int R = p.rows_per_split;
+  float* xs = lds3;
+  float* es = lds3 + 2 * R * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_order) {
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned j = L >> 3, yz = (j / gridDim.x) * 8 + (L & 7);
+    bx = j % gridDim.x; by = yz % gridDim.y; bz = yz / gridDim.y;
+  }
+  const int strips0 = p.head[0].N / 128;
+  const int h_idx = (int)bx >= strips0 ? 1 : 0;
+  const FcHead hd = dz_pick_head(p.head, h_idx);
+  const int n0 = ((int)bx - (h_idx ? strips0 : 0)) * 128 + 32 * wave;
+  const int split = (int)by, set = (int)bz;
+  const float* __restrict__ prm = set ? p.params[1] : p.params[0];
+  const int ng = set ? p.ng[1] : p.ng[0];
+  const int g0 = set ? p.grp[1][0] : p.grp[0][0];
+  const int g1 = set ? p.grp[1][1] : p.grp[0][1];
+  const float* __restrict__ nz0 = dz_pick3(p.noise, g0);
+  const float* __restrict__ nz1 = dz_pick3(p.noise, g1);
+  const int K = hd.K;
+  const int r0 = split * R;
+  const int nrows = max(min(K, r0 + R) - r0, 0);
+  const int ncol = n0 + l31;
+  const float eo0 = NOISY ? nz0[hd.eps_out + ncol] : 0.f;
+  const float eo1 = NOISY ? nz1[hd.eps_out + ncol] : 0.f;
+  const int mm = threadIdx.x & 31, q0 = threadIdx.x >> 5;
+  constexpr int NP = (2 * NL / 4 + 7) / 8;
+  float4 v[2][NP];
+  float e0 = 0.f, e1 = 0.f;
+  const float ok = mm < p.M ? 1.f : 0.f;
+  {
+    const int mc = min(mm, p.M - 1);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int k = min(r0 + 4 * (q0 + 8 * j), K - 4);
+      v[0][j] = dz_ld4(p.x + (long)(g0 * p.M + mc) * p.ldx + hd.x_off + k);
+      v[1][j] = dz_ld4(p.x + (long)(g1 * p.M + mc) * p.ldx + hd.x_off + k);
+    }
+    if (NOISY) {
+      const int k = min(r0 + (int)threadIdx.x, K - 1);
+      e0 = nz0[hd.eps_in + k]; e1 = nz1[hd.eps_in + k];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float wm[DEPTH][CH], wg[DEPTH][NOISY ? CH : 1];
+  const float* wmu = prm + hd.w_mu + ncol;
+  const float* wsg = prm + hd.w_sig + ncol;
+  auto issue = [&](int c, float (&m)[CH], float (&g)[NOISY ? CH : 1]) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int k = min(r0 + 2 * (c * CH + j) + half, K - 1);
+      m[j] = wmu[(long)k * hd.ldw];
+      if (NOISY) g[j] = wsg[(long)k * hd.ldw];
+    }
+  };
+  #pragma unroll
+  for (int c = 0; c < DEPTH; ++c) issue(c, wm[c], wg[c]);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int q = q0 + 8 * j;
+      if (4 * q < nrows) {
+        float* d0 = xs + (4 * q) * 32 + mm;
+        const float4 a = dz_scale4(v[0][j], ok), b = dz_scale4(v[1][j], ok);
+        d0[0] = a.x; d0[32] = a.y; d0[64] = a.z; d0[96] = a.w;
+        float* d1 = d0 + R * 32;
+        d1[0] = b.x; d1[32] = b.y; d1[64] = b.z; d1[96] = b.w;
+      }
+    }
+    if (NOISY && (int)threadIdx.x < R) { es[threadIdx.x] = e0; es[R + threadIdx.x] = e1; }
+  }
+  __syncthreads();
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  // LDS operands of a chunk (x of both applies, eps_in of both) are read one chunk
+  // AHEAD into registers: read right before each MFMA, every MFMA waits ~100 cycles
+  // for its ds_read (lgkmcnt(0) in front of all 100-150 MFMAs of the chain)
+  struct Ops { float a0[CH], a1[CH], e0[CH], e1[CH]; };
+  auto fetch = [&](int c, Ops& o, bool two) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int rl = 2 * (c * CH + j) + half;
+      const int rc = min(rl, R - 1);
+      const float keep = rl < nrows ? 1.f : 0.f;
+      o.a0[j] = xs[rc * 32 + l31] * keep;
+      o.e0[j] = NOISY ? es[rc] * eo0 : 0.f;
+      if (two) { o.a1[j] = xs[(R + rc) * 32 + l31] * keep; o.e1[j] = NOISY ? es[R + rc] * eo1 : 0.f; }
+    }
+  };
+  Ops ops[2];
+  if (ng > 1) {
+    fetch(0, ops[0], true);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float (&m)[CH] = wm[c % DEPTH];
+      float (&g)[NOISY ? CH : 1] = wg[c % DEPTH];
+      if (c + 1 < NCH) fetch(c + 1, ops[(c + 1) & 1], true);
+      const Ops& o = ops[c & 1];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const float w0 = NOISY ? __builtin_fmaf(g[j], o.e0[j], m[j]) : m[j];
+        const float w1 = NOISY ? __builtin_fmaf(g[j], o.e1[j], m[j]) : m[j];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a0[j], w0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1[j], w1, acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + DEPTH < NCH) issue(c + DEPTH, m, g);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    fetch(0, ops[0], false);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float (&m)[CH] = wm[c % DEPTH];
+      float (&g)[NOISY ? CH : 1] = wg[c % DEPTH];
+      if (c + 1 < NCH) fetch(c + 1, ops[(c + 1) & 1], false);
+      const Ops& o = ops[c & 1];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const float w0 = NOISY ? __builtin_fmaf(g[j], o.e0[j], m[j]) : m[j];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a0[j], w0, acc0, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + DEPTH < NCH) issue(c + DEPTH, m, g);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float* base = p.part + (long)split * p.G * p.M * p.ldo + hd.out_off + ncol;
+  if (NOSTORE) {
+    float sm = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sm += acc0[r] + acc1[r];
+    if (sm == 123.456f) base[0] = sm;
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mrow = dz_acc_row(r, lane);
+    if (mrow < p.M) {
+      base[(long)(g0 * p.M + mrow) * p.ldo] = acc0[r];
+      if (ng > 1) base[(long)(g1 * p.M + mrow) * p.ldo] = acc1[r];
+    }
+  }
+}
+
+template <class F> float time_us(F f, int iters = 200) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 20; ++i) f();
+  CK(hipDeviceSynchronize()); CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) f();
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms * 1e3f / iters;
+}
+
+int main() {
+  const int B = 32, G = 3, ld = 1056;
+  const long mat = (long)kFlat * ld;
+  const long pcount = 2 * mat + 8192;
+  float *prm_on, *prm_tg, *x, *nz, *part;
+  CK(hipMalloc(&prm_on, pcount * 4)); CK(hipMalloc(&prm_tg, pcount * 4));
+  CK(hipMalloc(&x, (long)G * B * kFlat * 4)); CK(hipMalloc(&nz, 3 * 16384 * 4));
+  CK(hipMalloc(&part, (long)32 * G * B * 1024 * 4));
+  CK(hipMemset(prm_on, 0, pcount * 4)); CK(hipMemset(prm_tg, 0, pcount * 4));
+  CK(hipMemset(x, 0, (long)G * B * kFlat * 4)); CK(hipMemset(nz, 0, 3 * 16384 * 4));
+  FcStreamFwd3Params q;
+  q.x = x; q.ldx = kFlat; q.M = B; q.noisy = 1; q.G = G;
+  const float* prm[3] = {prm_on, prm_on, prm_tg};
+  const float* nzp[3] = {nz, nz + 16384, nz + 32768};
+  const int ns = dz_fc3_assign_sets(q, G, prm, nzp);
+  FcHead h[2];
+  for (int i = 0; i < 2; ++i) {
+    h[i].w_mu = 512 * i; h[i].w_sig = mat + 512 * i; h[i].ldw = ld; h[i].N = 512; h[i].K = kFlat;
+    h[i].x_off = 0; h[i].eps_in = i ? kFlat : 0; h[i].eps_out = 2 * kFlat + 512 * i; h[i].out_off = 512 * i;
+  }
+  q.head[0] = h[0]; q.head[1] = h[1];
+  q.part = part; q.ldo = 1024;
+  q.rows_per_split = ((kFlat + 31) / 32 + 3) & ~3;
+  q.xcd_order = 1;
+  const size_t lds = (size_t)q.rows_per_split * 66 * sizeof(float);
+  printf("sets %d rows/split %d lds %zu\n", ns, q.rows_per_split, lds);
+#define RUN(MASK, label) { auto f = [&]() { hipLaunchKernelGGL((fwd3_var<1, 50, MASK>), dim3(8, 32, ns), dim3(256), lds, 0, q); }; \
+    printf("%-44s %.2f us\n", label, time_us(f)); }
+  { auto f = [&]() { hipLaunchKernelGGL((dz_fc_stream_fwd3<1, 50>), dim3(8, 32, ns), dim3(256), lds, 0, q); };
+    printf("%-44s %.2f us\n", "shipped kernel", time_us(f)); }
+  RUN(0, "copy of shipped kernel (mask 0)");
+  RUN(1, "no slab stores");
+  RUN(2, "no MFMA (VALU consume)");
+  RUN(3, "no stores, no MFMA");
+  RUN(4, "no x staging / LDS");
+  RUN(5, "no stores, no x staging");
+  RUN(7, "loads only");
+#define RUNP(CH, D, label) { auto f = [&]() { hipLaunchKernelGGL((fwd3_pipe<1, 50, CH, D>), dim3(8, 32, ns), dim3(256), lds, 0, q); }; \
+    printf("%-44s %.2f us\n", label, time_us(f)); }
+  RUNP(10, 3, "pipelined CH10 D3 (60 loads in flight)");
+  RUNP(5, 3, "pipelined CH5 D3 (30 in flight)");
+  RUNP(5, 4, "pipelined CH5 D4 (40 in flight)");
+  RUNP(5, 6, "pipelined CH5 D6 (60 in flight)");
+  RUNP(2, 5, "pipelined CH2 D5 (20 in flight)");
+  RUNP(2, 10, "pipelined CH2 D10 (40 in flight)");
+  RUNP(2, 15, "pipelined CH2 D15 (60 in flight)");
+  { auto f = [&]() { hipLaunchKernelGGL((fwd3_pipe<1, 50, 5, 3, 1>), dim3(8, 32, ns), dim3(256), lds, 0, q); };
+    printf("%-44s %.2f us\n", "pipelined CH5 D3, no stores", time_us(f)); }
+  { auto f = [&]() { hipLaunchKernelGGL((fwd3_pipe<1, 50, 2, 5, 1>), dim3(8, 32, ns), dim3(256), lds, 0, q); };
+    printf("%-44s %.2f us\n", "pipelined CH2 D5, no stores", time_us(f)); }
+  {  // S = 16: 100 k-pairs per wave, 256 workgroups
+    FcStreamFwd3Params q2 = q; q2.rows_per_split = 196; q2.xcd_order = 1;
+    const size_t lds2 = (size_t)q2.rows_per_split * 66 * sizeof(float);
+    CK(hipFuncSetAttribute((const void*)fwd3_pipe<1, 100, 5, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    auto f = [&]() { hipLaunchKernelGGL((fwd3_pipe<1, 100, 5, 3, 0>), dim3(8, 16, ns), dim3(256), lds2, 0, q2); };
+    printf("%-44s %.2f us\n", "pipelined CH5 D3, 16 splits (1 wave/SIMD)", time_us(f)); }
+  // correctness: shipped vs pipelined partial slabs (random data)
+  {
+    std::vector<float> hw(pcount), hx((size_t)G * B * kFlat), hn(3 * 16384);
+    srand(3);
+    for (auto& v : hw) v = ((rand() % 2001) - 1000) / 30000.f;
+    for (auto& v : hx) v = (rand() % 1000) / 1000.f;
+    for (auto& v : hn) v = ((rand() % 2001) - 1000) / 1000.f;
+    CK(hipMemcpy(prm_on, hw.data(), pcount * 4, hipMemcpyHostToDevice));
+    for (auto& v : hw) v = ((rand() % 2001) - 1000) / 30000.f;
+    CK(hipMemcpy(prm_tg, hw.data(), pcount * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(nz, hn.data(), hn.size() * 4, hipMemcpyHostToDevice));
+    const size_t n = (size_t)32 * G * B * 1024;
+    std::vector<float> a(n), b(n);
+    CK(hipMemset(part, 0, n * 4));
+    hipLaunchKernelGGL((dz_fc_stream_fwd3<1, 50>), dim3(8, 32, ns), dim3(256), lds, 0, q);
+    CK(hipMemcpy(a.data(), part, n * 4, hipMemcpyDeviceToHost));
+    CK(hipMemset(part, 0, n * 4));
+    hipLaunchKernelGGL((fwd3_pipe<1, 50, 5, 4>), dim3(8, 32, ns), dim3(256), lds, 0, q);
+    CK(hipMemcpy(b.data(), part, n * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0; double mx = 0;
+    for (size_t i = 0; i < n; ++i) { bad += a[i] != b[i]; mx = fmax(mx, fabs(a[i])); }
+    printf("pipelined vs shipped: %zu of %zu slab values differ (max |v| %.3g)\n", bad, n, mx);
+  }
+  return 0;
+}
