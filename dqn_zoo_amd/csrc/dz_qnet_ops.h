@@ -213,6 +213,33 @@ __device__ __forceinline__ FcHead dz_pick_head(const FcHead* hd, int h) {
   return r;
 }
 
+// An upstream split-K input gradient consumed WITHOUT its reduction launch: the
+// layer's dY operand is read as the sum of S partial slabs times the ReLU mask of
+// the activation it flows through,
+//     dY[m][c] = (act[m][c] > 0) * (part[0][m][c] + part[1][m][c] + ...)   (in that order)
+// by the loaders of BOTH contractions that consume it (weight gradient and input
+// gradient: same order, same bits).  S is a template parameter of the consuming
+// Ops: a run-time switch in a loader splits it into basic blocks that each wait
+// for their own loads.  Saves a ~4.7 us launch per layer (reduce_parts_kernel).
+struct DyParts {
+  const float* part = nullptr;  // [S][M][ld]
+  long stride = 0;              // floats between slabs
+  const float* mask = nullptr;  // [M][ld] post-ReLU activation
+  float* out = nullptr;         // optional [M][ld]: one consumer materialises dY (bias sums)
+};
+template <int S>
+__device__ __forceinline__ float4 dz_dy_parts4(const DyParts& q, long o) {
+  float4 v = dz_ld4(q.part + o);
+  const float4 mk = dz_ld4(q.mask + o);
+  float4 r[S > 1 ? S - 1 : 1];
+#pragma unroll
+  for (int i = 1; i < S; ++i) r[i - 1] = dz_ld4(q.part + i * q.stride + o);
+#pragma unroll
+  for (int i = 1; i < S; ++i) { v.x += r[i - 1].x; v.y += r[i - 1].y; v.z += r[i - 1].z; v.w += r[i - 1].w; }
+  return dz_f4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f,
+               mk.w > 0.f ? v.w : 0.f);
+}
+
 struct FcFwdParams {
   const float* x;  // [G*M][ldx]
   int ldx;
@@ -332,9 +359,11 @@ struct FcDgradParams {
   // S == 1 only: ReLU mask of the layer input fused into the store
   // (out = mask[m][col] > 0 ? acc : 0), saving the separate masking pass
   const float* relu_mask = nullptr;
+  DyParts dyp;      // DYS_ > 0: dY = masked sum of dyp's slabs instead of `dy`
 };
 
-template <int WM_, int WN_, int WK_, int KT_ = 1, int MI_ = 1, int NI_ = 1, int NZ_ = -1>
+template <int WM_, int WN_, int WK_, int KT_ = 1, int MI_ = 1, int NI_ = 1, int NZ_ = -1,
+          int DYS_ = 0>
 struct FcDgradOp {
   __device__ __forceinline__ static int nzy(const FcDgradParams& p) { return NZ_ >= 0 ? NZ_ : p.noisy; }  // see FcFwdOp
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
@@ -404,7 +433,10 @@ struct FcDgradOp {
     const int m = t.m0 + row;
     const int n = L.n0 + 4 * q;
     const int nc = min(n, L.ldw - 4);  // dY columns share the weights' padded pitch
-    float4 v = dz_ld4(p.dy + (long)min(m, p.M - 1) * p.ldy + L.out_off + nc);
+    const long o = (long)min(m, p.M - 1) * p.ldy + L.out_off + nc;
+    float4 v;
+    if constexpr (DYS_ > 0) v = dz_dy_parts4<DYS_>(p.dyp, o);
+    else v = dz_ld4(p.dy + o);
     const float4 e = dz_ld4(p.noise + L.eps_out + nc);
     v = dz_mul4(v, dz_one_or4(L.sig, e));
     return dz_mask4(dz_sel4(L.ok & (m < p.M), v), n, L.N);
@@ -472,9 +504,11 @@ struct FcWgradParams {
   // noisy only: do not store the sigma-weight gradient (it still enters sumsq);
   // the optimiser re-derives it as dWmu * eps_in (x) eps_out (adam_kernel DerivedGrad)
   int skip_sig_store = 0;
+  DyParts dyp;      // DYS_ > 0: dY = masked sum of dyp's slabs instead of `dy`; the
+                    // first row tile of every column tile also writes it to dyp.out
 };
 
-template <int WM_, int WN_, int WK_, int KT_ = 1>
+template <int WM_, int WN_, int WK_, int KT_ = 1, int DYS_ = 0>
 struct FcWgradOp {
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int A_LAYOUT = DZ_RC, B_LAYOUT = DZ_RC, A_MAP = DZ_MAP_QUAD;
@@ -508,7 +542,14 @@ struct FcWgradOp {
     const FcHead& hd = t.hd;
     const int m = st * BK + c * 16 + kk;
     const int n = min(t.n0 + 4 * rq, hd.ldw - 4);
-    return dz_sel4(m < p.M, dz_ld4(p.dy + (long)min(m, p.M - 1) * p.ldy + hd.out_off + n));
+    const long o = (long)min(m, p.M - 1) * p.ldy + hd.out_off + n;
+    if constexpr (DYS_ > 0) {
+      const float4 v = dz_dy_parts4<DYS_>(p.dyp, o);
+      if (t.m0 == 0 && p.dyp.out && m < p.M) *(float4*)(p.dyp.out + o) = v;
+      return dz_sel4(m < p.M, v);
+    } else {
+      return dz_sel4(m < p.M, dz_ld4(p.dy + o));
+    }
   }
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {

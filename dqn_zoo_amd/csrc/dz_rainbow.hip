@@ -253,9 +253,13 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   const bool derive_sig = (phases & DZ_PHASE_BACKWARD) && (phases & DZ_PHASE_OPTIMIZER) &&
                           !a->keep_all_grads;
   auto fc1_wgrad_params = [&](FcWgradParams& w) {
-    w.x = ws + L.ws_feat; w.ldx = kFlat; w.dy = ws + L.ws_dh1; w.ldy = 1024; w.M = B;
+    w.x = ws + L.ws_feat; w.ldx = kFlat; w.dy = nullptr; w.ldy = 1024; w.M = B;
     w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc1h[0]; w.head[1] = fc1h[1];
     w.grad = a->grad;
+    // dh1 = relu'(h1) * sum of the fc2 input-gradient slabs, formed in the loaders;
+    // the first row tiles also write it out for the bias column sums (finalize)
+    w.dyp.part = ws + L.ws_fc1_part; w.dyp.stride = (long)B * 1024; w.dyp.mask = ws + L.ws_h1;
+    w.dyp.out = ws + L.ws_dh1;
   };
   // optional priority write-back (dz_rainbow_args_t::prio_*), carried by one of this
   // call's launches as an extra block
@@ -301,7 +305,9 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         d[h].S = s_dh1; d[h].noisy = 1; d[h].params = a->online; d[h].noise = nz[0];
         d[h].head[0] = fc2h[h]; d[h].head[1] = fc2h[h];
         d[h].ldo = 1024; d[h].K = kHid; d[h].x_off = 512 * h;
-        d[h].part = ws + L.ws_dfeat_part;
+        // partial slabs of dh1: into the (now idle) fc1 forward slab buffer; they are
+        // summed and ReLU-masked by the loaders of the fc1 backward launch (DyParts)
+        d[h].part = ws + L.ws_fc1_part;
       }
       const dim3 gd(kHid / FcDg::BN, (B + 31) / 32, s_dh1);
       typedef FcDgradOp<1, 2, 2, 4, 1, 1, 1> FcDg1;  // noisy == 1 at compile time
@@ -309,11 +315,6 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
           w, dim3((NA + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 2), d[0], gd, d[1], gd, s);
       if (rc) return rc;
       DZ_PROF(s, "fc2_wgrad+dgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * 1024 + 63) / 64), dim3(256), 0,
-                         s, ws + L.ws_dfeat_part, s_dh1, (long)B * 1024, ws + L.ws_h1,
-                         ws + L.ws_dh1);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "dh1_reduce");
     }
     {  // fc1: weight gradients + input gradient (adv1 + val1 paths) -> dfeat
       FcWgradParams w;
@@ -323,12 +324,13 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       // input gradient against W_eff (built in the B loader: depth N instead of the
       // two-GEMM form's 2N, 14.2 vs 17.2 us), single-chunk stages
       FcDgradParams d;
-      d.dy = ws + L.ws_dh1; d.ldy = 1024; d.M = B; d.NH = 2; d.S = kFc1DgradSplits; d.noisy = 2;
+      d.dy = nullptr; d.ldy = 1024; d.M = B; d.NH = 2; d.S = kFc1DgradSplits; d.noisy = 2;
+      d.dyp = w.dyp; d.dyp.out = nullptr;
       d.params = a->online; d.noise = nz[0]; d.head[0] = fc1h[0]; d.head[1] = fc1h[1];
       d.part = ws + L.ws_dfeat_part; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
       // ONE launch for the 25.7 MB weight read and the 12.9 MB gradient write, the
       // weight-gradient blocks first (15 us vs 14 + 14 back to back)
-      rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 2>>(
+      rc = dz_launch_gemm2<FcWgradOp<2, 2, 1, 2, kS_dh1>, FcDgradOp<1, 2, 2, 1, 1, 1, 2, kS_dh1>>(
           w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), d,
           dim3(kFlat / 64, (B + 31) / 32, kFc1DgradSplits), s);
       if (rc) return rc;

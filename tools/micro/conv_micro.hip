@@ -15,6 +15,12 @@ void dz_prof_begin(hipStream_t) {}
 void dz_prof_pair(int, int, hipStream_t) {}
 void dz_prof_mark(hipStream_t, const char*) {}
 
+#include "gemm_body_var.inc"
+template <class Op, int MASK>
+__global__ __launch_bounds__(256) void gemm_var(typename Op::Params p) {
+  __shared__ __attribute__((aligned(16))) float smem[DzGemmSmem<Op>::ELEMS];
+  gemm_body_var<Op, MASK>(p, dim3(blockIdx.x, blockIdx.y, blockIdx.z), smem);
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %d at %s:%d\n", (int)e, __FILE__, __LINE__); exit(1); } } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -147,5 +153,17 @@ int main() {
   printf("conv2: max |ref-new| = %.3g (max |ref| %.3g, nonzero %.1f%%)\n", maxd, maxv, 100.0 * nz / a.size());
   printf("conv2 shipped kernel : %.2f us\n", time_us(run_ref));
   printf("conv2 weights-stationary (%d WGs): %.2f us\n", wgs, time_us(run_new));
+  const dim3 g2(64 / Conv2Fwd::BN, G * Conv2Fwd::tiles_per_group(B), 1);
+#define ABL(MASK, label) { auto f = [&]() { hipLaunchKernelGGL((gemm_var<Conv2Fwd, MASK>), g2, dim3(256), 0, 0, p); }; printf("conv2 %-40s %.2f us\n", label, time_us(f)); }
+  ABL(0, "copy of shipped");
+  ABL(1, "no global loads");
+  ABL(8, "no output store");
+  ABL(4, "no MFMA (VALU instead)");
+  ABL(2, "no LDS / barriers");
+  ABL(3, "no loads, no LDS");
+  ABL(7, "no loads, no LDS, no MFMA");
+  ABL(15, "nothing (launch + tile setup)");
+  ABL(11, "MFMA only");
+  { auto f = [&]() { hipLaunchKernelGGL((gemm_var<Conv2Fwd, 15>), dim3(1), dim3(64), 0, 0, p); }; printf("one-wave empty launch: %.2f us\n", time_us(f)); }
   return 0;
 }
