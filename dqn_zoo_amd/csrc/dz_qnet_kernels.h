@@ -600,8 +600,12 @@ template <int PRE>
 __global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_q_values_kernel(
     float* __restrict__ fc2_out, int ld, int val_off, int A, int K,
     const float* __restrict__ support, float* __restrict__ q_out,
-    int32_t* __restrict__ greedy_out, float* __restrict__ vmax_out, HeadPre pre) {
+    int32_t* __restrict__ greedy_out, float* __restrict__ vmax_out, HeadPre pre,
+    int32_t* __restrict__ bump = nullptr) {
   extern __shared__ float s_row[];  // PRE: [ld]
+  // the actor's noise-stream position (dz_rainbow_act step_counter): advanced by the
+  // LAST launch of an apply, read by the noise draw in the FIRST launch of the next
+  if (bump && blockIdx.x == 0 && threadIdx.x == 0) *bump = *bump + 1;
   const int b = blockIdx.x, k = threadIdx.x;
   const float z_ld = support[min(k, K - 1)];
   if (PRE) {

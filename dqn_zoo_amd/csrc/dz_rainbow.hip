@@ -531,7 +531,8 @@ extern "C" int dz_rainbow_apply(int num_actions, int num_atoms, int batch,
 // split-K fold inside the q-value kernel: 8 launches instead of 10 at batch 1.
 extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const float* params,
                               const uint8_t* states, float* noise, uint64_t noise_seed,
-                              uint64_t noise_counter, const float* support, float* ws,
+                              uint64_t noise_counter, int32_t* step_counter,
+                              const float* support, float* ws,
                               float* q_values_out, int32_t* greedy_out, float* vmax_out,
                               dz_stream_t stream) {
   DZ_REQUIRE(params && states && noise && support && ws && q_values_out);
@@ -546,7 +547,7 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
   const uint8_t* in[kG] = {states, states, states};
   const int ld2 = L.adv2_ld + L.val2_ld;
   const bool fuse = (size_t)ld2 * sizeof(float) <= 48 * 1024;
-  const NoiseParams nq = {noise, (long)L.noise_stride, noise_seed, noise_counter, nullptr};
+  const NoiseParams nq = {noise, (long)L.noise_stride, noise_seed, noise_counter, step_counter};
   const bool prof = g_dz_prof_on;
   g_dz_prof_on = false;  // marks belong to dz_rainbow_learn
   rc = rainbow_forward(L, H, 1, batch, prm, nz, in, ws, s, &nq, fuse);
@@ -559,11 +560,12 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
     pre.b_sig = L.fc2_sig_b; pre.eps_out = (int)L.n_fc2_out;
     hipLaunchKernelGGL(rainbow_q_values_kernel<1>, dim3(batch), dim3(256),
                        (size_t)ld2 * sizeof(float), s, ws + L.ws_fc2_out, ld2, L.adv2_ld,
-                       num_actions, num_atoms, support, q_values_out, greedy_out, vmax_out, pre);
+                       num_actions, num_atoms, support, q_values_out, greedy_out, vmax_out, pre,
+                       step_counter);
   } else {
     hipLaunchKernelGGL(rainbow_q_values_kernel<0>, dim3(batch), dim3(64), 0, s,
                        ws + L.ws_fc2_out, ld2, L.adv2_ld, num_actions, num_atoms, support,
-                       q_values_out, greedy_out, vmax_out, HeadPre{});
+                       q_values_out, greedy_out, vmax_out, HeadPre{}, step_counter);
   }
   DZ_LAUNCH_CHECK();
   return DZ_OK;

@@ -79,19 +79,24 @@ class DenseAgent(parts.Agent):
         raise RuntimeError('Cannot repeat if action has never been selected.')
       action = self._action
     else:
-      action = self._action = self._act(timestep)
+      # enqueued, not awaited (parts.PendingAction): the accumulator only stores a_t
+      action = self._act(timestep)
       for transition in self._transition_accumulator.step(timestep, action):
         self._add(transition)
-    if self._replay.size < self._min_replay_capacity:
-      return action
-    if self._frame_t % self._learn_period == 0:
-      self._learn()
-    if self._frame_t % self._target_network_update_period == 0:
-      self._learner.sync_target()
-      # the reference raises at the offending call when a priority or weight
-      # goes NaN/inf/negative (replay.py:233-242,281-282); here those land in a
-      # sticky device word, polled once per target period (one host sync)
-      self._replay.check_status()
+    if self._replay.size >= self._min_replay_capacity:
+      if self._frame_t % self._learn_period == 0:
+        self._learn()
+      if self._frame_t % self._target_network_update_period == 0:
+        self._learner.sync_target()
+        # the reference raises at the offending call when a priority or weight
+        # goes NaN/inf/negative (replay.py:233-242,281-282); here those land in a
+        # sticky device word, polled once per target period (one host sync)
+        self._replay.check_status()
+    if isinstance(action, parts.PendingAction):
+      # the frame's device work is queued; wait for the acting launches only
+      pending, action = action, parts.Action(action.resolve())
+      self._statistics['state_value'] = pending.state_value
+    self._action = action
     return action
 
   def reset(self) -> None:
@@ -120,12 +125,36 @@ class DenseAgent(parts.Agent):
       return head_out.reshape(net.num_atoms, net.num_actions).mean(axis=0)
     return head_out
 
-  def _act(self, timestep) -> parts.Action:
+  def _act(self, timestep) -> parts.PendingAction:
+    """Epsilon-greedy action from the online network's Q-values
+    (ref: dqn/agent.py:121-131, 162-170).  The apply is enqueued and its head
+    outputs copied to pinned host memory asynchronously; the host part (Q-values,
+    the policy's RNG draw) runs when `step()` resolves the action, after the rest
+    of the frame's device work has been queued."""
     out, _, _, _ = self._learner.apply(self._obs.upload(timestep.observation))
-    q = self.q_values(out[0].cpu().numpy())   # the one sync per decision
-    a_t = epsilon_greedy_sample(q, self.exploration_epsilon, self._policy_rng)
-    self._statistics['state_value'] = float(np.max(q))
-    return parts.Action(a_t)
+    return parts.PendingAction(self._deferred_policy(out[0], self.exploration_epsilon))
+
+  def _deferred_policy(self, head_row, epsilon):
+    import torch  # pylint: disable=import-outside-toplevel
+    host = getattr(self, '_act_host', None)
+    if host is None or host.shape[1] != head_row.numel():
+      host = self._act_host = torch.empty((8, head_row.numel()),
+                                          dtype=torch.float32).pin_memory()
+      self._act_events = [torch.cuda.Event() for _ in range(8)]
+      self._act_pos = 0
+    k = self._act_pos % 8
+    self._act_pos += 1
+    slot, ev = host[k], self._act_events[k]
+    slot.copy_(head_row, non_blocking=True)
+    ev.record(torch.cuda.current_stream(self._device))
+
+    def read():
+      ev.synchronize()   # the acting launches + this copy, not the learner step behind
+      q = self.q_values(slot.numpy().copy())
+      a_t = epsilon_greedy_sample(q, epsilon, self._policy_rng)
+      return a_t, float(np.max(q))
+
+    return read
 
   def _learn(self) -> None:
     ln = self._learner

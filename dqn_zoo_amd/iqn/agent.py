@@ -115,7 +115,7 @@ class Iqn(dense_agent.DenseAgent):
     self._act_counter = 0
     self._act_seed = (int(rng_key) * 0x9E3779B97F4A7C15 + 1) & 0xFFFFFFFFFFFFFFFF
 
-  def _act(self, timestep) -> parts.Action:
+  def _act(self, timestep) -> parts.PendingAction:
     """ref: iqn/agent.py:234-247 select_action: tau_samples_policy fresh draws,
     epsilon-greedy on the sample mean."""
     ln = self._learner
@@ -126,11 +126,12 @@ class Iqn(dense_agent.DenseAgent):
         torch.cuda.current_stream(self._device).cuda_stream), 'dz_uniform_fill')
     self._act_counter += n
     _, q, _, _ = ln.apply(obs_d, self._act_taus)
-    q = q[0].cpu().numpy()   # the one sync per decision
-    a_t = dense_agent.epsilon_greedy_sample(q, self.exploration_epsilon,
-                                            self._policy_rng)
-    self._statistics['state_value'] = float(np.max(q))
-    return parts.Action(a_t)
+    # Q-values to pinned host memory asynchronously; epsilon-greedy on the host when
+    # step() resolves the action (dense_agent.DenseAgent._deferred_policy)
+    return parts.PendingAction(self._deferred_policy(q[0], self.exploration_epsilon))
+
+  def q_values(self, head_out):   # the IQN apply already returns sample-mean Q-values
+    return head_out
 
   def _learn(self) -> None:
     t, _ = self._replay.sample_device(self._batch_size)

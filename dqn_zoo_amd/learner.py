@@ -98,6 +98,7 @@ class RainbowLearner:
     self._act_batch = 0
     self._act_ws = None
     self._act_noise = torch.zeros(L.noise_stride, **f32)
+    self.act_graphs = True   # replay the acting apply from a hipGraph (apply_async)
 
   # -- state ------------------------------------------------------------------
   def get_params(self, which='online') -> dict:
@@ -119,18 +120,30 @@ class RainbowLearner:
     blocks = [self.layout.pack_noise(n) for n in noises]
     self.noise.copy_(torch.from_numpy(np.concatenate(blocks)))
 
-  def set_noise_state(self, seed: int, counter: int) -> None:
-    """Restores the noise stream position (agent `set_state`).  The cached
+  def set_noise_state(self, seed: int, counter: int, act_step: int = 0) -> None:
+    """Restores the noise stream positions (agent `set_state`).  The cached
     argument block and every captured hipGraph bake the old seed in: drop them."""
     self._noise_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     self._noise_counter = int(counter)
     self._args = None
     self.drop_graphs()
+    if getattr(self, '_act_step', None) is None:
+      self._act_step = torch.zeros(1, dtype=torch.int32, device=self.device)
+      self._act_graphs = {}
+    self._act_step.fill_(int(act_step))
+
+  def act_step(self) -> int:
+    """Number of acting applies drawn so far (the actor's noise stream position)."""
+    return 0 if getattr(self, '_act_step', None) is None else int(self._act_step.item())
 
   def drop_graphs(self) -> None:
     graphs, self._graphs = self._graphs, {}
     for g in graphs.values():
       self._lib.dz_graph_destroy(g)
+    for g, _ in getattr(self, '_act_graphs', {}).values():
+      self._lib.dz_graph_destroy(g)
+    if getattr(self, '_act_graphs', None):
+      self._act_graphs = {}
 
   def resample_noise(self) -> None:
     """Fresh factorised noise for the 3 applies, generated on the device."""
@@ -141,7 +154,7 @@ class RainbowLearner:
     self._noise_counter += n
 
   def apply(self, states: torch.Tensor, which: str = 'online', noise=None,
-            resample_noise: bool = True):
+            resample_noise: bool = True, packed_out=None):
     """One network apply on uint8 states [B,84,84,4] (device tensor).
     Returns device tensors (q_values [B,A] f32, greedy action [B] i32,
     max_a q [B] f32).  ref: rainbow/agent.py:125-131 (select_action)."""
@@ -157,18 +170,33 @@ class RainbowLearner:
     q = torch.empty((b, a), dtype=torch.float32, device=self.device)
     # (greedy action, max q) packed in one 8-byte buffer per row so that the
     # actor's device->host read is ONE copy (read_action)
-    packed = torch.empty((2, b), dtype=torch.int32, device=self.device)
+    # (`packed_out`: a pinned host int32 [2, b] tensor the kernel writes through its
+    # device mapping instead, see apply_async)
+    packed = torch.empty((2, b), dtype=torch.int32, device=self.device) \
+        if packed_out is None else packed_out
     greedy, vmax = packed[0], packed[1].view(torch.float32)
     params = self.online if which == 'online' else self.target
     if noise is None and resample_noise:
-      # fresh noise drawn inside the apply's own launches (dz_rainbow_act)
-      n = self._act_noise.numel()
-      _lib.check(self._lib.dz_rainbow_act(
+      # fresh noise drawn inside the apply's own launches (dz_rainbow_act); the
+      # stream position is a DEVICE counter the apply advances itself, so the
+      # argument list is constant and the 8 launches replay from a hipGraph
+      if getattr(self, '_act_step', None) is None:
+        self._act_step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._act_graphs = {}
+      enqueue = lambda: _lib.check(self._lib.dz_rainbow_act(
           a, self.network.num_atoms, b, params.data_ptr(), states.data_ptr(),
-          self._act_noise.data_ptr(), self._noise_seed ^ 0xA5A5A5A5,
-          self._noise_counter, self.support.data_ptr(), self._act_ws.data_ptr(),
+          self._act_noise.data_ptr(), self._noise_seed ^ 0xA5A5A5A5, 0,
+          self._act_step.data_ptr(), self.support.data_ptr(), self._act_ws.data_ptr(),
           q.data_ptr(), greedy.data_ptr(), vmax.data_ptr(), stream), 'dz_rainbow_act')
-      self._noise_counter += n
+      if self.act_graphs and stream and packed_out is not None:
+        key = (states.data_ptr(), packed_out.data_ptr(), params.data_ptr(), b)
+        g = self._act_graphs.get(key)
+        if g is None:
+          q = self._act_q = torch.empty((b, a), dtype=torch.float32, device=self.device)
+          g = self._act_graphs[key] = (_lib.capture_graph(stream, enqueue), q)
+        _lib.check(self._lib.dz_graph_launch(g[0], stream), 'dz_graph_launch')
+        return g[1], greedy, vmax
+      enqueue()
       return q, greedy, vmax
     if noise is not None:
       self._act_noise.copy_(torch.from_numpy(self.layout.pack_noise(noise)))
@@ -178,6 +206,32 @@ class RainbowLearner:
         self._act_ws.data_ptr(), q.data_ptr(), greedy.data_ptr(),
         vmax.data_ptr(), stream), 'dz_rainbow_apply')
     return q, greedy, vmax
+
+  ACT_RING = 8   # acting results in flight (pinned host words)
+
+  def apply_async(self, states: torch.Tensor):
+    """Acting apply whose (greedy action, max q) pair is written by the kernel
+    straight into pinned, device-mapped HOST memory: no device->host copy is
+    enqueued and nothing synchronises here.  Returns `read() -> (action, value)`
+    which waits for THESE launches only (an event recorded right behind them), so
+    a learner step enqueued afterwards does not delay the action."""
+    b = int(states.shape[0])
+    if getattr(self, '_act_host', None) is None or self._act_host.shape[2] != b:
+      self._act_host = torch.empty((self.ACT_RING, 2, b), dtype=torch.int32).pin_memory()
+      self._act_events = [torch.cuda.Event() for _ in range(self.ACT_RING)]
+      self._act_pos = 0
+    k = self._act_pos % self.ACT_RING
+    self._act_pos += 1
+    slot = self._act_host[k]
+    self.apply(states, packed_out=slot)
+    ev = self._act_events[k]
+    ev.record(torch.cuda.current_stream(self.device))
+
+    def read():
+      ev.synchronize()
+      return int(slot[0, 0]), float(slot[1].view(torch.float32)[0])
+
+    return read
 
   @staticmethod
   def read_action(greedy: torch.Tensor, vmax: torch.Tensor):

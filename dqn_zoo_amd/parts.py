@@ -23,6 +23,44 @@ from dqn_zoo_amd import dm_env_shim as dm_env
 Action = int
 
 
+class PendingAction:
+  """An action (and its value estimate) that the GPU is still computing.
+
+  `agent.step()` enqueues the acting network's launches, then the replay insert
+  and -- every `learn_period` frames -- the learner step, and only THEN reads the
+  action back: none of that later work needs the new action's value (the
+  transition accumulators only store a_t for transitions they emit on later
+  steps, ref: replay.py:771-892), so the ~50 us of host bookkeeping per frame and
+  the device work overlap instead of alternating.  The object stands in for the
+  int wherever the action is merely carried (`int(x)`, `np.int64(x)`, indexing and
+  `==` resolve it; resolving waits for the acting launches only, not for the
+  learner step queued behind them)."""
+
+  __slots__ = ('_read', '_value', 'state_value')
+
+  def __init__(self, read):
+    self._read = read          # () -> (int action, float value); synchronises
+    self._value = None
+    self.state_value = None
+
+  def resolve(self) -> int:
+    if self._value is None:
+      a, v = self._read()
+      self._value, self.state_value, self._read = int(a), v, None
+    return self._value
+
+  __int__ = __index__ = resolve
+
+  def __eq__(self, other):
+    return self.resolve() == other
+
+  def __hash__(self):
+    return hash(self.resolve())
+
+  def __repr__(self):
+    return 'PendingAction(%s)' % ('?' if self._value is None else self._value)
+
+
 class Agent(abc.ABC):
   """Agent interface (ref: parts.py:42-67)."""
 

@@ -81,25 +81,29 @@ class Rainbow(parts.Agent):
         raise RuntimeError('Cannot repeat if action has never been selected.')
       action = self._action
     else:
-      action = self._action = self._act(timestep)
+      # enqueued, not awaited: the accumulator only STORES a_t (parts.PendingAction)
+      action = self._act(timestep)
       for transition in self._transition_accumulator.step(timestep, action):
         # priority = running max priority, kept on the device (agent.py:149)
         # both states are already in HBM (uploaded for acting): no re-upload
         self._replay.add_with_device_priority(self._obs.on_device(transition))
 
-    if self._replay.size < self._min_replay_capacity:
-      return action
+    if self._replay.size >= self._min_replay_capacity:
+      if self._frame_t % self._learn_period == 0:
+        self._learn()
 
-    if self._frame_t % self._learn_period == 0:
-      self._learn()
+      if self._frame_t % self._target_network_update_period == 0:
+        self._learner.sync_target()
+        # the reference raises at the offending call when a priority or weight
+        # goes NaN/inf/negative (replay.py:233-242,281-282); here those land in a
+        # sticky device word, polled once per target period (one host sync)
+        self._replay.check_status()
 
-    if self._frame_t % self._target_network_update_period == 0:
-      self._learner.sync_target()
-      # the reference raises at the offending call when a priority or weight
-      # goes NaN/inf/negative (replay.py:233-242,281-282); here those land in a
-      # sticky device word, polled once per target period (one host sync)
-      self._replay.check_status()
-
+    if isinstance(action, parts.PendingAction):
+      # everything of this frame is queued; now wait for the acting launches only
+      pending, action = action, parts.Action(action.resolve())
+      self._statistics['state_value'] = pending.state_value
+    self._action = action
     return action
 
   def reset(self) -> None:
@@ -108,15 +112,13 @@ class Rainbow(parts.Agent):
     processors.reset(self._preprocessor)
     self._action = None
 
-  def _act(self, timestep) -> parts.Action:
+  def _act(self, timestep) -> parts.PendingAction:
     """Greedy action w.r.t. a freshly-noised online network
-    (ref: rainbow/agent.py:171-179)."""
+    (ref: rainbow/agent.py:171-179), as a `PendingAction`: the launches are
+    enqueued, the (action, value) pair lands in pinned host memory, and `step()`
+    reads it after queueing the rest of the frame's device work."""
     obs_d = self._obs.upload(timestep.observation)
-    _, greedy, vmax = self._learner.apply(obs_d)
-    # the one device->host sync per decision: (action, value) in one read
-    a_t, v_t = self._learner.read_action(greedy, vmax)
-    self._statistics['state_value'] = v_t
-    return parts.Action(a_t)
+    return parts.PendingAction(self._learner.apply_async(obs_d))
 
   def _learn(self) -> None:
     """Samples a batch and learns from it, entirely on the device
@@ -159,7 +161,8 @@ class Rainbow(parts.Agent):
   def get_state(self) -> Mapping[str, Any]:
     ln = self._learner
     return {
-        'rng_key': (ln._noise_seed, ln._noise_counter),  # pylint: disable=protected-access
+        # (learner noise seed, learner stream position, actor stream position)
+        'rng_key': (ln._noise_seed, ln._noise_counter, ln.act_step()),  # pylint: disable=protected-access
         'frame_t': self._frame_t,
         'opt_state': ln.get_opt_state(),
         'online_params': ln.get_params('online'),

@@ -237,9 +237,10 @@ class _FieldRing:
       arr[i].dst = f.data_ptr()
       arr[i].row_bytes = f[0].numel() * f.element_size()
       if isinstance(x, torch.Tensor):
-        if (x.device != f.device or x.dtype != f.dtype or
+        on_dev = x.device == f.device or (x.device.type == 'cpu' and x.is_pinned())
+        if (not on_dev or x.dtype != f.dtype or
             tuple(x.shape) != tuple(shp) or not x.is_contiguous()):
-          raise ValueError('device field %d: need a contiguous %s%s tensor on %s'
+          raise ValueError('device field %d: need a contiguous %s%s tensor on %s (or pinned host memory)'
                            % (i, f.dtype, tuple(shp), f.device))
         arr[i].src_row = x.data_ptr()
         arr[i].imm = 0

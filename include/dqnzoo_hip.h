@@ -348,10 +348,17 @@ int dz_rainbow_apply(int num_actions, int num_atoms, int batch, const float* par
 /* The actor's apply: dz_rainbow_apply with the noise block (noise_stride floats)
  * first redrawn on the device from (noise_seed, noise_counter) -- inside the
  * conv1 launch -- and the fc2 split-K fold inside the q-value kernel.
+ * step_counter (nullable device int32): if given, the noise stream position is
+ * noise_counter + *step_counter * noise_stride and the apply's last launch does
+ * ++*step_counter, so that the SAME argument list draws fresh noise every time:
+ * the call can be captured once (dz_graph_capture_begin/end) and replayed per
+ * decision.  greedy_out / vmax_out may point into pinned, device-mapped host
+ * memory (the action is then on the host when the stream reaches that point).
  * ref: rainbow/agent.py:125-131, 171-179 (select_action with a fresh key).    */
 int dz_rainbow_act(int num_actions, int num_atoms, int batch, const float* params,
                    const uint8_t* states, float* noise, uint64_t noise_seed,
-                   uint64_t noise_counter, const float* support, float* ws,
+                   uint64_t noise_counter, int32_t* step_counter,
+                   const float* support, float* ws,
                    float* q_values_out, int32_t* greedy_out, float* vmax_out,
                    dz_stream_t stream);
 

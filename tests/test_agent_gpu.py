@@ -183,3 +183,41 @@ def test_get_state_set_state_roundtrip():
     assert i == j and a.a_tm1 == b.a_tm1 and a.r_t == b.r_t
     np.testing.assert_array_equal(a.s_t, b.s_t)
   assert rep2.size == rep.size and list(rep2.ids()) == list(rep.ids())
+
+
+def test_async_acting_path_matches_oracle_and_replays_from_a_graph():
+  """`apply_async` (the agents' acting path): launches enqueued, (action, value)
+  written by the kernel into pinned host memory, replayed from a hipGraph from
+  the second call on, fresh noise on every call (device-side stream counter) --
+  each decision checked against the oracle forward with the noise the device
+  actually drew."""
+  from dqn_zoo_amd import device_obs, learner, networks, parts
+  rs = np.random.RandomState(11)
+  params = qo.init_params('rainbow', A, rs)
+  for k in params:
+    if 'sigma' in k:
+      params[k] = (params[k] * 3).astype(np.float32)
+  ln = learner.RainbowLearner(networks.RainbowNetwork(A, SUPPORT), learner.AdamConfig(),
+                              8, params=params)
+  cache = device_obs.ObservationCache(ln.device)
+  prev = torch.cuda.current_stream()
+  torch.cuda.set_stream(torch.cuda.Stream())   # graph capture needs a real stream
+  try:
+    seen = []
+    for i in range(2 * cache._depth + 3):   # every ring slot twice: capture, then replay
+      x = rs.randint(0, 256, (84, 84, 4)).astype(np.uint8)
+      pending = parts.PendingAction(ln.apply_async(cache.upload(x)))
+      a = pending.resolve()
+      nz = ln.layout.unpack_noise(ln._act_noise.cpu().numpy())  # pylint: disable=protected-access
+      _, q_ref, _ = qo.rainbow_fwd(params, x[None], nz, SUPPORT, A)
+      assert a == int(q_ref[0].argmax())
+      assert abs(pending.state_value - q_ref[0].max()) < 1e-4
+      assert int(pending) == a and np.int64(pending) == a
+      seen.append(nz['adv1/in'][:8].copy())
+    assert ln.act_step() == len(seen)
+    assert len(ln._act_graphs) == cache._depth   # pylint: disable=protected-access
+    for u, v in zip(seen, seen[1:]):
+      assert not np.array_equal(u, v)          # fresh noise per decision
+  finally:
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(prev)
