@@ -206,31 +206,45 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       FcDgradParams d;
       d.dy = ws + L.ws_dout; d.ldy = ld2; d.M = B; d.NH = 1; d.S = s_dh1; d.noisy = 0;
       d.params = a->online; d.noise = zeros; d.head[0] = h2; d.head[1] = h2;
-      d.part = ws + L.ws_dfeat_part; d.ldo = kHid; d.K = kHid; d.x_off = 0;
+      // the usual head (s_dh1 == kS_dh1): the slabs go to the idle fc1 forward slab
+      // buffer and are summed + ReLU-masked by the loaders of the fc1 backward launch
+      // (DyParts, as in dz_rainbow.hip): no dh1 reduction launch
+      const bool fold = s_dh1 == kS_dh1 &&
+                        (int64_t)kS_dh1 * B * kHid <= (int64_t)kS_dfc1 * G * B * kHid;
+      d.part = fold ? ws + L.ws_fc1_part : ws + L.ws_dfeat_part;
+      d.ldo = kHid; d.K = kHid; d.x_off = 0;
       rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 4, 1, 1, 0>>(
           w, dim3((N + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 1), d,
           dim3(kHid / FcDg::BN, (B + 31) / 32, s_dh1), s);
       if (rc) return rc;
       DZ_PROF(s, "fc2_wgrad+dgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kHid + 63) / 64), dim3(256), 0, s,
-                         ws + L.ws_dfeat_part, s_dh1, (long)B * kHid, ws + L.ws_h1,
-                         ws + L.ws_dh1);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "dh1_reduce");
-    }
-    {  // fc1
-      FcWgradParams w;
-      w.x = ws + L.ws_feat; w.ldx = kFlat; w.dy = ws + L.ws_dh1; w.ldy = kHid; w.M = B;
-      w.NH = 1; w.noisy = 0; w.noise = zeros; w.head[0] = h1; w.head[1] = h1;
-      w.grad = grad;
-      FcDgradParams d;
-      d.dy = ws + L.ws_dh1; d.ldy = kHid; d.M = B; d.NH = 1; d.S = kS_ddfeat; d.noisy = 0;
-      d.params = a->online; d.noise = zeros; d.head[0] = h1; d.head[1] = h1;
-      d.part = ws + L.ws_dfeat_part; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
+      if (!fold) {
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kHid + 63) / 64), dim3(256), 0, s,
+                           ws + L.ws_dfeat_part, s_dh1, (long)B * kHid, ws + L.ws_h1,
+                           ws + L.ws_dh1);
+        DZ_LAUNCH_CHECK();
+        DZ_PROF(s, "dh1_reduce");
+      }
+      // fc1
+      FcWgradParams w1;
+      w1.x = ws + L.ws_feat; w1.ldx = kFlat; w1.dy = ws + L.ws_dh1; w1.ldy = kHid; w1.M = B;
+      w1.NH = 1; w1.noisy = 0; w1.noise = zeros; w1.head[0] = h1; w1.head[1] = h1;
+      w1.grad = grad;
+      FcDgradParams d1;
+      d1.dy = ws + L.ws_dh1; d1.ldy = kHid; d1.M = B; d1.NH = 1; d1.S = kS_ddfeat; d1.noisy = 0;
+      d1.params = a->online; d1.noise = zeros; d1.head[0] = h1; d1.head[1] = h1;
+      d1.part = ws + L.ws_dfeat_part; d1.ldo = kFlat; d1.K = kFlat; d1.x_off = 0;
       // weight gradient and input gradient in ONE launch (as in dz_rainbow.hip)
-      rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 0>>(
-          w, dim3(kHid / FcWg::BN, kFlat / FcWg::BM, 1), d,
-          dim3(kFlat / 64, (B + 31) / 32, kS_ddfeat), s);
+      const dim3 gw(kHid / FcWg::BN, kFlat / FcWg::BM, 1), gdd(kFlat / 64, (B + 31) / 32, kS_ddfeat);
+      if (fold) {
+        w1.dyp.part = ws + L.ws_fc1_part; w1.dyp.stride = (long)B * kHid;
+        w1.dyp.mask = ws + L.ws_h1; w1.dyp.out = ws + L.ws_dh1;
+        d1.dyp = w1.dyp; d1.dyp.out = nullptr;
+        rc = dz_launch_gemm2<FcWgradOp<2, 2, 1, 2, kS_dh1>, FcDgradOp<1, 2, 2, 1, 1, 1, 0, kS_dh1>>(
+            w1, gw, d1, gdd, s);
+      } else {
+        rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 1, 1, 1, 0>>(w1, gw, d1, gdd, s);
+      }
       if (rc) return rc;
       DZ_PROF(s, "fc1_wgrad+dgrad");
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0, s,
