@@ -358,10 +358,10 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
 
 def pmc_traffic(kernel):
   """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-  (profiles/r1_hbm_traffic.json: FETCH_SIZE/WRITE_SIZE collected separately and
+  (profiles/r2_hbm_traffic.json: FETCH_SIZE/WRITE_SIZE collected separately and
   corrected as MI355X_MICROARCH.md prescribes); None if not collected."""
   try:
-    with open(os.path.join(ROOT, 'profiles', 'r1_hbm_traffic.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r2_hbm_traffic.json')) as f:
       k = json.load(f)['kernels'].get(kernel)
     return None if k is None else k.get('hbm_bytes_corrected')
   except (OSError, ValueError, KeyError):
