@@ -221,3 +221,76 @@ def test_async_acting_path_matches_oracle_and_replays_from_a_graph():
   finally:
     torch.cuda.synchronize()
     torch.cuda.set_stream(prev)
+
+
+def test_diverged_priorities_stop_the_run_at_the_next_target_sync():
+  """NaN / negative priorities raise ValueError in the reference's
+  SumTree.set (replay.py:281-282).  Here they land in a sticky device status
+  word; the agents poll it at every target-network sync."""
+  ag, rep = _make_agent(target_period=8, min_frac=0.004, learn_period=1)
+  env = SyntheticEnv(2, episode_length=100)
+  ts = env.reset()
+  ag.reset()
+  for _ in range(9):
+    ts = env.step(ag.step(ts))
+  # poison the priorities of the next write-back the way a diverged loss would
+  ids = rep.sample_device(4).ids
+  rep.update_priorities(ids, torch.full((4,), float('nan'), device='cuda'))
+  with pytest.raises(ValueError, match='finite and positive'):
+    for _ in range(9):   # at most one target period later
+      ts = env.step(ag.step(ts))
+
+
+def test_scalar_dtypes_are_canonicalised_on_insert():
+  """an environment emitting np.float32 rewards / np.int32 actions must
+  not freeze the store to those dtypes (the learner kernels read int64/float64)."""
+  from dqn_zoo_amd import dm_env_shim as dm_env
+  from dqn_zoo_amd import learner
+  ag, rep = _make_agent(min_frac=0.004, learn_period=1)
+  rs = np.random.RandomState(0)
+  ts = dm_env.restart(rs.randint(0, 256, (84, 84, 4)).astype(np.uint8))
+  for _ in range(12):
+    ag.step(ts)
+    ts = dm_env.TimeStep(dm_env.StepType.MID, np.float32(1.0), np.float32(0.99),
+                         rs.randint(0, 256, (84, 84, 4)).astype(np.uint8))
+  torch.cuda.synchronize()
+  f = rep._ring.fields   # pylint: disable=protected-access
+  assert f[1].dtype == torch.int64 and f[2].dtype == torch.float64 and f[3].dtype == torch.float64
+  assert int(ag.learner.adam_count.item()) > 0
+  # and a wrong dtype handed to the learner directly is a TypeError, not an assert
+  t = rep.sample_device(10)
+  tr = t.transitions
+  with pytest.raises(TypeError, match='r_t'):
+    ag.learner.step(tr.s_tm1, tr.a_tm1, tr.r_t.float(), tr.discount_t, tr.s_t, t.weights32)
+
+
+def test_set_state_restores_the_noise_streams_of_a_stepped_agent():
+  """restoring into an agent that has already stepped (cached argument
+  block, captured graphs) must continue exactly like the agent the state came
+  from: same learner noise, same actor noise, same parameters."""
+  def run(ag, env, n):
+    ts = env.reset()
+    ag.reset()
+    acts = []
+    for _ in range(n):
+      a = ag.step(ts)
+      acts.append(a)
+      ts = env.step(a) if not ts.last() else env.reset()
+    return acts
+
+  a1, _ = _make_agent(min_frac=0.004, learn_period=1, capacity=64, batch=8)
+  run(a1, SyntheticEnv(5), 25)
+  state = a1.get_state()
+  rs_state = a1._replay._random_state.get_state()   # pylint: disable=protected-access
+  a2, _ = _make_agent(min_frac=0.004, learn_period=1, capacity=64, batch=8, seed=77)
+  run(a2, SyntheticEnv(6), 13)          # a DIFFERENT history first: caches are warm
+  a2.set_state(state)
+  a2._replay._random_state.set_state(rs_state)      # pylint: disable=protected-access
+  # identical continuations (fresh accumulators on both sides: reset() at the start)
+  acts1 = run(a1, SyntheticEnv(9), 20)
+  acts2 = run(a2, SyntheticEnv(9), 20)
+  assert acts1 == acts2
+  p1, p2 = a1.online_params, a2.online_params
+  for k in p1:
+    np.testing.assert_array_equal(p1[k], p2[k])
+  assert a1.learner.act_step() == a2.learner.act_step()
