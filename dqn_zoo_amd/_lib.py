@@ -308,6 +308,8 @@ def capture_graph(stream, enqueue):
   if not stream:
     raise RuntimeError('hipGraph capture needs a non-default stream: run under '
                        '`torch.cuda.stream(torch.cuda.Stream())`')
+  # (refused -- ValueError -- while the event profiler is on: its marks are
+  # event records between the kernels and cannot live inside a graph)
   check(lib.dz_graph_capture_begin(stream), 'dz_graph_capture_begin')
   h = ctypes.c_void_p()
   try:

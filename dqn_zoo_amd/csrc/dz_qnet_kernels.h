@@ -663,6 +663,161 @@ __global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_q_values_kernel(
   }
 }
 
+// --------------------------------------------------------------------------- //
+//  The actor's tail in ONE launch (batch <= 8): fc1 split-K epilogue, noisy fc2
+//  (adv2, val2) as a GEMV over W_eff, dueling + softmax + expectation + argmax.
+//  ref: networks.py:239-258 (heads), rainbow/agent.py:125-131 (select_action).
+//
+//  At batch 1 the three launches this replaces (fc_epilogue 4.5 us, split-K fc2
+//  5.2 us, q-values 7.2 us: tools/act_trace.py) are all launch floor.  Here
+//  grid = (column tiles of 32 over [adv2 | val2], batch rows): every workgroup
+//    1. rebuilds the row's h1 = relu(sum_s part[s] + b_mu + b_sig eps_out) in LDS
+//       (128 KB of L2 reads; cheaper than a launch boundary),
+//    2. computes its 32 output columns: thread (kg, c) sums 64 of the 512 k's of
+//       h1[k] (Wmu[k][c] + Wsig[k][c] eps_in[k] eps_out[c]), 8 partials per column
+//       combined through LDS in a fixed order, plus the sigma bias,
+//    3. publishes them and takes a ticket; the LAST workgroup of the row (agent-
+//       scope release / acquire around the ticket, MI355X_MICROARCH.md "Workgroup
+//       dispatch ... visibility") reads the whole row and emits q-values, greedy
+//       action and its value -- which may go straight to pinned host memory.
+// --------------------------------------------------------------------------- //
+struct ActTailParams {
+  const float* part; int S; int rows;        // fc1 slabs [S][rows][1024]
+  const float* prm; const float* nz;         // parameters, the apply's noise block
+  long fc1_mu_b, fc1_sig_b; int n_fc1_out;   // fc1 biases / their output noise
+  FcHead head[2];                            // adv2, val2 (K = 512, x_off 0 / 512)
+  long fc2_sig_b; int n_fc2_out;             // sigma bias [ld2] and its noise offset
+  int ld2, val_off, A, K;                    // padded row pitch, value-head column offset
+  const float* support;
+  float* fc2_out;                            // [rows][ld2]
+  float* q_out; int32_t* greedy_out; float* vmax_out;
+  int* tickets;                              // [rows], zero before the first launch
+  int tiles0, tiles;                         // column tiles of head 0 / in total
+  int32_t* bump;                             // actor noise-stream counter (nullable)
+};
+
+__global__ __launch_bounds__(256) void rainbow_act_tail_kernel(ActTailParams p) {
+  __shared__ float s_h1[512];     // this head's half of h1
+  __shared__ float s_ein[512];
+  __shared__ float s_red[8][32];
+  __shared__ float s_row[1024];   // the finished fc2 row (ld2 <= 1024 checked by the host)
+  __shared__ float s_q[64];
+  __shared__ float s_best;
+  __shared__ int s_arg;
+  __shared__ int s_last;
+  const int row = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  const int hsel = tile >= p.tiles0 ? 1 : 0;
+  const FcHead hd = dz_pick_head(p.head, hsel);
+  const int c = tid & 31, kg = tid >> 5;
+  const int col = (tile - (hsel ? p.tiles0 : 0)) * 32 + c;   // within the head
+  const int colc = min(col, hd.ldw - 1);
+  // Every load of the kernel's first two phases is issued before anything is
+  // consumed (the phases are dependent round trips otherwise: 26 us measured):
+  //   (a) the 32 fc1 slabs of this head's 512 h1 columns (2 per thread) + biases,
+  //   (b) this thread's 64 k's of Wmu / Wsig for its output column.
+  constexpr int SMAX = 32;
+  float x[2][SMAX];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int j = 0; j < SMAX; ++j)
+      x[e][j] = p.part[((long)min(j, p.S - 1) * p.rows + row) * 1024 + hd.x_off + tid + 256 * e];
+  float bm[2], bs[2], be[2], ei[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int cc = hd.x_off + tid + 256 * e;
+    bm[e] = p.prm[p.fc1_mu_b + cc]; bs[e] = p.prm[p.fc1_sig_b + cc]; be[e] = p.nz[p.n_fc1_out + cc];
+    ei[e] = p.nz[hd.eps_in + tid + 256 * e];
+  }
+  const float eo = p.nz[hd.eps_out + colc];
+  const float sb = p.prm[p.fc2_sig_b + hd.out_off + colc] * p.nz[p.n_fc2_out + hd.out_off + colc];
+  float m[64], g[64];
+  {
+    const float* wmu = p.prm + hd.w_mu + (long)(kg * 64) * hd.ldw + colc;
+    const float* wsg = p.prm + hd.w_sig + (long)(kg * 64) * hd.ldw + colc;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) { m[j] = wmu[(long)j * hd.ldw]; g[j] = wsg[(long)j * hd.ldw]; }
+  }
+  // ---- 1. h1 (this head's half) -------------------------------------------------
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < SMAX; ++j) v += j < p.S ? x[e][j] : 0.f;
+    const float h = v + bm[e] + bs[e] * be[e];
+    s_h1[tid + 256 * e] = h > 0.f ? h : 0.f;
+    s_ein[tid + 256 * e] = ei[e];
+  }
+  __syncthreads();
+  // ---- 2. this workgroup's 32 output columns ------------------------------------
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const int k = kg * 64 + j;
+      acc = __builtin_fmaf(s_h1[k], __builtin_fmaf(g[j], s_ein[k] * eo, m[j]), acc);
+    }
+    s_red[kg][c] = acc;
+  }
+  __syncthreads();
+  if (tid < 32 && col < hd.ldw) {
+    const float o = (((s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c])) +
+                     ((s_red[4][c] + s_red[5][c]) + (s_red[6][c] + s_red[7][c]))) + sb;
+    p.fc2_out[(long)row * p.ld2 + hd.out_off + col] = col < hd.N ? o : 0.f;
+  }
+  // ---- 3. ticket: the last workgroup of the row finishes it -----------------------
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(p.tickets + row, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == p.tiles - 1;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  for (int i = tid; i < p.ld2; i += 256)
+    s_row[i] = __hip_atomic_load(p.fc2_out + (long)row * p.ld2 + i, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (tid == 0) {
+    p.tickets[row] = 0;   // ready for the next apply (ordered by the kernel boundary)
+    if (p.bump && row == 0) *p.bump = *p.bump + 1;
+  }
+  // q-values: the 4 waves take the actions round-robin (3 wave reductions each)
+  const int k = tid & 63, wave = tid >> 6;
+  const bool on = k < p.K;
+  const float z = on ? p.support[k] : 0.f;
+  float mean_adv = 0.f;
+  for (int a = 0; a < p.A; ++a) mean_adv += on ? s_row[a * p.K + k] : 0.f;
+  mean_adv /= (float)p.A;
+  const float vv = on ? s_row[p.val_off + k] : 0.f;
+  for (int a0 = 0; a0 < p.A; a0 += 64) {        // A <= 256: 64 actions per round of s_q
+    for (int a = a0 + wave; a < min(p.A, a0 + 64); a += 4) {
+      const float lg = on ? (vv + s_row[a * p.K + k] - mean_adv) : -__builtin_inff();
+      const float mx = wave_max(lg);
+      const float e = on ? expf(lg - mx) : 0.f;
+      const float sm = wave_sum(e);
+      const float q = wave_sum((e / sm) * z);
+      if (k == 0) { s_q[a - a0] = q; p.q_out[row * p.A + a] = q; }
+    }
+    __syncthreads();
+    if (tid == 0) {   // first maximum, as jnp.argmax
+      float best = a0 ? s_best : -__builtin_inff();
+      int arg = a0 ? s_arg : 0;
+      for (int a = a0; a < min(p.A, a0 + 64); ++a)
+        if (s_q[a - a0] > best) { best = s_q[a - a0]; arg = a; }
+      s_best = best; s_arg = arg;
+      if (a0 + 64 >= p.A) {
+        if (p.greedy_out) p.greedy_out[row] = arg;
+        if (p.vmax_out) p.vmax_out[row] = best;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // rlax.q_learning / double_q_learning + clip_gradient + l2_loss (+ IS weights):
 //   td = r + g * q_target[a*] - q_tm1[a],  a* = argmax(selector)
 //   loss = mean(0.5 td^2 w);  d loss / d q_tm1[a] = -clip(w td / B, +-bound)

@@ -35,7 +35,7 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
                            const float* const* prm, const float* const* nz,
                            const uint8_t* const* in, float* ws, hipStream_t s,
                            const NoiseParams* resample = nullptr,
-                           bool skip_fc2_epilogue = false) {
+                           bool skip_fc2_epilogue = false, bool stop_after_fc1 = false) {
   int rc = DZ_OK;
   const int NA = L.num_actions * L.num_atoms;
   const int ld2 = L.adv2_ld + L.val2_ld;
@@ -76,6 +76,7 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
     }
     if (rc) return rc;
     DZ_PROF(s, "fc1_fwd");
+    if (stop_after_fc1) return rc;  // the caller's kernel folds the slabs (actor tail)
     hipLaunchKernelGGL(fc_epilogue_kernel, dim3(16, G * B), dim3(256), 0, s,
                        ws + L.ws_fc1_part, kFc1Splits, G * B, 1024, 1024, B,
                        prm[0], prm[1], prm[2], (long)L.fc1_mu_b, (long)L.fc1_sig_b,
@@ -550,9 +551,30 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
   const NoiseParams nq = {noise, (long)L.noise_stride, noise_seed, noise_counter, step_counter};
   const bool prof = g_dz_prof_on;
   g_dz_prof_on = false;  // marks belong to dz_rainbow_learn
-  rc = rainbow_forward(L, H, 1, batch, prm, nz, in, ws, s, &nq, fuse);
+  // Few rows: the tail (fc1 epilogue + fc2 + q-values) is ONE launch that folds the
+  // fc1 slabs itself (rainbow_act_tail_kernel): 5 launches per decision instead of 7.
+  const bool tail = batch <= 8 && ld2 <= 1024 && num_atoms <= 64;
+  rc = rainbow_forward(L, H, 1, batch, prm, nz, in, ws, s, &nq, fuse, tail);
   g_dz_prof_on = prof;
   if (rc) return rc;
+  if (tail) {
+    ActTailParams q;
+    q.part = ws + L.ws_fc1_part; q.S = kFc1Splits; q.rows = batch;
+    q.prm = params; q.nz = noise;
+    q.fc1_mu_b = L.fc1_mu_b; q.fc1_sig_b = L.fc1_sig_b; q.n_fc1_out = (int)L.n_fc1_out;
+    q.head[0] = H.fc2h[0]; q.head[1] = H.fc2h[1];
+    q.fc2_sig_b = L.fc2_sig_b; q.n_fc2_out = (int)L.n_fc2_out;
+    q.ld2 = ld2; q.val_off = L.adv2_ld; q.A = num_actions; q.K = num_atoms;
+    q.support = support; q.fc2_out = ws + L.ws_fc2_out;
+    q.q_out = q_values_out; q.greedy_out = greedy_out; q.vmax_out = vmax_out;
+    q.tickets = reinterpret_cast<int*>(ws + L.ws_scalars + 8);  // 8 ints, zero in a fresh workspace
+    q.tiles0 = (L.adv2_ld + 31) / 32; q.tiles = q.tiles0 + (L.val2_ld + 31) / 32;
+    q.bump = step_counter;
+    hipLaunchKernelGGL(rainbow_act_tail_kernel, dim3((unsigned)q.tiles, (unsigned)batch), dim3(256),
+                       0, s, q);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+  }
   if (fuse) {
     HeadPre pre = {};
     pre.part = ws + L.ws_fc2_part; pre.S = kFc2Splits; pre.rows = batch;

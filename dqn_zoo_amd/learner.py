@@ -89,7 +89,9 @@ class RainbowLearner:
     self._noise_counter = 0
     self._args = None
     self._graphs = {}        # (input pointers, phases, noise flag) -> hipGraphExec
-    self.use_graphs = False  # replay each distinct call signature from a hipGraph
+    # replay each distinct call signature from a hipGraph: True / False, or None =
+    # automatically whenever the current stream allows capture (any non-default stream)
+    self.use_graphs = None
     # False: a full step does not store the fc1 sigma-weight gradient (Adam derives it
     # from the mu-weight gradient and the noise); True: `grad` holds every block
     self.keep_all_grads = False
@@ -275,6 +277,20 @@ class RainbowLearner:
     inside its backward launches -- the caller then must NOT call
     `update_priorities` for this batch.  Needs PHASE_BACKWARD in `phases`."""
     b = self.batch_size
+    stream = torch.cuda.current_stream(self.device).cuda_stream
+    graphs = bool(stream) if self.use_graphs is None else self.use_graphs
+    if graphs and self._args is not None and weights is not None:
+      # fast path: a call signature that was validated and captured before (the
+      # replay hands out the same ring slots over and over) is one graph launch
+      sink = priority_sink if priority_sink is not None else (None,) * 4
+      key = (s_tm1.data_ptr(), s_t.data_ptr(), a_tm1.data_ptr(), r_t.data_ptr(),
+             discount_t.data_ptr(), weights.data_ptr(), phases,
+             int(bool(resample_noise) and bool(phases & _lib.PHASE_FORWARD)),
+             sink[0], sink[3], int(self.keep_all_grads))
+      g = self._graphs.get(key)
+      if g is not None:
+        _lib.check(self._lib.dz_graph_launch(g, stream), 'dz_graph_launch')
+        return
     check_batch(b, s_tm1, a_tm1, r_t, discount_t, s_t, weights)
     if weights is None:
       raise TypeError('weights must be a float32 device tensor')
@@ -320,7 +336,7 @@ class RainbowLearner:
       a.prio_node = None
       a.prio_ids = None
     stream = torch.cuda.current_stream(self.device).cuda_stream
-    if self.use_graphs:
+    if graphs:
       if not stream:
         raise RuntimeError(
             'hipGraph capture needs a non-default stream: run the learner under '
@@ -405,7 +421,7 @@ class DenseLearner:
     self._act_ws = None
     self._act_batch = 0
     self._graphs = {}        # (input pointers, phases, sink) -> hipGraphExec
-    self.use_graphs = False  # replay each distinct call signature from a hipGraph
+    self.use_graphs = None   # True / False / None = whenever the stream allows capture
 
   def get_params(self, which='online') -> dict:
     t = self.online if which == 'online' else self.target
@@ -485,7 +501,7 @@ class DenseLearner:
     stream = torch.cuda.current_stream(self.device).cuda_stream
     enqueue = lambda: _lib.check(self._lib.dz_dense_learn(
         ctypes.byref(a), phases, stream), 'dz_dense_learn')
-    if not self.use_graphs:
+    if not (bool(stream) if self.use_graphs is None else self.use_graphs):
       enqueue()
       return
     # every argument is a pointer or a constant of this object: the launches of

@@ -81,6 +81,7 @@ def main():
       step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+    ln.use_graphs = False   # per-kernel event marks need eager launches
     pk = prof(lib, step)
     print('%-9s %8.1f steps/s  %7.1f us/step  (kernel sum %.1f us)' % (
         name, 1 / dt, dt * 1e6, sum(pk.values())))

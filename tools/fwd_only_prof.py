@@ -9,6 +9,7 @@ A, B = 6, 32
 phases = int(sys.argv[1]) if len(sys.argv) > 1 else _lib.PHASE_FORWARD
 sup = np.linspace(-10, 10, 51).astype(np.float32)
 ln = ll.RainbowLearner(networks.RainbowNetwork(A, sup), ll.AdamConfig(), B)
+ln.use_graphs = False   # per-kernel event marks need eager launches
 g = torch.Generator(device='cuda'); g.manual_seed(0)
 dev = (torch.randint(0, 256, (B, 84, 84, 4), dtype=torch.uint8, device='cuda', generator=g),
        torch.randint(0, A, (B,), device='cuda', generator=g),
