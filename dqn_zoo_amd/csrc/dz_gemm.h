@@ -87,6 +87,16 @@ template <class Op> struct DzNI<Op, decltype((void)Op::NI)> { static constexpr i
 template <class Op, class = void> struct DzRaw16 { static constexpr int v = 0; };
 template <class Op> struct DzRaw16<Op, decltype((void)Op::A_RAW16)> { static constexpr int v = Op::A_RAW16; };
 
+// Optional distributed epilogue (WK > 1, MI = NI = 1): an Op with SPLIT_STORE = 1
+// takes  store(p, t, wm, wn, lane, acc, rmask)  and stores only the accumulator
+// registers r with bit r of rmask set.  All WK waves of a tile then exchange their
+// accumulators through LDS and each finishes 16/WK of the 16 registers (sum over
+// the k-groups in the order 0, 1, .. WK-1, as the single-wave epilogue does), instead
+// of WK-1 waves retiring while wave 0 reads 16 (WK-1) partials and issues all 16
+// row stores.
+template <class Op, class = void> struct DzSplitStore { static constexpr int v = 0; };
+template <class Op> struct DzSplitStore<Op, decltype((void)Op::SPLIT_STORE)> { static constexpr int v = Op::SPLIT_STORE; };
+
 template <int ROWS, int CPS, int LAYOUT>
 struct DzLdsTile {
   static constexpr int LD = (LAYOUT == DZ_KC) ? 20 : ROWS;
@@ -121,7 +131,7 @@ struct DzGemmSmem {
   using AT = DzLdsTile<32 * Op::WM * MI, CPS, Op::A_LAYOUT>;
   using BT = DzLdsTile<32 * Op::WN * NI, CPS, Op::B_LAYOUT>;
   static constexpr int RED =
-      (Op::WK > 1) ? (Op::WK - 1) * Op::WM * Op::WN * MI * NI * 16 * 64 : 0;
+      (Op::WK > 1) ? (Op::WK - (DzSplitStore<Op>::v ? 0 : 1)) * Op::WM * Op::WN * MI * NI * 16 * 64 : 0;
   static constexpr int TILE = AT::ELEMS + BT::ELEMS;
   static constexpr int ELEMS = TILE > RED ? TILE : RED;
 };
@@ -335,6 +345,32 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
     }
   }
 
+  if constexpr (WK > 1 && DzSplitStore<Op>::v && MI == 1 && NI == 1) {
+    __syncthreads();
+    float* red = smem;   // [WK][WM*WN][16][64]
+    constexpr int PER = WM * WN;
+    constexpr int RPW = 16 / WK;   // accumulator registers finished per wave
+    {
+      float* dst = red + ((wk * PER + wm * WN + wn) * 16) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dst[i * 64] = acc[0][0][i];
+    }
+    __syncthreads();
+    f32x16 out;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      out[i] = 0.f;
+      if (i / RPW == wk) {   // wave-uniform
+        const float* src = red + ((wm * WN + wn) * 16 + i) * 64 + lane;
+        float v = src[0];
+#pragma unroll
+        for (int k2 = 1; k2 < WK; ++k2) v += src[(long)k2 * PER * 16 * 64];
+        out[i] = v;
+      }
+    }
+    Op::store(p, t, wm, wn, lane, out, ((1u << RPW) - 1u) << (wk * RPW));
+    return;
+  }
   if constexpr (WK > 1) {
     __syncthreads();
     float* red = smem;

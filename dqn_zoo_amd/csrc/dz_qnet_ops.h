@@ -163,15 +163,16 @@ struct ConvFwdOp {
     const int k = st * BK + c * 16 + kk;
     return dz_ld4(t.w + (long)k * CO + t.n0 + 4 * rq);
   }
+  static constexpr int SPLIT_STORE = 1;
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
-                               int lane, const f32x16& acc) {
+                               int lane, const f32x16& acc, unsigned rmask = 0xffffu) {
     const int col = t.n0 + wn * 32 + (lane & 31);
     const float b = t.bias[col];
     const int rows = p.B * OH * OW;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ml = t.m0 + wm * 32 + dz_acc_row(r, lane);
-      if (ml < rows) {
+      if (((rmask >> r) & 1u) && ml < rows) {
         const float v = acc[r] + b;
         p.out[((long)t.z * rows + ml) * CO + col] = v > 0.f ? v : 0.f;
       }
@@ -322,8 +323,9 @@ struct FcFwdOp {
     }
     return dz_sel4(ok, dz_mul4(v, dz_one_or4(sig, e)));
   }
+  static constexpr int SPLIT_STORE = 0;  // distributed epilogue measured slower for this Op
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
-                               int lane, const f32x16& acc) {
+                               int lane, const f32x16& acc, unsigned rmask = 0xffffu) {
     const FcHead& hd = t.hd;
     const int split = t.z2 >> 8;
     const int col = t.n0 + wn * 32 + (lane & 31);
@@ -333,7 +335,7 @@ struct FcFwdOp {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = t.m0 + wm * 32 + dz_acc_row(r, lane);
-      if (m < p.M) base[(long)m * p.ldo] = acc[r];
+      if (((rmask >> r) & 1u) && m < p.M) base[(long)m * p.ldo] = acc[r];
     }
   }
 };
@@ -457,8 +459,9 @@ struct FcDgradOp {
     }
     return dz_scale4(v, L.sig ? e : 1.f);
   }
+  static constexpr int SPLIT_STORE = 0;  // distributed epilogue measured slower for this Op
   __device__ __forceinline__ static void store(const Params& p, const Tile& t, int wm, int wn,
-                               int lane, const f32x16& acc) {
+                               int lane, const f32x16& acc, unsigned rmask = 0xffffu) {
     const int col = t.n0 + wn * 32 + (lane & 31);
     if (col >= p.K) return;
     float* base = p.part + (long)t.z * p.M * p.ldo + p.x_off + col;
@@ -471,14 +474,14 @@ struct FcDgradOp {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = t.m0 + wm * 32 + dz_acc_row(r, lane);
-        if (m < p.M) base[(long)m * p.ldo] = mv[r] > 0.f ? acc[r] : 0.f;
+        if (((rmask >> r) & 1u) && m < p.M) base[(long)m * p.ldo] = mv[r] > 0.f ? acc[r] : 0.f;
       }
       return;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = t.m0 + wm * 32 + dz_acc_row(r, lane);
-      if (m < p.M) base[(long)m * p.ldo] = acc[r];
+      if (((rmask >> r) & 1u) && m < p.M) base[(long)m * p.ldo] = acc[r];
     }
   }
 };
@@ -734,20 +737,21 @@ struct ConvDgradOp {
     const int kh = (t.z / S) + (tap / TS) * S, kw = (t.z % S) + (tap % TS) * S;
     return dz_ld4(p.w + ((long)(kh * KS + kw) * C + ci) * CO + co);
   }
+  static constexpr int SPLIT_STORE = 0;  // distributed epilogue measured slower for this Op
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
-                               int lane, const f32x16& acc) {
+                               int lane, const f32x16& acc, unsigned rmask = 0xffffu) {
     const int ci = t.n0 + wn * 32 + (lane & 31);
-    // all 16 mask values first (pixel() clamps, so every address is valid): loaded
-    // inside the store loop they are 16 serial load -> wait -> store round trips
+    // all mask values of this wave's rows first (pixel() clamps, so every address is
+    // valid): loaded inside the store loop they are serial load -> wait -> store trips
     unsigned o[16];
     float mk[16];
     bool ok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int img, h, w;
-      ok[r] = pixel(p, t, wm * 32 + dz_acc_row(r, lane), img, h, w);
+      ok[r] = pixel(p, t, wm * 32 + dz_acc_row(r, lane), img, h, w) && ((rmask >> r) & 1u);
       o[r] = (unsigned)(((img * H + h) * W + w) * C + ci);
-      mk[r] = p.act[o[r]];
+      mk[r] = ((rmask >> r) & 1u) ? p.act[o[r]] : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r)
