@@ -59,6 +59,8 @@ class AdamConfig(typing.NamedTuple):
 
 class RainbowLearner:
 
+  MAX_AUTO_GRAPHS = 32   # distinct call signatures the automatic graph mode will capture
+
   def __init__(self, network: networks.RainbowNetwork, optimizer: AdamConfig,
                batch_size: int, seed: int = 1, device=None, params=None):
     self._lib = _lib.load()
@@ -345,6 +347,14 @@ class RainbowLearner:
              a.resample_noise, a.prio_node, a.prio_ids, a.keep_all_grads)
       g = self._graphs.get(key)
       if g is None:
+        if self.use_graphs is None and len(self._graphs) >= self.MAX_AUTO_GRAPHS:
+          # automatic mode met a caller that passes fresh buffers every step: a
+          # graph per call would only grow the cache -- launch eagerly from now on
+          self.drop_graphs()
+          self.use_graphs = False
+          _lib.check(self._lib.dz_rainbow_learn(ctypes.byref(a), phases, stream),
+                     'dz_rainbow_learn')
+          return
         h = ctypes.c_void_p()
         _lib.check(self._lib.dz_rainbow_graph_capture(
             ctypes.byref(a), phases, stream, ctypes.byref(h)),
@@ -510,6 +520,11 @@ class DenseLearner:
            a.prio_node, a.prio_ids)
     g = self._graphs.get(key)
     if g is None:
+      if self.use_graphs is None and len(self._graphs) >= RainbowLearner.MAX_AUTO_GRAPHS:
+        self.drop_graphs()       # fresh buffers every step: stop capturing (see RainbowLearner)
+        self.use_graphs = False
+        enqueue()
+        return
       g = self._graphs[key] = _lib.capture_graph(stream, enqueue)
     _lib.check(self._lib.dz_graph_launch(g, stream), 'dz_graph_launch')
 
@@ -593,7 +608,11 @@ class IqnLearner:
     self.huber_param = float(huber_param)
     self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     self._act_ws = {}
+    self._graphs = {}
+    self.use_graphs = None   # True / False / None = whenever the stream allows capture
 
+  drop_graphs = DenseLearner.drop_graphs
+  __del__ = DenseLearner.__del__
   get_params = DenseLearner.get_params
   set_params = DenseLearner.set_params
   sync_target = DenseLearner.sync_target
@@ -615,9 +634,7 @@ class IqnLearner:
     device tensors; default: drawn on the device."""
     b = self.batch_size
     check_batch(b, s_tm1, a_tm1, r_t, discount_t, s_t)
-    if taus is None:
-      self.sample_taus()
-    else:
+    if taus is not None:
       for dst, src in zip((self.tau_tm1, self.tau_sel, self.tau_t), taus):
         dst.copy_(src)
     a = _lib.IqnArgs()
@@ -644,9 +661,26 @@ class IqnLearner:
     a.lr, a.b1, a.b2 = self.opt.learning_rate, self.opt.b1, self.opt.b2
     a.eps, a.max_norm = self.opt.eps, self.opt.max_global_grad_norm
     a.huber = self.huber_param
-    _lib.check(self._lib.dz_iqn_learn(
-        ctypes.byref(a), phases,
-        torch.cuda.current_stream(self.device).cuda_stream), 'dz_iqn_learn')
+    stream = torch.cuda.current_stream(self.device).cuda_stream
+    def enqueue():
+      if taus is None:
+        self.sample_taus()   # device draw keyed by the optimiser step count: graph-safe
+      _lib.check(self._lib.dz_iqn_learn(ctypes.byref(a), phases, stream), 'dz_iqn_learn')
+
+    graphs = bool(stream) if self.use_graphs is None else self.use_graphs
+    if not graphs or taus is not None:   # caller-supplied taus are copied in per call
+      enqueue()
+      return
+    key = (a.s_tm1, a.s_t, a.a_tm1, a.r_t, a.discount_t, phases)
+    g = self._graphs.get(key)
+    if g is None:
+      if self.use_graphs is None and len(self._graphs) >= RainbowLearner.MAX_AUTO_GRAPHS:
+        self.drop_graphs()
+        self.use_graphs = False
+        enqueue()
+        return
+      g = self._graphs[key] = _lib.capture_graph(stream, enqueue)
+    _lib.check(self._lib.dz_graph_launch(g, stream), 'dz_graph_launch')
 
   def apply(self, states: torch.Tensor, taus: torch.Tensor, which: str = 'online'):
     """(q_dist [B,N,A], q_values [B,A], greedy [B], max [B]) for uint8 states

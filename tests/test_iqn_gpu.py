@@ -175,3 +175,38 @@ def test_iqn_agent_run_loop_and_actor():
   assert 0 <= actor.step(ts) < na
   actor.set_state(actor.get_state())
   actor.reset()
+
+
+def test_iqn_and_dense_learners_replay_from_graphs_bit_identically():
+  """Automatic hipGraph replay (any non-default stream) == eager launches: same
+  parameters after 4 steps, IQN (device tau draws inside the graph) and DQN."""
+  from dqn_zoo_amd import learner as ll, networks
+  rs = np.random.RandomState(3)
+  batch = _batch(rs, 8, scale_r=2.0)
+  dev = _dev(batch)
+
+  def run(make, graphs):
+    ln = make()
+    ln.use_graphs = None if graphs else False
+    prev = torch.cuda.current_stream()
+    torch.cuda.set_stream(torch.cuda.Stream())
+    try:
+      for _ in range(4):
+        ln.step(*dev)
+      torch.cuda.synchronize()
+      assert bool(ln._graphs) == graphs   # pylint: disable=protected-access
+      return ln.online.clone(), ln.opt_m.clone()
+    finally:
+      torch.cuda.set_stream(prev)
+
+  makers = [
+      lambda: ll.IqnLearner(networks.IqnNetwork(A, 64),
+                            ll.AdamConfig(learning_rate=5e-5, eps=0.01 / 32,
+                                          max_global_grad_norm=0.0), 8,
+                            tau_samples=(8, 8, 8), seed=5),
+      lambda: ll.DenseLearner(networks.DenseNetwork('dqn', A), 'q', ll.RmsPropConfig(), 8,
+                              seed=5)]
+  for make in makers:
+    p_g, m_g = run(make, True)
+    p_e, m_e = run(make, False)
+    assert torch.equal(p_g, p_e) and torch.equal(m_g, m_e)
