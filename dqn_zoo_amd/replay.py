@@ -618,8 +618,7 @@ class SumTree:
     return torch.cuda.current_stream(self._device).cuda_stream
 
   def _dev(self, a, dtype):
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))
-                            ).to(self._device)
+    return torch.from_numpy(np.array(a, dtype=dtype, order='C')).to(self._device)
 
   def resize(self, size: int) -> None:
     self._initialize(size, None)
@@ -1228,3 +1227,8 @@ class NStepTransitionAccumulator:
     self._window.clear()
     self._timestep_tm1 = None
     self._a_tm1 = None
+
+
+# The reference's general id distributions (arbitrary ids, removals, capacity
+# growth) for callers that use them directly; the replays above do not.
+from dqn_zoo_amd.distributions import PrioritizedDistribution, UniformDistribution  # noqa: E402,F401  pylint: disable=wrong-import-position
