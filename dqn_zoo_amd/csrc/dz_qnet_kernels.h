@@ -323,7 +323,17 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
   const float* o1 = PRE ? s_rows + sel_group * ld : fc2_out + (long)(sel_group * B + b) * ld;
   float mean_adv = 0.f;
   if (dueling) {
-    for (int a = 0; a < A; ++a) mean_adv += on ? o1[a * K + k] : 0.f;
+    if constexpr (PRE) {   // rows in LDS: the plain loop is the fastest form measured
+      for (int a = 0; a < A; ++a) mean_adv += on ? o1[a * K + k] : 0.f;
+    } else {               // rows in global memory: 8 loads in flight per round, same order
+      for (int a0 = 0; a0 < A; a0 += 8) {
+        float t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = o1[min(a0 + u, A - 1) * K + kk];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mean_adv += (on && a0 + u < A) ? t8[u] : 0.f;
+      }
+    }
     mean_adv /= (float)A;
   }
   const float v1 = (on && dueling) ? o1[NA + k] : 0.f;
@@ -350,7 +360,17 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
   const float* o2 = PRE ? s_rows + tgt_group * ld : fc2_out + (long)(tgt_group * B + b) * ld;
   float mean2 = 0.f;
   if (dueling) {
-    for (int a = 0; a < A; ++a) mean2 += on ? o2[a * K + k] : 0.f;
+    if constexpr (PRE) {   // rows in LDS: the plain loop is the fastest form measured
+      for (int a = 0; a < A; ++a) mean2 += on ? o2[a * K + k] : 0.f;
+    } else {               // rows in global memory: 8 loads in flight per round, same order
+      for (int a0 = 0; a0 < A; a0 += 8) {
+        float t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = o2[min(a0 + u, A - 1) * K + kk];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mean2 += (on && a0 + u < A) ? t8[u] : 0.f;
+      }
+    }
     mean2 /= (float)A;
   }
   const float lg2 = on ? ((dueling ? o2[NA + k] : 0.f) + o2[a_star * K + k] - mean2)
@@ -383,7 +403,17 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
   const float* o0 = PRE ? s_rows : fc2_out + (long)(0 * B + b) * ld;
   float mean0 = 0.f;
   if (dueling) {
-    for (int a = 0; a < A; ++a) mean0 += on ? o0[a * K + k] : 0.f;
+    if constexpr (PRE) {   // rows in LDS: the plain loop is the fastest form measured
+      for (int a = 0; a < A; ++a) mean0 += on ? o0[a * K + k] : 0.f;
+    } else {               // rows in global memory: 8 loads in flight per round, same order
+      for (int a0 = 0; a0 < A; a0 += 8) {
+        float t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = o0[min(a0 + u, A - 1) * K + kk];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mean0 += (on && a0 + u < A) ? t8[u] : 0.f;
+      }
+    }
     mean0 /= (float)A;
   }
   const float lg0 = on ? ((dueling ? o0[NA + k] : 0.f) + o0[a0 * K + k] - mean0)
