@@ -334,7 +334,7 @@ extern "C" int dz_dense_apply(int num_actions, int num_outputs, int shared_bias,
     DZ_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)num_outputs * sizeof(float), ws + L.ws_out,
                                   (size_t)L.fc2_ld * sizeof(float),
                                   (size_t)num_outputs * sizeof(float), batch,
-                                  hipMemcpyDeviceToDevice, s));
+                                  hipMemcpyDefault, s));  // `out` may be pinned host memory
   if (q_values_out) {
     DZ_REQUIRE(num_outputs == num_actions);
     hipLaunchKernelGGL(dense_q_values_kernel, dim3((batch + 63) / 64), dim3(64), 0, s,

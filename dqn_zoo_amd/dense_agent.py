@@ -131,30 +131,19 @@ class DenseAgent(parts.Agent):
     outputs copied to pinned host memory asynchronously; the host part (Q-values,
     the policy's RNG draw) runs when `step()` resolves the action, after the rest
     of the frame's device work has been queued."""
-    out, _, _, _ = self._learner.apply(self._obs.upload(timestep.observation))
-    return parts.PendingAction(self._deferred_policy(out[0], self.exploration_epsilon))
+    read = self._learner.head_async(self._obs.upload(timestep.observation))
+    return parts.PendingAction(self._deferred_policy(read, self.exploration_epsilon))
 
-  def _deferred_policy(self, head_row, epsilon):
-    import torch  # pylint: disable=import-outside-toplevel
-    host = getattr(self, '_act_host', None)
-    if host is None or host.shape[1] != head_row.numel():
-      host = self._act_host = torch.empty((8, head_row.numel()),
-                                          dtype=torch.float32).pin_memory()
-      self._act_events = [torch.cuda.Event() for _ in range(8)]
-      self._act_pos = 0
-    k = self._act_pos % 8
-    self._act_pos += 1
-    slot, ev = host[k], self._act_events[k]
-    slot.copy_(head_row, non_blocking=True)
-    ev.record(torch.cuda.current_stream(self._device))
+  def _deferred_policy(self, read_head, epsilon):
+    """`read_head() -> host array` of head outputs (or of Q-values, IQN); the
+    policy's host part runs when the action is resolved."""
 
-    def read():
-      ev.synchronize()   # the acting launches + this copy, not the learner step behind
-      q = self.q_values(slot.numpy().copy())
+    def resolve():
+      q = self.q_values(read_head())
       a_t = epsilon_greedy_sample(q, epsilon, self._policy_rng)
       return a_t, float(np.max(q))
 
-    return read
+    return resolve
 
   def _learn(self) -> None:
     ln = self._learner

@@ -128,7 +128,21 @@ class Iqn(dense_agent.DenseAgent):
     _, q, _, _ = ln.apply(obs_d, self._act_taus)
     # Q-values to pinned host memory asynchronously; epsilon-greedy on the host when
     # step() resolves the action (dense_agent.DenseAgent._deferred_policy)
-    return parts.PendingAction(self._deferred_policy(q[0], self.exploration_epsilon))
+    if getattr(self, '_q_host', None) is None:
+      self._q_host = torch.empty((8, q.shape[1]), dtype=torch.float32).pin_memory()
+      self._q_events = [torch.cuda.Event() for _ in range(8)]
+      self._q_pos = 0
+    k = self._q_pos % 8
+    self._q_pos += 1
+    slot, ev = self._q_host[k], self._q_events[k]
+    slot.copy_(q[0], non_blocking=True)
+    ev.record(torch.cuda.current_stream(self._device))
+
+    def read():
+      ev.synchronize()
+      return slot.numpy().copy()
+
+    return parts.PendingAction(self._deferred_policy(read, self.exploration_epsilon))
 
   def q_values(self, head_out):   # the IQN apply already returns sample-mean Q-values
     return head_out

@@ -532,12 +532,60 @@ class DenseLearner:
     graphs, self._graphs = self._graphs, {}
     for g in graphs.values():
       self._lib.dz_graph_destroy(g)
+    heads, self._head_graphs = getattr(self, '_head_graphs', {}), {}
+    for g in heads.values():
+      self._lib.dz_graph_destroy(g)
 
   def __del__(self):
     try:
       self.drop_graphs()
     except Exception:  # pylint: disable=broad-except
       pass
+
+  ACT_RING = 8
+
+  def head_async(self, states: torch.Tensor):
+    """Acting apply for ONE state: the head outputs go straight to a pinned host
+    slot (the copy-out of dz_dense_apply targets it), nothing synchronises here, and
+    the launches replay from a hipGraph per (state buffer, slot) pair when the stream
+    allows capture.  Returns `read() -> float32 [num_outputs]` (host array), which
+    waits for these launches only."""
+    if int(states.shape[0]) != 1:
+      raise ValueError('head_async takes one state')
+    net = self.network
+    if getattr(self, '_head_host', None) is None:
+      self._head_host = torch.empty((self.ACT_RING, net.num_outputs),
+                                    dtype=torch.float32).pin_memory()
+      self._head_events = [torch.cuda.Event() for _ in range(self.ACT_RING)]
+      self._head_graphs = {}
+      self._head_pos = 0
+    if self._act_batch != 1:
+      self._act_ws = torch.zeros(net.layout(1, 1).ws_count, dtype=torch.float32,
+                                 device=self.device)
+      self._act_batch = 1
+    k = self._head_pos % self.ACT_RING
+    self._head_pos += 1
+    slot, ev = self._head_host[k], self._head_events[k]
+    stream = torch.cuda.current_stream(self.device).cuda_stream
+    enqueue = lambda: _lib.check(self._lib.dz_dense_apply(
+        net.num_actions, net.num_outputs, int(net.shared_bias), 1, self.online.data_ptr(),
+        states.data_ptr(), self._act_ws.data_ptr(), slot.data_ptr(), None, None, None,
+        stream), 'dz_dense_apply')
+    if stream:
+      key = (states.data_ptr(), k)
+      g = self._head_graphs.get(key)
+      if g is None:
+        g = self._head_graphs[key] = _lib.capture_graph(stream, enqueue)
+      _lib.check(self._lib.dz_graph_launch(g, stream), 'dz_graph_launch')
+    else:
+      enqueue()
+    ev.record(torch.cuda.current_stream(self.device))
+
+    def read():
+      ev.synchronize()
+      return slot.numpy().copy()
+
+    return read
 
   def apply(self, states: torch.Tensor, which: str = 'online'):
     """Head outputs [B, num_outputs] for uint8 states; for Q heads also

@@ -34,12 +34,27 @@ class Env:
 
 def main():
   frames = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+  which = sys.argv[2] if len(sys.argv) > 2 else 'rainbow'
   torch.cuda.set_stream(torch.cuda.Stream())
-  rep = replay_lib.PrioritizedTransitionReplay(
-      100000, replay_lib.Transition(None, None, None, None, None), 0.5,
-      parts.LinearSchedule(begin_t=2000, end_t=10 ** 7, begin_value=0.4, end_value=1.0),
-      1e-3, True, np.random.RandomState(1))
-  ag = agent_lib.Rainbow(
+  if which == 'dqn':
+    from dqn_zoo_amd.dqn import agent as dqn_lib
+    rep = replay_lib.TransitionReplay(
+        100000, replay_lib.Transition(None, None, None, None, None), np.random.RandomState(1))
+    ag = dqn_lib.Dqn(
+        preprocessor=processors.Identity(), sample_network_input=np.zeros((84, 84, 4), np.uint8),
+        network=networks.DenseNetwork('dqn', A), optimizer=learner.RmsPropConfig(),
+        transition_accumulator=replay_lib.TransitionAccumulator(), replay=rep, batch_size=32,
+        exploration_epsilon=lambda t: 0.1, min_replay_capacity_fraction=0.005, learn_period=4,
+        target_network_update_period=2000, rng_key=1, grad_error_bound=1.0 / 32)
+    add_name = 'add'
+  else:
+    add_name = 'add_with_device_priority'
+    rep = replay_lib.PrioritizedTransitionReplay(
+        100000, replay_lib.Transition(None, None, None, None, None), 0.5,
+        parts.LinearSchedule(begin_t=2000, end_t=10 ** 7, begin_value=0.4, end_value=1.0),
+        1e-3, True, np.random.RandomState(1))
+  if which != 'dqn':
+   ag = agent_lib.Rainbow(
       preprocessor=processors.Identity(),
       sample_network_input=np.zeros((84, 84, 4), np.uint8),
       network=networks.RainbowNetwork(A, SUPPORT, 0.1), support=SUPPORT,
@@ -57,7 +72,7 @@ def main():
       acc[key] += time.perf_counter() - t0
       return r
     setattr(obj, name, g)
-  wrap(ag, '_act', 'act'); wrap(ag, '_learn', 'learn'); wrap(rep, 'add_with_device_priority', 'add')
+  wrap(ag, '_act', 'act'); wrap(ag, '_learn', 'learn'); wrap(rep, add_name, 'add')
   env = Env(3)
   loop = parts.run_loop(ag, env, max_steps_per_episode=0)
   for _ in range(1000):   # fill past min replay, warm up
@@ -69,7 +84,7 @@ def main():
     next(loop)
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
-  print('agent loop: %.0f agent steps/s (%.1f us/step); per step: act %.1f us, add %.1f us, '
+  print(which + ' agent loop: %.0f agent steps/s (%.1f us/step); per step: act %.1f us, add %.1f us, '
         'learn(enqueue, every 4th) %.1f us, other %.1f us' % (
             frames / dt, 1e6 * dt / frames, 1e6 * acc['act'] / frames, 1e6 * acc['add'] / frames,
             1e6 * acc['learn'] / frames,
