@@ -1,3 +1,7 @@
+#include <cstring>
+#include <map>
+#include <vector>
+#include <algorithm>
 // Micro-benchmark / prototype bench for the weights-stationary forward convolution
 // (tools only, not part of the library).  Builds against the library's headers so
 // that the shipped ConvFwdOp kernels can be timed and used as the reference.
@@ -16,10 +20,82 @@ void dz_prof_pair(int, int, hipStream_t) {}
 void dz_prof_mark(hipStream_t, const char*) {}
 
 #include "gemm_body_var.inc"
+__device__ unsigned long long g_stamp[8192 * 8];
+#define DZ_PATCH_STAMP(i) do { if ((threadIdx.x & 63) == 0) g_stamp[((blockIdx.x + gridDim.x * blockIdx.y) * 4 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); } while (0)
+#include "dz_conv_patch.h"
+using Conv1Patch = ConvPatchFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 2, 1, 2, 2>;
+using Conv2Patch = ConvPatchFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4, 2>;
+using Conv3Patch = ConvPatchFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4, 3>;
+template <class Op>
+__global__ __launch_bounds__(256) void conv_patch_kernel(typename Op::Params p) {
+  __shared__ __attribute__((aligned(16))) float smem[Op::SMEM_ELEMS];
+  Op::body(p, dim3(blockIdx.x, blockIdx.y, blockIdx.z), smem);
+}
+
+// per-workgroup trace: where it ran and when (100 MHz wall clock)
+__device__ unsigned long long g_trace[8192 * 4];
+template <class Op>
+__global__ __launch_bounds__(256) void gemm_trace(typename Op::Params p) {
+  __shared__ __attribute__((aligned(16))) float smem[DzGemmSmem<Op>::ELEMS];
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned long long t0 = wall_clock64();
+  dz_gemm_body<Op>(p, dim3(blockIdx.x, blockIdx.y, blockIdx.z), smem);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_trace[lin * 4 + 0] = hw; g_trace[lin * 4 + 1] = xcc;
+    g_trace[lin * 4 + 2] = t0; g_trace[lin * 4 + 3] = wall_clock64();
+  }
+}
+template <class Op>
+static void show_trace(const char* name, dim3 g, typename Op::Params p) {
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_trace<Op>), g, dim3(256), 0, 0, p);
+  (void)hipDeviceSynchronize();
+  const int n = g.x * g.y * g.z;
+  std::vector<unsigned long long> t(n * 4);
+  (void)hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_trace), n * 32);
+  unsigned long long tmin = ~0ull, tmax = 0;
+  for (int i = 0; i < n; ++i) { tmin = std::min(tmin, t[4 * i + 2]); tmax = std::max(tmax, t[4 * i + 3]); }
+  std::map<unsigned, std::vector<int>> cus;
+  double dsum = 0, smax = 0;
+  for (int i = 0; i < n; ++i) {
+    const unsigned hw = (unsigned)t[4 * i], xcc = (unsigned)t[4 * i + 1] & 15;
+    const unsigned cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+    cus[(xcc << 12) | (se << 8) | (sh << 4) | cu].push_back(i);
+    dsum += (t[4 * i + 3] - t[4 * i + 2]) * 0.01;
+    smax = std::max(smax, (t[4 * i + 2] - tmin) * 0.01);
+  }
+  std::map<int, int> hist;
+  for (auto& kv : cus) hist[(int)kv.second.size()]++;
+  printf("%s: %d WGs on %zu CUs; first start -> last end %.2f us; mean WG duration %.2f us; latest start +%.2f us\n",
+         name, n, cus.size(), (tmax - tmin) * 0.01, dsum / n, smax);
+  printf("  WGs per CU histogram:");
+  for (auto& kv : hist) printf("  %d:%d", kv.first, kv.second);
+  printf("\n");
+  int shown = 0;
+  for (auto& kv : cus) {
+    if (shown++ >= 6) break;
+    printf("  cu %05x:", kv.first);
+    for (int i : kv.second) printf("  wg%-4d [%5.2f..%5.2f]", i, (t[4 * i + 2] - tmin) * 0.01, (t[4 * i + 3] - tmin) * 0.01);
+    printf("\n");
+  }
+}
+
 template <class Op, int MASK>
 __global__ __launch_bounds__(256) void gemm_var(typename Op::Params p) {
   __shared__ __attribute__((aligned(16))) float smem[DzGemmSmem<Op>::ELEMS];
   gemm_body_var<Op, MASK>(p, dim3(blockIdx.x, blockIdx.y, blockIdx.z), smem);
+}
+// staggered start: workgroups of the second "round" (linear id >= 256: the ones that
+// share a CU with a first-round workgroup) begin SLEEP x 64 cycles later
+template <class Op, int SLEEP>
+__global__ __launch_bounds__(256) void gemm_stagger(typename Op::Params p) {
+  __shared__ __attribute__((aligned(16))) float smem[DzGemmSmem<Op>::ELEMS];
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if ((lin >> 8) & 1) { for (int i = 0; i < SLEEP; ++i) __builtin_amdgcn_s_sleep(15); }
+  dz_gemm_body<Op>(p, dim3(blockIdx.x, blockIdx.y, blockIdx.z), smem);
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %d at %s:%d\n", (int)e, __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -112,7 +188,60 @@ float time_us(F f, int iters = 200) {
   return ms * 1e3f / iters;
 }
 
-int main() {
+static size_t count_diff(const float* d_a, const float* d_b, size_t n) {
+  std::vector<float> a(n), b(n);
+  CK(hipMemcpy(a.data(), d_a, n * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(b.data(), d_b, n * 4, hipMemcpyDeviceToHost));
+  size_t bad = 0, nz = 0;
+  for (size_t i = 0; i < n; ++i) { bad += memcmp(&a[i], &b[i], 4) != 0; nz += a[i] != 0.f; }
+  printf("    (%zu outputs, %.1f%% nonzero)", n, 100.0 * nz / n);
+  return bad;
+}
+template <class T>
+static void fill_dev(T* d, size_t n, int kind) {  // 0: activations >= 0 with zeros, 1: weights, 2: bytes
+  std::vector<T> h(n);
+  for (auto& v : h) v = kind == 2 ? (T)(rand() & 255) : kind == 1 ? (T)(((rand() % 2000) - 1000) / 22627.0f)
+                                  : (T)((rand() % 1000) / 1000.0f * ((rand() & 3) ? 1.f : 0.f));
+  CK(hipMemcpy(d, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+}
+template <class Ref, class New>
+static void patch_vs_gemm(const char* name, dim3 g, ConvFwdParams p, size_t n_out) {
+  float* d_alt; CK(hipMalloc(&d_alt, n_out * 4)); CK(hipMemset(d_alt, 0xff, n_out * 4));
+  float* d_ref = p.out;
+  hipLaunchKernelGGL((dz_mfma_gemm<Ref>), g, dim3(256), 0, 0, p);
+  ConvFwdParams q = p; q.out = d_alt;
+  hipLaunchKernelGGL((conv_patch_kernel<New>), g, dim3(256), 0, 0, q);
+  CK(hipDeviceSynchronize());
+  printf("%s patch kernel: LDS %d B", name, New::SMEM_ELEMS * 4);
+  const size_t bad = count_diff(d_ref, d_alt, n_out);
+  printf(" differing outputs %zu\n", bad);
+  auto fr = [&]() { hipLaunchKernelGGL((dz_mfma_gemm<Ref>), g, dim3(256), 0, 0, p); };
+  auto fn = [&]() { hipLaunchKernelGGL((conv_patch_kernel<New>), g, dim3(256), 0, 0, q); };
+  printf("%s implicit GEMM %.2f us   patch-in-LDS %.2f us\n", name, time_us(fr), time_us(fn));
+  CK(hipDeviceSynchronize());
+  hipLaunchKernelGGL((conv_patch_kernel<New>), g, dim3(256), 0, 0, q);
+  CK(hipDeviceSynchronize());
+  {
+    const int nw = g.x * g.y * 4;
+    std::vector<unsigned long long> st(nw * 8);
+    CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamp), (size_t)nw * 64));
+    unsigned long long t0 = ~0ull;
+    for (int i = 0; i < nw; ++i) t0 = std::min(t0, st[i * 8]);
+    double mean[7] = {0};
+    for (int i = 0; i < nw; ++i) for (int k = 0; k < 7; ++k) mean[k] += (st[i * 8 + k] - t0) * 0.01 / nw;
+    printf("  mean stamps (us from first start): start %.2f | loads issued %.2f | patch in LDS %.2f | barrier %.2f | MFMA done %.2f | exchanged %.2f | stored %.2f\n",
+           mean[0], mean[1], mean[2], mean[3], mean[4], mean[5], mean[6]);
+    for (int w : {0, 1, nw / 2, nw - 1}) {
+      printf("  wave %4d:", w);
+      for (int k = 0; k < 7; ++k) printf(" %.2f", (st[w * 8 + k] - t0) * 0.01);
+      printf("\n");
+    }
+  }
+  CK(hipFree(d_alt));
+}
+
+int main(int argc, char**) {
+  const bool full = argc > 1;  // any argument: also the ablations and traces
   const int G = 3, B = 32;
   // conv2 geometry
   const int imgs = G * B, rows = imgs * 81;
@@ -154,16 +283,71 @@ int main() {
   printf("conv2 shipped kernel : %.2f us\n", time_us(run_ref));
   printf("conv2 weights-stationary (%d WGs): %.2f us\n", wgs, time_us(run_new));
   const dim3 g2(64 / Conv2Fwd::BN, G * Conv2Fwd::tiles_per_group(B), 1);
+  patch_vs_gemm<Conv2Fwd, Conv2Patch>("conv2", g2, p, (size_t)rows * 64);
 #define ABL(MASK, label) { auto f = [&]() { hipLaunchKernelGGL((gemm_var<Conv2Fwd, MASK>), g2, dim3(256), 0, 0, p); }; printf("conv2 %-40s %.2f us\n", label, time_us(f)); }
-  ABL(0, "copy of shipped");
-  ABL(1, "no global loads");
-  ABL(8, "no output store");
-  ABL(4, "no MFMA (VALU instead)");
-  ABL(2, "no LDS / barriers");
-  ABL(3, "no loads, no LDS");
-  ABL(7, "no loads, no LDS, no MFMA");
-  ABL(15, "nothing (launch + tile setup)");
-  ABL(11, "MFMA only");
+  if (full) ABL(0, "copy of shipped");
+  if (full) ABL(1, "no global loads");
+  if (full) ABL(8, "no output store");
+  if (full) ABL(4, "no MFMA (VALU instead)");
+  if (full) ABL(2, "no LDS / barriers");
+  if (full) ABL(3, "no loads, no LDS");
+  if (full) ABL(7, "no loads, no LDS, no MFMA");
+  if (full) ABL(15, "nothing (launch + tile setup)");
+  if (full) ABL(11, "MFMA only");
+  if (full) ABL(16, "no A (im2col) loads");
+  if (full) ABL(32, "no B (weight) loads");
+#define STG2(S) { auto f = [&]() { hipLaunchKernelGGL((gemm_stagger<Conv2Fwd, S>), g2, dim3(256), 0, 0, p); }; printf("conv2 stagger %d x 960 cycles: %.2f us\n", S, time_us(f)); }
+  if (full) { STG2(0); STG2(2); }
+  if (full) show_trace<Conv2Fwd>("conv2", g2, p);
   { auto f = [&]() { hipLaunchKernelGGL((gemm_var<Conv2Fwd, 15>), dim3(1), dim3(64), 0, 0, p); }; printf("one-wave empty launch: %.2f us\n", time_us(f)); }
+  {  // ---- conv1 forward (u8 input) ablation ----
+    const int imgs1 = G * B;
+    uint8_t* d_u8; float* d_w1; float* d_b1; float* d_o1;
+    CK(hipMalloc(&d_u8, (size_t)imgs1 * 84 * 84 * 4)); CK(hipMalloc(&d_w1, 256 * 32 * 4));
+    CK(hipMalloc(&d_b1, 128)); CK(hipMalloc(&d_o1, (size_t)imgs1 * 400 * 32 * 4));
+    fill_dev(d_u8, (size_t)imgs1 * 84 * 84 * 4, 2); fill_dev(d_w1, 256 * 32, 1); fill_dev(d_b1, 32, 1);
+    ConvFwdParams p1;
+    for (int g = 0; g < G; ++g) { p1.in[g] = d_u8; p1.in_img_base[g] = g * B; p1.w[g] = d_w1; p1.bias[g] = d_b1; }
+    p1.out = d_o1; p1.B = B; p1.G = G;
+    const dim3 g1(32 / Conv1Fwd::BN, G * Conv1Fwd::tiles_per_group(B), 1);
+    patch_vs_gemm<Conv1Fwd, Conv1Patch>("conv1", g1, p1, (size_t)imgs1 * 400 * 32);
+#define ABL1(MASK, label) { auto f = [&]() { hipLaunchKernelGGL((gemm_var<Conv1Fwd, MASK>), g1, dim3(256), 0, 0, p1); }; printf("conv1 %-40s %.2f us\n", label, time_us(f)); }
+    if (full) ABL1(0, "copy of shipped");
+    if (full) ABL1(1, "no global loads");
+    if (full) ABL1(8, "no output store");
+    if (full) ABL1(4, "no MFMA (VALU instead)");
+    if (full) ABL1(2, "no LDS / barriers (no u8 conversion)");
+    if (full) ABL1(11, "MFMA only");
+    if (full) ABL1(15, "nothing");
+    if (full) ABL1(16, "no A (u8 im2col) loads");
+    if (full) ABL1(32, "no B (weight) loads");
+#define STG1(S) { auto f = [&]() { hipLaunchKernelGGL((gemm_stagger<Conv1Fwd, S>), g1, dim3(256), 0, 0, p1); }; printf("conv1 stagger %d x 960 cycles: %.2f us\n", S, time_us(f)); }
+    if (full) { STG1(0); STG1(2); }
+    if (full) show_trace<Conv1Fwd>("conv1", g1, p1);
+  }
+  {  // ---- conv3 forward ablation ----
+    const int rows3 = G * B * 49;
+    float *d_i3, *d_w3, *d_b3, *d_o3;
+    CK(hipMalloc(&d_i3, (size_t)G * B * 81 * 64 * 4)); CK(hipMalloc(&d_w3, 576 * 64 * 4));
+    CK(hipMalloc(&d_b3, 256)); CK(hipMalloc(&d_o3, (size_t)rows3 * 64 * 4));
+    fill_dev(d_i3, (size_t)G * B * 81 * 64, 0); fill_dev(d_w3, 576 * 64, 1); fill_dev(d_b3, 64, 1);
+    ConvFwdParams p3;
+    for (int g = 0; g < G; ++g) { p3.in[g] = d_i3; p3.in_img_base[g] = g * B; p3.w[g] = d_w3; p3.bias[g] = d_b3; }
+    p3.out = d_o3; p3.B = B; p3.G = G;
+    const dim3 g3(64 / Conv3Fwd::BN, G * Conv3Fwd::tiles_per_group(B), 1);
+    patch_vs_gemm<Conv3Fwd, Conv3Patch>("conv3", g3, p3, (size_t)rows3 * 64);
+#define ABL3(MASK, label) { auto f = [&]() { hipLaunchKernelGGL((gemm_var<Conv3Fwd, MASK>), g3, dim3(256), 0, 0, p3); }; printf("conv3 %-40s %.2f us\n", label, time_us(f)); }
+    if (full) ABL3(0, "copy of shipped");
+    if (full) ABL3(1, "no global loads");
+    if (full) ABL3(8, "no output store");
+    if (full) ABL3(4, "no MFMA");
+    if (full) ABL3(2, "no LDS / barriers");
+    if (full) ABL3(11, "MFMA only");
+    if (full) ABL3(16, "no A (im2col) loads");
+    if (full) ABL3(32, "no B (weight) loads");
+#define STG3(S) { auto f = [&]() { hipLaunchKernelGGL((gemm_stagger<Conv3Fwd, S>), g3, dim3(256), 0, 0, p3); }; printf("conv3 stagger %d x 960 cycles: %.2f us\n", S, time_us(f)); }
+    if (full) { STG3(0); STG3(2); }
+    if (full) show_trace<Conv3Fwd>("conv3", g3, p3);
+  }
   return 0;
 }
