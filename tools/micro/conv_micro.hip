@@ -240,6 +240,13 @@ static void patch_vs_gemm(const char* name, dim3 g, ConvFwdParams p, size_t n_ou
   CK(hipFree(d_alt));
 }
 
+template <class Op>
+static void sweep_one(const char* name, ConvFwdParams p, int CO, int G, int B) {
+  const dim3 g(CO / Op::BN, G * Op::tiles_per_group(B), 1);
+  auto f = [&]() { hipLaunchKernelGGL((dz_mfma_gemm<Op>), g, dim3(256), 0, 0, p); };
+  printf("  %-28s %4d WGs  LDS %6d B  %.2f us\n", name, g.x * g.y, (int)DzGemmSmem<Op>::ELEMS * 4, time_us(f));
+}
+
 int main(int argc, char**) {
   const bool full = argc > 1;  // any argument: also the ablations and traces
   const int G = 3, B = 32;
@@ -284,6 +291,9 @@ int main(int argc, char**) {
   printf("conv2 weights-stationary (%d WGs): %.2f us\n", wgs, time_us(run_new));
   const dim3 g2(64 / Conv2Fwd::BN, G * Conv2Fwd::tiles_per_group(B), 1);
   patch_vs_gemm<Conv2Fwd, Conv2Patch>("conv2", g2, p, (size_t)rows * 64);
+  printf("conv2 tile sweep <WM,WN,WK,KT>:\n");
+#define SW2(a, b, c_, d) sweep_one<ConvFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, a, b, c_, d>>("<" #a "," #b "," #c_ "," #d ">", p, 64, G, B)
+  SW2(1, 1, 4, 2); SW2(1, 1, 4, 1); SW2(1, 1, 4, 4); SW2(1, 2, 2, 2); SW2(1, 2, 2, 4); SW2(2, 1, 2, 2); SW2(2, 1, 2, 4); SW2(2, 2, 1, 2); SW2(2, 2, 1, 4); SW2(1, 2, 2, 1);
 #define ABL(MASK, label) { auto f = [&]() { hipLaunchKernelGGL((gemm_var<Conv2Fwd, MASK>), g2, dim3(256), 0, 0, p); }; printf("conv2 %-40s %.2f us\n", label, time_us(f)); }
   if (full) ABL(0, "copy of shipped");
   if (full) ABL(1, "no global loads");
@@ -311,6 +321,9 @@ int main(int argc, char**) {
     p1.out = d_o1; p1.B = B; p1.G = G;
     const dim3 g1(32 / Conv1Fwd::BN, G * Conv1Fwd::tiles_per_group(B), 1);
     patch_vs_gemm<Conv1Fwd, Conv1Patch>("conv1", g1, p1, (size_t)imgs1 * 400 * 32);
+    printf("conv1 tile sweep <WM,WN,WK,KT>:\n");
+#define SW1(a, b, c_, d) sweep_one<ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, a, b, c_, d>>("<" #a "," #b "," #c_ "," #d ">", p1, 32, G, B)
+    SW1(2, 1, 2, 2); SW1(2, 1, 2, 1); SW1(2, 1, 2, 4); SW1(1, 1, 4, 1); SW1(1, 1, 4, 2); SW1(1, 1, 4, 4); SW1(4, 1, 1, 2); SW1(4, 1, 1, 4); SW1(4, 1, 1, 1);
 #define ABL1(MASK, label) { auto f = [&]() { hipLaunchKernelGGL((gemm_var<Conv1Fwd, MASK>), g1, dim3(256), 0, 0, p1); }; printf("conv1 %-40s %.2f us\n", label, time_us(f)); }
     if (full) ABL1(0, "copy of shipped");
     if (full) ABL1(1, "no global loads");
@@ -336,6 +349,9 @@ int main(int argc, char**) {
     p3.out = d_o3; p3.B = B; p3.G = G;
     const dim3 g3(64 / Conv3Fwd::BN, G * Conv3Fwd::tiles_per_group(B), 1);
     patch_vs_gemm<Conv3Fwd, Conv3Patch>("conv3", g3, p3, (size_t)rows3 * 64);
+    printf("conv3 tile sweep <WM,WN,WK,KT>:\n");
+#define SW3(a, b, c_, d) sweep_one<ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, a, b, c_, d>>("<" #a "," #b "," #c_ "," #d ">", p3, 64, G, B)
+    SW3(1, 1, 4, 3); SW3(1, 1, 4, 1); SW3(1, 2, 2, 3); SW3(1, 2, 2, 2); SW3(1, 2, 2, 6); SW3(2, 1, 2, 3); SW3(2, 1, 2, 6); SW3(2, 2, 1, 3); SW3(2, 2, 1, 6); SW3(1, 2, 2, 1);
 #define ABL3(MASK, label) { auto f = [&]() { hipLaunchKernelGGL((gemm_var<Conv3Fwd, MASK>), g3, dim3(256), 0, 0, p3); }; printf("conv3 %-40s %.2f us\n", label, time_us(f)); }
     if (full) ABL3(0, "copy of shipped");
     if (full) ABL3(1, "no global loads");
