@@ -216,7 +216,7 @@ def dense_kernel_work(b, g, a=NUM_ACTIONS):
   w['conv2_fwd'] = (f(g * b * 81, 64, 512), g * b * (12800 + 5184) * 4)
   w['conv3_fwd'] = (f(g * b * 49, 64, 576), g * b * (5184 + 3136) * 4)
   w['fc1_fwd'] = (f(g * b, 512, 3136), sets * 3136 * 512 * 4)
-  w['fc2_fwd'] = (f(g * b, a, 512), sets * 512 * a * 4)
+  w['head+loss'] = (f(g * b, a, 512), sets * 512 * a * 4 + 32 * g * b * 512 * 4)  # slab sums + second layer + TD loss
   w['fc1_wgrad+dgrad'] = (f(3136, 512, b) + f(b, 3136, 512), 2 * 3136 * 512 * 4)
   w['fc2_wgrad+dgrad'] = (f(512, a, b) + f(b, 512, a), 2 * 512 * a * 4)
   w['conv3_wgrad+dgrad'] = (f(576, 64, b * 49) + f(b * 81, 64, 576),

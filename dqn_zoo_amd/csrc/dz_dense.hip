@@ -65,8 +65,13 @@ static void dense_heads(const dz_dense_layout_t& L, FcHead& h1, FcHead& h2) {
 }
 
 // torso + head for G groups; outputs in ws_out rows [G*B][fc2_ld].
+// `head`: narrow Q heads (num_outputs <= 32) finish in ONE launch after the fc1 weight
+// stream (dense_head_kernel: fc1 epilogue + second layer + TD loss or q-values); the
+// caller presets the mode-specific fields, the common ones are filled in here.
+static inline bool dense_head_fused(const dz_dense_layout_t& L) { return L.num_outputs <= 32; }
 static int dense_forward(const dz_dense_layout_t& L, int G, int B, const float* const* prm,
-                         const uint8_t* const* in, float* ws, hipStream_t s) {
+                         const uint8_t* const* in, float* ws, hipStream_t s,
+                         DenseHeadParams* head = nullptr) {
   int rc;
   const float* zeros = ws + L.ws_zeros;
   FcHead h1, h2;
@@ -103,6 +108,19 @@ static int dense_forward(const dz_dense_layout_t& L, int G, int B, const float* 
       if (rc) return rc;
     }
     DZ_PROF(s, "fc1_fwd");
+    if (head && dense_head_fused(L)) {
+      DenseHeadParams& q = *head;
+      DZ_REQUIRE(G < 3 || p3[2] == p3[0]);  // the kernel reads groups 0 and 2 from one set
+      q.part = ws + L.ws_fc1_part; q.S = kS_dfc1; q.rows = G * B; q.B = B; q.G = G;
+      for (int g = 0; g < 3; ++g) q.prm[g] = p3[g];
+      q.fc1_b = L.fc1_b; q.fc2_w = L.fc2_w; q.fc2_b = L.fc2_b; q.ld2 = L.fc2_ld;
+      q.N = L.num_outputs; q.bias_shared = L.shared_bias;
+      q.h1 = ws + L.ws_h1; q.out = ws + L.ws_out;
+      hipLaunchKernelGGL(dense_head_kernel, dim3(B), dim3(512), 0, s, q);
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, q.mode == 1 ? "head+loss" : "head");
+      return DZ_OK;
+    }
     hipLaunchKernelGGL(fc_epilogue_kernel, dim3(kHid / 64, G * B), dim3(256), 0, s,
                        ws + L.ws_fc1_part, kS_dfc1, G * B, kHid, kHid, B, p3[0], p3[1],
                        p3[2], (long)L.fc1_b, (long)-1, zeros, zeros, zeros, 0, 1,
@@ -160,10 +178,24 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
   if (g_dz_prof_on) dz_prof_begin(s);
 
   if (phases & DZ_PHASE_FORWARD) {
-    rc = dense_forward(L, G, B, prm, in, ws, s);
-    if (rc) return rc;
     float* out = ws + L.ws_out;
     float* dout = ws + L.ws_dout;
+    const bool q_loss = a->loss == DZ_LOSS_Q || a->loss == DZ_LOSS_DOUBLE_Q;
+    DenseHeadParams hp = {};
+    if (q_loss && dense_head_fused(L)) {
+      hp.mode = 1; hp.sel_group = a->loss == DZ_LOSS_DOUBLE_Q ? 2 : 1; hp.tgt_group = 1;
+      hp.a_tm1 = a->a_tm1; hp.r_t = a->r_t; hp.d_t = a->discount_t; hp.weights = a->weights;
+      hp.bound = a->grad_error_bound; hp.dout = dout; hp.td_out = a->losses;
+      hp.prio_out = a->priorities;
+      // shared scalar bias: its gradient is the sum of all of dout = sum_b rowsum[b]
+      // (B values for finalize instead of a serial walk over B*ld2); the fc2 slab
+      // buffer is idle on this path
+      hp.dout_rowsum = ws + L.ws_fc2_part;
+      rc = dense_forward(L, G, B, prm, in, ws, s, &hp);
+      if (rc) return rc;
+    } else {
+    rc = dense_forward(L, G, B, prm, in, ws, s);
+    if (rc) return rc;
     switch (a->loss) {
       case DZ_LOSS_Q:
       case DZ_LOSS_DOUBLE_Q:
@@ -191,6 +223,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
     }
     DZ_LAUNCH_CHECK();
     DZ_PROF(s, "loss");
+    }
   }
 
   if (phases & DZ_PHASE_BACKWARD) {
@@ -273,7 +306,11 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       unsigned acc = 0;
       for (int j = 0; j < 3; ++j) { acc += (unsigned)((J.r[j].n + 63) / 64); J.r_end[j] = acc; }
       J.c[0] = {ws + L.ws_dh1, B, kHid, kHid, grad + L.fc1_b, nullptr, nullptr};
-      if (a->shared_bias)  // one scalar: sum over every element of dout
+      const bool q_fused = (a->loss == DZ_LOSS_Q || a->loss == DZ_LOSS_DOUBLE_Q) &&
+                           dense_head_fused(L);  // (the forward phase left the row sums)
+      if (a->shared_bias && q_fused)  // one scalar: the sum of the per-sample row sums
+        J.c[1] = {ws + L.ws_fc2_part, B, 1, 1, grad + L.fc2_b, nullptr, nullptr};
+      else if (a->shared_bias)  // one scalar: sum over every element of dout
         J.c[1] = {ws + L.ws_dout, B * ld2, 1, 1, grad + L.fc2_b, nullptr, nullptr};
       else
         J.c[1] = {ws + L.ws_dout, B, N, ld2, grad + L.fc2_b, nullptr, nullptr};
@@ -327,7 +364,13 @@ extern "C" int dz_dense_apply(int num_actions, int num_outputs, int shared_bias,
   const uint8_t* in[3] = {states, states, states};
   const bool prof = g_dz_prof_on;
   g_dz_prof_on = false;
-  rc = dense_forward(L, 1, batch, prm, in, ws, s);
+  DenseHeadParams hp = {};
+  const bool fused = dense_head_fused(L);
+  if (fused && q_values_out) {
+    DZ_REQUIRE(num_outputs == num_actions);
+    hp.mode = 2; hp.q_values = q_values_out; hp.greedy = greedy_out; hp.vmax = vmax_out;
+  }
+  rc = dense_forward(L, 1, batch, prm, in, ws, s, &hp);
   g_dz_prof_on = prof;
   if (rc) return rc;
   if (out)
@@ -335,7 +378,7 @@ extern "C" int dz_dense_apply(int num_actions, int num_outputs, int shared_bias,
                                   (size_t)L.fc2_ld * sizeof(float),
                                   (size_t)num_outputs * sizeof(float), batch,
                                   hipMemcpyDefault, s));  // `out` may be pinned host memory
-  if (q_values_out) {
+  if (q_values_out && !fused) {
     DZ_REQUIRE(num_outputs == num_actions);
     hipLaunchKernelGGL(dense_q_values_kernel, dim3((batch + 63) / 64), dim3(64), 0, s,
                        ws + L.ws_out, L.fc2_ld, batch, num_actions, q_values_out,

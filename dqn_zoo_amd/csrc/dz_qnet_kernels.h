@@ -1005,6 +1005,141 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(
   }
 }
 
+// Whole Q head for narrow outputs (N <= 32: DQN / double-Q / prioritized, i.e. one value
+// per action) in ONE launch, one workgroup per sample b over its G rows g*B + b:
+//   h1  = relu(sum of the fc1 split-K slabs + b1)       (networks.py:117-119; written
+//         out for the backward pass)                     -- was fc_epilogue_kernel
+//   out = h1 . W2 + b2 (vector or shared scalar bias)    -- was FcFwdOp + fc_epilogue_kernel
+//   then the TD loss of td_loss_kernel (mode 1) or q-values / greedy action (mode 2).
+// At 512 x N the second layer is 3 x 512 x N MACs per sample: a 4-wave tile GEMM
+// launch plus its split-K epilogue were two launch floors (~4.5 us each) for < 1 us
+// of arithmetic.  The slab sums reproduce fc_epilogue_kernel's order exactly
+// (four interleaved chains (v0 + v1) + (v2 + v3)), so h1 is bit-identical.
+struct DenseHeadParams {
+  const float* part; int S; int rows;   // fc1 slabs [S][rows][512], rows = G*B
+  int B; int G;
+  const float* prm[3];                  // parameter set of each group
+  long fc1_b, fc2_w, fc2_b; int ld2;    // offsets into prm; W2 is [512][ld2]
+  int N; int bias_shared;
+  float* h1;                            // [rows][512]
+  float* out;                           // [rows][ld2]
+  int mode;                             // 0: outputs only, 1: TD loss, 2: acting
+  int sel_group, tgt_group;
+  const int64_t* a_tm1; const double* r_t; const double* d_t; const float* weights;
+  float bound;
+  float* dout; float* td_out; float* prio_out;
+  float* dout_rowsum;                   // optional [B]: sum of sample b's dout row (= -g)
+  float* q_values; int32_t* greedy; float* vmax;
+};
+
+__global__ __launch_bounds__(512) void dense_head_kernel(DenseHeadParams p) {
+  constexpr int KH = 512, MAXS = 32, NMAX = 32, KS = 16, KPS = KH / KS;
+  __shared__ float s_h[3][KH];
+  __shared__ float s_red[KS][3][NMAX];
+  __shared__ float s_out[3][NMAX];
+  const int t = threadIdx.x;
+  const int b = blockIdx.x;
+  // (1) every load of the kernel is issued before the first use, in order of use:
+  //     the slabs of all rows, the fc1 biases, the second-layer weights, the loss scalars
+  float x[3][MAXS];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const int r = min(g, p.G - 1) * p.B + b;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s)
+      x[g][s] = p.part[((long)min(s, p.S - 1) * p.rows + r) * KH + t];
+  }
+  float b1[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) b1[g] = dz_pick3(p.prm, min(g, p.G - 1))[p.fc1_b + t];
+  // second layer: thread (ks, n) = (t / 32, t % 32) owns k in [ks*32, ks*32+32) of column n;
+  // the parameter sets of group 0/2 (online) and group 1 (target)
+  const int n = t & 31, ks = t >> 5, nc = min(n, p.N - 1);
+  float w_on[KPS], w_tg[KPS];
+  {
+    const float* w0 = p.prm[0] + p.fc2_w + (long)(ks * KPS) * p.ld2 + nc;
+    const float* w1 = p.prm[1] + p.fc2_w + (long)(ks * KPS) * p.ld2 + nc;
+#pragma unroll
+    for (int k = 0; k < KPS; ++k) { w_on[k] = w0[(long)k * p.ld2]; w_tg[k] = w1[(long)k * p.ld2]; }
+  }
+  const float b2_on = p.prm[0][p.fc2_b + (p.bias_shared ? 0 : nc)];  // networks.py:120-134
+  const float b2_tg = p.prm[1][p.fc2_b + (p.bias_shared ? 0 : nc)];
+  int a0 = 0; float r_t = 0.f, d_t = 0.f, wt = 1.f;
+  if (p.mode == 1) {   // uniform branch; same addresses for every lane
+    a0 = (int)p.a_tm1[b]; r_t = (float)p.r_t[b]; d_t = (float)p.d_t[b];
+    wt = p.weights ? p.weights[b] : 1.0f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // (2) h1 = relu(slab sum + b1), in fc_epilogue_kernel's order
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    if (g < p.G) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s) v[s & 3] += s < p.S ? x[g][s] : 0.f;
+      float h = ((v[0] + v[1]) + (v[2] + v[3])) + b1[g];
+      h = h > 0.f ? h : 0.f;
+      p.h1[(long)(g * p.B + b) * KH + t] = h;
+      s_h[g][t] = h;
+    }
+  }
+  __syncthreads();
+  // (3) out[g][n] = sum_k h1[g][k] W2[k][n] + b2: 16 k-slices, folded in slice order
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    if (g < p.G) {
+      float acc = 0.f;
+      const float* h = &s_h[g][ks * KPS];
+#pragma unroll
+      for (int k = 0; k < KPS; ++k) acc = __builtin_fmaf(h[k], g == 1 ? w_tg[k] : w_on[k], acc);
+      s_red[ks][g][n] = acc;
+    }
+  }
+  __syncthreads();
+  if (t < 3 * NMAX) {
+    const int g = t >> 5;
+    if (g < p.G && n < p.N) {
+      float v = s_red[0][g][n];
+#pragma unroll
+      for (int k2 = 1; k2 < KS; ++k2) v += s_red[k2][g][n];
+      v += g == 1 ? b2_tg : b2_on;
+      s_out[g][n] = v;
+      p.out[(long)(g * p.B + b) * p.ld2 + n] = v;
+    }
+  }
+  if (p.mode == 0) return;
+  __syncthreads();
+  if (t != 0) return;
+  if (p.mode == 1) {  // td_loss_kernel's arithmetic for sample b
+    const float* q0 = s_out[0];
+    const float* qs = s_out[p.sel_group];
+    const float* qt = s_out[p.tgt_group];
+    int a_star = 0;
+    float best = qs[0];
+    for (int a = 1; a < p.N; ++a)
+      if (qs[a] > best) { best = qs[a]; a_star = a; }
+    const float td = (r_t + d_t * qt[a_star]) - q0[a0];
+    float g = td * wt / (float)p.B;
+    g = fminf(fmaxf(g, -p.bound), p.bound);
+    float* d = p.dout + (long)b * p.ld2;
+    for (int a = 0; a < p.N; ++a) d[a] = (a == a0) ? -g : 0.f;
+    p.td_out[b] = td;
+    if (p.prio_out) p.prio_out[b] = fabsf(td);
+    if (p.dout_rowsum) p.dout_rowsum[b] = -g;
+  } else {            // dense_q_values_kernel's outputs for row b
+    int arg = 0;
+    float best = s_out[0][0];
+    for (int a = 0; a < p.N; ++a) {
+      const float q = s_out[0][a];
+      if (p.q_values) p.q_values[b * p.N + a] = q;
+      if (q > best) { best = q; arg = a; }
+    }
+    if (p.greedy) p.greedy[b] = arg;
+    if (p.vmax) p.vmax[b] = best;
+  }
+}
+
 // q_values of a plain Q head + greedy action + max (dqn/agent.py:121-131)
 __global__ void dense_q_values_kernel(const float* __restrict__ out, int ld, int B, int A,
                                       float* __restrict__ q_out,

@@ -39,11 +39,6 @@ def main():
   w = torch.from_numpy(rs.uniform(0.2, 1, size=B).astype(np.float32)).to(dev)
   rms, adam = ll.RmsPropConfig(), ll.AdamConfig(learning_rate=5e-5, eps=0.01 / 32)
   for name in names:
-    if '=' in name:
-      k, v = name.split('=')
-      lib.dz_set_tuning(int(k), int(v))
-      print('set tuning', k, v)
-      continue
     if name == 'dqn_full':  # uniform replay sample + DQN update (BASELINE configs[1] shape)
       from dqn_zoo_amd import replay as rl
       cap = 100000
