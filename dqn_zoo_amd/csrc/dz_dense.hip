@@ -191,6 +191,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       // (B values for finalize instead of a serial walk over B*ld2); the fc2 slab
       // buffer is idle on this path
       hp.dout_rowsum = ws + L.ws_fc2_part;
+      hp.dh1 = ws + L.ws_dh1;   // second-layer input gradient (see the backward phase)
       rc = dense_forward(L, G, B, prm, in, ws, s, &hp);
       if (rc) return rc;
     } else {
@@ -231,6 +232,10 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
     float* grad = a->grad;
     int s_dh1 = (N + 127) / 128;  // one split per 128 outputs of reduction depth
     s_dh1 = s_dh1 < kS_dh1 ? kS_dh1 : (s_dh1 > kMaxS_ddh1 ? kMaxS_ddh1 : s_dh1);
+    // narrow Q heads: the fused forward kernel already left dh1, and the second layer's
+    // weight gradient (512 x N, B terms each) is a job of the finalize launch
+    const bool q_fused = (a->loss == DZ_LOSS_Q || a->loss == DZ_LOSS_DOUBLE_Q) &&
+                         dense_head_fused(L);
     {  // fc2: weight gradient + input gradient -> dh1 (relu(h1) mask)
       FcWgradParams w;
       w.x = ws + L.ws_h1; w.ldx = kHid; w.dy = ws + L.ws_dout; w.ldy = ld2; w.M = B;
@@ -242,16 +247,18 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       // the usual head (s_dh1 == kS_dh1): the slabs go to the idle fc1 forward slab
       // buffer and are summed + ReLU-masked by the loaders of the fc1 backward launch
       // (DyParts, as in dz_rainbow.hip): no dh1 reduction launch
-      const bool fold = s_dh1 == kS_dh1 &&
+      const bool fold = !q_fused && s_dh1 == kS_dh1 &&
                         (int64_t)kS_dh1 * B * kHid <= (int64_t)kS_dfc1 * G * B * kHid;
       d.part = fold ? ws + L.ws_fc1_part : ws + L.ws_dfeat_part;
       d.ldo = kHid; d.K = kHid; d.x_off = 0;
+      if (!q_fused) {
       rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 4, 1, 1, 0>>(
           w, dim3((N + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 1), d,
           dim3(kHid / FcDg::BN, (B + 31) / 32, s_dh1), s);
       if (rc) return rc;
       DZ_PROF(s, "fc2_wgrad+dgrad");
-      if (!fold) {
+      }
+      if (!fold && !q_fused) {
         hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kHid + 63) / 64), dim3(256), 0, s,
                            ws + L.ws_dfeat_part, s_dh1, (long)B * kHid, ws + L.ws_h1,
                            ws + L.ws_dh1);
@@ -306,8 +313,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       unsigned acc = 0;
       for (int j = 0; j < 3; ++j) { acc += (unsigned)((J.r[j].n + 63) / 64); J.r_end[j] = acc; }
       J.c[0] = {ws + L.ws_dh1, B, kHid, kHid, grad + L.fc1_b, nullptr, nullptr};
-      const bool q_fused = (a->loss == DZ_LOSS_Q || a->loss == DZ_LOSS_DOUBLE_Q) &&
-                           dense_head_fused(L);  // (the forward phase left the row sums)
+      // (q_fused: the forward phase left the row sums)
       if (a->shared_bias && q_fused)  // one scalar: the sum of the per-sample row sums
         J.c[1] = {ws + L.ws_fc2_part, B, 1, 1, grad + L.fc2_b, nullptr, nullptr};
       else if (a->shared_bias)  // one scalar: sum over every element of dout
@@ -316,8 +322,12 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
         J.c[1] = {ws + L.ws_dout, B, N, ld2, grad + L.fc2_b, nullptr, nullptr};
       J.c_tiles[0] = kHid / 64;
       J.c_tiles[1] = (unsigned)(((a->shared_bias ? 1 : N) + 63) / 64);
-      hipLaunchKernelGGL(finalize_grads_kernel, dim3(acc + J.c_tiles[0] + J.c_tiles[1]),
-                         dim3(256), 0, s, J);
+      if (q_fused) {
+        J.o_x = ws + L.ws_h1; J.o_dy = ws + L.ws_dout; J.o_out = grad + L.fc2_w;
+        J.o_B = B; J.o_ld = ld2; J.o_tiles = (unsigned)(kHid * ld2 / 64);
+      }
+      hipLaunchKernelGGL(finalize_grads_kernel,
+                         dim3(acc + J.c_tiles[0] + J.c_tiles[1] + J.o_tiles), dim3(256), 0, s, J);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "finalize_grads");
     }

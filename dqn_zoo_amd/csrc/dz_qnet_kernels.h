@@ -156,6 +156,10 @@ struct FinalizeJobs {
   // `presum_blocks` extra blocks fold the weight-gradient kernels' per-wave slots
   // (presum_src[0..presum_n), 1024 per block) the same way, so that
   // sumsq[0..gridDim.x) is the complete list of partials for adam_kernel.
+  // Optional narrow-head weight gradient  out[k][n] = sum_b x[b][k] dy[b][n]  (k < 512,
+  // n < ld; flat index k*ld + n, 64 per block, after the colsum tiles)
+  const float* o_x = nullptr; const float* o_dy = nullptr; float* o_out = nullptr;
+  int o_B = 0, o_ld = 0; unsigned o_tiles = 0;
   float* sumsq = nullptr;           // null: off
   const float* presum_src = nullptr;
   int presum_n = 0;
@@ -207,7 +211,26 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
     }
     return;
   }
-  b -= J.c_tiles[0] + J.c_tiles[1];  // presum block
+  b -= J.c_tiles[0] + J.c_tiles[1];
+  if (b < J.o_tiles) {  // (not combined with the fused norm: dense learners only)
+    const int i = (int)b * 64 + l, k = i / J.o_ld, n = i % J.o_ld;
+    for (int s0 = 0; s0 < J.o_B; s0 += 32) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int s = s0 + w + 4 * j, sc = min(s, J.o_B - 1);
+        const float y = J.o_x[(long)sc * 512 + k] * J.o_dy[(long)sc * J.o_ld + n];
+        x[j] = s < J.o_B ? y : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v += x[j];
+    }
+    red[w][l] = v;
+    __syncthreads();
+    if (w == 0) J.o_out[i] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    return;
+  }
+  b -= J.o_tiles;  // presum block
   {
     const int i0 = (int)b * 1024 + threadIdx.x;
 #pragma unroll
@@ -1029,6 +1052,7 @@ struct DenseHeadParams {
   float bound;
   float* dout; float* td_out; float* prio_out;
   float* dout_rowsum;                   // optional [B]: sum of sample b's dout row (= -g)
+  float* dh1;                           // optional [B][512]: d loss / d (fc1 pre-activation)
   float* q_values; int32_t* greedy; float* vmax;
 };
 
@@ -1037,6 +1061,8 @@ __global__ __launch_bounds__(512) void dense_head_kernel(DenseHeadParams p) {
   __shared__ float s_h[3][KH];
   __shared__ float s_red[KS][3][NMAX];
   __shared__ float s_out[3][NMAX];
+  __shared__ float s_w[KH];   // W2_online[:, a_tm1]
+  __shared__ float s_g;
   const int t = threadIdx.x;
   const int b = blockIdx.x;
   // (1) every load of the kernel is issued before the first use, in order of use:
@@ -1096,6 +1122,10 @@ __global__ __launch_bounds__(512) void dense_head_kernel(DenseHeadParams p) {
       s_red[ks][g][n] = acc;
     }
   }
+  if (p.mode == 1 && p.dh1 && n == a0) {
+#pragma unroll
+    for (int k = 0; k < KPS; ++k) s_w[ks * KPS + k] = w_on[k];
+  }
   __syncthreads();
   if (t < 3 * NMAX) {
     const int g = t >> 5;
@@ -1110,6 +1140,24 @@ __global__ __launch_bounds__(512) void dense_head_kernel(DenseHeadParams p) {
   }
   if (p.mode == 0) return;
   __syncthreads();
+  if (p.mode == 1 && p.dh1) {
+    // the second layer's input gradient on the spot: dout has ONE non-zero per sample
+    // (-g at a_tm1), so dh1[b][k] = relu'(h1) * (-g) * W2[k][a_tm1] (what FcDgradOp
+    // computes from the dout row, the other terms being exact zeros)
+    if (t == 0) {
+      const float* qs = s_out[p.sel_group];
+      int a_star = 0;
+      float best = qs[0];
+      for (int a = 1; a < p.N; ++a)
+        if (qs[a] > best) { best = qs[a]; a_star = a; }
+      const float td = (r_t + d_t * s_out[p.tgt_group][a_star]) - s_out[0][a0];
+      float g = td * wt / (float)p.B;
+      s_g = fminf(fmaxf(g, -p.bound), p.bound);
+    }
+    __syncthreads();
+    const float v = (-s_g) * s_w[t];
+    p.dh1[(long)b * KH + t] = s_h[0][t] > 0.f ? v : 0.f;
+  }
   if (t != 0) return;
   if (p.mode == 1) {  // td_loss_kernel's arithmetic for sample b
     const float* q0 = s_out[0];
