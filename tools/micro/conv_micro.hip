@@ -23,6 +23,8 @@ void dz_prof_mark(hipStream_t, const char*) {}
 __device__ unsigned long long g_stamp[8192 * 8];
 #define DZ_PATCH_STAMP(i) do { if ((threadIdx.x & 63) == 0) g_stamp[((blockIdx.x + gridDim.x * blockIdx.y) * 4 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); } while (0)
 #include "dz_conv_patch.h"
+#define DZ_C23_STAMP(i) do { if ((threadIdx.x & 63) == 0) g_stamp[((blockIdx.x + 2 * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); } while (0)
+#include "dz_conv23.h"
 using Conv1Patch = ConvPatchFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 2, 1, 2, 2>;
 using Conv2Patch = ConvPatchFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4, 2>;
 using Conv3Patch = ConvPatchFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4, 3>;
@@ -240,6 +242,27 @@ static void patch_vs_gemm(const char* name, dim3 g, ConvFwdParams p, size_t n_ou
   CK(hipFree(d_alt));
 }
 
+__global__ void skew_probe(int spin) {
+  extern __shared__ float sm[];
+  const unsigned long long t0 = wall_clock64();
+  if (threadIdx.x == 0) g_stamp[blockIdx.x] = t0;
+  // keep the workgroup resident for a while (like a real kernel would)
+  while (wall_clock64() - t0 < (unsigned long long)spin) {}
+  if (spin < 0) sm[threadIdx.x] = 1.f;
+}
+static void probe(int wgs, int threads, int lds, int spin) {
+  CK(hipFuncSetAttribute((const void*)skew_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(skew_probe, dim3(wgs), dim3(threads), lds, 0, spin);
+  CK(hipDeviceSynchronize());
+  std::vector<unsigned long long> st(wgs);
+  CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamp), (size_t)wgs * 8));
+  unsigned long long t0 = ~0ull, t1 = 0; double mean = 0;
+  for (auto v : st) { t0 = std::min(t0, v); t1 = std::max(t1, v); }
+  for (auto v : st) mean += (v - t0) * 0.01 / wgs;
+  printf("  start skew: %4d WGs x %4d threads, %6d B LDS, resident %d ns: mean +%.2f us, last +%.2f us\n",
+         wgs, threads, lds, spin * 10, mean, (t1 - t0) * 0.01);
+}
+
 template <class Op>
 static void sweep_one(const char* name, ConvFwdParams p, int CO, int G, int B) {
   const dim3 g(CO / Op::BN, G * Op::tiles_per_group(B), 1);
@@ -364,6 +387,61 @@ int main(int argc, char**) {
 #define STG3(S) { auto f = [&]() { hipLaunchKernelGGL((gemm_stagger<Conv3Fwd, S>), g3, dim3(256), 0, 0, p3); }; printf("conv3 stagger %d x 960 cycles: %.2f us\n", S, time_us(f)); }
     if (full) { STG3(0); STG3(2); }
     if (full) show_trace<Conv3Fwd>("conv3", g3, p3);
+  }
+  printf("workgroup start skew:\n");
+  probe(192, 512, 79584, 500); probe(192, 512, 16384, 500); probe(192, 256, 79584, 500); probe(192, 256, 16384, 500);
+  probe(384, 256, 40000, 500); probe(486, 256, 37376, 500); probe(192, 1024, 79584, 500); probe(192, 512, 79584, 0);
+  {  // ---- conv2 -> conv3 fused per (image, band) vs the two shipped launches ----
+    float *a1, *w2, *b2, *w3, *b3, *act2_ref, *feat_ref, *act2_new, *feat_new;
+    const size_t n1 = (size_t)G * B * 400 * 32, n2 = (size_t)G * B * 81 * 64, n3 = (size_t)G * B * 49 * 64;
+    CK(hipMalloc(&a1, n1 * 4)); CK(hipMalloc(&w2, 512 * 64 * 4)); CK(hipMalloc(&b2, 256));
+    CK(hipMalloc(&w3, 576 * 64 * 4)); CK(hipMalloc(&b3, 256));
+    CK(hipMalloc(&act2_ref, n2 * 4)); CK(hipMalloc(&feat_ref, n3 * 4));
+    CK(hipMalloc(&act2_new, n2 * 4)); CK(hipMalloc(&feat_new, n3 * 4));
+    fill_dev(a1, n1, 0); fill_dev(w2, 512 * 64, 1); fill_dev(b2, 64, 1); fill_dev(w3, 576 * 64, 1); fill_dev(b3, 64, 1);
+    CK(hipMemset(act2_new, 0xff, n2 * 4)); CK(hipMemset(feat_new, 0xff, n3 * 4));
+    ConvFwdParams q2, q3;
+    for (int g = 0; g < G; ++g) {
+      q2.in[g] = a1; q2.in_img_base[g] = g * B; q2.w[g] = w2; q2.bias[g] = b2;
+      q3.in[g] = act2_ref; q3.in_img_base[g] = g * B; q3.w[g] = w3; q3.bias[g] = b3;
+    }
+    q2.out = act2_ref; q2.B = B; q2.G = G; q3.out = feat_ref; q3.B = B; q3.G = G;
+    const dim3 gg2(64 / Conv2Fwd::BN, G * Conv2Fwd::tiles_per_group(B), 1), gg3(64 / Conv3Fwd::BN, G * Conv3Fwd::tiles_per_group(B), 1);
+    auto ref = [&]() {
+      hipLaunchKernelGGL((dz_mfma_gemm<Conv2Fwd>), gg2, dim3(256), 0, 0, q2);
+      hipLaunchKernelGGL((dz_mfma_gemm<Conv3Fwd>), gg3, dim3(256), 0, 0, q3);
+    };
+    Conv23Params f;
+    for (int g = 0; g < G; ++g) { f.act1[g] = a1; f.img_base[g] = g * B; f.w2[g] = w2; f.b2[g] = b2; f.w3[g] = w3; f.b3[g] = b3; }
+    f.act2 = act2_new; f.feat = feat_new; f.B = B; f.G = G; f.act2_groups = 7;
+    CK(hipFuncSetAttribute((const void*)conv23_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, conv23::SMEM * 4));
+    auto fused = [&]() { hipLaunchKernelGGL(conv23_fused_kernel, dim3(2, B, G), dim3(512), conv23::SMEM * 4, 0, f); };
+    ref(); fused();
+    CK(hipDeviceSynchronize());
+    auto maxdiff = [&](const float* da, const float* db, size_t n, const char* what) {
+      std::vector<float> a(n), b(n);
+      CK(hipMemcpy(a.data(), da, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), db, n * 4, hipMemcpyDeviceToHost));
+      double md = 0, mv = 0; size_t bad = 0;
+      for (size_t i = 0; i < n; ++i) { const double d = fabs((double)a[i] - b[i]); if (!(d <= 1e30)) ++bad; else md = fmax(md, d); mv = fmax(mv, fabs(a[i])); }
+      printf("  %s: max |ref - fused| = %.3g (max |ref| %.3g, non-finite %zu)\n", what, md, mv, bad);
+    };
+    maxdiff(act2_ref, act2_new, n2, "act2");
+    maxdiff(feat_ref, feat_new, n3, "feat");
+    {
+      CK(hipDeviceSynchronize()); fused(); CK(hipDeviceSynchronize());
+      const int nw = 2 * B * G * 8;
+      std::vector<unsigned long long> st(nw * 8);
+      CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamp), (size_t)nw * 64));
+      unsigned long long t0 = ~0ull;
+      for (int i = 0; i < nw; ++i) t0 = std::min(t0, st[i * 8]);
+      double mean[6] = {0};
+      for (int i = 0; i < nw; ++i) for (int k = 0; k < 6; ++k) mean[k] += (st[i * 8 + k] - t0) * 0.01 / nw;
+      printf("  fused stamps (mean us): start %.2f | act1 in LDS %.2f | conv2 MFMAs done %.2f | act2 in LDS %.2f | conv3 MFMAs done %.2f | end %.2f\n",
+             mean[0], mean[1], mean[2], mean[3], mean[4], mean[5]);
+      for (int w : {0, 4, nw / 2, nw - 1}) { printf("  wave %4d:", w); for (int k = 0; k < 6; ++k) printf(" %.2f", (st[w * 8 + k] - t0) * 0.01); printf("\n"); }
+    }
+    printf("conv2 + conv3, two launches %.2f us   fused (192 WGs x 512 threads, %d B LDS) %.2f us\n",
+           time_us(ref), conv23::SMEM * 4, time_us(fused));
   }
   return 0;
 }
