@@ -227,6 +227,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
     }
   }
 
+  bool rms_in_finalize = false;
   if (phases & DZ_PHASE_BACKWARD) {
     DZ_REQUIRE(a->grad);
     float* grad = a->grad;
@@ -326,10 +327,23 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
         J.o_x = ws + L.ws_h1; J.o_dy = ws + L.ws_dout; J.o_out = grad + L.fc2_w;
         J.o_B = B; J.o_ld = ld2; J.o_tiles = (unsigned)(kHid * ld2 / 64);
       }
+      // RMSProp needs no global norm: when this call also runs the optimiser, every
+      // small gradient is applied where finalize produces it and the flat update of the
+      // GEMM-written ranges (fc1 weights; fc2 weights on the wide-head path) shares the launch
+      rms_in_finalize = (phases & DZ_PHASE_OPTIMIZER) && a->optimizer != DZ_OPT_ADAM;
+      if (rms_in_finalize) {
+        DZ_REQUIRE(a->opt_m && a->opt_v);
+        J.rms.p = a->online; J.rms.mu = a->opt_m; J.rms.nu = a->opt_v; J.rms.grad = grad;
+        J.rms.lr = a->lr; J.rms.decay = a->decay_or_b1; J.rms.eps = a->eps;
+        J.rms.lo4[0] = L.fc1_w >> 2; J.rms.n4[0] = ((int64_t)kFlat * L.fc1_ld) >> 2;
+        if (!q_fused) { J.rms.lo4[1] = L.fc2_w >> 2; J.rms.n4[1] = ((int64_t)kHid * ld2) >> 2; }
+        J.rms.flat_blocks = 1024;
+      }
       hipLaunchKernelGGL(finalize_grads_kernel,
-                         dim3(acc + J.c_tiles[0] + J.c_tiles[1] + J.o_tiles), dim3(256), 0, s, J);
+                         dim3(acc + J.c_tiles[0] + J.c_tiles[1] + J.o_tiles + J.rms.flat_blocks),
+                         dim3(256), 0, s, J);
       DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "finalize_grads");
+      DZ_PROF(s, rms_in_finalize ? "finalize+rmsprop" : "finalize_grads");
     }
   }
 
@@ -350,7 +364,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
                          sc, a->lr, a->decay_or_b1, a->b2, a->eps, a->max_norm);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "adam");
-    } else {
+    } else if (!rms_in_finalize) {
       hipLaunchKernelGGL(rmsprop_kernel, dim3(1024), dim3(256), 0, s, a->online, a->grad,
                          a->opt_m, a->opt_v, (long)(L.param_count >> 2), a->lr,
                          a->decay_or_b1, a->eps);

@@ -146,6 +146,56 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumJobs jobs) {
 // the linear-layer bias gradients (column sums) are formed.  blockIdx.x ranges:
 // [0, t0) reduce job 0, [t0, t1) job 1, [t1, t2) job 2, then the colsum tiles.
 struct ReduceJob { const float* part; int S; long n; float* out; };
+// Optional optimiser riding in the finalize launch (dense learners with RMSProp, which
+// needs no global norm): every gradient value a finalize block produces is applied to
+// its parameter on the spot, and `flat_blocks` extra blocks run the flat update over the
+// (at most two) parameter ranges whose gradients were stored by GEMM launches.
+// optax.rmsprop(lr, decay, eps, centered=True) + apply_updates (dqn/run_atari.py:205-210):
+// eps INSIDE the sqrt, no bias correction -- the arithmetic of rmsprop_kernel.
+struct RmsApply {
+  float* p = nullptr; float* mu = nullptr; float* nu = nullptr;
+  const float* grad = nullptr;           // gradient buffer base (parameter index = g - grad)
+  float lr = 0.f, decay = 0.f, eps = 0.f;
+  long lo4[2] = {0, 0}, n4[2] = {0, 0};  // float4 ranges of the flat part
+  unsigned flat_blocks = 0;
+};
+__device__ __forceinline__ void dz_rms_one(float g, float& m, float& v, float& p, float lr,
+                                           float decay, float eps) {
+  m = (1.0f - decay) * g + decay * m;
+  v = (1.0f - decay) * (g * g) + decay * v;
+  const float upd = g / sqrtf(v - m * m + eps);
+  p = p + (-lr) * upd;
+}
+__device__ __forceinline__ void dz_rms_apply_at(const RmsApply& R, const float* gptr, float g) {
+  const long idx = gptr - R.grad;
+  float m = R.mu[idx], v = R.nu[idx], pp = R.p[idx];
+  dz_rms_one(g, m, v, pp, R.lr, R.decay, R.eps);
+  R.mu[idx] = m; R.nu[idx] = v; R.p[idx] = pp;
+}
+__device__ __forceinline__ void dz_rms_flat(const RmsApply& R, unsigned fb) {
+  // software-pipelined like rmsprop_kernel: the next element's loads (clamped,
+  // unconditional) are issued before the current element's arithmetic
+  const long total = R.n4[0] + R.n4[1];
+  const long stride = (long)R.flat_blocks * 256;
+  auto at = [&](long i) { return i < R.n4[0] ? R.lo4[0] + i : R.lo4[1] + (i - R.n4[0]); };
+  long i = (long)fb * 256 + threadIdx.x;
+  long ic = at(min(i, total - 1));
+  float4 gv = ((const float4*)R.grad)[ic], mv = ((const float4*)R.mu)[ic];
+  float4 vv = ((const float4*)R.nu)[ic], pv = ((const float4*)R.p)[ic];
+  while (i < total) {
+    const long inext = i + stride;
+    const long cur = ic;
+    ic = at(min(inext, total - 1));
+    const float4 gn = ((const float4*)R.grad)[ic], mn = ((const float4*)R.mu)[ic];
+    const float4 vn = ((const float4*)R.nu)[ic], pn = ((const float4*)R.p)[ic];
+    float* G = (float*)&gv; float* M = (float*)&mv; float* V = (float*)&vv;
+    float* P = (float*)&pv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dz_rms_one(G[j], M[j], V[j], P[j], R.lr, R.decay, R.eps);
+    ((float4*)R.mu)[cur] = mv; ((float4*)R.nu)[cur] = vv; ((float4*)R.p)[cur] = pv;
+    gv = gn; mv = mn; vv = vn; pv = pn; i = inext;
+  }
+}
 struct FinalizeJobs {
   ReduceJob r[3];
   unsigned r_end[3];      // exclusive prefix of 64-wide tiles
@@ -164,6 +214,7 @@ struct FinalizeJobs {
   const float* presum_src = nullptr;
   int presum_n = 0;
   int32_t* bump_count = nullptr;    // optax count_inc, done here when the optimiser follows
+  RmsApply rms;                     // p == nullptr: off
 };
 __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
   __shared__ float red[4][64];
@@ -183,6 +234,7 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
     if (i < jb.n) {
       o = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
       jb.out[i] = o;
+      if (J.rms.p) dz_rms_apply_at(J.rms, jb.out + i, o);
     }
     if (J.sumsq) {
       o = dz_wave_sum(o * o);
@@ -202,7 +254,7 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
     float sq = 0.f;
     if (c < jb.cols) {
       const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
-      if (jb.out) { jb.out[c] = s; sq += s * s; }
+      if (jb.out) { jb.out[c] = s; sq += s * s; if (J.rms.p) dz_rms_apply_at(J.rms, jb.out + c, s); }
       if (jb.out_scaled) { const float t = s * jb.scale[c]; jb.out_scaled[c] = t; sq += t * t; }
     }
     if (J.sumsq) {
@@ -227,10 +279,19 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
     }
     red[w][l] = v;
     __syncthreads();
-    if (w == 0) J.o_out[i] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    if (w == 0) {
+      const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+      J.o_out[i] = s;
+      if (J.rms.p) dz_rms_apply_at(J.rms, J.o_out + i, s);
+    }
     return;
   }
-  b -= J.o_tiles;  // presum block
+  b -= J.o_tiles;
+  if (J.rms.p) {  // flat optimiser blocks (dense learners: no presum blocks)
+    dz_rms_flat(J.rms, b);
+    return;
+  }
+  // presum block
   {
     const int i0 = (int)b * 1024 + threadIdx.x;
 #pragma unroll
@@ -1017,12 +1078,7 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(
     float* G = (float*)&gv; float* M = (float*)&mv; float* V = (float*)&vv;
     float* P = (float*)&pv;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      M[j] = (1.0f - decay) * G[j] + decay * M[j];
-      V[j] = (1.0f - decay) * (G[j] * G[j]) + decay * V[j];
-      const float upd = G[j] / sqrtf(V[j] - M[j] * M[j] + eps);
-      P[j] = P[j] + (-lr) * upd;
-    }
+    for (int j = 0; j < 4; ++j) dz_rms_one(G[j], M[j], V[j], P[j], lr, decay, eps);
     ((float4*)mu)[i] = mv; ((float4*)nu)[i] = vv; ((float4*)p)[i] = pv;
     gv = gn; mv = mn; vv = vn; pv = pn; i = inext;
   }
