@@ -304,14 +304,8 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
   }
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return dz_wave_max(v); }
+__device__ __forceinline__ float wave_sum(float v) { return dz_wave_sum(v); }
 
 // One wave per sample; lane k owns atom k (K <= 64).
 // ref: networks.py:254-258 (dueling, softmax, expectation),

@@ -56,9 +56,33 @@ __device__ __forceinline__ float4 dz_u8x4_to_unit(unsigned w) {
   return dz_f4(dz_div255((float)(w & 0xff)), dz_div255((float)((w >> 8) & 0xff)),
                dz_div255((float)((w >> 16) & 0xff)), dz_div255((float)(w >> 24)));
 }
+// Wave-wide reductions on the DPP crossbar.  `__shfl_xor` compiles to ds_bpermute_b32 +
+// s_waitcnt lgkmcnt(0): six dependent LDS round trips per reduction (54 of them on
+// the critical path of the Rainbow loss kernel).  Here: two quad permutes, row_half_mirror
+// and row_mirror leave every lane of a 16-lane row with the row's total (4 VALU ops), the
+// four row totals are read with v_readlane and added in a fixed order.  Every lane gets
+// the same bits; all 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float dz_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+      0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dz_lane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float dz_wave_sum(float v) {
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dz_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dz_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dz_dpp<0x141>(v);   // row_half_mirror
+  v += dz_dpp<0x140>(v);   // row_mirror
+  return (dz_lane(v, 0) + dz_lane(v, 16)) + (dz_lane(v, 32) + dz_lane(v, 48));
+}
+__device__ __forceinline__ float dz_wave_max(float v) {
+  v = fmaxf(v, dz_dpp<0xB1>(v));
+  v = fmaxf(v, dz_dpp<0x4E>(v));
+  v = fmaxf(v, dz_dpp<0x141>(v));
+  v = fmaxf(v, dz_dpp<0x140>(v));
+  return fmaxf(fmaxf(dz_lane(v, 0), dz_lane(v, 16)), fmaxf(dz_lane(v, 32), dz_lane(v, 48)));
 }
 // arr[g] for g in [0, 3) with static indices only (see the second loader rule).
 template <class T>
