@@ -81,24 +81,31 @@ __device__ __forceinline__ int64_t descend(const double* __restrict__ node,
   return i - cap;
 }
 
-// The same descent by 8 consecutive lanes (sub = lane & 7, all with the same
-// target), THREE levels per memory round trip: lane sub loads the left-child sum
-// of one of the 7 nodes that can be the current node within the next 3 steps
-//   sub 1: 2i     sub 2, 3: 4i, 4i+2     sub 4..7: 8i, 8i+2, 8i+4, 8i+6
-// and the group then takes the 3 decisions from registers (shuffles).  Same
-// comparisons and subtractions on the same node values as descend(): the result is
-// identical; the chain is ceil(levels/3) dependent loads instead of `levels`.
-__device__ __forceinline__ int64_t descend8(const double* __restrict__ node, int64_t cap,
-                                            double target, int sub) {
-  const int base = (int)(threadIdx.x & 63) & ~7;  // first lane of this group in the wave
+// The same descent by LANES (8 or 16) consecutive lanes (sub = lane % LANES, all with the
+// same target), L = log2(LANES) levels per memory round trip: lane sub >= 1 loads the
+// left-child sum of one of the LANES-1 nodes that can be the current node within the next
+// L steps
+//   sub 1: 2i     sub 2, 3: 4i, 4i+2     sub 4..7: 8i, 8i+2, 8i+4, 8i+6     sub 8..15: 16i + 2(sub-8)
+// and the group then takes the L decisions from registers (shuffles).  Same comparisons
+// and subtractions on the same node values as descend(): the result is identical; the
+// chain is ceil(levels/L) dependent loads instead of `levels` (20 levels: 7 round trips
+// with 8 lanes, 5 with 16).
+template <int LANES>
+__device__ __forceinline__ int64_t descend_coop(const double* __restrict__ node, int64_t cap,
+                                                double target, int sub) {
+  constexpr int L = LANES == 16 ? 4 : 3;
+  static_assert(LANES == 8 || LANES == 16, "group size");
+  const int base = (int)(threadIdx.x & 63) & ~(LANES - 1);  // first lane of this group
   int64_t i = 1;
   while (i < cap) {
-    int64_t idx = sub < 2 ? 2 * i : (sub < 4 ? 4 * i + 2 * (sub - 2) : 8 * i + 2 * (sub - 4));
-    idx = idx < 2 * cap ? idx : 2 * cap - 1;  // past the leaves: unused
+    // sub in [2^j, 2^(j+1)): node 2^(j+1) i + 2 (sub - 2^j)
+    const int j = sub < 2 ? 0 : (sub < 4 ? 1 : (sub < 8 ? 2 : 3));
+    int64_t idx = (i << (j + 1)) + 2 * (sub - (1 << j));
+    idx = (sub >= 1 && idx < 2 * cap) ? idx : 2 * cap - 1;  // past the leaves / lane 0: unused
     const double v = node[idx];
     int pick = 1;
 #pragma unroll
-    for (int step = 0; step < 3; ++step) {
+    for (int step = 0; step < L; ++step) {
       const double left = __shfl(v, base + pick);
       if (i < cap) {  // group-uniform
         int d = 0;
@@ -109,7 +116,7 @@ __device__ __forceinline__ int64_t descend8(const double* __restrict__ node, int
           i = 2 * i + 1;
           d = 1;
         }
-        pick = 2 * pick + d;  // 1 -> 2|3 -> 4..7
+        pick = 2 * pick + d;  // 1 -> 2|3 -> 4..7 -> 8..15
       }
     }
   }
@@ -159,7 +166,8 @@ struct HostDraws {
 
 // Tree index drawn for batch element i (replay.py:551-567): uniform candidate,
 // prioritized candidate (descent), mix.  `bad` reports a target outside [0, root).
-// COOP: called by 8 consecutive lanes with the same i; `sub` = lane & 7 (descend8).
+// COOP = 8 or 16: called by COOP consecutive lanes with the same i; `sub` = lane % COOP
+// (descend_coop).
 template <int HOST_DRAWS, int COOP = 0>
 __device__ __forceinline__ int64_t sample_tree_index(const dz_prio_sample_args_t& a,
                                                      const HostDraws& hd, int i, double root,
@@ -174,15 +182,15 @@ __device__ __forceinline__ int64_t sample_tree_index(const dz_prio_sample_args_t
   if (!zero_root) {
     const double target = ut_i * root;
     if (!(0.0 <= target && target < root)) bad = true;
-    else pri_ti = COOP ? descend8(a.node, a.cap_pow2, target, sub)
-                       : descend(a.node, a.cap_pow2, target);
+    else if constexpr (COOP != 0) pri_ti = descend_coop<COOP>(a.node, a.cap_pow2, target, sub);
+    else pri_ti = descend(a.node, a.cap_pow2, target);
   }
   return (um_i < a.usp) ? uni_ti : pri_ti;
 }
 
-// s_ti != null (256-thread block, n <= 64): the descents are done first, 8 lanes per
-// batch element (descend8), and parked in s_ti[]; otherwise one thread per element.
-template <int HOST_DRAWS>
+// s_ti != null (n <= 64): the descents are done first, COOP lanes per batch element
+// (descend_coop), and parked in s_ti[]; otherwise one thread per element.
+template <int HOST_DRAWS, int COOP = 8>
 __device__ __forceinline__ void prioritized_sample_body(
     const dz_prio_sample_args_t& a, const HostDraws& hd, int n, int64_t* __restrict__ ids_out,
     int64_t* __restrict__ tree_idx_out, double* __restrict__ probs_out,
@@ -196,10 +204,11 @@ __device__ __forceinline__ void prioritized_sample_body(
   const bool zero_root = (root == 0.0);
   if (zero_root && a.assume_nonzero_root && i == 0) raise(status, DZ_ST_ZERO_ROOT);
   if (s_ti) {
-    for (int q = i >> 3; q < n; q += (int)blockDim.x >> 3) {
+    for (int q = i / COOP; q < n; q += (int)blockDim.x / COOP) {
       bool bad;
-      const int64_t ti = sample_tree_index<HOST_DRAWS, 1>(a, hd, q, root, zero_root, bad, i & 7);
-      if ((i & 7) == 0) {
+      const int64_t ti =
+          sample_tree_index<HOST_DRAWS, COOP>(a, hd, q, root, zero_root, bad, i % COOP);
+      if ((i % COOP) == 0) {
         if (bad) raise(status, DZ_ST_BAD_TARGET);
         s_ti[q] = ti;
       }
@@ -273,29 +282,31 @@ __global__ __launch_bounds__(kMaxBatch) void prioritized_sample_kernel(
 // Sample AND gather in one launch (batch <= 64, draws in the kernel arguments).
 // Block row y == n is the sampler proper (ids, probabilities, IS weights: exactly
 // prioritized_sample_body); every gather block (x = chunk, y = batch element,
-// z = field) re-derives ITS element's tree index with the same arithmetic (8
-// lanes, 7 dependent round trips for 20 levels: descend8) instead of
+// z = field) re-derives ITS element's tree index with the same arithmetic (16
+// lanes, 5 dependent round trips for 20 levels: descend_coop<16>) instead of
 // waiting for a second launch to read ids[]: the descent and the copy overlap.
+// 512 threads: the sampler block walks 32 elements x 16 lanes in one pass.
 struct SampleGatherFields { dz_field_t f[DZ_MAX_FIELDS]; int num_fields; };
-__global__ __launch_bounds__(256) void prioritized_sample_gather_kernel(
+constexpr int kSampleGatherThreads = 512;
+__global__ __launch_bounds__(kSampleGatherThreads) void prioritized_sample_gather_kernel(
     dz_prio_sample_args_t a, HostDraws hd, int n, SampleGatherFields gf,
     int64_t* __restrict__ ids_out, double* __restrict__ probs_out,
     double* __restrict__ weights_out, float* __restrict__ weights32_out, uint32_t* status) {
-  __shared__ double s_red[4];
+  __shared__ double s_red[kSampleGatherThreads / 64];
   __shared__ double s_max;
   __shared__ int64_t s_slot;
   __shared__ int64_t s_ti[kMaxHostDraws];
   if ((int)blockIdx.y == n) {
     if (blockIdx.x == 0 && blockIdx.z == 0)
-      prioritized_sample_body<1>(a, hd, n, ids_out, nullptr, probs_out, weights_out,
+      prioritized_sample_body<1, 16>(a, hd, n, ids_out, nullptr, probs_out, weights_out,
                                  weights32_out, status, s_red, s_max, s_ti);
     return;
   }
   const int b = blockIdx.y;
-  if (threadIdx.x < 8) {  // 8 lanes walk the element's descent, 3 levels per round trip
+  if (threadIdx.x < 16) {  // 16 lanes walk the element's descent, 4 levels per round trip
     const double root = a.node[1];
     bool bad;
-    const int64_t ti = sample_tree_index<1, 1>(a, hd, b, root, root == 0.0, bad, threadIdx.x);
+    const int64_t ti = sample_tree_index<1, 16>(a, hd, b, root, root == 0.0, bad, threadIdx.x);
     if (threadIdx.x == 0)
       s_slot = dz_mod(id_of_tree_index(ti, a.capacity, a.t, a.size), a.capacity);
   }
@@ -309,10 +320,12 @@ __global__ __launch_bounds__(256) void prioritized_sample_gather_kernel(
   if (vec_ok) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int64_t nvec = rb >> 4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256)
+    for (int64_t i = (int64_t)blockIdx.x * kSampleGatherThreads + threadIdx.x; i < nvec;
+         i += (int64_t)gridDim.x * kSampleGatherThreads)
       ((u32x4*)dst)[i] = __builtin_nontemporal_load((const u32x4*)src + i);
   } else {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rb; i += (int64_t)gridDim.x * 256)
+    for (int64_t i = (int64_t)blockIdx.x * kSampleGatherThreads + threadIdx.x; i < rb;
+         i += (int64_t)gridDim.x * kSampleGatherThreads)
       dst[i] = src[i];
   }
 }
@@ -508,13 +521,13 @@ extern "C" int dz_prioritized_sample_gather(
     gf.f[i] = fields[i];
     if (fields[i].row_bytes > max_rb) max_rb = fields[i].row_bytes;
   }
-  int64_t chunks = ((max_rb >> 4) + 255) / 256;
+  int64_t chunks = ((max_rb >> 4) + kSampleGatherThreads - 1) / kSampleGatherThreads;
   if (chunks < 1) chunks = 1;
   if (chunks > 64) chunks = 64;
   dz_prof_pair(0, 0, dz_s(stream));
   hipLaunchKernelGGL(prioritized_sample_gather_kernel,
-                     dim3((unsigned)chunks, (unsigned)batch + 1, (unsigned)num_fields), dim3(256),
-                     0, dz_s(stream), *args, hd, batch, gf, ids_out, probs_out, weights_out,
+                     dim3((unsigned)chunks, (unsigned)batch + 1, (unsigned)num_fields),
+                     dim3(kSampleGatherThreads), 0, dz_s(stream), *args, hd, batch, gf, ids_out, probs_out, weights_out,
                      weights32_out, status);
   DZ_LAUNCH_CHECK();
   dz_prof_pair(0, 1, dz_s(stream));
