@@ -59,6 +59,35 @@ __global__ void sumtree_zero_tail_kernel(double* node, int64_t cap, int64_t size
   if (k < cap) node[cap + k] = 0.0;
 }
 
+// Wave-wide NaN-propagating max of doubles without ds_bpermute round trips: quad permutes,
+// row_half_mirror and row_mirror on both 32-bit halves give every lane of a 16-lane row
+// the row's result, the four rows are combined through v_readlane.  max is exact, so
+// the order of the combination does not matter.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ double dz_dpp_f64(double v) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, true);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double dz_lane_f64(double v, int l) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double dz_nanmax(double a, double b) {
+  return (a != a || b != b) ? __builtin_nan("") : (b > a ? b : a);
+}
+__device__ __forceinline__ double dz_wave_nanmax_f64(double m) {
+  m = dz_nanmax(m, dz_dpp_f64<0xB1>(m));
+  m = dz_nanmax(m, dz_dpp_f64<0x4E>(m));
+  m = dz_nanmax(m, dz_dpp_f64<0x141>(m));
+  m = dz_nanmax(m, dz_dpp_f64<0x140>(m));
+  return dz_nanmax(dz_nanmax(dz_lane_f64(m, 0), dz_lane_f64(m, 16)),
+                   dz_nanmax(dz_lane_f64(m, 32), dz_lane_f64(m, 48)));
+}
+
 // One launch per level: node[i] = node[2i] + node[2i+1] for i in [first, 2*first).
 __global__ void sumtree_level_kernel(double* node, int64_t first) {
   const int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,11 +271,8 @@ __device__ __forceinline__ void prioritized_sample_body(
 
   if (a.normalize) {  // replay.py:239-240: weights /= max(weights)
     double m = active ? w : -__builtin_inf();
-    // NaN-propagating max like np.max.
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double o = __shfl_xor(m, off);
-      m = (m != m || o != o) ? __builtin_nan("") : (o > m ? o : m);
-    }
+    // NaN-propagating max like np.max (order-independent: exact), on the DPP crossbar
+    m = dz_wave_nanmax_f64(m);
     if ((i & 63) == 0) s_red[i >> 6] = m;
     __syncthreads();
     if (i == 0) {
