@@ -25,6 +25,7 @@ __device__ unsigned long long g_stamp[8192 * 8];
 #include "dz_conv_patch.h"
 #define DZ_C23_STAMP(i) do { if ((threadIdx.x & 63) == 0) g_stamp[((blockIdx.x + 2 * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); } while (0)
 #include "dz_conv23.h"
+#include "dz_conv1_persist.h"
 using Conv1Patch = ConvPatchFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 2, 1, 2, 2>;
 using Conv2Patch = ConvPatchFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4, 2>;
 using Conv3Patch = ConvPatchFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4, 3>;
@@ -344,6 +345,24 @@ int main(int argc, char**) {
     p1.out = d_o1; p1.B = B; p1.G = G;
     const dim3 g1(32 / Conv1Fwd::BN, G * Conv1Fwd::tiles_per_group(B), 1);
     patch_vs_gemm<Conv1Fwd, Conv1Patch>("conv1", g1, p1, (size_t)imgs1 * 400 * 32);
+    {
+      float* d_p1; CK(hipMalloc(&d_p1, (size_t)imgs1 * 400 * 32 * 4)); CK(hipMemset(d_p1, 0xff, (size_t)imgs1 * 400 * 32 * 4));
+      ConvFwdParams q1 = p1; q1.out = d_p1;
+      constexpr int WPG = 85;
+      CK(hipFuncSetAttribute((const void*)conv1_persist_kernel<WPG>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1p::SMEM * 4));
+      auto fp = [&]() { hipLaunchKernelGGL((conv1_persist_kernel<WPG>), dim3(WPG, G), dim3(256), conv1p::SMEM * 4, 0, q1); };
+      auto fr = [&]() { hipLaunchKernelGGL((dz_mfma_gemm<Conv1Fwd>), g1, dim3(256), 0, 0, p1); };
+      fr(); fp(); CK(hipDeviceSynchronize());
+      const size_t n = (size_t)imgs1 * 400 * 32;
+      std::vector<float> a(n), b(n);
+      CK(hipMemcpy(a.data(), d_o1, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), d_p1, n * 4, hipMemcpyDeviceToHost));
+      double md = 0, mv = 0; size_t bad = 0;
+      for (size_t i = 0; i < n; ++i) { const double d = fabs((double)a[i] - b[i]); if (!(d <= 1e30)) ++bad; else md = fmax(md, d); mv = fmax(mv, fabs(a[i])); }
+      printf("conv1 persistent (weights in registers, %d WGs, %d B LDS): max |ref - new| = %.3g (max |ref| %.3g, non-finite %zu)\n", WPG * G, conv1p::SMEM * 4, md, mv, bad);
+      printf("conv1 shipped %.2f us   persistent %.2f us\n", time_us(fr), time_us(fp));
+#define PW(N) { CK(hipFuncSetAttribute((const void*)conv1_persist_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, conv1p::SMEM * 4)); auto f = [&]() { hipLaunchKernelGGL((conv1_persist_kernel<N>), dim3(N, G), dim3(256), conv1p::SMEM * 4, 0, q1); }; printf("  persistent, %d workgroups per group: %.2f us\n", N, time_us(f)); }
+      PW(100); PW(134); PW(170); PW(200); PW(256); PW(400);
+    }
     printf("conv1 tile sweep <WM,WN,WK,KT>:\n");
 #define SW1(a, b, c_, d) sweep_one<ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, a, b, c_, d>>("<" #a "," #b "," #c_ "," #d ">", p1, 32, G, B)
     SW1(2, 1, 2, 2); SW1(2, 1, 2, 1); SW1(2, 1, 2, 4); SW1(1, 1, 4, 1); SW1(1, 1, 4, 2); SW1(1, 1, 4, 4); SW1(4, 1, 1, 2); SW1(4, 1, 1, 4); SW1(4, 1, 1, 1);
