@@ -331,3 +331,37 @@ def ptr(t):
 def current_stream_ptr():
   import torch
   return torch.cuda.current_stream().cuda_stream
+
+
+# torch.cuda.current_stream() builds a Stream object through three Python layers
+# (~4 us; the agent loop asked for it 3-4 times per frame).  The raw handle of torch's
+# CURRENT stream comes from one C call; Stream objects (needed by Event.record) are
+# cached per raw handle.
+_stream_objects = {}
+
+
+def _device_index(device):
+  import torch
+  idx = getattr(device, 'index', device)
+  return torch.cuda.current_device() if idx is None else idx
+
+
+def stream_ptr(device=None):
+  """hipStream_t of torch's current stream on `device`, as an integer."""
+  import torch
+  raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+  if raw is None:
+    return torch.cuda.current_stream(device).cuda_stream
+  return raw(_device_index(device))
+
+
+def current_stream(device=None):
+  """torch's current stream on `device` as a (cached) torch.cuda.Stream object."""
+  import torch
+  idx = _device_index(device)
+  key = (idx, stream_ptr(idx))
+  s = _stream_objects.get(key)
+  if s is None:
+    s = torch.cuda.current_stream(idx)
+    _stream_objects[key] = s
+  return s

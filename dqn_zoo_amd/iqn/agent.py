@@ -123,7 +123,7 @@ class Iqn(dense_agent.DenseAgent):
     n = self._tau_samples_policy
     learner_lib._lib.check(ln._lib.dz_uniform_fill(  # pylint: disable=protected-access
         self._act_taus.data_ptr(), n, self._act_seed, self._act_counter, None,
-        torch.cuda.current_stream(self._device).cuda_stream), 'dz_uniform_fill')
+        learner_lib._lib.stream_ptr(self._device)), 'dz_uniform_fill')
     self._act_counter += n
     _, q, _, _ = ln.apply(obs_d, self._act_taus)
     # Q-values to pinned host memory asynchronously; epsilon-greedy on the host when
@@ -136,7 +136,7 @@ class Iqn(dense_agent.DenseAgent):
     self._q_pos += 1
     slot, ev = self._q_host[k], self._q_events[k]
     slot.copy_(q[0], non_blocking=True)
-    ev.record(torch.cuda.current_stream(self._device))
+    ev.record(learner_lib._lib.current_stream(self._device))
 
     def read():
       ev.synchronize()

@@ -103,6 +103,7 @@ class RainbowLearner:
     self._act_ws = None
     self._act_noise = torch.zeros(L.noise_stride, **f32)
     self.act_graphs = True   # replay the acting apply from a hipGraph (apply_async)
+    self._act_graphs = {}    # (state buffer, result slot, parameters) -> (graph, q, greedy, vmax)
 
   # -- state ------------------------------------------------------------------
   def get_params(self, which='online') -> dict:
@@ -117,7 +118,7 @@ class RainbowLearner:
     """target <- online (ref: rainbow/agent.py:157-158)."""
     _lib.check(self._lib.dz_param_copy(
         self.target.data_ptr(), self.online.data_ptr(), self.layout.param_count,
-        torch.cuda.current_stream(self.device).cuda_stream), 'dz_param_copy')
+        _lib.stream_ptr(self.device)), 'dz_param_copy')
 
   def set_noise(self, noises: typing.Sequence[dict]) -> None:
     """Explicit noise for the 3 applies (parity runs)."""
@@ -133,7 +134,6 @@ class RainbowLearner:
     self.drop_graphs()
     if getattr(self, '_act_step', None) is None:
       self._act_step = torch.zeros(1, dtype=torch.int32, device=self.device)
-      self._act_graphs = {}
     self._act_step.fill_(int(act_step))
 
   def act_step(self) -> int:
@@ -144,8 +144,8 @@ class RainbowLearner:
     graphs, self._graphs = self._graphs, {}
     for g in graphs.values():
       self._lib.dz_graph_destroy(g)
-    for g, _ in getattr(self, '_act_graphs', {}).values():
-      self._lib.dz_graph_destroy(g)
+    for g in getattr(self, '_act_graphs', {}).values():
+      self._lib.dz_graph_destroy(g[0])
     if getattr(self, '_act_graphs', None):
       self._act_graphs = {}
 
@@ -154,7 +154,7 @@ class RainbowLearner:
     n = self.noise.numel()
     _lib.check(self._lib.dz_noise_fill(
         self.noise.data_ptr(), n, self._noise_seed, self._noise_counter,
-        torch.cuda.current_stream(self.device).cuda_stream), 'dz_noise_fill')
+        _lib.stream_ptr(self.device)), 'dz_noise_fill')
     self._noise_counter += n
 
   def apply(self, states: torch.Tensor, which: str = 'online', noise=None,
@@ -162,6 +162,15 @@ class RainbowLearner:
     """One network apply on uint8 states [B,84,84,4] (device tensor).
     Returns device tensors (q_values [B,A] f32, greedy action [B] i32,
     max_a q [B] f32).  ref: rainbow/agent.py:125-131 (select_action)."""
+    stream = _lib.stream_ptr(self.device)
+    params = self.online if which == 'online' else self.target
+    if packed_out is not None and noise is None and resample_noise and self.act_graphs and stream:
+      # steady state of the agent loop: same observation slot, same result slot, same
+      # parameters -> replay the captured launches, nothing to allocate or check
+      g = self._act_graphs.get((states.data_ptr(), packed_out.data_ptr(), params.data_ptr()))
+      if g is not None:
+        _lib.check(self._lib.dz_graph_launch(g[0], stream), 'dz_graph_launch')
+        return g[1], g[2], g[3]
     assert states.dtype == torch.uint8 and states.is_contiguous()
     b = int(states.shape[0])
     assert tuple(states.shape[1:]) == (84, 84, 4)
@@ -169,7 +178,7 @@ class RainbowLearner:
       self._act_ws = torch.zeros(self.network.layout(b).ws_count,
                                  dtype=torch.float32, device=self.device)
       self._act_batch = b
-    stream = torch.cuda.current_stream(self.device).cuda_stream
+      self._act_graphs = {}    # captured against the old workspace
     a = self.network.num_actions
     q = torch.empty((b, a), dtype=torch.float32, device=self.device)
     # (greedy action, max q) packed in one 8-byte buffer per row so that the
@@ -179,27 +188,23 @@ class RainbowLearner:
     packed = torch.empty((2, b), dtype=torch.int32, device=self.device) \
         if packed_out is None else packed_out
     greedy, vmax = packed[0], packed[1].view(torch.float32)
-    params = self.online if which == 'online' else self.target
     if noise is None and resample_noise:
       # fresh noise drawn inside the apply's own launches (dz_rainbow_act); the
       # stream position is a DEVICE counter the apply advances itself, so the
       # argument list is constant and the 8 launches replay from a hipGraph
       if getattr(self, '_act_step', None) is None:
         self._act_step = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._act_graphs = {}
       enqueue = lambda: _lib.check(self._lib.dz_rainbow_act(
           a, self.network.num_atoms, b, params.data_ptr(), states.data_ptr(),
           self._act_noise.data_ptr(), self._noise_seed ^ 0xA5A5A5A5, 0,
           self._act_step.data_ptr(), self.support.data_ptr(), self._act_ws.data_ptr(),
           q.data_ptr(), greedy.data_ptr(), vmax.data_ptr(), stream), 'dz_rainbow_act')
       if self.act_graphs and stream and packed_out is not None:
-        key = (states.data_ptr(), packed_out.data_ptr(), params.data_ptr(), b)
-        g = self._act_graphs.get(key)
-        if g is None:
-          q = self._act_q = torch.empty((b, a), dtype=torch.float32, device=self.device)
-          g = self._act_graphs[key] = (_lib.capture_graph(stream, enqueue), q)
+        key = (states.data_ptr(), packed_out.data_ptr(), params.data_ptr())
+        q = self._act_q = torch.empty((b, a), dtype=torch.float32, device=self.device)
+        g = self._act_graphs[key] = (_lib.capture_graph(stream, enqueue), q, greedy, vmax)
         _lib.check(self._lib.dz_graph_launch(g[0], stream), 'dz_graph_launch')
-        return g[1], greedy, vmax
+        return q, greedy, vmax
       enqueue()
       return q, greedy, vmax
     if noise is not None:
@@ -229,7 +234,7 @@ class RainbowLearner:
     slot = self._act_host[k]
     self.apply(states, packed_out=slot)
     ev = self._act_events[k]
-    ev.record(torch.cuda.current_stream(self.device))
+    ev.record(_lib.current_stream(self.device))
 
     def read():
       ev.synchronize()
@@ -279,7 +284,7 @@ class RainbowLearner:
     inside its backward launches -- the caller then must NOT call
     `update_priorities` for this batch.  Needs PHASE_BACKWARD in `phases`."""
     b = self.batch_size
-    stream = torch.cuda.current_stream(self.device).cuda_stream
+    stream = _lib.stream_ptr(self.device)
     graphs = bool(stream) if self.use_graphs is None else self.use_graphs
     if graphs and self._args is not None and weights is not None:
       # fast path: a call signature that was validated and captured before (the
@@ -337,7 +342,7 @@ class RainbowLearner:
     else:
       a.prio_node = None
       a.prio_ids = None
-    stream = torch.cuda.current_stream(self.device).cuda_stream
+    stream = _lib.stream_ptr(self.device)
     if graphs:
       if not stream:
         raise RuntimeError(
@@ -444,7 +449,7 @@ class DenseLearner:
   def sync_target(self) -> None:
     _lib.check(self._lib.dz_param_copy(
         self.target.data_ptr(), self.online.data_ptr(), self.layout.param_count,
-        torch.cuda.current_stream(self.device).cuda_stream), 'dz_param_copy')
+        _lib.stream_ptr(self.device)), 'dz_param_copy')
 
   def get_opt_state(self) -> dict:
     return dict(count=int(self.opt_count.item()),
@@ -508,7 +513,7 @@ class DenseLearner:
         raise ValueError('priority_sink needs the backward phase in this call')
       (a.prio_node, a.prio_cap_pow2, a.prio_capacity, a.prio_ids, a.prio_exponent,
        a.prio_max_seen, a.prio_status) = priority_sink
-    stream = torch.cuda.current_stream(self.device).cuda_stream
+    stream = _lib.stream_ptr(self.device)
     enqueue = lambda: _lib.check(self._lib.dz_dense_learn(
         ctypes.byref(a), phases, stream), 'dz_dense_learn')
     if not (bool(stream) if self.use_graphs is None else self.use_graphs):
@@ -566,11 +571,14 @@ class DenseLearner:
     k = self._head_pos % self.ACT_RING
     self._head_pos += 1
     slot, ev = self._head_host[k], self._head_events[k]
-    stream = torch.cuda.current_stream(self.device).cuda_stream
+    stream = _lib.stream_ptr(self.device)
+    # Q heads: the head kernel writes the q-values through the slot's device mapping
+    # itself (no copy node); distributional heads copy their outputs out
+    is_q = net.num_outputs == net.num_actions
     enqueue = lambda: _lib.check(self._lib.dz_dense_apply(
         net.num_actions, net.num_outputs, int(net.shared_bias), 1, self.online.data_ptr(),
-        states.data_ptr(), self._act_ws.data_ptr(), slot.data_ptr(), None, None, None,
-        stream), 'dz_dense_apply')
+        states.data_ptr(), self._act_ws.data_ptr(), None if is_q else slot.data_ptr(),
+        slot.data_ptr() if is_q else None, None, None, stream), 'dz_dense_apply')
     if stream:
       key = (states.data_ptr(), k)
       g = self._head_graphs.get(key)
@@ -579,7 +587,7 @@ class DenseLearner:
       _lib.check(self._lib.dz_graph_launch(g, stream), 'dz_graph_launch')
     else:
       enqueue()
-    ev.record(torch.cuda.current_stream(self.device))
+    ev.record(_lib.current_stream(self.device))
 
     def read():
       ev.synchronize()
@@ -610,7 +618,7 @@ class DenseLearner:
         out.data_ptr(), None if q is None else q.data_ptr(),
         None if greedy is None else greedy.data_ptr(),
         None if vmax is None else vmax.data_ptr(),
-        torch.cuda.current_stream(self.device).cuda_stream), 'dz_dense_apply')
+        _lib.stream_ptr(self.device)), 'dz_dense_apply')
     return out, q, greedy, vmax
 
 
@@ -674,7 +682,7 @@ class IqnLearner:
     _lib.check(self._lib.dz_uniform_fill(
         self.taus.data_ptr(), self.taus.numel(), self._seed, 0,
         self.opt_count.data_ptr(),
-        torch.cuda.current_stream(self.device).cuda_stream), 'dz_uniform_fill')
+        _lib.stream_ptr(self.device)), 'dz_uniform_fill')
 
   def step(self, s_tm1, a_tm1, r_t, discount_t, s_t, taus=None,
            phases: int = _lib.PHASE_ALL) -> None:
@@ -709,7 +717,7 @@ class IqnLearner:
     a.lr, a.b1, a.b2 = self.opt.learning_rate, self.opt.b1, self.opt.b2
     a.eps, a.max_norm = self.opt.eps, self.opt.max_global_grad_norm
     a.huber = self.huber_param
-    stream = torch.cuda.current_stream(self.device).cuda_stream
+    stream = _lib.stream_ptr(self.device)
     def enqueue():
       if taus is None:
         self.sample_taus()   # device draw keyed by the optimiser step count: graph-safe
@@ -756,7 +764,7 @@ def iqn_apply(lib, net, ws_cache, params, states, taus, device):
       net.num_actions, net.latent_dim, b, n, params.data_ptr(), states.data_ptr(),
       taus.data_ptr(), ws_cache[key].data_ptr(), q_dist.data_ptr(), q.data_ptr(),
       greedy.data_ptr(), vmax.data_ptr(),
-      torch.cuda.current_stream(device).cuda_stream), 'dz_iqn_apply')
+      _lib.stream_ptr(device)), 'dz_iqn_apply')
   return q_dist, q, greedy, vmax
 
 
@@ -807,7 +815,7 @@ class InferenceNet:
     tau draws (ref: iqn/agent.py:72-83)."""
     if not self._has_params:
       raise RuntimeError('network_params have not been set')
-    stream = torch.cuda.current_stream(self.device).cuda_stream
+    stream = _lib.stream_ptr(self.device)
     taus = torch.empty((1, tau_samples), dtype=torch.float32, device=self.device)
     _lib.check(self._lib.dz_uniform_fill(taus.data_ptr(), tau_samples, self._seed,
                                          self._counter, None, stream),
@@ -822,7 +830,7 @@ class InferenceNet:
     if not self._has_params:
       raise RuntimeError('network_params have not been set')
     net = self.network
-    stream = torch.cuda.current_stream(self.device).cuda_stream
+    stream = _lib.stream_ptr(self.device)
     if self.is_rainbow:
       n = self.noise.numel()
       _lib.check(self._lib.dz_noise_fill(self.noise.data_ptr(), n, self._seed,

@@ -444,7 +444,7 @@ class ObservationPipeline:
     self._stage += 1
     if self._events[k] is not None:
       self._events[k].synchronize()   # the upload that last used this slot is done
-    stream = torch.cuda.current_stream(self._device)
+    stream = self._lib_mod.current_stream(self._device)
     for i, f in enumerate(frames):
       a = np.asarray(f)
       if a.dtype != np.uint8 or tuple(a.shape) != self._in_shape:

@@ -221,6 +221,11 @@ class _FieldRing:
       self._stage = (pins, devs, [None] * self.STAGE_DEPTH)
       self._stage_pos = 0
       self._insert_arr = (_lib.InsertField * len(self.fields))()
+      # destination and row size never change: filled once, not per add
+      for i, f in enumerate(self.fields):
+        self._insert_arr[i].dst = f.data_ptr()
+        self._insert_arr[i].row_bytes = f[0].numel() * f.element_size()
+      self._tshapes = [tuple(s) for s in self.shapes]
     return self._stage
 
   def insert_fields(self, item):
@@ -233,13 +238,11 @@ class _FieldRing:
     arr = self._insert_arr
     k = None
     for i, (f, x, dt, shp) in enumerate(zip(self.fields, item, self.np_dtypes,
-                                            self.shapes)):
-      arr[i].dst = f.data_ptr()
-      arr[i].row_bytes = f[0].numel() * f.element_size()
+                                            self._tshapes)):
       if isinstance(x, torch.Tensor):
         on_dev = x.device == f.device or (x.device.type == 'cpu' and x.is_pinned())
         if (not on_dev or x.dtype != f.dtype or
-            tuple(x.shape) != tuple(shp) or not x.is_contiguous()):
+            tuple(x.shape) != shp or not x.is_contiguous()):
           raise ValueError('device field %d: need a contiguous %s%s tensor on %s (or pinned host memory)'
                            % (i, f.dtype, tuple(shp), f.device))
         arr[i].src_row = x.data_ptr()
@@ -265,7 +268,7 @@ class _FieldRing:
     if k is not None:
       if events[k] is None:
         events[k] = torch.cuda.Event()
-      events[k].record(torch.cuda.current_stream(self.device))
+      events[k].record(_lib.current_stream(self.device))
     return arr, len(self.fields)
 
   def read(self, slot):
@@ -332,7 +335,7 @@ class _ReplayBase(Generic[ReplayStructure]):
       yield self._ring.read(i % self._capacity)
 
   def _stream(self):
-    return torch.cuda.current_stream(self._device).cuda_stream
+    return _lib.stream_ptr(self._device)
 
   def _store(self, item, node=None, cap_pow2=0, priority_d=None, exponent=0.0,
              status=None):
@@ -615,7 +618,7 @@ class SumTree:
     self._status = _Status(self._device)
 
   def _stream(self):
-    return torch.cuda.current_stream(self._device).cuda_stream
+    return _lib.stream_ptr(self._device)
 
   def _dev(self, a, dtype):
     return torch.from_numpy(np.array(a, dtype=dtype, order='C')).to(self._device)
@@ -920,7 +923,7 @@ class PrioritizedTransitionReplay(_ReplayBase):
       slot.draws.copy_(slot.host, non_blocking=True)
       if slot.copied is None:
         slot.copied = torch.cuda.Event()
-      slot.copied.record(torch.cuda.current_stream(self._device))
+      slot.copied.record(_lib.current_stream(self._device))
     a = slot.args
     a.size = self._size
     a.t = self._t
