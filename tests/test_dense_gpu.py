@@ -102,6 +102,30 @@ def test_dqn_family_step(kind):
       assert np.abs(p_dev[k] - p[k]).max() <= 2e-3 * opt.learning_rate * 40, k
     p, st = p_dev, dict(mu=mu_dev, nu=L.unpack(ln.opt_v.cpu().numpy()))
 
+@pytest.mark.parametrize('kind', ['dqn', 'prioritized'])
+def test_rmsprop_inside_finalize_is_bit_identical_to_the_split_phases(kind):
+  """A full step applies RMSProp where finalize produces the small gradients and in
+  extra blocks of that launch for the GEMM-written ranges; forward+backward followed
+  by the optimiser phase alone goes through finalize_grads_kernel + rmsprop_kernel.
+  Same arithmetic, same operands: parameters and both moments must agree bitwise."""
+  from dqn_zoo_amd import learner as ll, _lib
+  net = 'dqn' if kind == 'dqn' else 'double_dqn'
+  loss = 'q' if kind == 'dqn' else 'double_q'
+  opt = ll.RmsPropConfig(learning_rate=0.00025, decay=0.95, eps=0.01 / 32 ** 2)
+  rs, _, _, fused = _make(net, loss, opt, 11, grad_error_bound=1.0 / 32)
+  _, _, _, split = _make(net, loss, opt, 11, grad_error_bound=1.0 / 32)
+  w = rs.uniform(0.2, 1.0, size=B).astype(np.float32) if kind == 'prioritized' else None
+  wd = None if w is None else torch.from_numpy(w).cuda()
+  for it in range(3):
+    batch = _dev(_batch(rs, scale_r=2.5))
+    fused.step(*batch, wd)
+    split.step(*batch, wd, phases=_lib.PHASE_FORWARD | _lib.PHASE_BACKWARD)
+    split.step(*batch, wd, phases=_lib.PHASE_OPTIMIZER)
+    torch.cuda.synchronize()
+    for name in ('online', 'opt_m', 'opt_v', 'grad'):
+      a, b = getattr(fused, name).cpu().numpy(), getattr(split, name).cpu().numpy()
+      assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (it, name)
+
 
 @pytest.mark.parametrize('kind', ['c51', 'qr'])
 def test_distributional_dense_step(kind):
