@@ -50,7 +50,7 @@ extern "C" int dz_dense_layout(int N, int shared_bias, int B, int G,
   L->ws_dact2 = take((int64_t)B * 81 * 64);
   L->ws_dact1 = take((int64_t)B * 400 * 32);
   L->ws_wgrad_part = take(torso_wgrad_part_elems());
-  L->ws_norm_part = take(kNormBlocks);
+  L->ws_norm_part = take(kNormFinal + kNormSlots);   // fused-norm partials + per-wave slots
   L->ws_scalars = take(16);
   L->ws_zeros = take(kFlat + 1024);   // stands in for the (absent) noise vectors
   L->ws_count = w;
@@ -71,7 +71,7 @@ static void dense_heads(const dz_dense_layout_t& L, FcHead& h1, FcHead& h2) {
 static inline bool dense_head_fused(const dz_dense_layout_t& L) { return L.num_outputs <= 32; }
 static int dense_forward(const dz_dense_layout_t& L, int G, int B, const float* const* prm,
                          const uint8_t* const* in, float* ws, hipStream_t s,
-                         DenseHeadParams* head = nullptr) {
+                         DenseHeadParams* head = nullptr, bool skip_fc2_epilogue = false) {
   int rc;
   const float* zeros = ws + L.ws_zeros;
   FcHead h1, h2;
@@ -140,6 +140,7 @@ static int dense_forward(const dz_dense_layout_t& L, int G, int B, const float* 
                                       G * kS_fc2), s);
     if (rc) return rc;
     DZ_PROF(s, "fc2_fwd");
+    if (skip_fc2_epilogue) return DZ_OK;  // the loss kernel folds the partial slabs itself
     hipLaunchKernelGGL(fc_epilogue_kernel, dim3((N + 63) / 64, G * B), dim3(256), 0, s,
                        ws + L.ws_fc2_part, kS_fc2, G * B, N, ld2, B, p3[0], p3[1], p3[2],
                        (long)L.fc2_b, (long)-1, zeros, zeros, zeros, 0, 0,
@@ -195,7 +196,10 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       rc = dense_forward(L, G, B, prm, in, ws, s, &hp);
       if (rc) return rc;
     } else {
-    rc = dense_forward(L, G, B, prm, in, ws, s);
+    // C51: the fc2 split-K slabs (+ bias) are folded by the loss kernel (as in dz_rainbow.hip)
+    const bool fold_fc2 = a->loss == DZ_LOSS_CATEGORICAL && !a->shared_bias &&
+                          (size_t)3 * ld2 * sizeof(float) <= 48 * 1024 && kS_fc2 <= 8;
+    rc = dense_forward(L, G, B, prm, in, ws, s, nullptr, fold_fc2);
     if (rc) return rc;
     switch (a->loss) {
       case DZ_LOSS_Q:
@@ -209,6 +213,19 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
         DZ_REQUIRE(a->weights);  // c51 passes all-ones weights
         float* scratch = a->priorities ? a->priorities : ws + L.ws_scalars + 8;
         (void)scratch;
+        if (fold_fc2) {
+          HeadPre pre = {};
+          pre.part = ws + L.ws_fc2_part; pre.S = kS_fc2; pre.rows = G * B; pre.groups = G;
+          for (int g = 0; g < 3; ++g) { pre.prm[g] = prm[g < G ? g : 0]; pre.nz[g] = zeros; }
+          pre.b_sig = L.fc2_b; pre.eps_out = 0; pre.plain_bias = 1;
+          hipLaunchKernelGGL(rainbow_head_loss_kernel<1>, dim3(B), dim3(256),
+                             (size_t)3 * ld2 * sizeof(float), s, out, ld2, 0, B, A,
+                             a->num_atoms, 0, 1, 1, a->a_tm1, a->r_t, a->discount_t, a->weights,
+                             a->aux, dout, a->losses,
+                             a->priorities ? a->priorities : (ws + L.ws_dfeat_part),
+                             (float*)nullptr, (float*)nullptr, pre);
+          break;
+        }
         hipLaunchKernelGGL(rainbow_head_loss_kernel<0>, dim3(B), dim3(256), 0, s, out, ld2, 0,
                            B, A, a->num_atoms, 0, 1, 1, a->a_tm1, a->r_t, a->discount_t,
                            a->weights, a->aux, dout, a->losses,
@@ -228,6 +245,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
   }
 
   bool rms_in_finalize = false;
+  int n_final = 0;   // fused-norm partials left by this call's backward phase (Adam)
   if (phases & DZ_PHASE_BACKWARD) {
     DZ_REQUIRE(a->grad);
     float* grad = a->grad;
@@ -237,11 +255,23 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
     // weight gradient (512 x N, B terms each) is a job of the finalize launch
     const bool q_fused = (a->loss == DZ_LOSS_Q || a->loss == DZ_LOSS_DOUBLE_Q) &&
                          dense_head_fused(L);
+    // Adam (clip by global norm): the weight-gradient kernels leave per-wave sums of squares
+    // in sq_slots (fc2 first, then fc1), finalize folds them and adds its own, so that
+    // ws_norm_part[0..n_final) is the partial list for adam_kernel -- no sumsq launch over
+    // the whole gradient (as in dz_rainbow.hip)
+    const bool fused_norm = a->optimizer == DZ_OPT_ADAM;
+    float* sq_final = ws + L.ws_norm_part;
+    float* sq_slots = sq_final + kNormFinal;
+    const int fc2_nx = (N + FcWg::BN - 1) / FcWg::BN, fc2_ny = kHid / FcWg::BM;
+    const int fc2_slots = q_fused ? 0 : fc2_nx * fc2_ny * 4;
+    const int fc1_slots = (kHid / FcWg::BN) * (kFlat / FcWg::BM) * 4;
+    if (fused_norm) DZ_REQUIRE(fc2_slots + fc1_slots <= kNormSlots);
     {  // fc2: weight gradient + input gradient -> dh1 (relu(h1) mask)
       FcWgradParams w;
       w.x = ws + L.ws_h1; w.ldx = kHid; w.dy = ws + L.ws_dout; w.ldy = ld2; w.M = B;
       w.NH = 1; w.noisy = 0; w.noise = zeros; w.head[0] = h2; w.head[1] = h2;
       w.grad = grad;
+      if (fused_norm) { w.sumsq = sq_slots; w.sq_nx = fc2_nx; w.sq_ny = fc2_ny; }
       FcDgradParams d;
       d.dy = ws + L.ws_dout; d.ldy = ld2; d.M = B; d.NH = 1; d.S = s_dh1; d.noisy = 0;
       d.params = a->online; d.noise = zeros; d.head[0] = h2; d.head[1] = h2;
@@ -271,6 +301,9 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       w1.x = ws + L.ws_feat; w1.ldx = kFlat; w1.dy = ws + L.ws_dh1; w1.ldy = kHid; w1.M = B;
       w1.NH = 1; w1.noisy = 0; w1.noise = zeros; w1.head[0] = h1; w1.head[1] = h1;
       w1.grad = grad;
+      if (fused_norm) {
+        w1.sumsq = sq_slots + fc2_slots; w1.sq_nx = kHid / FcWg::BN; w1.sq_ny = kFlat / FcWg::BM;
+      }
       FcDgradParams d1;
       d1.dy = ws + L.ws_dh1; d1.ldy = kHid; d1.M = B; d1.NH = 1; d1.S = kS_ddfeat; d1.noisy = 0;
       d1.params = a->online; d1.noise = zeros; d1.head[0] = h1; d1.head[1] = h1;
@@ -330,6 +363,14 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       // RMSProp needs no global norm: when this call also runs the optimiser, every
       // small gradient is applied where finalize produces it and the flat update of the
       // GEMM-written ranges (fc1 weights; fc2 weights on the wide-head path) shares the launch
+      unsigned presum = 0;
+      if (fused_norm) {
+        presum = (unsigned)((fc2_slots + fc1_slots + 1023) / 1024);
+        n_final = (int)(acc + J.c_tiles[0] + J.c_tiles[1] + J.o_tiles + presum);
+        DZ_REQUIRE(n_final <= kNormFinal);
+        J.sumsq = sq_final; J.presum_src = sq_slots; J.presum_n = fc2_slots + fc1_slots;
+        J.bump_count = (phases & DZ_PHASE_OPTIMIZER) ? a->opt_count : nullptr;
+      }
       rms_in_finalize = (phases & DZ_PHASE_OPTIMIZER) && a->optimizer != DZ_OPT_ADAM;
       if (rms_in_finalize) {
         DZ_REQUIRE(a->opt_m && a->opt_v);
@@ -340,7 +381,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
         J.rms.flat_blocks = 1024;
       }
       hipLaunchKernelGGL(finalize_grads_kernel,
-                         dim3(acc + J.c_tiles[0] + J.c_tiles[1] + J.o_tiles + J.rms.flat_blocks),
+                         dim3(acc + J.c_tiles[0] + J.c_tiles[1] + J.o_tiles + J.rms.flat_blocks + presum),
                          dim3(256), 0, s, J);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, rms_in_finalize ? "finalize+rmsprop" : "finalize_grads");
@@ -354,13 +395,17 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
     // not needed by the reference (no loss statistic is logged); gnorm is.
     const float* wts = a->weights ? a->weights : zeros;
     if (a->optimizer == DZ_OPT_ADAM) {
-      hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
-                         (long)L.param_count, ws + L.ws_norm_part, a->opt_count);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "grad_sumsq");
+      int nparts = n_final;
+      if (!(phases & DZ_PHASE_BACKWARD)) {  // optimiser alone: norm from the stored gradient
+        hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
+                           (long)L.param_count, ws + L.ws_norm_part, a->opt_count);
+        DZ_LAUNCH_CHECK();
+        DZ_PROF(s, "grad_sumsq");
+        nparts = kNormBlocks;
+      }
       hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
                          a->opt_m, a->opt_v, (long)(L.param_count >> 2),
-                         ws + L.ws_norm_part, kNormBlocks, a->opt_count, a->losses, wts, B,
+                         ws + L.ws_norm_part, nparts, a->opt_count, a->losses, wts, B,
                          sc, a->lr, a->decay_or_b1, a->b2, a->eps, a->max_norm);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "adam");

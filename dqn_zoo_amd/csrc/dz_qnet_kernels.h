@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
     return;
   }
   b -= J.c_tiles[0] + J.c_tiles[1];
-  if (b < J.o_tiles) {  // (not combined with the fused norm: dense learners only)
+  if (b < J.o_tiles) {
     const int i = (int)b * 64 + l, k = i / J.o_ld, n = i % J.o_ld;
     for (int s0 = 0; s0 < J.o_B; s0 += 32) {
       float x[8];
@@ -283,6 +283,10 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
       const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
       J.o_out[i] = s;
       if (J.rms.p) dz_rms_apply_at(J.rms, J.o_out + i, s);
+      if (J.sumsq) {
+        const float sq = dz_wave_sum(s * s);
+        if (l == 0) J.sumsq[blockIdx.x] = sq;
+      }
     }
     return;
   }
@@ -323,6 +327,8 @@ struct HeadPre {
   const float* nz[3];
   long b_sig;          // sigma-bias offset in the parameter vector
   int eps_out;         // its noise offset
+  int plain_bias;      // 1: the bias at b_sig is an ordinary one (no noise factor): C51
+  int groups;          // rows g*B + b formed per sample (0 = 3: Rainbow)
 };
 // Launch with 256 threads: the 4 waves share the selector's per-action softmaxes
 // (A of them, 3 wave reductions each); wave 0 alone runs the rest.
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
     // written by the previous kernel: every load is a ~2 us trip past L2, so the
     // number of round trips, not the 34 KB, is what this phase costs).
     constexpr int E = 5, SMAX = 8;
-    const int n = 3 * ld;
+    const int n = (pre.groups ? pre.groups : 3) * ld;
     for (int base = 0; base < n; base += 256 * E) {
       float v[E][SMAX];
       float bs[E];
@@ -370,7 +376,8 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
         }
         const float* prm = g == 0 ? pre.prm[0] : (g == 1 ? pre.prm[1] : pre.prm[2]);
         const float* nz = g == 0 ? pre.nz[0] : (g == 1 ? pre.nz[1] : pre.nz[2]);
-        bs[e] = prm[pre.b_sig + c] * nz[pre.eps_out + c];
+        const float ez = nz[pre.eps_out + c];
+        bs[e] = prm[pre.b_sig + c] * (pre.plain_bias ? 1.0f : ez);
       }
 #pragma unroll
       for (int e = 0; e < E; ++e) {
