@@ -182,8 +182,9 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
     float* out = ws + L.ws_out;
     float* dout = ws + L.ws_dout;
     const bool q_loss = a->loss == DZ_LOSS_Q || a->loss == DZ_LOSS_DOUBLE_Q;
-    DenseHeadParams hp = {};
     if (q_loss && dense_head_fused(L)) {
+      // one value per action: fc1 epilogue + second layer + TD loss + dh1 in one launch
+      DenseHeadParams hp = {};
       hp.mode = 1; hp.sel_group = a->loss == DZ_LOSS_DOUBLE_Q ? 2 : 1; hp.tgt_group = 1;
       hp.a_tm1 = a->a_tm1; hp.r_t = a->r_t; hp.d_t = a->discount_t; hp.weights = a->weights;
       hp.bound = a->grad_error_bound; hp.dout = dout; hp.td_out = a->losses;
@@ -196,51 +197,49 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       rc = dense_forward(L, G, B, prm, in, ws, s, &hp);
       if (rc) return rc;
     } else {
-    // C51: the fc2 split-K slabs (+ bias) are folded by the loss kernel (as in dz_rainbow.hip)
-    const bool fold_fc2 = a->loss == DZ_LOSS_CATEGORICAL && !a->shared_bias &&
-                          (size_t)3 * ld2 * sizeof(float) <= 48 * 1024 && kS_fc2 <= 8;
-    rc = dense_forward(L, G, B, prm, in, ws, s, nullptr, fold_fc2);
-    if (rc) return rc;
-    switch (a->loss) {
-      case DZ_LOSS_Q:
-      case DZ_LOSS_DOUBLE_Q:
-        hipLaunchKernelGGL(td_loss_kernel, dim3((B + 63) / 64), dim3(64), 0, s, out, ld2, B,
-                           A, a->loss == DZ_LOSS_DOUBLE_Q ? 2 : 1, 1, a->a_tm1, a->r_t,
-                           a->discount_t, a->weights, a->grad_error_bound, dout, a->losses,
-                           a->priorities);
-        break;
-      case DZ_LOSS_CATEGORICAL: {
-        DZ_REQUIRE(a->weights);  // c51 passes all-ones weights
-        float* scratch = a->priorities ? a->priorities : ws + L.ws_scalars + 8;
-        (void)scratch;
-        if (fold_fc2) {
-          HeadPre pre = {};
-          pre.part = ws + L.ws_fc2_part; pre.S = kS_fc2; pre.rows = G * B; pre.groups = G;
-          for (int g = 0; g < 3; ++g) { pre.prm[g] = prm[g < G ? g : 0]; pre.nz[g] = zeros; }
-          pre.b_sig = L.fc2_b; pre.eps_out = 0; pre.plain_bias = 1;
-          hipLaunchKernelGGL(rainbow_head_loss_kernel<1>, dim3(B), dim3(256),
-                             (size_t)3 * ld2 * sizeof(float), s, out, ld2, 0, B, A,
-                             a->num_atoms, 0, 1, 1, a->a_tm1, a->r_t, a->discount_t, a->weights,
-                             a->aux, dout, a->losses,
-                             a->priorities ? a->priorities : (ws + L.ws_dfeat_part),
-                             (float*)nullptr, (float*)nullptr, pre);
+      // C51: the fc2 split-K slabs (+ bias) are folded by the loss kernel (as in
+      // dz_rainbow.hip) instead of an epilogue launch
+      const bool fold_fc2 = a->loss == DZ_LOSS_CATEGORICAL && !a->shared_bias &&
+                            (size_t)3 * ld2 * sizeof(float) <= 48 * 1024 && kS_fc2 <= 8;
+      rc = dense_forward(L, G, B, prm, in, ws, s, nullptr, fold_fc2);
+      if (rc) return rc;
+      switch (a->loss) {
+        case DZ_LOSS_Q:
+        case DZ_LOSS_DOUBLE_Q:   // more than 32 actions: separate launches
+          hipLaunchKernelGGL(td_loss_kernel, dim3((B + 63) / 64), dim3(64), 0, s, out, ld2, B,
+                             A, a->loss == DZ_LOSS_DOUBLE_Q ? 2 : 1, 1, a->a_tm1, a->r_t,
+                             a->discount_t, a->weights, a->grad_error_bound, dout, a->losses,
+                             a->priorities);
+          break;
+        case DZ_LOSS_CATEGORICAL: {
+          DZ_REQUIRE(a->weights);  // c51 passes all-ones weights
+          float* prio = a->priorities ? a->priorities : (ws + L.ws_dfeat_part);
+          if (fold_fc2) {
+            HeadPre pre = {};
+            pre.part = ws + L.ws_fc2_part; pre.S = kS_fc2; pre.rows = G * B; pre.groups = G;
+            for (int g = 0; g < 3; ++g) { pre.prm[g] = prm[g < G ? g : 0]; pre.nz[g] = zeros; }
+            pre.b_sig = L.fc2_b; pre.eps_out = 0; pre.plain_bias = 1;
+            hipLaunchKernelGGL(rainbow_head_loss_kernel<1>, dim3(B), dim3(256),
+                               (size_t)3 * ld2 * sizeof(float), s, out, ld2, 0, B, A,
+                               a->num_atoms, 0, 1, 1, a->a_tm1, a->r_t, a->discount_t,
+                               a->weights, a->aux, dout, a->losses, prio, (float*)nullptr,
+                               (float*)nullptr, pre);
+          } else {
+            hipLaunchKernelGGL(rainbow_head_loss_kernel<0>, dim3(B), dim3(256), 0, s, out, ld2,
+                               0, B, A, a->num_atoms, 0, 1, 1, a->a_tm1, a->r_t, a->discount_t,
+                               a->weights, a->aux, dout, a->losses, prio, (float*)nullptr,
+                               (float*)nullptr, HeadPre{});
+          }
           break;
         }
-        hipLaunchKernelGGL(rainbow_head_loss_kernel<0>, dim3(B), dim3(256), 0, s, out, ld2, 0,
-                           B, A, a->num_atoms, 0, 1, 1, a->a_tm1, a->r_t, a->discount_t,
-                           a->weights, a->aux, dout, a->losses,
-                           a->priorities ? a->priorities : (ws + L.ws_dfeat_part),
-                           (float*)nullptr, (float*)nullptr, HeadPre{});
-        break;
+        case DZ_LOSS_QUANTILE:
+          hipLaunchKernelGGL(quantile_loss_kernel, dim3(B), dim3(1024), 0, s, out, ld2, B, A,
+                             a->num_atoms, 1, 1, a->aux, a->a_tm1, a->r_t, a->discount_t,
+                             a->huber, dout, a->losses);
+          break;
       }
-      case DZ_LOSS_QUANTILE:
-        hipLaunchKernelGGL(quantile_loss_kernel, dim3(B), dim3(1024), 0, s, out, ld2, B, A,
-                           a->num_atoms, 1, 1, a->aux, a->a_tm1, a->r_t, a->discount_t,
-                           a->huber, dout, a->losses);
-        break;
-    }
-    DZ_LAUNCH_CHECK();
-    DZ_PROF(s, "loss");
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "loss");
     }
   }
 
@@ -283,11 +282,11 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       d.part = fold ? ws + L.ws_fc1_part : ws + L.ws_dfeat_part;
       d.ldo = kHid; d.K = kHid; d.x_off = 0;
       if (!q_fused) {
-      rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 4, 1, 1, 0>>(
-          w, dim3((N + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 1), d,
-          dim3(kHid / FcDg::BN, (B + 31) / 32, s_dh1), s);
-      if (rc) return rc;
-      DZ_PROF(s, "fc2_wgrad+dgrad");
+        rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 4, 1, 1, 0>>(
+            w, dim3((N + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 1), d,
+            dim3(kHid / FcDg::BN, (B + 31) / 32, s_dh1), s);
+        if (rc) return rc;
+        DZ_PROF(s, "fc2_wgrad+dgrad");
       }
       if (!fold && !q_fused) {
         hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kHid + 63) / 64), dim3(256), 0, s,
