@@ -18,7 +18,9 @@ constexpr int kS_dh1 = 5;
 constexpr int kS_dfeat = 8;
 constexpr int kMaxS_dfeat = 32;
 constexpr int kMaxS_fc2 = 8;
-constexpr int kS_cw1 = 50, kS_cw2 = 27, kS_cw3 = 14;
+// conv weight-gradient split-K counts.  kS_cw3 = 9 makes conv3's backward launch 90 + 162 = 252
+// workgroups: one round on 256 CUs (10 splits = 262 workgroups: 15.6 us; 9: 13.0; 8: 14.3 by events)
+constexpr int kS_cw1 = 50, kS_cw2 = 27, kS_cw3 = 9;
 constexpr int kNormBlocks = 512;
 constexpr int kNormFinal = 4096;    // fused-norm partials: one per finalize block
 constexpr int kNormSlots = 12288;   // per-wave slots of the weight-gradient kernels
