@@ -8,7 +8,7 @@
 namespace {
 constexpr int kS_dfc1 = 32;   // fc1 forward k-splits (100 rows each: dz_fc_stream_fwd3<0, 50>)
 constexpr int kMaxS_ddh1 = 32; // fc2 input-gradient k-splits grow with the head width (QR: 3618 outputs)
-constexpr int kS_ddfeat = 16; // fc1 input-gradient k-splits (FcDgradOp<1,2,2,1>, as tuned for Rainbow)
+constexpr int kS_ddfeat = 8;  // fc1 input-gradient k-splits (FcDgradOp<1,2,2,1>): 8 x 4 stages (16 x 2: +1.5 us)
 }
 
 extern "C" int dz_dense_layout(int N, int shared_bias, int B, int G,

@@ -21,7 +21,7 @@ namespace {
 // Launch constants: the measured best on MI355X at B = 32 (the sweeps and the
 // alternatives that lost are in DESIGN.md 6b; the code that implemented them is gone).
 constexpr int kFc1Splits = 32;       // fc1 forward k-splits (98 rows each)
-constexpr int kFc1DgradSplits = 16;  // fc1 input-gradient k-splits
+constexpr int kFc1DgradSplits = 12;  // fc1 input-gradient k-splits: 11 slabs of 6 single-chunk stages (17.9 us; 16 x 4: 19.2; 10 x 7: 19.6)
 constexpr int kFc2Splits = 8;        // fc2 forward k-splits
 constexpr int kAdamBlocks = 2048;    // grid-stride Adam launch width (8 blocks per CU)
 
