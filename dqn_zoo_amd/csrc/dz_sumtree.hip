@@ -329,6 +329,10 @@ __global__ __launch_bounds__(kSampleGatherThreads) void prioritized_sample_gathe
     return;
   }
   const int b = blockIdx.y;
+  // chunk blocks beyond this field's row have nothing to copy (the grid is sized for the
+  // widest field; the scalar fields need one block): leave before walking the tree
+  if ((int64_t)blockIdx.x * kSampleGatherThreads * 16 >= gf.f[blockIdx.z].row_bytes && blockIdx.x > 0)
+    return;
   if (threadIdx.x < 16) {  // 16 lanes walk the element's descent, 4 levels per round trip
     const double root = a.node[1];
     bool bad;
