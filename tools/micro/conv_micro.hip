@@ -35,6 +35,17 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(typename Op::Params p) 
   Op::body(p, dim3(blockIdx.x, blockIdx.y, blockIdx.z), smem);
 }
 
+// conv3 forward, 32x64 per workgroup: K over 4 waves, two accumulators per wave sharing the
+// A fragment (Op::NI = 2) -- 147 workgroups instead of 294
+struct Conv3FwdNI2 : Conv3Fwd {
+  static constexpr int NI = 2;
+  static constexpr int BN = 64;
+  __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
+    const bool ok = Conv3Fwd::tile(p, bid, t);
+    t.n0 = bid.x * 64;
+    return ok;
+  }
+};
 // per-workgroup trace: where it ran and when (100 MHz wall clock)
 __device__ unsigned long long g_trace[8192 * 4];
 template <class Op>
@@ -391,6 +402,19 @@ int main(int argc, char**) {
     p3.out = d_o3; p3.B = B; p3.G = G;
     const dim3 g3(64 / Conv3Fwd::BN, G * Conv3Fwd::tiles_per_group(B), 1);
     patch_vs_gemm<Conv3Fwd, Conv3Patch>("conv3", g3, p3, (size_t)rows3 * 64);
+    {
+      float* d_alt; CK(hipMalloc(&d_alt, (size_t)rows3 * 64 * 4)); CK(hipMemset(d_alt, 0xff, (size_t)rows3 * 64 * 4));
+      ConvFwdParams q3 = p3; q3.out = d_alt;
+      const dim3 gn(1, G * Conv3Fwd::tiles_per_group(B), 1);
+      hipLaunchKernelGGL((dz_mfma_gemm<Conv3Fwd>), g3, dim3(256), 0, 0, p3);
+      hipLaunchKernelGGL((dz_mfma_gemm<Conv3FwdNI2>), gn, dim3(256), 0, 0, q3);
+      CK(hipDeviceSynchronize());
+      printf("conv3 NI=2 (147 WGs, LDS %d B):", (int)DzGemmSmem<Conv3FwdNI2>::ELEMS * 4);
+      printf(" differing outputs %zu\n", count_diff(d_o3, d_alt, (size_t)rows3 * 64));
+      auto fn = [&]() { hipLaunchKernelGGL((dz_mfma_gemm<Conv3FwdNI2>), gn, dim3(256), 0, 0, q3); };
+      auto fr = [&]() { hipLaunchKernelGGL((dz_mfma_gemm<Conv3Fwd>), g3, dim3(256), 0, 0, p3); };
+      printf("conv3 shipped %.2f us   NI=2 %.2f us\n", time_us(fr), time_us(fn));
+    }
     printf("conv3 tile sweep <WM,WN,WK,KT>:\n");
 #define SW3(a, b, c_, d) sweep_one<ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, a, b, c_, d>>("<" #a "," #b "," #c_ "," #d ">", p3, 64, G, B)
     SW3(1, 1, 4, 3); SW3(1, 1, 4, 1); SW3(1, 2, 2, 3); SW3(1, 2, 2, 2); SW3(1, 2, 2, 6); SW3(2, 1, 2, 3); SW3(2, 1, 2, 6); SW3(2, 2, 1, 3); SW3(2, 2, 1, 6); SW3(1, 2, 2, 1);
