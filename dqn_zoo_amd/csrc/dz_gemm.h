@@ -449,6 +449,27 @@ __global__ __launch_bounds__(256) void dz_mfma_gemm2(typename OpA::Params pa, di
   else dz_gemm_body<OpB>(pb, dz_unflatten(blockIdx.x - na, gb), smem);
 }
 
+// dz_mfma_gemm2 compiled for OCC waves per SIMD (register budget 512 / OCC): for launches
+// whose workgroup count exceeds the co-resident slots at the default allocation.
+template <class OpA, class OpB, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
+void dz_mfma_gemm2_occ(typename OpA::Params pa, dim3 ga, typename OpB::Params pb, dim3 gb) {
+  constexpr int SM = DzGemmSmem<OpA>::ELEMS > DzGemmSmem<OpB>::ELEMS
+                         ? DzGemmSmem<OpA>::ELEMS : DzGemmSmem<OpB>::ELEMS;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  const unsigned na = ga.x * ga.y * ga.z;
+  if (blockIdx.x < na) dz_gemm_body<OpA>(pa, dz_unflatten(blockIdx.x, ga), smem);
+  else dz_gemm_body<OpB>(pb, dz_unflatten(blockIdx.x - na, gb), smem);
+}
+template <class OpA, class OpB, int OCC>
+static inline int dz_launch_gemm2_occ(const typename OpA::Params& pa, dim3 ga,
+                                      const typename OpB::Params& pb, dim3 gb, hipStream_t s) {
+  hipLaunchKernelGGL((dz_mfma_gemm2_occ<OpA, OpB, OCC>), dim3(dz_count(ga) + dz_count(gb)),
+                     dim3(256), 0, s, pa, ga, pb, gb);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
 template <class OpA, class OpB, class OpC>
 __global__ __launch_bounds__(256) void dz_mfma_gemm3(typename OpA::Params pa, dim3 ga,
                                                      typename OpB::Params pb, dim3 gb,

@@ -331,7 +331,8 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       d.part = ws + L.ws_dfeat_part; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
       // ONE launch for the 25.7 MB weight read and the 12.9 MB gradient write, the
       // weight-gradient blocks first (15 us vs 14 + 14 back to back)
-      rc = dz_launch_gemm2<FcWgradOp<2, 2, 1, 2, kS_dh1>, FcDgradOp<1, 2, 2, 1, 1, 1, 2, kS_dh1>>(
+      // (compiled for 5 waves per SIMD: 1323 workgroups then find 1280 co-resident slots instead of 1024)
+      rc = dz_launch_gemm2_occ<FcWgradOp<2, 2, 1, 2, kS_dh1>, FcDgradOp<1, 2, 2, 1, 1, 1, 2, kS_dh1>, 5>(
           w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), d,
           dim3(kFlat / 64, (B + 31) / 32, kFc1DgradSplits), s);
       if (rc) return rc;
