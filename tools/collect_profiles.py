@@ -25,7 +25,7 @@ with open(os.path.join(dst, '%s_pmc_fetch_write.csv' % tag), 'w') as f:
     f.write('"%s",%s,%s\n' % (k, '' if a is None else '%.1f' % a, '' if b is None else '%.1f' % b))
 path = os.path.join(dst, '%s_hbm_traffic.json' % tag)
 doc = json.load(open(path))
-pick = {'adam': 'adam_kernel', 'fc1_fwd': 'dz_fc_stream_fwd3', 'fc1_dgrad+wgrad': 'dz_mfma_gemm2<FcWgradOp'}
+pick = {'adam': 'adam_kernel', 'fc1_fwd': 'dz_fc_stream_fwd3', 'fc1_dgrad+wgrad': 'FcWgradOp<2, 2, 1, 2, 5>, FcDgradOp'}
 for key, pat in pick.items():
   k = next(k for k in rows if pat in k)
   fetch, write = rows[k][0] * 1024, rows[k][1] * 1024
