@@ -314,7 +314,7 @@ int main() {
   float *prm_on, *prm_tg, *x, *nz, *part;
   CK(hipMalloc(&prm_on, pcount * 4)); CK(hipMalloc(&prm_tg, pcount * 4));
   CK(hipMalloc(&x, (long)G * B * kFlat * 4)); CK(hipMalloc(&nz, 3 * 16384 * 4));
-  CK(hipMalloc(&part, (long)32 * G * B * 1024 * 4));
+  CK(hipMalloc(&part, (long)96 * G * B * 1024 * 4));
   CK(hipMemset(prm_on, 0, pcount * 4)); CK(hipMemset(prm_tg, 0, pcount * 4));
   CK(hipMemset(x, 0, (long)G * B * kFlat * 4)); CK(hipMemset(nz, 0, 3 * 16384 * 4));
   FcStreamFwd3Params q;
@@ -363,6 +363,13 @@ int main() {
     CK(hipFuncSetAttribute((const void*)fwd3_pipe<1, 100, 5, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     auto f = [&]() { hipLaunchKernelGGL((fwd3_pipe<1, 100, 5, 3, 0>), dim3(8, 16, ns), dim3(256), lds2, 0, q2); };
     printf("%-44s %.2f us\n", "pipelined CH5 D3, 16 splits (1 wave/SIMD)", time_us(f)); }
+  // other (k-pairs per wave, splits) geometries of the shipped kernel: more, shorter workgroups
+#define GEO(NLV, S) { FcStreamFwd3Params q3 = q; q3.rows_per_split = ((kFlat + S - 1) / S + 3) & ~3; \
+    if (q3.rows_per_split > 2 * NLV) printf("NL %d S %d: rows %d do not fit\n", NLV, S, q3.rows_per_split); else { \
+    q3.xcd_order = (S * ns) % 8 == 0; const size_t l3 = (size_t)q3.rows_per_split * 66 * sizeof(float); \
+    auto f = [&]() { hipLaunchKernelGGL((dz_fc_stream_fwd3<1, NLV, 5, 3>), dim3(8, S, ns), dim3(256), l3, 0, q3); }; \
+    printf("shipped kernel, %d k-pairs/wave, %d splits (%d WGs, %d rows): %.2f us\n", NLV, S, 8 * S * ns, q3.rows_per_split, time_us(f)); } }
+  GEO(50, 32); GEO(40, 40); GEO(35, 47); GEO(30, 53); GEO(25, 64); GEO(20, 79);
   // correctness: shipped vs pipelined partial slabs (random data)
   {
     std::vector<float> hw(pcount), hx((size_t)G * B * kFlat), hn(3 * 16384);
