@@ -126,6 +126,43 @@ def test_rmsprop_inside_finalize_is_bit_identical_to_the_split_phases(kind):
       a, b = getattr(fused, name).cpu().numpy(), getattr(split, name).cpu().numpy()
       assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (it, name)
 
+@pytest.mark.parametrize('actions,batch,kind', [(3, 10, 'dqn'), (18, 32, 'prioritized'),
+                                                (32, 48, 'double_q'), (4, 7, 'prioritized')])
+def test_fused_q_head_other_shapes(actions, batch, kind):
+  """The one-launch Q head (fc1 epilogue + second layer + TD loss + dh1, the
+  second layer's weight gradient in finalize) at other action counts and batch
+  sizes than BASELINE's, against the oracle: outputs, TD errors, every gradient."""
+  from dqn_zoo_amd import learner as ll, networks, _lib
+  rs = np.random.RandomState(100 + actions + batch)
+  net_kind = 'dqn' if kind == 'dqn' else 'double_dqn'
+  loss = 'q' if kind == 'dqn' else 'double_q'
+  online = qo.init_params(net_kind, actions, rs)
+  target = qo.init_params(net_kind, actions, rs)
+  net = networks.DenseNetwork(net_kind, actions)
+  opt = ll.RmsPropConfig(learning_rate=0.00025, decay=0.95, eps=0.01 / 32 ** 2)
+  ln = ll.DenseLearner(net, loss, opt, batch, params=online, grad_error_bound=1.0 / 32)
+  ln.set_params(target, 'target')
+  s_tm1 = rs.randint(0, 256, (batch, 84, 84, 4)).astype(np.uint8)
+  s_t = rs.randint(0, 256, (batch, 84, 84, 4)).astype(np.uint8)
+  a = rs.randint(actions, size=batch).astype(np.int64)
+  r = rs.choice([-1.0, 0.0, 1.0], size=batch) * 2.5
+  d = rs.choice([0.0, 0.99], size=batch)
+  b = (s_tm1, a, r, d, s_t)
+  w = rs.uniform(0.2, 1.0, size=batch).astype(np.float32) if kind == 'prioritized' else None
+  wd = None if w is None else torch.from_numpy(w).cuda()
+  ln.step(*_dev(b), wd, phases=_lib.PHASE_FORWARD | _lib.PHASE_BACKWARD)
+  torch.cuda.synchronize()
+  _, td, g32, aux = qo.dqn_family_loss_and_grads(kind, online, target, b, w, 1.0 / 32)
+  _, _, g64, _ = qo.dqn_family_loss_and_grads(kind, _f64(online), _f64(target), b, w,
+                                              1.0 / 32, np.float64)
+  L = ln.layout
+  out = ln.ws_view('out', ln.groups * batch * L.c.fc2_ld).cpu().numpy().reshape(
+      ln.groups, batch, L.c.fc2_ld)[:, :, :actions]
+  np.testing.assert_allclose(out[0], aux['q_tm1'], rtol=2e-5, atol=2e-6)
+  np.testing.assert_allclose(out[1], aux['q_target'], rtol=2e-5, atol=2e-6)
+  np.testing.assert_allclose(ln.losses.cpu().numpy(), td, rtol=1e-5, atol=2e-6)
+  _check_grads(L.unpack(ln.grad.cpu().numpy()), g32, g64)
+
 
 @pytest.mark.parametrize('kind', ['c51', 'qr'])
 def test_distributional_dense_step(kind):
