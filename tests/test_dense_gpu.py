@@ -127,7 +127,8 @@ def test_rmsprop_inside_finalize_is_bit_identical_to_the_split_phases(kind):
       assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (it, name)
 
 @pytest.mark.parametrize('actions,batch,kind', [(3, 10, 'dqn'), (18, 32, 'prioritized'),
-                                                (32, 48, 'double_q'), (4, 7, 'prioritized')])
+                                                (32, 48, 'double_q'), (4, 7, 'prioritized'),
+                                                (33, 16, 'double_q')])  # 33 actions: the unfused fallback
 def test_fused_q_head_other_shapes(actions, batch, kind):
   """The one-launch Q head (fc1 epilogue + second layer + TD loss + dh1, the
   second layer's weight gradient in finalize) at other action counts and batch
