@@ -126,6 +126,38 @@ def test_rmsprop_inside_finalize_is_bit_identical_to_the_split_phases(kind):
       a, b = getattr(fused, name).cpu().numpy(), getattr(split, name).cpu().numpy()
       assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (it, name)
 
+def test_rmsprop_inside_finalize_two_flat_ranges():
+  """33 actions: the second layer's weight gradient is written by the GEMM launch, so
+  the optimiser blocks of the finalize launch walk TWO flat ranges (fc1 and fc2 weights).
+  Must still be bit-identical to finalize + rmsprop_kernel."""
+  from dqn_zoo_amd import learner as ll, networks, _lib
+  actions, batch = 33, 16
+  opt = ll.RmsPropConfig(learning_rate=0.00025, decay=0.95, eps=0.01 / 32 ** 2)
+  lns = []
+  for _ in range(2):
+    rs = np.random.RandomState(5)
+    online = qo.init_params('double_dqn', actions, rs)
+    target = qo.init_params('double_dqn', actions, rs)
+    ln = ll.DenseLearner(networks.DenseNetwork('double_dqn', actions), 'double_q', opt, batch,
+                         params=online, grad_error_bound=1.0 / 32)
+    ln.set_params(target, 'target')
+    lns.append(ln)
+  fused, split = lns
+  for it in range(2):
+    b = [torch.from_numpy(x).cuda() for x in (
+        rs.randint(0, 256, (batch, 84, 84, 4)).astype(np.uint8),
+        rs.randint(actions, size=batch).astype(np.int64),
+        rs.choice([-1.0, 0.0, 1.0], size=batch) * 2.5, rs.choice([0.0, 0.99], size=batch),
+        rs.randint(0, 256, (batch, 84, 84, 4)).astype(np.uint8))]
+    fused.step(*b, None)
+    split.step(*b, None, phases=_lib.PHASE_FORWARD | _lib.PHASE_BACKWARD)
+    split.step(*b, None, phases=_lib.PHASE_OPTIMIZER)
+    torch.cuda.synchronize()
+    for name in ('online', 'opt_m', 'opt_v', 'grad'):
+      x, y = getattr(fused, name).cpu().numpy(), getattr(split, name).cpu().numpy()
+      assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (it, name)
+
+
 @pytest.mark.parametrize('actions,batch,kind', [(3, 10, 'dqn'), (18, 32, 'prioritized'),
                                                 (32, 48, 'double_q'), (4, 7, 'prioritized'),
                                                 (33, 16, 'double_q')])  # 33 actions: the unfused fallback
