@@ -157,6 +157,40 @@ def test_rmsprop_inside_finalize_two_flat_ranges():
       x, y = getattr(fused, name).cpu().numpy(), getattr(split, name).cpu().numpy()
       assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (it, name)
 
+@pytest.mark.parametrize('kind_net,loss,actions', [('dqn', 'q', 6), ('c51', 'categorical', 6)])
+def test_fused_global_norm_matches_the_norm_of_the_stored_gradient(kind_net, loss, actions):
+  """With Adam the global norm of a full step is assembled from partials the gradient
+  writers leave (weight-gradient kernels, finalize incl. the narrow head's weight-gradient
+  job); forward+backward followed by the optimiser phase alone takes it from the stored
+  gradient (sumsq_kernel).  With a clip that binds hard, a missing block of the norm would
+  scale the whole update: the two paths must agree to float rounding."""
+  from dqn_zoo_amd import learner as ll, networks, _lib
+  opt = ll.AdamConfig(learning_rate=1e-3, max_global_grad_norm=1e-3)
+  lns = []
+  for _ in range(2):
+    rs = np.random.RandomState(9)
+    online = qo.init_params(kind_net, actions, rs, num_atoms=K, num_quantiles=NQ)
+    target = qo.init_params(kind_net, actions, rs, num_atoms=K, num_quantiles=NQ)
+    net = networks.DenseNetwork(kind_net, actions, support=SUPPORT, quantiles=QUANTILES)
+    kw = dict(grad_error_bound=1.0 / 32) if loss == 'q' else {}
+    ln = ll.DenseLearner(net, loss, opt, B, params=online, **kw)
+    ln.set_params(target, 'target')
+    lns.append(ln)
+  fused, split = lns
+  batch = _dev(_batch(rs, scale_r=2.5))
+  wd = torch.ones(B, dtype=torch.float32, device='cuda') if loss == 'categorical' else None
+  p0 = fused.online.clone()
+  fused.step(*batch, wd)
+  split.step(*batch, wd, phases=_lib.PHASE_FORWARD | _lib.PHASE_BACKWARD)
+  split.step(*batch, wd, phases=_lib.PHASE_OPTIMIZER)
+  torch.cuda.synchronize()
+  du_f = (fused.online - p0).cpu().numpy().astype(np.float64)
+  du_s = (split.online - p0).cpu().numpy().astype(np.float64)
+  assert np.abs(du_s).max() > 0
+  # the update is proportional to the clip scale: compare the two updates as vectors
+  rel = np.linalg.norm(du_f - du_s) / np.linalg.norm(du_s)
+  assert rel < 1e-5, rel
+
 
 @pytest.mark.parametrize('actions,batch,kind', [(3, 10, 'dqn'), (18, 32, 'prioritized'),
                                                 (32, 48, 'double_q'), (4, 7, 'prioritized'),
