@@ -47,7 +47,8 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
       p.w[g] = prm[g] + T.conv_w[0]; p.bias[g] = prm[g] + T.conv_b[0];
     }
     p.out = T.act1; p.B = B; p.G = G;
-    rc = launch_conv1_fwd<Conv1Fwd>(p, G, B, side, s);
+    rc = B <= 8 ? launch_conv1_fwd<Conv1FwdAct>(p, G, B, side, s)
+                : launch_conv1_fwd<Conv1Fwd>(p, G, B, side, s);
     if (rc) return rc;
     DZ_PROF(s, side ? "conv1_fwd+noise" : "conv1_fwd");
   }
