@@ -314,7 +314,7 @@ int main() {
   float *prm_on, *prm_tg, *x, *nz, *part;
   CK(hipMalloc(&prm_on, pcount * 4)); CK(hipMalloc(&prm_tg, pcount * 4));
   CK(hipMalloc(&x, (long)G * B * kFlat * 4)); CK(hipMalloc(&nz, 3 * 16384 * 4));
-  CK(hipMalloc(&part, (long)96 * G * B * 1024 * 4));
+  CK(hipMalloc(&part, (long)128 * G * B * 1024 * 4));
   CK(hipMemset(prm_on, 0, pcount * 4)); CK(hipMemset(prm_tg, 0, pcount * 4));
   CK(hipMemset(x, 0, (long)G * B * kFlat * 4)); CK(hipMemset(nz, 0, 3 * 16384 * 4));
   FcStreamFwd3Params q;
@@ -370,6 +370,17 @@ int main() {
     auto f = [&]() { hipLaunchKernelGGL((dz_fc_stream_fwd3<1, NLV, 5, 3>), dim3(8, S, ns), dim3(256), l3, 0, q3); }; \
     printf("shipped kernel, %d k-pairs/wave, %d splits (%d WGs, %d rows): %.2f us\n", NLV, S, 8 * S * ns, q3.rows_per_split, time_us(f)); } }
   GEO(50, 32); GEO(40, 40); GEO(35, 47); GEO(30, 53); GEO(25, 64); GEO(20, 79);
+  {  // acting: ONE apply, one parameter set (256 workgroups in the shipped geometry = 1 wave per SIMD)
+    FcStreamFwd3Params qa = q; qa.G = 1; qa.M = 1;
+    const float* p1[1] = {prm_on}; const float* n1[1] = {nz};
+    const int nsa = dz_fc3_assign_sets(qa, 1, p1, n1);
+#define GEOA(NLV, S) { FcStreamFwd3Params q3 = qa; q3.rows_per_split = ((kFlat + S - 1) / S + 3) & ~3; \
+    if (q3.rows_per_split > 2 * NLV) printf("NL %d S %d: rows %d do not fit\n", NLV, S, q3.rows_per_split); else { \
+    q3.xcd_order = (S * nsa) % 8 == 0; const size_t l3 = (size_t)q3.rows_per_split * 66 * sizeof(float); \
+    auto f = [&]() { hipLaunchKernelGGL((dz_fc_stream_fwd3<1, NLV, 5, 3>), dim3(8, S, nsa), dim3(256), l3, 0, q3); }; \
+    printf("acting (1 apply): %d k-pairs/wave, %d splits (%d WGs): %.2f us\n", NLV, S, 8 * S * nsa, time_us(f)); } }
+    GEOA(50, 32); GEOA(40, 40); GEOA(30, 53); GEOA(25, 66); GEOA(20, 79); GEOA(15, 112);
+  }
   // correctness: shipped vs pipelined partial slabs (random data)
   {
     std::vector<float> hw(pcount), hx((size_t)G * B * kFlat), hn(3 * 16384);
