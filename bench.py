@@ -57,10 +57,13 @@ def parse_args():
                        'double-Q + prioritized) after the headline (0 disables)')
   ap.add_argument('--no-graphs', action='store_true',
                   help='launch the learner kernels eagerly instead of hipGraph replay')
-  ap.add_argument('--pipelined', action='store_true',
-                  help='run replay write-back/sample on a side stream under the '
-                       'backward pass (measured slower here: cross-stream event '
-                       'hops cost 7-14 us each)')
+  ap.add_argument('--sequential', action='store_true',
+                  help='one stream, three applies per step (the form Rainbow._learn '
+                       'enqueues); default: the two-stream pipelined loop '
+                       '(dqn_zoo_amd/pipeline.py), bit-identical results')
+  ap.add_argument('--host-scope-events', action='store_true',
+                  help='pipelined loop with default (system-fence) events instead of '
+                       'device-scope ones (measurement aid)')
   return ap.parse_args()
 
 
@@ -134,40 +137,17 @@ def make_step(replay, learner, batch, fused_write_back=True):
   return step
 
 
-def make_step_pipelined(replay, learner, batch, device):
-  """Same steps, same order of replay operations (sample k+1 still sees the
-  priorities written by step k), but the latency-bound replay kernels run on a
-  second HIP stream underneath the backward pass and the optimiser of step k:
-      main : forward+loss(k) ................ backward + clip/Adam(k) | forward(k+1)
-      side :                 write-back(k), sample(k+1), gather(k+1)  |
-  """
-  from dqn_zoo_amd import _lib
-  main = torch.cuda.current_stream(device)
-  side = torch.cuda.Stream(device)
-  ev_sample = torch.cuda.Event()
-  ev_fwd = torch.cuda.Event()
-  nxt = [None]
-
-  def step():
-    if nxt[0] is None:
-      with torch.cuda.stream(side):
-        nxt[0] = replay.sample_device(batch)
-        ev_sample.record(side)
-    s = nxt[0]
-    main.wait_event(ev_sample)
-    t = s.transitions
-    learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
-                 phases=_lib.PHASE_FORWARD)
-    ev_fwd.record(main)
-    with torch.cuda.stream(side):
-      side.wait_event(ev_fwd)
-      replay.update_priorities(s.ids, learner.priorities)
-      nxt[0] = replay.sample_device(batch)
-      ev_sample.record(side)
-    learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
-                 phases=_lib.PHASE_BACKWARD | _lib.PHASE_OPTIMIZER,
-                 resample_noise=False)
-
+def make_step_pipelined(replay, learner, batch, device, device_scope_events=True):
+  """The same steps, software-pipelined across steps on two HIP streams
+  (dqn_zoo_amd/pipeline.py): write-back(k), sample+gather(k+1) and the TARGET
+  network's apply for batch k+1 run on a side stream underneath backward(k) and
+  Adam(k); the main stream carries only the two online applies, the loss, the
+  backward pass and the optimiser.  Bit-identical to the sequential step."""
+  from dqn_zoo_amd import pipeline
+  loop = pipeline.PipelinedRainbowLoop(replay, learner, batch,
+                                       device_scope_events=device_scope_events)
+  step = loop.step
+  step.loop = loop
   return step
 
 
@@ -587,11 +567,11 @@ def main():
   torch.cuda.synchronize(device)
   torch.cuda.set_stream(torch.cuda.Stream(device))
   learner.use_graphs = not args.no_graphs
-  args.sequential = not args.pipelined
   if args.sequential:
     step = make_step(replay, learner, args.batch)
   else:
-    step = make_step_pipelined(replay, learner, args.batch, device)
+    step = make_step_pipelined(replay, learner, args.batch, device,
+                               device_scope_events=not args.host_scope_events)
   seq_step = make_step(replay, learner, args.batch)
 
   # ---- setup that is NOT a step, all of it before the clock starts ----------

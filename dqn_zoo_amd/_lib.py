@@ -85,6 +85,7 @@ class RainbowArgs(ctypes.Structure):
       ('prio_node', c_vp), ('prio_cap_pow2', c_i64), ('prio_capacity', c_i64),
       ('prio_ids', c_vp), ('prio_exponent', c_f64), ('prio_max_seen', c_vp),
       ('prio_status', c_vp), ('keep_all_grads', c_i32), ('pad_', c_i32),
+      ('tgt_part', c_vp), ('tgt_noise', c_vp),
   ]
 
 
@@ -157,6 +158,7 @@ LOSS_Q, LOSS_DOUBLE_Q, LOSS_CATEGORICAL, LOSS_QUANTILE = 0, 1, 2, 3
 OPT_RMSPROP, OPT_ADAM = 0, 1
 SC_GNORM, SC_LOSS, SC_BC1, SC_BC2, SC_CLIP = 0, 1, 2, 3, 4
 PHASE_FORWARD, PHASE_BACKWARD, PHASE_OPTIMIZER, PHASE_ALL = 1, 2, 4, 7
+PHASE_FWD_NETS, PHASE_FWD_LOSS = 8, 16   # the two halves of PHASE_FORWARD
 
 STRUCT_IDS = {0: FieldDesc, 1: PrioSampleArgs, 2: RainbowLayout, 3: RainbowArgs,
               4: DenseLayout, 5: DenseArgs, 6: IqnLayout, 7: IqnArgs,
@@ -176,6 +178,12 @@ SIGNATURES = {
                                  c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dz_rainbow_act': (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, ctypes.c_uint64,
                                ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'dz_rainbow_target_forward': (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp,
+                                          ctypes.c_uint64, c_vp, c_vp, c_vp]),
+    'dz_event_create': (c_int, [c_int, ctypes.POINTER(c_vp)]),
+    'dz_event_destroy': (c_int, [c_vp]),
+    'dz_event_record': (c_int, [c_vp, c_vp]),
+    'dz_stream_wait_event': (c_int, [c_vp, c_vp]),
     'dz_rainbow_graph_capture': (c_int, [ctypes.POINTER(RainbowArgs), c_int, c_vp,
                                          ctypes.POINTER(c_vp)]),
     'dz_atari_observation': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int,

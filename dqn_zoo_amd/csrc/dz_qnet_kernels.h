@@ -335,6 +335,11 @@ struct HeadPre {
   int eps_out;         // its noise offset
   int plain_bias;      // 1: the bias at b_sig is an ordinary one (no noise factor): C51
   int groups;          // rows g*B + b formed per sample (0 = 3: Rainbow)
+  // Optional: group 2 (the target apply) comes from ANOTHER slab set -- the one
+  // dz_rainbow_target_forward left for this batch ([S][rows2][ld], row b) -- and
+  // `part` then holds groups 0 and 1 only (rows = 2B).  Same fold order: same bits.
+  const float* part2;
+  int rows2;
 };
 // Launch with 256 threads: the 4 waves share the selector's per-action softmaxes
 // (A of them, 3 wave reductions each); wave 0 alone runs the rest.
@@ -374,10 +379,14 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
       for (int e = 0; e < E; ++e) {
         const int i = min(base + (int)threadIdx.x + 256 * e, n - 1);
         const int g = i / ld, c = i - g * ld;
-        const long row = (long)g * B + b;
+        // (dz_val: selects on VALUES -- see FcDgradOp::locate)
+        const bool alt = pre.part2 != nullptr && g == 2;
+        const float* src = dz_val(alt, pre.part2, pre.part);
+        const long row = dz_val(alt, (long)b, (long)g * B + b);
+        const long rows = dz_val(alt, (long)pre.rows2, (long)pre.rows);
 #pragma unroll
         for (int sidx = 0; sidx < SMAX; ++sidx) {
-          const float t = pre.part[((long)min(sidx, pre.S - 1) * pre.rows + row) * ld + c];
+          const float t = src[((long)min(sidx, pre.S - 1) * rows + row) * ld + c];
           v[e][sidx] = sidx < pre.S ? t : 0.f;
         }
         const float* prm = g == 0 ? pre.prm[0] : (g == 1 ? pre.prm[1] : pre.prm[2]);
@@ -687,11 +696,18 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
 }
-struct NoiseParams { float* out; long n; uint64_t seed; uint64_t counter; const int32_t* step; };
+// Element i of the call is stream position  counter + *step * step_mul + i0 + i
+// (step_mul == 0: n, i.e. consecutive calls tile the stream).  step_mul / i0 let a
+// call draw a SUB-RANGE of a step's block -- the precomputed target apply draws
+// block 2 of 3 at the positions the three-apply step would use.
+struct NoiseParams {
+  float* out; long n; uint64_t seed; uint64_t counter; const int32_t* step;
+  long step_mul = 0; long i0 = 0;
+};
 __device__ __forceinline__ void noise_fill_at(const NoiseParams& q, long i) {
   if (i >= q.n) return;
-  uint64_t counter = q.counter;
-  if (q.step) counter += (uint64_t)(*q.step) * (uint64_t)q.n;  // per-step stream offset
+  uint64_t counter = q.counter + (uint64_t)q.i0;
+  if (q.step) counter += (uint64_t)(*q.step) * (uint64_t)(q.step_mul ? q.step_mul : q.n);  // per-step stream offset
   const uint64_t h = mix64(mix64(q.seed) ^ mix64(counter + (uint64_t)i));
   // jax.random.truncated_normal: sqrt2 * erfinv(U(erf(lo/sqrt2), erf(hi/sqrt2)))
   const float u01 = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
@@ -710,6 +726,15 @@ struct NoiseSide {
   typedef NoiseParams Params;
   __device__ static void run(const Params& q, unsigned block) {
     noise_fill_at(q, (long)block * 256 + threadIdx.x);
+  }
+};
+
+// ++*p as one extra block of a launch (a device-side step counter advanced by the
+// LAST launch of a sequence whose FIRST launch read it).
+struct BumpSide {
+  struct Params { int32_t* p; };
+  __device__ static void run(const Params& q, unsigned block) {
+    if (block == 0 && threadIdx.x == 0) *q.p = *q.p + 1;
   }
 };
 

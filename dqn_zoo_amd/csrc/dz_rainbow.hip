@@ -35,7 +35,8 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
                            const float* const* prm, const float* const* nz,
                            const uint8_t* const* in, float* ws, hipStream_t s,
                            const NoiseParams* resample = nullptr,
-                           bool skip_fc2_epilogue = false, bool stop_after_fc1 = false) {
+                           bool skip_fc2_epilogue = false, bool stop_after_fc1 = false,
+                           int32_t* bump = nullptr) {
   int rc = DZ_OK;
   const int NA = L.num_actions * L.num_atoms;
   const int ld2 = L.adv2_ld + L.val2_ld;
@@ -92,7 +93,10 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
     p.head[0] = fc2h[0]; p.head[1] = fc2h[1];
     p.part = ws + L.ws_fc2_part; p.ldo = ld2;
     const dim3 g2((NA + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32, G * 2 * kFc2Splits);
-    rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4, 2>>(p, g2, s);
+    if (bump)  // ++*bump by one extra block of this (last) launch: the first launch read it
+      rc = dz_launch_gemm_side<FcFwdOp<1, 2, 2, 4, 2>, BumpSide>(p, g2, BumpSide::Params{bump}, 1, s);
+    else
+      rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4, 2>>(p, g2, s);
     if (rc) return rc;
     DZ_PROF(s, "fc2_fwd");
     if (skip_fc2_epilogue) return rc;  // the loss kernel folds the partial slabs itself
@@ -217,21 +221,33 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   const FcHead* fc2h = H.fc2h;
 
   if (g_dz_prof_on) dz_prof_begin(s);
-  NoiseParams nq = {const_cast<float*>(a->noise), 3 * (long)L.noise_stride, a->noise_seed,
-                    (uint64_t)0x5eed, a->adam_count};
-  if ((phases & DZ_PHASE_FORWARD) && a->resample_noise) DZ_REQUIRE(a->adam_count);
-  if (phases & DZ_PHASE_FORWARD) {
+  // Precomputed target apply (dz_rainbow_target_forward, tgt_part): only the two
+  // online applies run here; the loss kernel folds group 2 from the other slab set.
+  const bool tgt_pre = a->tgt_part != nullptr;
+  const int Gf = tgt_pre ? 2 : kG;
+  if (tgt_pre) { DZ_REQUIRE(a->tgt_noise); nz[2] = a->tgt_noise; }
+  const bool fuse = (size_t)3 * ld2 * sizeof(float) <= 48 * 1024;
+  DZ_REQUIRE(fuse || !tgt_pre);  // the slab hand-over lives in the fused loss kernel
+  const bool do_nets = (phases & (DZ_PHASE_FORWARD | DZ_PHASE_FWD_NETS)) != 0;
+  const bool do_loss = (phases & (DZ_PHASE_FORWARD | DZ_PHASE_FWD_LOSS)) != 0;
+  // the step's noise: blocks [0, Gf) of 3 at stream position *adam_count * 3 * stride
+  NoiseParams nq = {const_cast<float*>(a->noise), Gf * (long)L.noise_stride, a->noise_seed,
+                    (uint64_t)0x5eed, a->adam_count, 3 * (long)L.noise_stride, 0};
+  if (do_nets && a->resample_noise) DZ_REQUIRE(a->adam_count);
+  if (do_nets) {
+    const uint8_t* in[kG] = {a->s_tm1, a->s_t, a->s_t};
+    rc = rainbow_forward(L, H, Gf, B, prm, nz, in, ws, s,
+                         a->resample_noise ? &nq : nullptr, fuse);
+    if (rc) return rc;
+  }
+  if (do_loss) {
     {
-      const uint8_t* in[kG] = {a->s_tm1, a->s_t, a->s_t};
-      const bool fuse = (size_t)3 * ld2 * sizeof(float) <= 48 * 1024;
-      rc = rainbow_forward(L, H, kG, B, prm, nz, in, ws, s,
-                           a->resample_noise ? &nq : nullptr, fuse);
-      if (rc) return rc;
       HeadPre pre = {};
       if (fuse) {
-        pre.part = ws + L.ws_fc2_part; pre.S = kFc2Splits; pre.rows = kG * B;
+        pre.part = ws + L.ws_fc2_part; pre.S = kFc2Splits; pre.rows = Gf * B;
         for (int g = 0; g < kG; ++g) { pre.prm[g] = prm[g]; pre.nz[g] = nz[g]; }
         pre.b_sig = L.fc2_sig_b; pre.eps_out = (int)L.n_fc2_out;
+        if (tgt_pre) { pre.part2 = a->tgt_part; pre.rows2 = B; }
         hipLaunchKernelGGL(rainbow_head_loss_kernel<1>, dim3(B), dim3(256),
                            (size_t)3 * ld2 * sizeof(float), s, ws + L.ws_fc2_out, ld2, NAp, B,
                            A, K, 1, 1, 2, a->a_tm1, a->r_t, a->discount_t, a->weights,
@@ -526,6 +542,37 @@ extern "C" int dz_rainbow_apply(int num_actions, int num_atoms, int batch,
                      num_atoms, support, q_values_out, greedy_out, vmax_out, HeadPre{});
   DZ_LAUNCH_CHECK();
   return DZ_OK;
+}
+
+// The target network's apply run ahead of its consumer (header: dz_rainbow_args_t::
+// tgt_part).  Same launches as group 2 of the three-apply forward, tile for tile, so
+// the slabs -- and everything the loss kernel derives from them -- are bit-identical.
+extern "C" int dz_rainbow_target_forward(int num_actions, int num_atoms, int batch,
+                                         const float* target_params, const uint8_t* s_t,
+                                         float* noise, uint64_t noise_seed,
+                                         int32_t* step_counter, float* ws,
+                                         dz_stream_t stream) {
+  DZ_REQUIRE(target_params && s_t && noise && ws);
+  dz_rainbow_layout_t L;
+  int rc = dz_rainbow_layout(num_actions, num_atoms, batch, &L);
+  if (rc != DZ_OK) return rc;
+  hipStream_t s = dz_s(stream);
+  FwdHeads H;
+  make_heads(L, H);
+  const float* prm[kG] = {target_params, target_params, target_params};
+  const float* nz[kG] = {noise, noise, noise};
+  const uint8_t* in[kG] = {s_t, s_t, s_t};
+  const int ld2 = L.adv2_ld + L.val2_ld;
+  DZ_REQUIRE((size_t)3 * ld2 * sizeof(float) <= 48 * 1024);  // consumer folds the slabs
+  // block 2 of the consuming step's three noise blocks (dz_rainbow_learn's nq)
+  const NoiseParams nq = {noise, (long)L.noise_stride, noise_seed, (uint64_t)0x5eed,
+                          step_counter, 3 * (long)L.noise_stride, 2 * (long)L.noise_stride};
+  const bool prof = g_dz_prof_on;
+  g_dz_prof_on = false;  // marks belong to dz_rainbow_learn
+  rc = rainbow_forward(L, H, 1, batch, prm, nz, in, ws, s, step_counter ? &nq : nullptr,
+                       /*skip_fc2_epilogue=*/true, /*stop_after_fc1=*/false, step_counter);
+  g_dz_prof_on = prof;
+  return rc;
 }
 
 // The actor's apply (ref: rainbow/agent.py:125-131, 171-179): fresh noise from

@@ -1,7 +1,8 @@
-"""The multi-stream form of the step (replay write-back/sample prefetch on a
-side stream in bench.make_step_pipelined) and the hipGraph form must be
-BIT-IDENTICAL to the sequential
-single-stream step: same sampled ids, same losses, same parameters."""
+"""The two-stream, software-pipelined form of the step (dqn_zoo_amd/pipeline.py:
+write-back(k), sample(k+1) and the TARGET network's apply for batch k+1 on a side
+stream under backward(k)/Adam(k); two online applies on the main stream) and the
+hipGraph form must be BIT-IDENTICAL to the sequential single-stream three-apply
+step: same sampled ids, same losses, same parameters, same tree."""
 
 import types
 
@@ -12,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(pipelined, steps=12, graphs=False):
+def _run(pipelined, steps=12, graphs=False, sync_every_step=True, sync_target_at=()):
   import bench
   args = types.SimpleNamespace(capacity=2048, batch=32)
   dev = torch.device('cuda', 0)
@@ -23,23 +24,36 @@ def _run(pipelined, steps=12, graphs=False):
   torch.cuda.set_stream(torch.cuda.Stream(dev))
   step = (bench.make_step_pipelined(replay, learner, 32, dev) if pipelined
           else bench.make_step(replay, learner, 32))
-  losses = []
-  for _ in range(steps):
-    step()
-    torch.cuda.synchronize()
+  losses, ids = [], []
+  for k in range(steps):
+    if k in sync_target_at:   # target <- online between two steps
+      (step.loop if pipelined else learner).sync_target()
+    if pipelined:
+      s = step()
+      # (the loss buffer is rewritten by the next step: read it before enqueueing more)
+      if sync_every_step:
+        torch.cuda.synchronize()
+      else:
+        torch.cuda.current_stream(dev).synchronize()   # main only; side keeps running
+      ids.append(s.ids.cpu().numpy().copy())
+    else:
+      step()
+      torch.cuda.synchronize()
     losses.append(learner.losses.cpu().numpy().copy())
   replay.check_status()
   torch.cuda.synchronize()
   torch.cuda.set_stream(prev)
   return (np.stack(losses), learner.online.cpu().numpy(),
           replay.tree_storage.cpu().numpy(),
-          float(replay.max_seen_priority_device.item()))
+          float(replay.max_seen_priority_device.item()),
+          learner.target.cpu().numpy())
 
 
 def test_overlapped_steps_are_bit_identical_to_sequential():
   ref = _run(pipelined=False)
-  for pipelined, graphs in ((True, False), (False, True), (True, True)):
-    got = _run(pipelined, graphs=graphs)
+  for pipelined, graphs, sync in ((True, False, True), (False, True, True),
+                                  (True, True, True), (True, True, False)):
+    got = _run(pipelined, graphs=graphs, sync_every_step=sync)
     np.testing.assert_array_equal(got[0], ref[0])
     np.testing.assert_array_equal(got[1], ref[1])
     # the pipelined loop has prefetched one extra sample but the tree only
@@ -47,6 +61,56 @@ def test_overlapped_steps_are_bit_identical_to_sequential():
     np.testing.assert_array_equal(got[2], ref[2])
     assert got[3] == ref[3]
   assert np.isfinite(ref[0]).all() and ref[0].std() > 0
+
+
+def test_pipelined_target_sync_matches_sequential():
+  """sync_target() between two pipelined steps: the prefetched target apply used
+  the OLD parameters and is redone in line -- same bits as the sequential loop."""
+  ref = _run(pipelined=False, steps=9, sync_target_at=(3, 4, 7))
+  for graphs in (False, True):
+    got = _run(pipelined=True, steps=9, graphs=graphs, sync_every_step=False,
+               sync_target_at=(3, 4, 7))
+    for a, b in zip(got, ref):
+      np.testing.assert_array_equal(a, b)
+  # the sync matters: without it the losses differ from step 3 on
+  plain = _run(pipelined=False, steps=9)
+  assert (plain[0][:3] == ref[0][:3]).all() and (plain[0][3:] != ref[0][3:]).any()
+
+
+def test_target_pre_equals_three_apply_step():
+  """One stream, no pipeline: target_forward(s_t) followed by step(target_pre=True)
+  gives the bits of the three-apply step, with device-drawn noise (the target block's
+  stream positions) over several optimiser steps, and with injected noise."""
+  from dqn_zoo_amd import learner as ll, networks
+  A, B = 5, 32
+  sup = np.linspace(-10, 10, 51).astype(np.float32)
+  rs = np.random.RandomState(0)
+  dev = torch.device('cuda', 0)
+  mk = lambda: ll.RainbowLearner(networks.RainbowNetwork(A, sup, 0.1), ll.AdamConfig(), B, seed=7)
+  la, lb = mk(), mk()
+  lb.target.copy_(torch.from_numpy(rs.uniform(-0.05, 0.05, lb.target.numel()).astype(np.float32)) + lb.target)
+  la.target.copy_(lb.target)
+  for ln in (la, lb):
+    ln.use_graphs = False
+  for it in range(4):
+    s_tm1 = torch.from_numpy(rs.randint(0, 256, (B, 84, 84, 4)).astype(np.uint8)).to(dev)
+    s_t = torch.from_numpy(rs.randint(0, 256, (B, 84, 84, 4)).astype(np.uint8)).to(dev)
+    a = torch.from_numpy(rs.randint(0, A, B).astype(np.int64)).to(dev)
+    r = torch.from_numpy(rs.randint(-1, 2, B).astype(np.float64)).to(dev)
+    d = torch.from_numpy((rs.randint(0, 2, B) * 0.97).astype(np.float64)).to(dev)
+    w = torch.from_numpy(rs.uniform(0.3, 1.0, B).astype(np.float32)).to(dev)
+    la.step(s_tm1, a, r, d, s_t, w)
+    lb.target_forward(s_t, step_from=lb.adam_count if it == 0 else None)
+    lb.step(s_tm1, a, r, d, s_t, w, target_pre=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(la.losses.cpu().numpy(), lb.losses.cpu().numpy())
+    np.testing.assert_array_equal(la.priorities.cpu().numpy(), lb.priorities.cpu().numpy())
+    np.testing.assert_array_equal(la.online.cpu().numpy(), lb.online.cpu().numpy())
+    # the target block of the three-apply step's noise == the block target_forward drew
+    st = int(la.layout.noise_stride)
+    np.testing.assert_array_equal(la.noise[2 * st:3 * st].cpu().numpy(),
+                                  lb._tgt_noise.cpu().numpy())  # pylint: disable=protected-access
+  assert np.isfinite(la.losses.cpu().numpy()).all()
 
 
 def test_priority_sink_equals_separate_update():
