@@ -55,14 +55,30 @@ def parse_args():
   ap.add_argument('--other-configs', type=int, default=1,
                   help='also measure BASELINE configs 2 and 3 (DQN + uniform replay; '
                        'double-Q + prioritized) after the headline (0 disables)')
-  ap.add_argument('--no-graphs', action='store_true',
-                  help='launch the learner kernels eagerly instead of hipGraph replay')
-  ap.add_argument('--sequential', action='store_true',
-                  help='one stream, three applies per step (the form Rainbow._learn '
-                       'enqueues); default: the two-stream pipelined loop '
-                       '(dqn_zoo_amd/pipeline.py), bit-identical results')
+  ap.add_argument('--mode', default='fused', choices=('fused', 'sequential', 'two-stream'),
+                  help="how the steps are enqueued.  'sequential': sample launch, then the "
+                       "learner step with the write-back inside Adam -- what Rainbow._learn "
+                       "enqueues per learn period.  'fused' (default): the same operations in "
+                       "the same order, but the replay is static between two learner steps "
+                       "here, so sample(k+1)+gather(k+1) ride in step k's optimiser launch "
+                       "(after write-back(k)): one launch fewer on the dependent chain.  "
+                       "'two-stream': write-back, sample AND the target network's apply for "
+                       "step k+1 on a side stream under backward(k) "
+                       "(dqn_zoo_amd/pipeline.py; measured slower, DESIGN.md 6b).  All three "
+                       "are bit-identical (tests/test_pipeline_gpu.py)")
+  ap.add_argument('--graphs', action='store_true',
+                  help='replay the learner launches from hipGraphs (sequential / two-stream '
+                       'modes; measured 3 %% slower than eager launches for this step, kept '
+                       'for host-bound callers such as the agent loop)')
+  ap.add_argument('--no-graphs', action='store_true', help='(default now; accepted for old scripts)')
+  ap.add_argument('--sequential', action='store_true', help="same as --mode sequential")
+  ap.add_argument('--fused-sample', action='store_true', help="same as --mode fused")
+  ap.add_argument('--replay-only-prefetch', action='store_true',
+                  help='two-stream mode that runs only write-back/sample/gather ahead')
+  ap.add_argument('--prime-steps', type=int, default=-1,
+                  help='untimed steps before the warm-up (default: one per ring slot)')
   ap.add_argument('--host-scope-events', action='store_true',
-                  help='pipelined loop with default (system-fence) events instead of '
+                  help='two-stream mode with default (system-fence) events instead of '
                        'device-scope ones (measurement aid)')
   return ap.parse_args()
 
@@ -119,10 +135,24 @@ def build_workload(args, device, seed):
   return replay, learner, None
 
 
-def make_step(replay, learner, batch, fused_write_back=True):
+def make_step(replay, learner, batch, fused_write_back=True, fused_next_sample=False):
   """The step: sample -> update -> priority write-back (rainbow/agent.py:181-198),
   as `Rainbow._learn` enqueues it.  fused_write_back=False keeps the write-back
-  as its own kernel after the update (the reference's literal order)."""
+  as its own kernel after the update (the reference's literal order).
+  fused_next_sample: the replay is static between steps, so sample(k+1) + gather(k+1)
+  ride in step k's optimiser launch (after write-back(k), which moves into an earlier
+  backward launch): same operations, same order, one launch fewer on the chain."""
+  nxt = [None]
+
+  def step_fused():
+    s = nxt[0] if nxt[0] is not None else replay.sample_device(batch)
+    t = s.transitions
+    desc, nxt[0] = replay.prepare_next_sample(batch)
+    learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
+                 priority_sink=replay.priority_sink(s.ids), next_sample=desc)
+
+  if fused_next_sample:
+    return step_fused
 
   def step():
     s = replay.sample_device(batch)
@@ -137,7 +167,8 @@ def make_step(replay, learner, batch, fused_write_back=True):
   return step
 
 
-def make_step_pipelined(replay, learner, batch, device, device_scope_events=True):
+def make_step_pipelined(replay, learner, batch, device, device_scope_events=True,
+                        prefetch_target=True):
   """The same steps, software-pipelined across steps on two HIP streams
   (dqn_zoo_amd/pipeline.py): write-back(k), sample+gather(k+1) and the TARGET
   network's apply for batch k+1 run on a side stream underneath backward(k) and
@@ -145,8 +176,12 @@ def make_step_pipelined(replay, learner, batch, device, device_scope_events=True
   backward pass and the optimiser.  Bit-identical to the sequential step."""
   from dqn_zoo_amd import pipeline
   loop = pipeline.PipelinedRainbowLoop(replay, learner, batch,
-                                       device_scope_events=device_scope_events)
-  step = loop.step
+                                       device_scope_events=device_scope_events,
+                                       prefetch_target=prefetch_target)
+
+  def step():
+    return loop.step()
+
   step.loop = loop
   return step
 
@@ -260,7 +295,7 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
   out = {}
 
   def run(name, replay, learner, step, work, desc):
-    learner.use_graphs = not args.no_graphs
+    learner.use_graphs = args.other_graphs
     for _ in range(max(warmup, replay.SAMPLE_RING_DEPTH)):
       step()
     torch.cuda.synchronize()
@@ -276,7 +311,7 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
          'replay_samples_per_sec': round(steps / dt * b, 1), 'dtype': 'f32',
          'config': dict(desc, replay_capacity=cap, global_batch=b,
                         num_actions=NUM_ACTIONS,
-                        launch='eager' if args.no_graphs else
+                        launch='eager' if not args.other_graphs else
                                'hipGraph replay (learner) + 1 eager sample launch')}
     if prof_steps > 0:
       learner.use_graphs = False
@@ -566,12 +601,19 @@ def main():
   # here on runs on an explicit stream.
   torch.cuda.synchronize(device)
   torch.cuda.set_stream(torch.cuda.Stream(device))
-  learner.use_graphs = not args.no_graphs
   if args.sequential:
-    step = make_step(replay, learner, args.batch)
-  else:
+    args.mode = 'sequential'
+  if args.fused_sample:
+    args.mode = 'fused'
+  args.other_graphs = not args.no_graphs   # configs 2/3 keep hipGraph replay unless --no-graphs
+  args.no_graphs = not args.graphs or args.mode == 'fused'
+  learner.use_graphs = not args.no_graphs
+  if args.mode == 'two-stream':
     step = make_step_pipelined(replay, learner, args.batch, device,
-                               device_scope_events=not args.host_scope_events)
+                               device_scope_events=not args.host_scope_events,
+                               prefetch_target=not args.replay_only_prefetch)
+  else:
+    step = make_step(replay, learner, args.batch, fused_next_sample=args.mode == 'fused')
   seq_step = make_step(replay, learner, args.batch)
 
   # ---- setup that is NOT a step, all of it before the clock starts ----------
@@ -581,7 +623,9 @@ def main():
   from dqn_zoo_amd import distributed as dz_dist
   # one hipGraph per slot of the replay's sample ring: capture them all now so
   # that no --warmup value can leave a capture inside the timed region
-  prime = 0 if args.no_graphs else replay.SAMPLE_RING_DEPTH
+  prime = replay.SAMPLE_RING_DEPTH
+  if args.prime_steps >= 0:
+    prime = args.prime_steps
   for _ in range(prime):
     step()
   # the statistics path once, end to end (allocations, first-use kernels, the
@@ -602,6 +646,7 @@ def main():
   t0 = time.perf_counter()
   for _ in range(args.steps):
     step()
+  dt_host = time.perf_counter() - t0   # host enqueue time (the GPU may still be running)
   torch.cuda.synchronize()
   if dist is not None:
     dist.barrier()
@@ -626,21 +671,24 @@ def main():
         'value': round(value, 2), 'unit': 'steps/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * dt / args.steps, 4),
+        'host_enqueue_ms_per_step': round(1e3 * dt_host / args.steps, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'replay_samples_per_sec': round(value * args.batch, 1),
         'config': {
             'workload': 'rainbow learner step: prioritized sum-tree sample + '
                         'gather + 3x noisy dueling C51 apply + double-Q loss + '
-                        'backward (+ priority write-back as a side block) + clip/Adam',
+                        'backward (+ priority write-back as a side block) + clip/Adam'
+                        + (' (+ the next step\'s sample + gather as side blocks)'
+                           if args.mode == 'fused' else ''),
             'replay_capacity': args.capacity, 'global_batch': args.batch * world,
             'state': '84x84x4 uint8', 'num_actions': NUM_ACTIONS,
             'num_atoms': NUM_ATOMS, 'parallelism': 'replicas x%d' % world,
             'launch': 'eager' if args.no_graphs else 'hipGraph replay',
             'collective': 'rccl' if dist is not None else 'none (single process)',
             'untimed_setup_steps': prime,
-            'streams': 'sequential' if args.sequential else
-                       'replay ops overlapped on a side stream'},
+            'mode': args.mode,
+            'streams': 'two (dqn_zoo_amd/pipeline.py)' if args.mode == 'two-stream' else 'one'},
     }
     if args.prof_steps > 0:
       learner.use_graphs = False  # per-kernel events need eager launches

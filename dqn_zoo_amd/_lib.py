@@ -85,7 +85,18 @@ class RainbowArgs(ctypes.Structure):
       ('prio_node', c_vp), ('prio_cap_pow2', c_i64), ('prio_capacity', c_i64),
       ('prio_ids', c_vp), ('prio_exponent', c_f64), ('prio_max_seen', c_vp),
       ('prio_status', c_vp), ('keep_all_grads', c_i32), ('pad_', c_i32),
-      ('tgt_part', c_vp), ('tgt_noise', c_vp),
+      ('tgt_part', c_vp), ('tgt_noise', c_vp), ('next_sample', c_vp),
+  ]
+
+
+class NextSample(ctypes.Structure):
+  """dz_next_sample_t: the arguments of dz_prioritized_sample_gather, carried by a
+  learner step (RainbowArgs.next_sample)."""
+  _fields_ = [
+      ('args', PrioSampleArgs), ('pos_h', c_vp), ('u_target_h', c_vp), ('u_mix_h', c_vp),
+      ('fields', c_vp), ('num_fields', c_i32), ('n', c_i32), ('ids_out', c_vp),
+      ('probs_out', c_vp), ('weights_out', c_vp), ('weights32_out', c_vp),
+      ('status', c_vp),
   ]
 
 
@@ -162,7 +173,7 @@ PHASE_FWD_NETS, PHASE_FWD_LOSS = 8, 16   # the two halves of PHASE_FORWARD
 
 STRUCT_IDS = {0: FieldDesc, 1: PrioSampleArgs, 2: RainbowLayout, 3: RainbowArgs,
               4: DenseLayout, 5: DenseArgs, 6: IqnLayout, 7: IqnArgs,
-              8: InsertField}
+              8: InsertField, 9: NextSample}
 
 # name -> (restype, argtypes).  tests/test_abi.py checks this table against
 # the prototypes in include/dqnzoo_hip.h and against the built library.

@@ -18,6 +18,7 @@ extern "C" int dz_struct_size(int which) {
     case 6: return (int)sizeof(dz_iqn_layout_t);
     case 7: return (int)sizeof(dz_iqn_args_t);
     case 8: return (int)sizeof(dz_insert_field_t);
+    case 9: return (int)sizeof(dz_next_sample_t);
     default: return -1;
   }
 }

@@ -244,6 +244,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
   }
 
   bool rms_in_finalize = false;
+  bool norm_fused = false;  // this call's backward phase left the norm partials (Adam)
   int n_final = 0;   // fused-norm partials left by this call's backward phase (Adam)
   if (phases & DZ_PHASE_BACKWARD) {
     DZ_REQUIRE(a->grad);
@@ -258,13 +259,15 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
     // in sq_slots (fc2 first, then fc1), finalize folds them and adds its own, so that
     // ws_norm_part[0..n_final) is the partial list for adam_kernel -- no sumsq launch over
     // the whole gradient (as in dz_rainbow.hip)
-    const bool fused_norm = a->optimizer == DZ_OPT_ADAM;
+    // (heads too wide for the slot array -- beyond ~21k outputs -- keep the separate
+    // sumsq launch over the stored gradient)
     float* sq_final = ws + L.ws_norm_part;
     float* sq_slots = sq_final + kNormFinal;
     const int fc2_nx = (N + FcWg::BN - 1) / FcWg::BN, fc2_ny = kHid / FcWg::BM;
     const int fc2_slots = q_fused ? 0 : fc2_nx * fc2_ny * 4;
     const int fc1_slots = (kHid / FcWg::BN) * (kFlat / FcWg::BM) * 4;
-    if (fused_norm) DZ_REQUIRE(fc2_slots + fc1_slots <= kNormSlots);
+    const bool fused_norm = a->optimizer == DZ_OPT_ADAM && fc2_slots + fc1_slots <= kNormSlots;
+    norm_fused = fused_norm;
     {  // fc2: weight gradient + input gradient -> dh1 (relu(h1) mask)
       FcWgradParams w;
       w.x = ws + L.ws_h1; w.ldx = kHid; w.dy = ws + L.ws_dout; w.ldy = ld2; w.M = B;
@@ -395,7 +398,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
     const float* wts = a->weights ? a->weights : zeros;
     if (a->optimizer == DZ_OPT_ADAM) {
       int nparts = n_final;
-      if (!(phases & DZ_PHASE_BACKWARD)) {  // optimiser alone: norm from the stored gradient
+      if (!norm_fused) {  // optimiser alone / very wide head: norm from the stored gradient
         hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
                            (long)L.param_count, ws + L.ws_norm_part, a->opt_count);
         DZ_LAUNCH_CHECK();

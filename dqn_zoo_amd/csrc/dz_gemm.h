@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void dz_mfma_gemm2_side(typename OpA::Params p
   const unsigned na = ga.x * ga.y * ga.z, nb = gb.x * gb.y * gb.z;
   if (blockIdx.x < na) dz_gemm_body<OpA>(pa, dz_unflatten(blockIdx.x, ga), smem);
   else if (blockIdx.x < na + nb) dz_gemm_body<OpB>(pb, dz_unflatten(blockIdx.x - na, gb), smem);
-  else Side::run(sp, blockIdx.x - na - nb);
+  else Side::run(sp, blockIdx.x - na - nb, smem, (int)sizeof(smem));
 }
 template <class OpA, class OpB, class Side>
 static inline int dz_launch_gemm2_side(const typename OpA::Params& pa, dim3 ga,

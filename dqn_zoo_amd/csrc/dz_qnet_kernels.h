@@ -594,23 +594,14 @@ __device__ __forceinline__ void adam_elem(float& P, float G, float& M, float& V,
 // scalars in all blocks) instead of waiting on a one-block "scalars" launch
 // (that launch cost ~5 us + a ~2 us gap for 2 KB of work); block 0 publishes
 // the scalars (global norm, bias corrections, clip flag, mean weighted loss).
-__global__ __launch_bounds__(256) void adam_kernel(
+// Optimiser block `bid` of `nblk` (the kernels below map their grids onto these).
+__device__ __forceinline__ void adam_body(
+    unsigned bid, unsigned nblk,
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
     float* __restrict__ v, long n4, const float* __restrict__ part, int nparts,
     const int32_t* __restrict__ count, const float* __restrict__ losses,
     const float* __restrict__ weights, int B, float* __restrict__ sc, float lr, float b1,
-    float b2, float eps, float max_norm, DerivedGrad dg = DerivedGrad{},
-    PrioUpdateParams prio = PrioUpdateParams{}) {
-  // Optional side job (prio.node != null): block 0 is the sum-tree priority
-  // write-back (a ~10 us chain of dependent loads on one workgroup that needs only
-  // the loss kernel's priorities); this launch is the longest of the step and does
-  // not touch the tree, so the chain disappears inside it.  The optimiser blocks
-  // are [1, gridDim.x).
-  unsigned bid = blockIdx.x, nblk = gridDim.x;
-  if (prio.node) {
-    if (bid == 0) { PrioUpdateSide::run(prio, 0); return; }
-    bid -= 1; nblk -= 1;
-  }
+    float b2, float eps, float max_norm, const DerivedGrad& dg) {
   __shared__ float red[4];
   // Branch-free loads (derived block or not: clamped pointers, the noise factors
   // select to 1, x * (1 * 1) == x), the first element's loads issued before the
@@ -679,6 +670,44 @@ __global__ __launch_bounds__(256) void adam_kernel(
     ((float4*)m)[ip] = cur.m; ((float4*)v)[ip] = cur.v; ((float4*)p)[ip] = cur.p;
     cur = nxt; ip = inext;
   }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+    float* __restrict__ v, long n4, const float* __restrict__ part, int nparts,
+    const int32_t* __restrict__ count, const float* __restrict__ losses,
+    const float* __restrict__ weights, int B, float* __restrict__ sc, float lr, float b1,
+    float b2, float eps, float max_norm, DerivedGrad dg = DerivedGrad{},
+    PrioUpdateParams prio = PrioUpdateParams{}) {
+  // Optional side job (prio.node != null): block 0 is the sum-tree priority
+  // write-back (a ~10 us chain of dependent loads on one workgroup that needs only
+  // the loss kernel's priorities); this launch is the longest of the step and does
+  // not touch the tree, so the chain disappears inside it.  The optimiser blocks
+  // are [1, gridDim.x).
+  unsigned bid = blockIdx.x, nblk = gridDim.x;
+  if (prio.node) {
+    if (bid == 0) { PrioUpdateSide::run(prio, 0); return; }
+    bid -= 1; nblk -= 1;
+  }
+  adam_body(bid, nblk, p, g, m, v, n4, part, nparts, count, losses, weights, B, sc, lr, b1, b2,
+            eps, max_norm, dg);
+}
+
+// The optimiser with the NEXT step's replay sample + gather as its first `sg_blocks`
+// blocks (SampleGatherSide: one sampler block, the rest copy 4 KB each after a 5-trip
+// descent): a learner that consumes a static replay has nothing between write-back(k)
+// -- which an earlier launch of the step carried -- and sample(k+1), so the 8 us
+// sample launch of the next step disappears inside this step's longest launch.
+__global__ __launch_bounds__(256) void adam_sg_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+    float* __restrict__ v, long n4, const float* __restrict__ part, int nparts,
+    const int32_t* __restrict__ count, const float* __restrict__ losses,
+    const float* __restrict__ weights, int B, float* __restrict__ sc, float lr, float b1,
+    float b2, float eps, float max_norm, DerivedGrad dg, SampleGatherParams sg,
+    unsigned sg_blocks) {
+  if (blockIdx.x < sg_blocks) { SampleGatherSide::run(sg, blockIdx.x); return; }
+  adam_body(blockIdx.x - sg_blocks, gridDim.x - sg_blocks, p, g, m, v, n4, part, nparts, count,
+            losses, weights, B, sc, lr, b1, b2, eps, max_norm, dg);
 }
 
 __global__ void copy_kernel(float* __restrict__ dst, const float* __restrict__ src,

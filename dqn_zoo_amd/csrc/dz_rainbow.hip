@@ -24,6 +24,7 @@ constexpr int kFc1Splits = 32;       // fc1 forward k-splits (98 rows each)
 constexpr int kFc1DgradSplits = 12;  // fc1 input-gradient k-splits: 11 slabs of 6 single-chunk stages (17.9 us; 16 x 4: 19.2; 10 x 7: 19.6)
 constexpr int kFc2Splits = 8;        // fc2 forward k-splits
 constexpr int kAdamBlocks = 2048;    // grid-stride Adam launch width (8 blocks per CU)
+constexpr int kAdamBlocksSG = 1536;  // with ~550 sample+gather blocks in front: 6 per CU, so that the whole launch is co-resident
 
 }  // namespace
 
@@ -366,14 +367,16 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       d.dy = ws + L.ws_dfeat; d.w = a->online + L.conv_w[2]; d.act = ws + L.ws_act2;
       d.dx = ws + L.ws_dact2; d.B = B;
       const dim3 gw(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), gd(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1);
-      const bool prio_in_adam = (phases & DZ_PHASE_OPTIMIZER) != 0;
+      // (with the next step's sample riding in the optimiser launch the write-back must
+      // be complete BEFORE that launch: it stays here)
+      const bool prio_in_adam = (phases & DZ_PHASE_OPTIMIZER) != 0 && !a->next_sample;
       if (prio_pending && !prio_in_adam) {
         // The sum-tree priority write-back rides in this launch as one extra block:
         // it needs only the loss kernel's priorities and nothing here reads the tree.
         // (Measured hosts: this launch hides it completely; inside the HBM-heavy fc1
         // launch its dependent loads stretch to 18 us, inside conv1's 8.5 us launch
         // it sticks out by 4 us.)
-        rc = dz_launch_gemm2_side<Conv3Wg, Conv3Dg, PrioUpdateSide>(w, gw, d, gd, prio_q, 1, s);
+        rc = dz_launch_gemm2_side<Conv3Wg, Conv3Dg, PrioUpdateSideFast>(w, gw, d, gd, prio_q, 1, s);
         prio_pending = false;
       } else {
         rc = dz_launch_gemm2<Conv3Wg, Conv3Dg>(w, gw, d, gd, s);
@@ -442,15 +445,46 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       dg.eps_out = nz[0] + L.n_fc1_out;
       dg.on = 1;
     }
-    // with the write-back as block 0 the grid stays g_adam_blocks wide (all blocks
-    // co-resident at 8 per CU): one optimiser block fewer
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)kAdamBlocks), dim3(256), 0, s, a->online,
-                       a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
-                       ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,
-                       a->lr, a->b1, a->b2, a->eps, a->max_norm, dg,
-                       prio_pending ? prio_q : PrioUpdateParams{});
-    DZ_LAUNCH_CHECK();
-    DZ_PROF(s, "adam");
+    if (a->next_sample) {
+      // sample(k+1) + gather(k+1) as the first blocks of this launch (write-back(k) was
+      // carried by the conv3 backward launch above)
+      const dz_next_sample_t* ns = a->next_sample;
+      DZ_REQUIRE((phases & DZ_PHASE_BACKWARD) && !prio_pending);
+      DZ_REQUIRE(ns->ids_out && ns->n > 0 && ns->n <= kMaxHostDraws && ns->pos_h &&
+                 ns->u_target_h && ns->u_mix_h && ns->fields && ns->num_fields > 0 &&
+                 ns->num_fields <= DZ_MAX_FIELDS);
+      DZ_REQUIRE(ns->args.node && dz_is_pow2(ns->args.cap_pow2) && ns->args.capacity > 0 &&
+                 ns->args.capacity <= ns->args.cap_pow2 && ns->args.size > 0 &&
+                 ns->args.size <= ns->args.capacity && ns->args.t >= ns->args.size);
+      SampleGatherParams q;
+      q.a = ns->args;
+      for (int i = 0; i < kMaxHostDraws; ++i) {
+        const int j = i < ns->n ? i : 0;
+        q.hd.pos[i] = ns->pos_h[j]; q.hd.u_target[i] = ns->u_target_h[j]; q.hd.u_mix[i] = ns->u_mix_h[j];
+      }
+      for (int i = 0; i < ns->num_fields; ++i)
+        DZ_REQUIRE(ns->fields[i].src && ns->fields[i].dst && ns->fields[i].row_bytes > 0);
+      // (chunk caps 1..64 and 1024..2048 optimiser blocks all measure within +-1 %)
+      const unsigned sgb = sample_gather_plan(q, ns->fields, ns->num_fields, ns->n, 256);
+      q.ids_out = ns->ids_out; q.probs_out = ns->probs_out; q.weights_out = ns->weights_out;
+      q.weights32_out = ns->weights32_out; q.status = ns->status;
+      hipLaunchKernelGGL(adam_sg_kernel, dim3(sgb + (unsigned)kAdamBlocksSG), dim3(256), 0, s,
+                         a->online, a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
+                         ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,
+                         a->lr, a->b1, a->b2, a->eps, a->max_norm, dg, q, sgb);
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "adam+next_sample");
+    } else {
+      // with the write-back as block 0 the grid stays g_adam_blocks wide (all blocks
+      // co-resident at 8 per CU): one optimiser block fewer
+      hipLaunchKernelGGL(adam_kernel, dim3((unsigned)kAdamBlocks), dim3(256), 0, s, a->online,
+                         a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
+                         ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,
+                         a->lr, a->b1, a->b2, a->eps, a->max_norm, dg,
+                         prio_pending ? prio_q : PrioUpdateParams{});
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "adam");
+    }
     prio_pending = false;
   }
   if (prio_pending) {  // no launch of this call carried it
@@ -464,6 +498,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
 extern "C" int dz_rainbow_graph_capture(const dz_rainbow_args_t* args, int phases,
                                         dz_stream_t stream, void** graph_exec_out) {
   DZ_REQUIRE(args && graph_exec_out && stream && !g_dz_prof_on);
+  DZ_REQUIRE(!args->next_sample);  // its draws are by-value kernel arguments
   int rc;
   hipStream_t s = dz_s(stream);
   hipGraph_t graph = nullptr;

@@ -5,6 +5,10 @@
 
 #include "dz_common.h"
 
+#ifndef DZ_WB_STAMP
+#define DZ_WB_STAMP(k)   // tools/micro/wb_micro.hip: in-kernel time stamps
+#endif
+
 namespace {
 
 constexpr int kMaxBatch = 1024;
@@ -41,6 +45,101 @@ __device__ void set_leaves_and_ancestors(double* node, int64_t cap, int64_t my_l
   }
 }
 
+// The same result with TWO dependent trips to memory instead of one per level (a batch of
+// n <= 256 leaves, one workgroup of 256 threads, cap <= 2^31).
+//   1. every thread requests the sibling of each node on its leaf's path -- up to 31
+//      independent loads, one round trip -- before anything is stored;
+//   2. one scan over the batch finds, per thread, the duplicates of its leaf (the LAST
+//      one's value wins) and its PARTNERS: thread j's path runs through the sibling of
+//      thread i's path node at exactly one level, l = floor(log2(x_i ^ x_j)) (the
+//      highest bit in which the leaves' node indices differ); partner[l][i] = any such j
+//      (all of them carry the same node at level l, hence the same value);
+//   3. the walk: at level l a thread takes its sibling's value from its partner's LDS
+//      slot (fresh) or, without a partner, from the prefetch (that node is on nobody's
+//      path: untouched by this batch) -- two LDS round trips per level, no global access;
+//   4. all path nodes are stored at the end, back to back.
+// Each touched node ends up exactly fl(left + right) of its final children (IEEE addition
+// is commutative: operand order is immaterial), every duplicate of a leaf carries the last
+// duplicate's value: the tree is bit-identical to set_leaves_and_ancestors (tools/micro/
+// wb_micro.hip, tests/test_pipeline_gpu.py).  As a side block of a busy launch the
+// level-by-level form's 21 dependent round trips stretch to 15-30 us; this one does not.
+// (First version: an O(n) LDS scan for the sibling at EVERY level -- 1.3 us per level of
+// 64-bit compares, 33 us per call; the partner table makes the scan a one-off.)
+constexpr int kWbMaxLevels = 31;
+struct WbScratch {                       // 14.3 KB; may alias a host kernel's idle LDS
+  uint32_t x[256];                       // node index of the leaf (cap + leaf < 2^32)
+  double v0[256];                        // leaf values (scan), then level values, ping ...
+  double v1[256];                        //   ... pong (one barrier per level)
+  unsigned char partner[kWbMaxLevels + 1][256];   // [l][i]: thread i's partner at level l (0xFF: none)
+};
+__device__ __forceinline__ void set_leaves_and_ancestors_fast(
+    double* node, int64_t cap, int64_t my_leaf, double my_val, bool active, int n,
+    WbScratch& S) {
+  constexpr int kMaxLevels = kWbMaxLevels;
+  const int i = threadIdx.x;
+  const int lg = 63 - __builtin_clzll((unsigned long long)cap);   // levels above the leaves
+  const int64_t x0 = active ? cap + my_leaf : 0;
+  const uint32_t x32 = (uint32_t)x0;
+  DZ_WB_STAMP(0);
+  // (unconditional loads from clamped indices: a conditional load is an exec-mask block
+  // with its own full wait, i.e. one round trip per level again)
+  double sib[kMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) {
+    const int64_t xl = x0 >> l;
+    sib[l] = node[(active && xl > 1) ? (xl ^ 1) : 1];
+  }
+  S.x[i] = x32; S.v0[i] = my_val;
+#pragma unroll
+  for (int l = 0; l <= kMaxLevels; ++l) S.partner[l][i] = 0xFF;
+  __syncthreads();
+  DZ_WB_STAMP(1);
+  // the one scan, in batches of 8 (all LDS reads of a batch issued before any use)
+  double val = my_val;
+  if (i < ((n + 63) & ~63)) {            // waves without a batch element have nothing to find
+    for (int j0 = 0; j0 < n; j0 += 8) {
+      uint32_t xs[8]; double vs[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int j = min(j0 + u, n - 1); xs[u] = S.x[j]; vs[u] = S.v0[j]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u;
+        const bool live = active && j < n;
+        val = (live && xs[u] == x32 && j > i) ? vs[u] : val;   // ascending j: the last match stays
+        const uint32_t d = xs[u] ^ x32;
+        const int bb = 31 - __builtin_clz(d | 1u);             // level of the sibling relation (< lg)
+        if (live && d != 0) S.partner[bb][i] = (unsigned char)j;
+      }
+    }
+  }
+  double pv[kMaxLevels + 1];
+  int64_t x = x0;
+  DZ_WB_STAMP(2);
+#pragma unroll
+  for (int l = 0; l <= kMaxLevels; ++l) {
+    pv[l] = val;
+    DZ_WB_STAMP(3 + l);
+    if (l < lg) {                         // uniform
+      double* buf = (l & 1) ? S.v1 : S.v0;
+      if (l > 0 || true) {
+        if (l == 0) __syncthreads();      // every scan read of v0 is done before it is reused
+        buf[i] = val;
+      }
+      __syncthreads();
+      const uint32_t pj = S.partner[l < kMaxLevels ? l : 0][i];   // (own writes: ordered by the barrier)
+      const double fresh = buf[pj == 0xFFu ? (uint32_t)i : pj];
+      const double sv = pj == 0xFFu ? sib[l < kMaxLevels ? l : 0] : fresh;
+      val = (x & 1) ? sv + val : val + sv;   // fl(left + right)
+      x >>= 1;
+    }
+  }
+  // all stores of the path at the end, back to back
+#pragma unroll
+  for (int l = 0; l <= kMaxLevels; ++l)
+    if (active && l <= lg) node[x0 >> l] = pv[l];
+  DZ_WB_STAMP(40);
+}
+
 // id -> tree index and back for the fixed-capacity distribution
 // (ref: replay.py:457,499,533: the free stack is popped from its END, and an
 // evicted index is pushed and popped straight back).
@@ -73,7 +172,7 @@ struct PrioUpdateParams {
   int check_ids;   // 0: ids come straight from this replay's sampler (live by construction)
 };
 __device__ __forceinline__ void prio_update_body(const PrioUpdateParams& q, int64_t* s_leaf,
-                                                 double* s_red) {
+                                                 double* s_red, WbScratch* wb = nullptr) {
   double* node = q.node;
   const int64_t cap = q.cap, N = q.N, size = q.size, t = q.t;
   const int64_t* __restrict__ ids = q.ids;
@@ -124,23 +223,352 @@ __device__ __forceinline__ void prio_update_body(const PrioUpdateParams& q, int6
       *max_seen = mm;
     }
   }
-  set_leaves_and_ancestors(node, cap, leaf, v, active, s_leaf, n);
+  if (wb && n <= 256 && blockDim.x == 256 && cap <= ((int64_t)1 << 31)) {
+    __syncthreads();
+    set_leaves_and_ancestors_fast(node, cap, leaf, v, active, n, *wb);
+  } else {
+    set_leaves_and_ancestors(node, cap, leaf, v, active, s_leaf, n);
+  }
 }
 
 // The same write-back as a side job of a learner launch (dz_mfma_gemm_side): one
 // extra 256-thread block, so the 10 us single-workgroup kernel disappears inside a
 // contraction that does not depend on the tree.
-struct PrioUpdateSide {
+// FAST: the two-round-trip walk (set_leaves_and_ancestors_fast) -- for hosts whose
+// register budget is a GEMM's anyway: its prefetched siblings and path values cost
+// ~130 VGPRs, which would take adam_kernel from 8 to 3 waves per SIMD (Adam's block 0
+// keeps the level-by-level form).  `scratch`: the host kernel's LDS, idle in this block.
+template <int FAST>
+struct PrioUpdateSideT {
   typedef PrioUpdateParams Params;
-  __device__ static void run(const Params& q, unsigned block) {
+  __device__ static void run(const Params& q, unsigned block, void* scratch = nullptr,
+                             int scratch_bytes = 0) {
     __shared__ int64_t s_leaf[256];
     __shared__ double s_red[4];
-    if (block == 0) prio_update_body(q, s_leaf, s_red);
+    if (block != 0) return;
+    if constexpr (FAST) {   // (no scratch offered: the level-by-level form)
+      WbScratch* wb = (scratch && scratch_bytes >= (int)sizeof(WbScratch))
+                          ? reinterpret_cast<WbScratch*>(scratch) : nullptr;
+      prio_update_body(q, s_leaf, s_red, wb);
+    } else {
+      prio_update_body(q, s_leaf, s_red, nullptr);
+    }
   }
 };
+typedef PrioUpdateSideT<0> PrioUpdateSide;
+typedef PrioUpdateSideT<1> PrioUpdateSideFast;
 
 __global__ __launch_bounds__(256) void prio_update_side_kernel(PrioUpdateParams q) {
   PrioUpdateSide::run(q, 0);
 }
+
+
+// --------------------------------------------------------------------------- //
+//  Sampling (moved here from dz_sumtree.hip so that a learner launch can carry the
+//  NEXT step's sample + gather as side blocks).
+// --------------------------------------------------------------------------- //
+// Wave-wide NaN-propagating max of doubles without ds_bpermute round trips: quad permutes,
+// row_half_mirror and row_mirror on both 32-bit halves give every lane of a 16-lane row
+// the row's result, the four rows are combined through v_readlane.  max is exact, so
+// the order of the combination does not matter.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ double dz_dpp_f64(double v) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, true);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double dz_lane_f64(double v, int l) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double dz_nanmax(double a, double b) {
+  return (a != a || b != b) ? __builtin_nan("") : (b > a ? b : a);
+}
+__device__ __forceinline__ double dz_wave_nanmax_f64(double m) {
+  m = dz_nanmax(m, dz_dpp_f64<0xB1>(m));
+  m = dz_nanmax(m, dz_dpp_f64<0x4E>(m));
+  m = dz_nanmax(m, dz_dpp_f64<0x141>(m));
+  m = dz_nanmax(m, dz_dpp_f64<0x140>(m));
+  return dz_nanmax(dz_nanmax(dz_lane_f64(m, 0), dz_lane_f64(m, 16)),
+                   dz_nanmax(dz_lane_f64(m, 32), dz_lane_f64(m, 48)));
+}
+
+// ref: replay.py:406-426.
+__device__ __forceinline__ int64_t descend(const double* __restrict__ node,
+                                           int64_t cap, double target) {
+  int64_t i = 1;
+  while (i < cap) {
+    const double left = node[2 * i];
+    if (target < left) {
+      i = 2 * i;
+    } else {
+      target -= left;
+      i = 2 * i + 1;
+    }
+  }
+  return i - cap;
+}
+
+// The same descent by LANES (8 or 16) consecutive lanes (sub = lane % LANES, all with the
+// same target), L = log2(LANES) levels per memory round trip: lane sub >= 1 loads the
+// left-child sum of one of the LANES-1 nodes that can be the current node within the next
+// L steps
+//   sub 1: 2i     sub 2, 3: 4i, 4i+2     sub 4..7: 8i, 8i+2, 8i+4, 8i+6     sub 8..15: 16i + 2(sub-8)
+// and the group then takes the L decisions from registers (shuffles).  Same comparisons
+// and subtractions on the same node values as descend(): the result is identical; the
+// chain is ceil(levels/L) dependent loads instead of `levels` (20 levels: 7 round trips
+// with 8 lanes, 5 with 16).
+template <int LANES>
+__device__ __forceinline__ int64_t descend_coop(const double* __restrict__ node, int64_t cap,
+                                                double target, int sub) {
+  constexpr int L = LANES == 16 ? 4 : 3;
+  static_assert(LANES == 8 || LANES == 16, "group size");
+  const int base = (int)(threadIdx.x & 63) & ~(LANES - 1);  // first lane of this group
+  int64_t i = 1;
+  while (i < cap) {
+    // sub in [2^j, 2^(j+1)): node 2^(j+1) i + 2 (sub - 2^j)
+    const int j = sub < 2 ? 0 : (sub < 4 ? 1 : (sub < 8 ? 2 : 3));
+    int64_t idx = (i << (j + 1)) + 2 * (sub - (1 << j));
+    idx = (sub >= 1 && idx < 2 * cap) ? idx : 2 * cap - 1;  // past the leaves / lane 0: unused
+    const double v = node[idx];
+    int pick = 1;
+#pragma unroll
+    for (int step = 0; step < L; ++step) {
+      const double left = __shfl(v, base + pick);
+      if (i < cap) {  // group-uniform
+        int d = 0;
+        if (target < left) {
+          i = 2 * i;
+        } else {
+          target -= left;
+          i = 2 * i + 1;
+          d = 1;
+        }
+        pick = 2 * pick + d;  // 1 -> 2|3 -> 4..7 -> 8..15
+      }
+    }
+  }
+  return i - cap;
+}
+
+// The live id whose slot is N-1-ti; live ids are [t-size, t).
+__device__ __forceinline__ int64_t id_of_tree_index(int64_t ti, int64_t N,
+                                                    int64_t t, int64_t size) {
+  const int64_t slot = N - 1 - ti;
+  const int64_t base = t - size;
+  return base + dz_mod(slot - base, N);
+}
+// ref: replay.py:52-82 applied to _active_indices (positions hold tree indices
+// of the ids of the uniform swap-remove list).
+__device__ __forceinline__ int64_t id_at_position(int64_t j, int64_t N, int64_t t) {
+  if (t <= N || N == 1) return (N == 1) ? t - 1 : j;
+  if (j == N - 1) return t - 1;
+  const int64_t base = t - N;
+  return base + dz_mod(j - base, N - 1);
+}
+
+// RNG draws of a small batch passed BY VALUE in the kernel arguments (1.5 KB of
+// the 4 KB kernarg segment): no staging buffer, no H2D copy, no blit kernel in
+// front of the sample (that copy was a 4 us launch of its own per step).
+constexpr int kMaxHostDraws = 64;
+struct HostDraws {
+  int64_t pos[kMaxHostDraws];
+  double u_target[kMaxHostDraws];
+  double u_mix[kMaxHostDraws];
+};
+
+// Tree index drawn for batch element i (replay.py:551-567): uniform candidate,
+// prioritized candidate (descent), mix.  `bad` reports a target outside [0, root).
+// COOP = 8 or 16: called by COOP consecutive lanes with the same i; `sub` = lane % COOP
+// (descend_coop).
+template <int HOST_DRAWS, int COOP = 0>
+__device__ __forceinline__ int64_t sample_tree_index(const dz_prio_sample_args_t& a,
+                                                     const HostDraws& hd, int i, double root,
+                                                     bool zero_root, bool& bad, int sub = 0) {
+  const int64_t N = a.capacity;
+  const int64_t pos_i = HOST_DRAWS ? hd.pos[i & (kMaxHostDraws - 1)] : a.pos[i];
+  const double ut_i = HOST_DRAWS ? hd.u_target[i & (kMaxHostDraws - 1)] : a.u_target[i];
+  const double um_i = HOST_DRAWS ? hd.u_mix[i & (kMaxHostDraws - 1)] : a.u_mix[i];
+  const int64_t uni_ti = tree_index_of_id(id_at_position(pos_i, N, a.t), N);
+  int64_t pri_ti = uni_ti;
+  bad = false;
+  if (!zero_root) {
+    const double target = ut_i * root;
+    if (!(0.0 <= target && target < root)) bad = true;
+    else if constexpr (COOP != 0) pri_ti = descend_coop<COOP>(a.node, a.cap_pow2, target, sub);
+    else pri_ti = descend(a.node, a.cap_pow2, target);
+  }
+  return (um_i < a.usp) ? uni_ti : pri_ti;
+}
+
+// s_ti != null (n <= 64): the descents are done first, COOP lanes per batch element
+// (descend_coop), and parked in s_ti[]; otherwise one thread per element.
+template <int HOST_DRAWS, int COOP = 8>
+__device__ __forceinline__ void prioritized_sample_body(
+    const dz_prio_sample_args_t& a, const HostDraws& hd, int n, int64_t* __restrict__ ids_out,
+    int64_t* __restrict__ tree_idx_out, double* __restrict__ probs_out,
+    double* __restrict__ weights_out, float* __restrict__ weights32_out,
+    uint32_t* status, double* s_red, double& s_max, int64_t* s_ti = nullptr) {
+  const int i = threadIdx.x;
+  const bool active = i < n;
+  const double* __restrict__ node = a.node;
+  const int64_t N = a.capacity, cap = a.cap_pow2;
+  const double root = node[1];
+  const bool zero_root = (root == 0.0);
+  if (zero_root && a.assume_nonzero_root && i == 0) raise(status, DZ_ST_ZERO_ROOT);
+  if (s_ti) {
+    for (int q = i / COOP; q < n; q += (int)blockDim.x / COOP) {
+      bool bad;
+      const int64_t ti =
+          sample_tree_index<HOST_DRAWS, COOP>(a, hd, q, root, zero_root, bad, i % COOP);
+      if ((i % COOP) == 0) {
+        if (bad) raise(status, DZ_ST_BAD_TARGET);
+        s_ti[q] = ti;
+      }
+    }
+    __syncthreads();
+  }
+
+  double w = 0.0;
+  if (active) {
+    bool bad = false;
+    const int64_t ti = s_ti ? s_ti[i]
+                            : sample_tree_index<HOST_DRAWS>(a, hd, i, root, zero_root, bad);
+    if (bad) raise(status, DZ_ST_BAD_TARGET);
+    // probabilities: replay.py:569-577 (separate mul, mul, add: no FMA)
+    const double leaf = node[cap + ti];
+    const double pp = zero_root ? a.uniform_prob : leaf / root;
+    const double m1 = a.one_minus_usp * pp;
+    const double prob = m1 + a.usp_times_up;
+    if (ids_out) ids_out[i] = id_of_tree_index(ti, N, a.t, a.size);
+    if (tree_idx_out) tree_idx_out[i] = ti;
+    if (probs_out) probs_out[i] = prob;
+    if (a.compute_weights) {
+      // replay.py:238: (uniform_probability / probabilities) ** exponent
+      const double ratio = a.uniform_prob / prob;
+      if (a.beta == 1.0) w = ratio;            // NumPy scalar fast path
+      else if (a.beta == 0.5) w = sqrt(ratio); //   "
+      else w = pow(ratio, a.beta);
+    }
+  }
+  if (!a.compute_weights) return;
+
+  if (a.normalize) {  // replay.py:239-240: weights /= max(weights)
+    double m = active ? w : -__builtin_inf();
+    // NaN-propagating max like np.max (order-independent: exact), on the DPP crossbar
+    m = dz_wave_nanmax_f64(m);
+    if ((i & 63) == 0) s_red[i >> 6] = m;
+    __syncthreads();
+    if (i == 0) {
+      double mm = s_red[0];
+      for (int k = 1; k < (int)((blockDim.x + 63) / 64); ++k) {
+        const double o = s_red[k];
+        mm = (mm != mm || o != o) ? __builtin_nan("") : (o > mm ? o : mm);
+      }
+      s_max = mm;
+    }
+    __syncthreads();
+    w = w / s_max;
+  }
+  if (active) {
+    if (!(w - w == 0.0)) raise(status, DZ_ST_NONFINITE_WEIGHT);  // replay.py:241
+    if (weights_out) weights_out[i] = w;
+    if (weights32_out) weights32_out[i] = (float)w;  // the jit-boundary cast
+  }
+}
+
+// Sample AND gather as the blocks of ONE launch (batch <= 64, draws in the kernel
+// arguments).  Block 0 is the sampler proper (ids, probabilities, IS weights: exactly
+// prioritized_sample_body); every other block copies one chunk of one field of one
+// batch element and re-derives ITS element's tree index with the same arithmetic (16
+// lanes, 5 dependent round trips for 20 levels: descend_coop<16>) instead of waiting
+// for a second launch to read ids[]: the descent and the copy overlap.  The block
+// list is compact: field f owns blocks [first[f], first[f+1]) = n elements x chunks[f]
+// (a chunk = THREADS 16-byte vectors, or THREADS bytes on the byte path -- a row that
+// is not a multiple of 16 bytes or not 16-byte aligned; at most 64 chunks per row,
+// longer rows loop).
+struct SampleGatherParams {
+  dz_prio_sample_args_t a;
+  HostDraws hd;
+  dz_field_t f[DZ_MAX_FIELDS];
+  int first[DZ_MAX_FIELDS + 1];
+  int chunks[DZ_MAX_FIELDS];
+  int num_fields, n;
+  int64_t* ids_out; double* probs_out; double* weights_out; float* weights32_out;
+  uint32_t* status;
+};
+__host__ __device__ static inline bool dz_field_vec_ok(const dz_field_t& f) {
+  return ((f.row_bytes & 15) == 0) && ((((uintptr_t)f.src) & 15) == 0) &&
+         ((((uintptr_t)f.dst) & 15) == 0);
+}
+// Fills q.f / first / chunks for `threads`-wide blocks; returns the block count.
+static inline unsigned sample_gather_plan(SampleGatherParams& q, const dz_field_t* fields,
+                                          int num_fields, int n, int threads,
+                                          int max_chunks = 64) {
+  q.num_fields = num_fields; q.n = n;
+  int next = 1;
+  for (int i = 0; i < DZ_MAX_FIELDS; ++i) {
+    if (i < num_fields) {
+      q.f[i] = fields[i];
+      const int64_t units = dz_field_vec_ok(fields[i]) ? fields[i].row_bytes >> 4
+                                                        : fields[i].row_bytes;
+      int64_t c = (units + threads - 1) / threads;
+      c = c < 1 ? 1 : (c > max_chunks ? max_chunks : c);
+      q.first[i] = next; q.chunks[i] = (int)c;
+      next += n * (int)c;
+    } else {
+      q.f[i] = fields[0]; q.first[i] = next; q.chunks[i] = 1;
+    }
+  }
+  q.first[DZ_MAX_FIELDS] = next;
+  return (unsigned)next;
+}
+template <int THREADS>
+__device__ __forceinline__ void sample_gather_block(const SampleGatherParams& q, unsigned blk) {
+  __shared__ double s_red[THREADS / 64];
+  __shared__ double s_max;
+  __shared__ int64_t s_slot;
+  __shared__ int64_t s_ti[kMaxHostDraws];
+  if (blk == 0) {
+    prioritized_sample_body<1, 16>(q.a, q.hd, q.n, q.ids_out, nullptr, q.probs_out,
+                                   q.weights_out, q.weights32_out, q.status, s_red, s_max, s_ti);
+    return;
+  }
+  int fi = 0;
+#pragma unroll
+  for (int g = 1; g < DZ_MAX_FIELDS; ++g) fi = (g < q.num_fields && (int)blk >= q.first[g]) ? g : fi;
+  if ((int)blk >= q.first[DZ_MAX_FIELDS]) return;
+  const int rel = (int)blk - q.first[fi], chunks = q.chunks[fi];
+  const int b = rel / chunks, c = rel - b * chunks;
+  if (threadIdx.x < 16) {  // 16 lanes walk the element's descent, 4 levels per round trip
+    const double root = q.a.node[1];
+    bool bad;
+    const int64_t ti = sample_tree_index<1, 16>(q.a, q.hd, b, root, root == 0.0, bad, threadIdx.x);
+    if (threadIdx.x == 0)
+      s_slot = dz_mod(id_of_tree_index(ti, q.a.capacity, q.a.t, q.a.size), q.a.capacity);
+  }
+  __syncthreads();
+  const dz_field_t fd = q.f[fi];
+  const int64_t rb = fd.row_bytes;
+  const char* src = (const char*)fd.src + s_slot * rb;
+  char* dst = (char*)fd.dst + (int64_t)b * rb;
+  if (dz_field_vec_ok(fd)) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int64_t nvec = rb >> 4;
+    for (int64_t i = (int64_t)c * THREADS + threadIdx.x; i < nvec; i += (int64_t)chunks * THREADS)
+      ((u32x4*)dst)[i] = __builtin_nontemporal_load((const u32x4*)src + i);
+  } else {
+    for (int64_t i = (int64_t)c * THREADS + threadIdx.x; i < rb; i += (int64_t)chunks * THREADS)
+      dst[i] = src[i];
+  }
+}
+// The same blocks as extra blocks of a learner launch (256-thread workgroups).
+struct SampleGatherSide {
+  typedef SampleGatherParams Params;
+  __device__ static void run(const Params& q, unsigned block) { sample_gather_block<256>(q, block); }
+};
 
 }  // namespace

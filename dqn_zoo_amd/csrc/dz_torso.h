@@ -102,7 +102,7 @@ inline int torso_backward(const TorsoBufs& T, int B, const float* online,
     d.dy = dfeat; d.w = online + T.conv_w[2]; d.act = T.act2; d.dx = dact2; d.B = B;
     const dim3 gw(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), gd(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1);
     if (prio)
-      rc = dz_launch_gemm2_side<Conv3Wg, Conv3Dg, PrioUpdateSide>(w, gw, d, gd, *prio, 1, s);
+      rc = dz_launch_gemm2_side<Conv3Wg, Conv3Dg, PrioUpdateSideFast>(w, gw, d, gd, *prio, 1, s);
     else
       rc = dz_launch_gemm2<Conv3Wg, Conv3Dg>(w, gw, d, gd, s);
     if (rc) return rc;

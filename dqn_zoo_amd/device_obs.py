@@ -24,6 +24,17 @@ def canonical_scalars(transition):
                              discount_t=np.float64(transition.discount_t))
 
 
+def depth_for(accumulator, floor: int = 8) -> int:
+  """Slots an ObservationCache needs so that no slot is rewritten while a replay
+  insert that reads it can still be queued: the insert enqueued at frame t-1 reads
+  the observations of frames t-1 and t-1-n (n-step window), and `step()` waits only
+  for the acting launches, so slot reuse must be at least n + 2 frames apart (one
+  spare frame on top).  n = 3 (Rainbow) fits the default 8; n = 7 would alias."""
+  window = getattr(accumulator, '_window', None)
+  n = getattr(window, 'maxlen', None) or 1
+  return max(int(floor), int(n) + 3)
+
+
 class ObservationCache:
 
   def __init__(self, device, depth: int = 8, shape=(84, 84, 4)):
@@ -38,9 +49,9 @@ class ObservationCache:
   def upload(self, observation) -> torch.Tensor:
     """Makes the observation readable by kernels; returns a [1, H, W, C] uint8
     tensor whose data_ptr() is valid on the device (a pinned host slot, or the
-    caller's own CUDA tensor).  A slot is reused `depth` calls later: callers
-    synchronise once per step (they read the selected action), which is what
-    makes that safe."""
+    caller's own CUDA tensor).  A slot is reused `depth` calls later; the agent
+    waits for the acting launches of every frame, and the replay insert queued
+    behind them reads slots at most n + 1 frames old (`depth_for`)."""
     k = self._pos % self._depth
     self._pos += 1
     if isinstance(observation, torch.Tensor):

@@ -109,7 +109,8 @@ class Iqn(dense_agent.DenseAgent):
     self._action = None
     self._frame_t = -1
     self._statistics = {'state_value': np.nan}
-    self._obs = device_obs.ObservationCache(self._device)
+    self._obs = device_obs.ObservationCache(
+        self._device, depth=device_obs.depth_for(transition_accumulator))
     self._act_taus = torch.empty((1, self._tau_samples_policy),
                                  dtype=torch.float32, device=self._device)
     self._act_counter = 0

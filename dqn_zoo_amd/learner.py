@@ -140,14 +140,18 @@ class RainbowLearner:
     """Number of acting applies drawn so far (the actor's noise stream position)."""
     return 0 if getattr(self, '_act_step', None) is None else int(self._act_step.item())
 
+  MAX_ACT_GRAPHS = 64    # acting graphs: ACT_RING result slots x observation slots
+
+  def _drop_act_graphs(self) -> None:
+    graphs, self._act_graphs = getattr(self, '_act_graphs', {}), {}
+    for g in graphs.values():
+      self._lib.dz_graph_destroy(g[0])
+
   def drop_graphs(self) -> None:
     graphs, self._graphs = self._graphs, {}
     for g in graphs.values():
       self._lib.dz_graph_destroy(g)
-    for g in getattr(self, '_act_graphs', {}).values():
-      self._lib.dz_graph_destroy(g[0])
-    if getattr(self, '_act_graphs', None):
-      self._act_graphs = {}
+    self._drop_act_graphs()
 
   def resample_noise(self) -> None:
     """Fresh factorised noise for the 3 applies, generated on the device."""
@@ -166,8 +170,11 @@ class RainbowLearner:
     params = self.online if which == 'online' else self.target
     if packed_out is not None and noise is None and resample_noise and self.act_graphs and stream:
       # steady state of the agent loop: same observation slot, same result slot, same
-      # parameters -> replay the captured launches, nothing to allocate or check
-      g = self._act_graphs.get((states.data_ptr(), packed_out.data_ptr(), params.data_ptr()))
+      # parameters -> replay the captured launches, nothing to allocate
+      # (the key carries shape and dtype: an address the allocator recycled for a
+      # different tensor must not replay a graph captured for the old one)
+      g = self._act_graphs.get((states.data_ptr(), packed_out.data_ptr(), params.data_ptr(),
+                                states.shape, states.dtype))
       if g is not None:
         _lib.check(self._lib.dz_graph_launch(g[0], stream), 'dz_graph_launch')
         return g[1], g[2], g[3]
@@ -175,10 +182,10 @@ class RainbowLearner:
     b = int(states.shape[0])
     assert tuple(states.shape[1:]) == (84, 84, 4)
     if self._act_batch != b:
+      self._drop_act_graphs()  # captured against the old workspace
       self._act_ws = torch.zeros(self.network.layout(b).ws_count,
                                  dtype=torch.float32, device=self.device)
       self._act_batch = b
-      self._act_graphs = {}    # captured against the old workspace
     a = self.network.num_actions
     q = torch.empty((b, a), dtype=torch.float32, device=self.device)
     # (greedy action, max q) packed in one 8-byte buffer per row so that the
@@ -199,8 +206,13 @@ class RainbowLearner:
           self._act_noise.data_ptr(), self._noise_seed ^ 0xA5A5A5A5, 0,
           self._act_step.data_ptr(), self.support.data_ptr(), self._act_ws.data_ptr(),
           q.data_ptr(), greedy.data_ptr(), vmax.data_ptr(), stream), 'dz_rainbow_act')
-      if self.act_graphs and stream and packed_out is not None:
-        key = (states.data_ptr(), packed_out.data_ptr(), params.data_ptr())
+      if (self.act_graphs and stream and packed_out is not None and
+          len(self._act_graphs) < self.MAX_ACT_GRAPHS):
+        # (a caller that hands over a fresh observation tensor per decision --
+        # atari(device_observations=True) -- fills the cache with single-use graphs:
+        # beyond the cap the apply launches eagerly, as the learn step does)
+        key = (states.data_ptr(), packed_out.data_ptr(), params.data_ptr(),
+               states.shape, states.dtype)
         q = self._act_q = torch.empty((b, a), dtype=torch.float32, device=self.device)
         g = self._act_graphs[key] = (_lib.capture_graph(stream, enqueue), q, greedy, vmax)
         _lib.check(self._lib.dz_graph_launch(g[0], stream), 'dz_graph_launch')
@@ -322,7 +334,7 @@ class RainbowLearner:
 
   def step(self, s_tm1, a_tm1, r_t, discount_t, s_t, weights,
            phases: int = _lib.PHASE_ALL, resample_noise: bool = True,
-           priority_sink=None, target_pre: bool = False) -> None:
+           priority_sink=None, target_pre: bool = False, next_sample=None) -> None:
     """Enqueues one learner step.  Inputs are device tensors exactly as
     `PrioritizedTransitionReplay.sample_device` returns them: uint8 states
     [B,84,84,4], int64 actions, float64 rewards/discounts, float32 weights.
@@ -334,10 +346,20 @@ class RainbowLearner:
     `update_priorities` for this batch.  Needs PHASE_BACKWARD in `phases`.
 
     `target_pre`: target(s_t) of this batch was computed by `target_forward`
-    (ordered before this call): only the two online applies run here."""
+    (ordered before this call): only the two online applies run here.
+
+    `next_sample` (descriptor from `PrioritizedTransitionReplay.prepare_next_sample`,
+    with `priority_sink` and a full step): the optimiser launch carries the NEXT
+    step's sample + gather as extra blocks -- after this step's write-back, so the
+    order of replay operations is the sequential one.  Launches eagerly."""
     b = self.batch_size
     stream = _lib.stream_ptr(self.device)
     graphs = bool(stream) if self.use_graphs is None else self.use_graphs
+    if next_sample is not None:
+      graphs = False   # the draws are by-value kernel arguments
+      if phases & (_lib.PHASE_BACKWARD | _lib.PHASE_OPTIMIZER) != (
+          _lib.PHASE_BACKWARD | _lib.PHASE_OPTIMIZER):
+        raise ValueError('next_sample needs the backward and optimiser phases in this call')
     nets = bool(phases & (_lib.PHASE_FORWARD | _lib.PHASE_FWD_NETS))
     if graphs and self._args is not None and weights is not None:
       # fast path: a call signature that was validated and captured before (the
@@ -387,6 +409,7 @@ class RainbowLearner:
     # (seed, Adam step count): no per-step host argument, graph-replayable.
     a.resample_noise = int(bool(resample_noise) and nets)
     a.keep_all_grads = int(self.keep_all_grads)
+    a.next_sample = None if next_sample is None else ctypes.addressof(next_sample)
     if target_pre:
       self._tgt_alloc()
       a.tgt_part = self._tgt_part_ptr
@@ -433,8 +456,7 @@ class RainbowLearner:
 
   def __del__(self):
     try:
-      for g in self._graphs.values():
-        self._lib.dz_graph_destroy(g)
+      self.drop_graphs()
     except Exception:  # pylint: disable=broad-except
       pass
 
@@ -610,6 +632,17 @@ class DenseLearner:
 
   ACT_RING = 8
 
+  def _realloc_act_ws(self, b: int) -> None:
+    """New acting workspace for batch b.  The captured head graphs bake the OLD
+    workspace's address in: destroy them first (replaying one would run the whole
+    acting forward in memory the allocator may have handed to another tensor)."""
+    heads, self._head_graphs = getattr(self, '_head_graphs', {}), {}
+    for g in heads.values():
+      self._lib.dz_graph_destroy(g)
+    self._act_ws = torch.zeros(self.network.layout(b, 1).ws_count, dtype=torch.float32,
+                               device=self.device)
+    self._act_batch = b
+
   def head_async(self, states: torch.Tensor):
     """Acting apply for ONE state: the head outputs go straight to a pinned host
     slot (the copy-out of dz_dense_apply targets it), nothing synchronises here, and
@@ -623,12 +656,10 @@ class DenseLearner:
       self._head_host = torch.empty((self.ACT_RING, net.num_outputs),
                                     dtype=torch.float32).pin_memory()
       self._head_events = [torch.cuda.Event() for _ in range(self.ACT_RING)]
-      self._head_graphs = {}
+      self._head_graphs = getattr(self, '_head_graphs', {})
       self._head_pos = 0
     if self._act_batch != 1:
-      self._act_ws = torch.zeros(net.layout(1, 1).ws_count, dtype=torch.float32,
-                                 device=self.device)
-      self._act_batch = 1
+      self._realloc_act_ws(1)
     k = self._head_pos % self.ACT_RING
     self._head_pos += 1
     slot, ev = self._head_host[k], self._head_events[k]
@@ -663,9 +694,7 @@ class DenseLearner:
     b = int(states.shape[0])
     net = self.network
     if self._act_batch != b:
-      self._act_ws = torch.zeros(net.layout(b, 1).ws_count, dtype=torch.float32,
-                                 device=self.device)
-      self._act_batch = b
+      self._realloc_act_ws(b)
     out = torch.empty((b, net.num_outputs), dtype=torch.float32, device=self.device)
     is_q = net.num_outputs == net.num_actions
     q = torch.empty((b, net.num_actions), dtype=torch.float32, device=self.device) \

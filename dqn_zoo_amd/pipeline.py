@@ -61,7 +61,8 @@ class PipelinedRainbowLoop:
 
   RING = 4
 
-  def __init__(self, replay, learner, batch_size: int, device_scope_events: bool = True):
+  def __init__(self, replay, learner, batch_size: int, device_scope_events: bool = True,
+               prefetch_target: bool = True):
     self._lib = _lib.load()
     self.replay, self.learner, self.batch = replay, learner, int(batch_size)
     self.device = learner.device
@@ -71,6 +72,9 @@ class PipelinedRainbowLoop:
     self._side_ptr = self.side.cuda_stream
     mk = lambda: _Events(self._lib, self.RING, device_scope_events)
     self._e_sample, self._e_target, self._e_loss, self._e_misc = mk(), mk(), mk(), mk()
+    # False: only the replay operations (write-back, sample, gather) run ahead on the
+    # side stream; the main stream keeps the three-apply step
+    self.prefetch_target = bool(prefetch_target)
     self._k = 0
     self._next = None
     self._target_stale = False
@@ -89,8 +93,9 @@ class PipelinedRainbowLoop:
     try:
       s = self.replay.sample_device(self.batch)
       self._record(self._e_sample[k], self._side_ptr)
-      ln.target_forward(s.transitions.s_t, step_from=ln.adam_count if first else None)
-      self._record(self._e_target[k], self._side_ptr)
+      if self.prefetch_target:
+        ln.target_forward(s.transitions.s_t, step_from=ln.adam_count if first else None)
+        self._record(self._e_target[k], self._side_ptr)
     finally:
       torch.cuda.set_stream(self.main)
     return s
@@ -111,6 +116,12 @@ class PipelinedRainbowLoop:
     batch = (t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32)
     # main: the two online applies need the sampled batch ...
     self._wait(self._main_ptr, self._e_sample[k])
+    if not self.prefetch_target:
+      ln.step(*batch, phases=_lib.PHASE_FORWARD)
+      self._record(self._e_loss[k], self._main_ptr)
+      ln.step(*batch, phases=_lib.PHASE_BACKWARD | _lib.PHASE_OPTIMIZER)
+      self._after_loss(k, s)
+      return s
     ln.step(*batch, phases=_lib.PHASE_FWD_NETS, target_pre=True)
     # ... the loss needs target(s_t)
     self._wait(self._main_ptr, self._e_target[k])
@@ -122,20 +133,23 @@ class PipelinedRainbowLoop:
     ln.step(*batch, phases=_lib.PHASE_FWD_LOSS, target_pre=True)
     self._record(self._e_loss[k], self._main_ptr)
     ln.step(*batch, phases=_lib.PHASE_BACKWARD | _lib.PHASE_OPTIMIZER, target_pre=True)
+    self._after_loss(k, s)
+    return s
+
+  def _after_loss(self, k, s):
     # side, under the backward pass: write-back(k) -> sample(k+1) -> target apply(k+1)
     self._wait(self._side_ptr, self._e_loss[k])
     torch.cuda.set_stream(self.side)
     try:
-      rep.update_priorities(s.ids, ln.priorities)
+      self.replay.update_priorities(s.ids, self.learner.priorities)
     finally:
       torch.cuda.set_stream(self.main)
     self._k = k + 1
     self._next = self._prefetch(self._k, first=False)
-    return s
 
   def sync_target(self):
     """target <- online between two steps (rainbow/agent.py:157-158)."""
-    if self._next is not None:
+    if self._next is not None and self.prefetch_target:
       # the prefetched target apply may still be reading the old parameters
       self._wait(self._main_ptr, self._e_target[self._k])
       self._target_stale = True

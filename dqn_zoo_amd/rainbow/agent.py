@@ -67,7 +67,8 @@ class Rainbow(parts.Agent):
     self._action = None
     self._frame_t = -1
     self._statistics = {'state_value': np.nan}
-    self._obs = device_obs.ObservationCache(self._device)
+    self._obs = device_obs.ObservationCache(
+        self._device, depth=device_obs.depth_for(transition_accumulator))
 
   # -- acting / stepping -------------------------------------------------------
   def step(self, timestep) -> parts.Action:

@@ -950,6 +950,59 @@ class PrioritizedTransitionReplay(_ReplayBase):
                                     stream), 'dz_replay_gather')
     return slot.sample
 
+  def prepare_next_sample(self, size: int):
+    """The NEXT `sample_device(size)` as a descriptor instead of a launch: makes the
+    host RNG draws now (in the reference's order, replay.py:551-566), reserves the
+    ring slot and returns `(descriptor, sample)`.  The descriptor goes to
+    `RainbowLearner.step(next_sample=...)`, whose optimiser launch then carries the
+    sample + gather as extra blocks AFTER that step's priority write-back; `sample`
+    (a DeviceSample over the slot's buffers) is the next batch once that step has
+    run.  Valid only if nothing is added to this replay in between (a learner over a
+    static replay): `take_prepared()` checks that."""
+    if self._size == 0:
+      raise RuntimeError('No IDs to sample.')
+    if size > 64:
+      raise ValueError('prepare_next_sample handles batches <= 64 (draws travel in kernel arguments)')
+    beta = float(self.importance_sampling_exponent)
+    if not 0.0 <= beta <= 1.0:
+      raise ValueError('Require 0 <= exponent <= 1.')
+    slot = self._ring_slot(size)
+    rs = self._random_state
+    h = slot.host_np
+    h[:size] = rs.randint(self._size, size=size)
+    h[size:2 * size] = rs.uniform(size=size).view(np.int64)
+    h[2 * size:] = rs.uniform(size=size).view(np.int64)
+    a = slot.args
+    a.size = self._size
+    a.t = self._t
+    up = 1.0 / self._size
+    a.usp_times_up = self._usp * up
+    a.uniform_prob = up
+    a.beta = beta
+    d = getattr(slot, 'next_desc', None)
+    if d is None:
+      d = slot.next_desc = _lib.NextSample()
+      hp = slot.host.data_ptr()
+      d.pos_h, d.u_target_h, d.u_mix_h = hp, hp + 8 * size, hp + 16 * size
+      d.fields = ctypes.cast(slot.fields, ctypes.c_void_p)
+      d.num_fields = len(self._ring.fields)
+      d.n = size
+      d.ids_out = slot.ids.data_ptr()
+      d.probs_out = slot.probs.data_ptr()
+      d.weights_out = slot.w64.data_ptr()
+      d.weights32_out = slot.w32.data_ptr()
+      d.status = self._status.word.data_ptr()
+    d.args = a   # by-value copy of the slot's sample arguments
+    self._prepared = (slot, self._t)
+    return d, slot.sample
+
+  def take_prepared(self) -> DeviceSample:
+    """The batch a learner step produced from `prepare_next_sample`'s descriptor."""
+    slot, t = self._prepared
+    if t != self._t:
+      raise RuntimeError('the replay changed between prepare_next_sample and its use')
+    return slot.sample
+
   SAMPLE_RING_DEPTH = 4
 
   def _ring_slot(self, size):

@@ -52,7 +52,7 @@ int dz_last_hip_error(void);
 const char* dz_built_arch(void);
 /* sizeof() of the ABI structs as the library was compiled, so that a binding
  * can verify its mirror: 0 dz_field_t, 1 dz_prio_sample_args_t,
- * 2 dz_rainbow_layout_t, 3 dz_rainbow_args_t, 4 dz_dense_layout_t,
+ * 2 dz_rainbow_layout_t, 3 dz_rainbow_args_t, 4 dz_dense_layout_t, 9 dz_next_sample_t,
  * 5 dz_dense_args_t, 6 dz_iqn_layout_t, 7 dz_iqn_args_t, 8 dz_insert_field_t.
  * -1 for an unknown id.                                                      */
 int dz_struct_size(int which);
@@ -276,6 +276,23 @@ int dz_rainbow_layout(int num_actions, int num_atoms, int batch,
 #define DZ_SC_BC2 3       /* 1 - b2^count                                     */
 #define DZ_SC_CLIP 4      /* 1 if gnorm < max_norm else 0                     */
 
+/* The NEXT step's replay sample, carried by a learner step (dz_rainbow_args_t::
+ * next_sample): exactly the arguments of dz_prioritized_sample_gather.  The draws
+ * are HOST arrays (n each), copied into the kernel arguments at enqueue time.     */
+typedef struct {
+  dz_prio_sample_args_t args;
+  const int64_t* pos_h;
+  const double* u_target_h;
+  const double* u_mix_h;
+  const dz_field_t* fields;
+  int32_t num_fields, n;
+  int64_t* ids_out;
+  double* probs_out;
+  double* weights_out;
+  float* weights32_out;
+  uint32_t* status;
+} dz_next_sample_t;
+
 typedef struct {
   int32_t num_actions, num_atoms, batch;
   /* parameter-shaped buffers (dz_rainbow_layout.param_count floats each) */
@@ -335,6 +352,15 @@ typedef struct {
    * stream.  Results are bit-identical to the three-apply form.                  */
   const float* tgt_part;
   const float* tgt_noise;
+  /* Optional (needs DZ_PHASE_BACKWARD | DZ_PHASE_OPTIMIZER in the call): the sample +
+   * gather of the NEXT step rides in this step's optimiser launch as extra blocks, and
+   * the priority write-back (prio_*) moves into an EARLIER backward launch, so that
+   * sample(k+1) sees write-back(k) as in the sequential order (rainbow/agent.py:
+   * 181-198).  Only valid when nothing is added to the replay between this step and
+   * the next sample (a learner over a static replay); the caller then uses the
+   * buffers of `next_sample` as the next batch instead of sampling.  Eager launches
+   * only (the draws are by-value kernel arguments: not graph-replayable).          */
+  const dz_next_sample_t* next_sample;
 } dz_rainbow_args_t;
 
 #define DZ_PHASE_FORWARD 1   /* the applies + loss (+ dlogits) = NETS | LOSS   */

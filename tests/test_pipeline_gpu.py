@@ -13,9 +13,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(pipelined, steps=12, graphs=False, sync_every_step=True, sync_target_at=()):
+def _run(pipelined, steps=12, graphs=False, sync_every_step=True, sync_target_at=(),
+         fused_sample=False, capacity=2048):
   import bench
-  args = types.SimpleNamespace(capacity=2048, batch=32)
+  args = types.SimpleNamespace(capacity=capacity, batch=32)
   dev = torch.device('cuda', 0)
   replay, learner, _ = bench.build_workload(args, dev, seed=3)
   learner.use_graphs = graphs
@@ -23,7 +24,7 @@ def _run(pipelined, steps=12, graphs=False, sync_every_step=True, sync_target_at
   prev = torch.cuda.current_stream(dev)
   torch.cuda.set_stream(torch.cuda.Stream(dev))
   step = (bench.make_step_pipelined(replay, learner, 32, dev) if pipelined
-          else bench.make_step(replay, learner, 32))
+          else bench.make_step(replay, learner, 32, fused_next_sample=fused_sample))
   losses, ids = [], []
   for k in range(steps):
     if k in sync_target_at:   # target <- online between two steps
@@ -63,6 +64,20 @@ def test_overlapped_steps_are_bit_identical_to_sequential():
   assert np.isfinite(ref[0]).all() and ref[0].std() > 0
 
 
+@pytest.mark.parametrize('capacity', [2048, 40])
+def test_fused_next_sample_is_bit_identical_to_sequential(capacity):
+  """sample(k+1) + gather(k+1) as side blocks of step k's optimiser launch, with
+  write-back(k) in an earlier backward launch (the two-round-trip LDS walk): same ids
+  (through the losses), losses, parameters, tree and running max as the sequential
+  step.  capacity 40 < batch: duplicate ids in every batch (last-wins) and shared
+  tree paths from the leaves up."""
+  ref = _run(pipelined=False, capacity=capacity)
+  got = _run(pipelined=False, fused_sample=True, capacity=capacity)
+  for a, b in zip(got, ref):
+    np.testing.assert_array_equal(a, b)
+  assert np.isfinite(ref[0]).all() and ref[0].std() > 0
+
+
 def test_pipelined_target_sync_matches_sequential():
   """sync_target() between two pipelined steps: the prefetched target apply used
   the OLD parameters and is redone in line -- same bits as the sequential loop."""
@@ -88,7 +103,7 @@ def test_target_pre_equals_three_apply_step():
   dev = torch.device('cuda', 0)
   mk = lambda: ll.RainbowLearner(networks.RainbowNetwork(A, sup, 0.1), ll.AdamConfig(), B, seed=7)
   la, lb = mk(), mk()
-  lb.target.copy_(torch.from_numpy(rs.uniform(-0.05, 0.05, lb.target.numel()).astype(np.float32)) + lb.target)
+  lb.target.add_(torch.from_numpy(rs.uniform(-0.05, 0.05, lb.target.numel()).astype(np.float32)).to(dev))
   la.target.copy_(lb.target)
   for ln in (la, lb):
     ln.use_graphs = False

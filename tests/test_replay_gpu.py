@@ -317,6 +317,39 @@ def test_gather_bytes_and_dtypes(rl):
     assert got[1].a_tm1 == host[cap + 56].a_tm1
 
 
+def test_sample_gather_ragged_field_sizes(rl):
+  """The one-launch sample+gather with a generic structure whose fields mix a wide
+  16-byte-aligned row (several chunk blocks), rows of 1000 and 600 bytes (16-byte path
+  impossible: byte copies, still more than one block's 512 bytes) and a scalar: every
+  byte of every sampled row arrives (the early exit of the surplus chunk
+  blocks used the vector path's unit for byte-path fields)."""
+  import collections
+  import torch
+  S = collections.namedtuple('S', ['wide', 'odd', 'odd2', 'k'])
+  cap, batch = 64, 16
+  rep = rl.PrioritizedTransitionReplay(cap, S(None, None, None, None), 0.5, lambda t: 0.6,
+                                       1e-3, True, np.random.RandomState(9))
+  rs = np.random.RandomState(4)
+  host = {}
+  for i in range(cap + 9):
+    it = S(rs.randint(0, 256, (84, 84, 4)).astype(np.uint8),
+           rs.randint(0, 256, (1000,)).astype(np.uint8),
+           rs.randint(0, 256, (3, 200)).astype(np.uint8), int(i))
+    host[i] = it
+    rep.add(it, 1.0 + i % 5)
+  for _ in range(4):
+    s = rep.sample_device(batch)
+    torch.cuda.synchronize()
+    ids = s.ids.cpu().numpy()
+    t = s.transitions
+    for b, i in enumerate(ids):
+      np.testing.assert_array_equal(t.wide[b].cpu().numpy(), host[i].wide)
+      np.testing.assert_array_equal(t.odd[b].cpu().numpy(), host[i].odd)
+      np.testing.assert_array_equal(t.odd2[b].cpu().numpy(), host[i].odd2)
+      assert int(t.k[b]) == host[i].k
+  rep.check_status()
+
+
 def test_error_behaviour(rl):
   S = protocol.Item(None, None)
   with pytest.raises(ValueError, match='priority_exponent'):

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/s1
 mkdir -p $OUT
 cd $R
-timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1
+timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1
 echo "pytest rc=$?"; tail -5 $OUT/pytest.log
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 3000 --warmup 300 --cpu-seconds 0 --prof-steps 0 --other-configs 0"

@@ -16,7 +16,7 @@ def main():
   for r in rows:
     r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
   rows.sort(key=lambda r: r['s'])
-  adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+  adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name'] or 'adam_sg_kernel' in r['Kernel_Name']]
   if len(adam) < n + 1:
     n = len(adam) - 1
   a, b = adam[-n - 1], adam[-1]
@@ -50,6 +50,19 @@ def main():
     # main-queue gaps (idle between consecutive main kernels)
     gaps = sum(max(0, mains[i + 1][0] - mains[i][1]) for i in range(len(mains) - 1))
     print('main-queue gaps: %.1f us/step' % (gaps / n / 1e3))
+  if len(sys.argv) > 3:   # timeline of the last k steps
+    k = int(sys.argv[3])
+    a2 = adam[-k - 1]
+    tl0 = rows[a2]['e']
+    print('--- timeline of the last %d steps (us from the end of the previous Adam) ---' % k)
+    for r in rows:
+      if r['e'] > tl0 and r['e'] <= t1:
+        nm = r['Kernel_Name']
+        for pre in ('void ', '(anonymous namespace)::'):
+          nm = nm.replace(pre, '')
+        print('%s %8.1f -> %8.1f  (%5.1f)  %s' % (
+            'M' if (not qkey or r.get(qkey) == main_q) else ' s', (r['s'] - tl0) / 1e3,
+            (r['e'] - tl0) / 1e3, (r['e'] - r['s']) / 1e3, nm[:70]))
   d = defaultdict(lambda: [0, 0])
   for r in seg:
     k = (r.get(qkey) == main_q if qkey else True, r['Kernel_Name'][:100])
