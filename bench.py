@@ -52,6 +52,9 @@ def parse_args():
   ap.add_argument('--cpu-seconds', type=float, default=15.0,
                   help='CPU-baseline time budget (0 disables)')
   ap.add_argument('--prof-steps', type=int, default=100)
+  ap.add_argument('--sustain-steps', type=int, default=2000,
+                  help='after the timed --steps window, also report the rate over this many '
+                       'further steps (`sustained`; 0 disables)')
   ap.add_argument('--other-configs', type=int, default=1,
                   help='also measure BASELINE configs 2 and 3 (DQN + uniform replay; '
                        'double-Q + prioritized) after the headline (0 disables)')
@@ -216,6 +219,8 @@ def kernel_work(b, a=NUM_ACTIONS, k=NUM_ATOMS):
                             2 * b * (12800 + 5184) * 4)
   w['conv1_wgrad'] = (f(256, 32, b * 400), b * 28224 + b * 12800 * 4)
   w['adam'] = (0.0, 7.0 * p_ref * 4)           # read g,p,m,v; write p,m,v
+  # fused mode: the next step's sample + gather (2 x 32 states read and written) rides along
+  w['adam+next_sample'] = (0.0, 7.0 * p_ref * 4 + 2.0 * b * (2 * 28224 + 20))
   w['grad_sumsq'] = (0.0, 1.0 * p_ref * 4)
   return w
 
@@ -371,16 +376,34 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
   return out
 
 
+def _profile_json(name):
+  """A committed profile table (profiles/r3_<name>.json, else the round-2 file)."""
+  for tag in ('r3', 'r2'):
+    try:
+      with open(os.path.join(ROOT, 'profiles', '%s_%s.json' % (tag, name))) as f:
+        return json.load(f), tag
+    except (OSError, ValueError):
+      continue
+  return None, None
+
+
 def pmc_traffic(kernel):
   """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-  (profiles/r2_hbm_traffic.json: FETCH_SIZE/WRITE_SIZE collected separately and
-  corrected as MI355X_MICROARCH.md prescribes); None if not collected."""
-  try:
-    with open(os.path.join(ROOT, 'profiles', 'r2_hbm_traffic.json')) as f:
-      k = json.load(f)['kernels'].get(kernel)
-    return None if k is None else k.get('hbm_bytes_corrected')
-  except (OSError, ValueError, KeyError):
+  (profiles/r3_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate passes and
+  corrected as MI355X_MICROARCH.md prescribes, the dword-operand kernels with a factor
+  calibrated on a known byte count in the same access pattern); None if not collected."""
+  doc, _ = _profile_json('hbm_traffic')
+  if not doc:
     return None
+  k = doc.get('kernels', {}).get(kernel.split('+next_sample')[0])
+  return None if k is None else k.get('hbm_bytes_corrected')
+
+
+def pmc_mfma_util():
+  """mark name -> MFMA-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x
+  kernel cycles)) from the committed SQ counter pass (profiles/r3_mfma_util.json)."""
+  doc, tag = _profile_json('mfma_util')
+  return ({}, None) if not doc else (doc.get('kernels', {}), tag)
 
 
 def measure_roofline(step, prof_steps, batch):
@@ -417,6 +440,7 @@ def measure_roofline(step, prof_steps, batch):
     out['frac'] = out['achieved'] / out['peak']
     out['achieved'] = round(out['achieved'], 3)
     out['frac'] = round(out['frac'], 4)
+  util, util_tag = pmc_mfma_util()
   table = {}
   for k2, v in sorted(avg.items(), key=lambda kv: -kv[1]):
     e = {'us': round(v * 1e6, 2)}
@@ -424,10 +448,37 @@ def measure_roofline(step, prof_steps, batch):
       fl, nb = work[k2]
       e['tflops'] = round(fl / v / 1e12, 2)
       e['gbps'] = round(nb / v / 1e9, 1)
+    u = util.get(k2.split('+next_sample')[0].split('+noise')[0])
+    if u is not None:
+      e['mfma_util'] = u     # from the committed SQ counter pass, not from this run
+    t = pmc_traffic(k2)
+    if t is not None:
+      e['hbm_bytes_pmc'] = t
+      if k2 in work and work[k2][1]:
+        e['traffic_over_algorithmic'] = round(t / work[k2][1], 2)
     table[k2] = e
   out['per_kernel'] = table
+  out['mfma_util_source'] = None if util_tag is None else 'profiles/%s_mfma_util.json' % util_tag
   out['learn_kernels_us'] = round(sum(avg.values()) * 1e6, 1)
+  out['launches'] = len(avg)
   return out
+
+
+def step_roofline(roofline, ms_per_step, batch, extra_launches=0):
+  """The whole step against the chip: 4.438 GFLOP of fp32 matrix work and
+  194 MB of compulsory traffic per Rainbow gradient step at batch 32."""
+  flops = batch * 138700800.0          # 3 applies + backward (two-GEMM noisy form)
+  p_ref = 6868485
+  nbytes = 7.0 * p_ref * 4 + batch * 2 * 28224
+  sec = ms_per_step * 1e-3
+  return {'flops': flops, 'bytes': nbytes,
+          'frac_mfma': round(flops / sec / PEAK_F32_MFMA, 4),
+          'frac_hbm': round(nbytes / sec / PEAK_HBM, 4),
+          'busy_us': roofline['learn_kernels_us'],   # HIP-event sum (adds ~2-3 us per launch)
+          'launches': roofline['launches'] + extra_launches,
+          'floor_us': round(max(flops / PEAK_F32_MFMA, nbytes / PEAK_HBM) * 1e6, 1),
+          'note': 'frac_* = algorithmic work / measured step time / chip peak; the step is a '
+                  'chain of latency-bound launches (DESIGN.md 4), only Adam is near a roofline'}
 
 
 def measure_replay(replay, learner, batch, n=100):
@@ -548,6 +599,10 @@ def cpu_baseline(args, seed, budget_s):
   dt = time.perf_counter() - t0
   return {'value': round(n / dt, 2), 'unit': 'steps/s',
           'cores': int(torch.get_num_threads()), 'kind': 'port',
+          'replay': 'oracle port (oracle/replay_oracle.py: the reference\'s algorithms '
+                    'restated; /root/reference itself does not travel to the GPU box)',
+          'update': 'torch-CPU fp32 port (oracle/qnet_torch_cpu.py); JAX/XLA-CPU is not '
+                    'installable here',
           'host_cpus_usable': ncpu, 'host_cpus_total': os.cpu_count(),
           'sample': '%d Rainbow steps (oracle replay sample + torch-CPU update '
                     '+ priority write-back), capacity %d, batch %d, %.1f s' %
@@ -596,7 +651,11 @@ def main():
     dist.init_process_group('nccl', rank=rank, world_size=world,
                             device_id=device)
 
-  replay, learner, _ = build_workload(args, device, args.seed + 1000 * rank)
+  from dqn_zoo_amd import distributed as dz_dist
+  # one host thread per replica, pinned to its own slice of the node's cores
+  local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+  cpus = dz_dist.pin_rank(local_rank, local_world)
+  replay, learner, _ = build_workload(args, device, dz_dist.replica_seed(args.seed, rank))
   # hipGraph capture is illegal on the legacy default stream: everything from
   # here on runs on an explicit stream.
   torch.cuda.synchronize(device)
@@ -620,7 +679,6 @@ def main():
   # (round 1 had these inside the timed window: at the driver's --steps 20 the
   # first-use costs of torch.distributed / ReplicaStats / the .cpu() reads were
   # 75 % of the measurement)
-  from dqn_zoo_amd import distributed as dz_dist
   # one hipGraph per slot of the replay's sample ring: capture them all now so
   # that no --warmup value can leave a capture inside the timed region
   prime = replay.SAMPLE_RING_DEPTH
@@ -655,14 +713,10 @@ def main():
   # statistics boundary (not a gradient step, outside the clock): one RCCL
   # all-reduce of packed sums over xGMI (keys of
   # EpisodeTracker/StepRateTracker, parts.py:239-284)
-  stats.add(grad_steps=args.steps, loss_sum=learner.losses.double().sum())
-  totals = stats.all_reduce()
-  if dist is not None:
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+  totals = dz_dist.reduce_run(stats, dt, args.steps, learner.losses.double().sum(), device)
+  dt = totals['seconds_max']   # MAX over ranks
   replay.check_status()
-  assert int(totals['grad_steps']) == world * args.steps
+  assert int(totals['grad_steps']) == world * args.steps and int(totals['replicas']) == world
 
   if rank == 0:
     value = world * args.steps / dt
@@ -686,13 +740,30 @@ def main():
             'num_atoms': NUM_ATOMS, 'parallelism': 'replicas x%d' % world,
             'launch': 'eager' if args.no_graphs else 'hipGraph replay',
             'collective': 'rccl' if dist is not None else 'none (single process)',
+            'host_cpus_rank0': len(cpus),
             'untimed_setup_steps': prime,
             'mode': args.mode,
             'streams': 'two (dqn_zoo_amd/pipeline.py)' if args.mode == 'two-stream' else 'one'},
     }
+    if args.sustain_steps > 0:
+      # the same loop over a window long enough that pipeline fill and host jitter do
+      # not matter (the contract's `value` above is EXACTLY --steps steps)
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      for _ in range(args.sustain_steps):
+        step()
+      torch.cuda.synchronize()
+      ds = time.perf_counter() - t1
+      out['sustained'] = {'steps': args.sustain_steps,
+                          'value': round(args.sustain_steps / ds, 2),
+                          'ms_per_step': round(1e3 * ds / args.sustain_steps, 4)}
     if args.prof_steps > 0:
       learner.use_graphs = False  # per-kernel events need eager launches
-      out['roofline'] = measure_roofline(seq_step, args.prof_steps, args.batch)
+      prof_step = step if args.mode == 'fused' else seq_step
+      out['roofline'] = measure_roofline(prof_step, args.prof_steps, args.batch)
+      out['roofline']['step'] = step_roofline(
+          out['roofline'], out['ms_per_step'], args.batch,
+          extra_launches=0 if args.mode == 'fused' else 1)   # + the sample launch
       # the write-back timed as its own kernel (in the measured step it rides
       # inside a backward launch)
       out['replay'] = measure_replay(replay, learner, args.batch)

@@ -197,7 +197,7 @@ SIGNATURES = {
     'dz_stream_wait_event': (c_int, [c_vp, c_vp]),
     'dz_rainbow_graph_capture': (c_int, [ctypes.POINTER(RainbowArgs), c_int, c_vp,
                                          ctypes.POINTER(c_vp)]),
-    'dz_atari_observation': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int,
+    'dz_atari_observation': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int,
                                      c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int,
                                      c_int, c_vp, c_vp]),
     'dz_graph_capture_begin': (c_int, [c_vp]),

@@ -29,15 +29,18 @@ constexpr int kMaxStack = 8;      // stacked frames per observation
 
 struct AtariParams {
   const uint8_t* frames[kMaxPooled];  // [H][W][C] each
-  int n_frames, H, W, C;              // C = 3 (RGB -> gray) or 1 (already gray)
+  int n_frames, H, W, C;              // C = 3 (RGB) or 1 (already gray)
+  int planes;                         // 1: one output plane (C = 3: grayscaled); 3: RGB kept
+                                      // (grayscaling=False: every band resampled on its own,
+                                      // as Pillow does for mode "RGB")
   const int32_t* xb; const int32_t* xk; int xks;   // horizontal [OW][2], [OW][xks]
   const int32_t* yb; const int32_t* yk; int yks;   // vertical   [OH][2], [OH][yks]
   int OH, OW;
-  uint8_t* ring;     // [stack][OH][OW]
+  uint8_t* ring;     // [stack][OH][OW][planes]
   int stack;         // ring depth = stacked frames
   int slot;          // ring slot the new frame goes to
   int count;         // frames in the stack INCLUDING the new one (1..stack)
-  uint8_t* obs;      // [OH][OW][stack], oldest first, trailing zeros
+  uint8_t* obs;      // [OH][OW][planes][stack] ([OH][OW][stack] for one plane), oldest first, trailing zeros
 };
 
 __device__ __forceinline__ uint8_t clip8(int v) {
@@ -50,6 +53,8 @@ __global__ __launch_bounds__(256) void atari_observation_kernel(AtariParams p) {
   uint8_t* gray = lds;                       // [yks][W]
   uint8_t* hres = lds + p.yks * p.W;         // [yks][OW]
   const int yy = blockIdx.x;
+  const int band = blockIdx.y;               // < planes
+  const bool to_gray = p.C == 3 && p.planes == 1;
   const int ymin = p.yb[2 * yy], ycnt = p.yb[2 * yy + 1];
   const int tid = threadIdx.x;
   // ---- max-pool + grayscale of the rows this output row needs ----
@@ -61,12 +66,12 @@ __global__ __launch_bounds__(256) void atari_observation_kernel(AtariParams p) {
     for (int f = 0; f < kMaxPooled; ++f) {
       if (f < p.n_frames) {
         const uint8_t* s = p.frames[f] + px;
-        c0 = max(c0, (int)s[0]);
-        if (p.C == 3) { c1 = max(c1, (int)s[1]); c2 = max(c2, (int)s[2]); }
+        c0 = max(c0, (int)s[to_gray ? 0 : band]);
+        if (to_gray) { c1 = max(c1, (int)s[1]); c2 = max(c2, (int)s[2]); }
       }
     }
     uint8_t g = (uint8_t)c0;
-    if (p.C == 3) {
+    if (to_gray) {
       const double c2w = 1 - (0.299 + 0.587);   // processors.py:370, folded like Python
       double y = (double)c0 * 0.299;
       y = y + (double)c1 * 0.587;
@@ -92,8 +97,9 @@ __global__ __launch_bounds__(256) void atari_observation_kernel(AtariParams p) {
     int acc = 1 << (kPrecisionBits - 1);
     for (int r = 0; r < ycnt; ++r) acc += (int)hres[r * p.OW + xx] * k[r];
     const uint8_t v = clip8(acc);
-    const long o = (long)yy * p.OW + xx;
-    p.ring[(long)p.slot * p.OH * p.OW + o] = v;
+    const long o = ((long)yy * p.OW + xx) * p.planes + band;
+    const long plane_sz = (long)p.OH * p.OW * p.planes;
+    p.ring[(long)p.slot * plane_sz + o] = v;
     // stack position j holds the (count-1-j)-th newest frame; j >= count: zero pad
     for (int j = 0; j < p.stack; ++j) {
       uint8_t s = 0;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void atari_observation_kernel(AtariParams p) {
       } else if (j < p.count - 1) {
         int sl = p.slot - (p.count - 1 - j);
         sl = sl < 0 ? sl + p.stack : sl;
-        s = p.ring[(long)sl * p.OH * p.OW + o];
+        s = p.ring[(long)sl * plane_sz + o];
       }
       p.obs[o * p.stack + j] = s;
     }
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void atari_observation_kernel(AtariParams p) {
 }  // namespace
 
 extern "C" int dz_atari_observation(const uint8_t* const* frames, int n_frames, int height,
-                                    int width, int channels, const int32_t* xbounds,
+                                    int width, int channels, int grayscale, const int32_t* xbounds,
                                     const int32_t* xcoeffs, int xksize, const int32_t* ybounds,
                                     const int32_t* ycoeffs, int yksize, int out_h, int out_w,
                                     uint8_t* ring, int stack, int slot, int count,
@@ -126,13 +132,14 @@ extern "C" int dz_atari_observation(const uint8_t* const* frames, int n_frames, 
   AtariParams p = {};
   for (int f = 0; f < n_frames; ++f) { DZ_REQUIRE(frames[f]); p.frames[f] = frames[f]; }
   p.n_frames = n_frames; p.H = height; p.W = width; p.C = channels;
+  p.planes = (channels == 3 && !grayscale) ? 3 : 1;
   p.xb = xbounds; p.xk = xcoeffs; p.xks = xksize;
   p.yb = ybounds; p.yk = ycoeffs; p.yks = yksize;
   p.OH = out_h; p.OW = out_w; p.ring = ring; p.stack = stack; p.slot = slot; p.count = count;
   p.obs = obs;
   const size_t lds = (size_t)yksize * (size_t)(width + out_w);
   DZ_REQUIRE(lds <= 64 * 1024);
-  hipLaunchKernelGGL(atari_observation_kernel, dim3((unsigned)out_h), dim3(256), lds,
+  hipLaunchKernelGGL(atari_observation_kernel, dim3((unsigned)out_h, (unsigned)p.planes), dim3(256), lds,
                      dz_s(stream), p);
   DZ_LAUNCH_CHECK();
   return DZ_OK;

@@ -14,7 +14,8 @@ Works with any initialised torch.distributed backend ("nccl" == RCCL on ROCm;
 """
 
 import collections
-from typing import Mapping
+import os
+from typing import Mapping, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -82,3 +83,52 @@ class ReplicaStats:
     out['step_rate'] = (out['num_steps_since_reset'] / out['duration']
                         if out['duration'] > 0 else float('nan'))
     return out
+
+
+# ---- replica set-up (one process per GPU) ------------------------------------------
+def replica_seed(seed: int, rank: int) -> int:
+  """Seed of replica `rank`: replicas are independent runs (different replay RNG,
+  network init and noise streams), not shards of one run."""
+  return int(seed) + 1000 * int(rank)
+
+
+def rank_cpus(local_rank: int, local_world: int,
+              available: Optional[Sequence[int]] = None) -> Sequence[int]:
+  """Host cores for one of `local_world` replicas: a contiguous, disjoint slice of the
+  cores this process may use (sorted ids: on a two-socket MI355X node the lower half
+  of the ids -- and GPUs 0-3 -- sit on socket 0, so contiguous slices keep a replica's
+  host thread on the socket its GPU hangs off).  Every replica's host thread draws
+  RNG numbers and enqueues ~17 launches every ~165 us; unpinned, the 8 threads migrate
+  and share cores with each other's runtime helper threads."""
+  cpus = sorted(os.sched_getaffinity(0)) if available is None else sorted(available)
+  if local_world <= 1 or len(cpus) < local_world:
+    return cpus
+  per = len(cpus) // local_world
+  return cpus[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_rank(local_rank: int, local_world: int) -> Sequence[int]:
+  """Applies `rank_cpus` to this process; returns the core list (empty list: the
+  platform has no affinity control and nothing was done)."""
+  try:
+    cpus = rank_cpus(local_rank, local_world)
+    if local_world > 1 and cpus:
+      os.sched_setaffinity(0, cpus)
+    return list(cpus)
+  except (AttributeError, OSError):
+    return []
+
+
+def reduce_run(stats: 'ReplicaStats', seconds: float, grad_steps: int, loss_sum,
+               device='cpu') -> Mapping[str, float]:
+  """The statistics boundary of a replicated run (bench.py after its timed region):
+  ONE packed SUM all-reduce of the replicas' counts and sums, and the MAX over ranks of
+  the elapsed time, which is what whole-job throughput divides by.  Returns the
+  reduced dict plus `seconds_max` and `steps_per_second` = all replicas' steps / the
+  slowest replica's time."""
+  stats.add(grad_steps=grad_steps, loss_sum=loss_sum, duration=seconds)
+  out = dict(stats.all_reduce())
+  out['seconds_max'] = out['duration']
+  out['steps_per_second'] = out['grad_steps'] / out['duration'] if out['duration'] > 0 \
+      else float('nan')
+  return out

@@ -402,12 +402,15 @@ class ObservationPipeline:
           'the Atari observation pipeline needs an AMD GPU; no CPU fallback')
     self._device = torch.device('cuda', torch.cuda.current_device()) \
         if self._device_arg is None else torch.device(self._device_arg)
-    want = 3 if self._gray else 2
-    if frame.ndim != want or (self._gray and frame.shape[2] != 3):
-      raise NotImplementedError(
-          'frames must be uint8 %s; resizing un-grayscaled RGB frames is not '
-          'implemented on the device' % ('[H, W, 3]' if self._gray else '[H, W]'))
+    # [H, W, 3] RGB (grayscaled, or with grayscaling=False kept as three bands that
+    # are resampled independently, like PIL's mode "RGB": processors.py:429,495) or,
+    # with grayscaling=False, an already-gray [H, W] frame
+    ok = (frame.ndim == 3 and frame.shape[2] == 3) or (frame.ndim == 2 and not self._gray)
+    if not ok:
+      raise ValueError('frames must be uint8 [H, W, 3]%s, got shape %s' % (
+          '' if self._gray else ' or [H, W]', tuple(frame.shape)))
     self._in_shape = tuple(frame.shape)
+    self._planes = 3 if (frame.ndim == 3 and not self._gray) else 1
     h, w = frame.shape[:2]
     oh, ow = self._shape
     xb, xk = resample_coeffs(w, ow)
@@ -415,7 +418,8 @@ class ObservationPipeline:
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self._device)
     self._xb, self._xk, self._yb, self._yk = dev(xb), dev(xk), dev(yb), dev(yk)
     self._xks, self._yks = int(xk.shape[1]), int(yk.shape[1])
-    self._ring = torch.zeros((self._stack, oh, ow), dtype=torch.uint8, device=self._device)
+    self._ring = torch.zeros((self._stack, oh, ow, self._planes), dtype=torch.uint8,
+                             device=self._device)
     # pinned staging for the raw frames: DEPTH launches may be in flight
     self._depth = 4
     self._pin = torch.empty((self._depth, self._pooled) + self._in_shape, dtype=torch.uint8,
@@ -459,10 +463,11 @@ class ObservationPipeline:
     self._slot = (self._slot + 1) % self._stack
     self._count = min(self._count + 1, self._stack)
     oh, ow = self._shape
-    obs = torch.empty((oh, ow, self._stack), dtype=torch.uint8, device=self._device)
+    shape = (oh, ow, self._stack) if self._planes == 1 else (oh, ow, 3, self._stack)
+    obs = torch.empty(shape, dtype=torch.uint8, device=self._device)
     h, w = self._in_shape[:2]
     self._lib_mod.check(self._lib.dz_atari_observation(
-        self._ptrs, len(frames), h, w, 3 if self._gray else 1,
+        self._ptrs, len(frames), h, w, 3 if len(self._in_shape) == 3 else 1, int(self._gray),
         self._xb.data_ptr(), self._xk.data_ptr(), self._xks,
         self._yb.data_ptr(), self._yk.data_ptr(), self._yks, oh, ow,
         self._ring.data_ptr(), self._stack, self._slot, self._count, obs.data_ptr(),

@@ -620,7 +620,10 @@ int dz_prof_read_replay(float* ms_out);
  *   obs[y][x][j] = j-th oldest of the `count` newest ring frames, zeros after
  * frames[f]: device uint8 [height][width][channels] (host array of n_frames <= 4
  *   device pointers; n_frames = 0 pools nothing: a black frame); channels 3 = RGB (grayscaled with the reference's float64
- *   weights, un-fused, truncated) or 1 = already gray.
+ *   weights, un-fused, truncated, when grayscale != 0; with grayscale == 0 the three
+ *   bands are kept and resampled independently, as PIL does for mode "RGB" --
+ *   atari(grayscaling=False), processors.py:429,495: ring is then
+ *   [stack][out_h][out_w][3] and obs [out_h][out_w][3][stack]) or 1 = already gray.
  * xbounds/xcoeffs, ybounds/ycoeffs: Pillow's 8-bit resample tables for each axis,
  *   device int32 [out][2] = (first input index, taps) and [out][ksize] 22-bit
  *   fixed-point weights (ksize <= 64); the horizontal pass runs first with a
@@ -629,7 +632,7 @@ int dz_prof_read_replay(float* ms_out);
  *   frame is written to `slot`, `count` = frames held including it.
  * obs: device uint8 [out_h][out_w][stack] (np.stack(..., axis=-1) order).     */
 int dz_atari_observation(const uint8_t* const* frames, int n_frames, int height, int width,
-                         int channels, const int32_t* xbounds, const int32_t* xcoeffs,
+                         int channels, int grayscale, const int32_t* xbounds, const int32_t* xcoeffs,
                          int xksize, const int32_t* ybounds, const int32_t* ycoeffs,
                          int yksize, int out_h, int out_w, uint8_t* ring, int stack,
                          int slot, int count, uint8_t* obs, dz_stream_t stream);

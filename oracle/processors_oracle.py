@@ -105,9 +105,21 @@ def resize_bilinear(gray: np.ndarray, shape=(84, 84)) -> np.ndarray:
   return np.ascontiguousarray(img)
 
 
-def pooled_frame(frames, shape=(84, 84)) -> np.ndarray:
-  """max over the given RGB frames -> grayscale -> resize: one stack entry."""
+def resize_bilinear_rgb(rgb: np.ndarray, shape=(84, 84)) -> np.ndarray:
+  """PIL `Image.fromarray(rgb).resize((W, H), BILINEAR)` for uint8 [H,W,3] (mode "RGB"):
+  Pillow's 8-bit resampler treats every band of a multi-band image on its own with the
+  same coefficient tables (ImagingResampleHorizontal/Vertical_8bpc), i.e. three
+  single-band resizes (checked against PIL in tests/test_oracle_processors.py)."""
+  return np.stack([resize_bilinear(np.ascontiguousarray(rgb[:, :, c]), shape)
+                   for c in range(rgb.shape[2])], axis=-1)
+
+
+def pooled_frame(frames, shape=(84, 84), grayscaling=True) -> np.ndarray:
+  """max over the given RGB frames -> grayscale -> resize: one stack entry
+  (processors.py:488-494; grayscaling=False keeps the three bands)."""
   pooled = np.max(np.stack(frames, axis=0), axis=0)
+  if not grayscaling:
+    return resize_bilinear_rgb(pooled, shape) if pooled.ndim == 3 else resize_bilinear(pooled, shape)
   return resize_bilinear(rgb2y(pooled), shape)
 
 

@@ -58,6 +58,22 @@ def test_resize_equals_pillow(in_shape, out_shape):
     assert (po.resize_bilinear(g, out_shape) == v).all()
 
 
+@pytest.mark.parametrize('in_shape,out_shape', [
+    ((210, 160), (84, 84)), ((100, 37), (84, 84)), ((250, 160), (42, 64))])
+def test_rgb_resize_equals_pillow(in_shape, out_shape):
+  """atari(grayscaling=False) (processors.py:429,495): the un-grayscaled RGB frame goes
+  through PIL as mode "RGB" -- every band resampled on its own."""
+  from PIL import Image
+  rs = np.random.RandomState(in_shape[1] * 3 + out_shape[0])
+  for _ in range(3):
+    a = rs.randint(0, 256, size=in_shape + (3,), dtype=np.uint8)
+    want = np.array(Image.fromarray(a).resize((out_shape[1], out_shape[0]),
+                                              Image.Resampling.BILINEAR), dtype=np.uint8)
+    assert want.shape == out_shape + (3,)
+    np.testing.assert_array_equal(po.resize_bilinear_rgb(a, out_shape), want)
+    np.testing.assert_array_equal(po.pooled_frame([a], out_shape, grayscaling=False), want)
+
+
 def test_rgb2y_is_plain_left_to_right_float64():
   """All 2^24 colours: the restatement equals the un-fused evaluation; the
   known-answer corners are exact."""

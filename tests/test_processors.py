@@ -145,8 +145,8 @@ def test_resample_tables_match_the_oracle_and_pillow_geometry():
 class OraclePixels:
   """Pixel path of the test double: the CPU oracle (tests may use it)."""
 
-  def __init__(self, pooled=2, stacked=4):
-    self._pooled, self._stacked = pooled, stacked
+  def __init__(self, pooled=2, stacked=4, grayscaling=True):
+    self._pooled, self._stacked, self._gray = pooled, stacked, grayscaling
     self._frames = collections.deque(maxlen=stacked)
 
   def reset(self):
@@ -155,7 +155,8 @@ class OraclePixels:
   def __call__(self, frames):
     shape = next(f for f in frames if f is not None).shape
     real = [f for f in list(frames)[-self._pooled:] if f is not None]
-    self._frames.append(po.pooled_frame(real + [np.zeros(shape, np.uint8)]))
+    self._frames.append(po.pooled_frame(real + [np.zeros(shape, np.uint8)],
+                                        grayscaling=self._gray))
     return po.stack_frames(list(self._frames), self._stacked)
 
 
@@ -199,21 +200,24 @@ def same_timestep(a, b):
 
 @pytest.mark.skipif(not rpl.reference_available(),
                     reason='needs /root/reference (dev container only)')
-@pytest.mark.parametrize('seed,repeats,pooled,life_loss,clip', [
-    (0, 4, 2, True, 1.0), (1, 4, 2, False, None), (2, 3, 1, True, 1.0), (3, 2, 2, True, 2.5)])
-def test_state_machine_equals_live_reference(seed, repeats, pooled, life_loss, clip):
+@pytest.mark.parametrize('seed,repeats,pooled,life_loss,clip,gray', [
+    (0, 4, 2, True, 1.0, True), (1, 4, 2, False, None, True), (2, 3, 1, True, 1.0, True),
+    (3, 2, 2, True, 2.5, True), (4, 4, 2, True, 1.0, False)])
+def test_state_machine_equals_live_reference(seed, repeats, pooled, life_loss, clip, gray):
+  """(gray=False: the reference's atari(grayscaling=False), whose RGB frames go through
+  PIL as mode "RGB" -- observations [84, 84, 3, 4].)"""
   ref = rpl.load_reference_processors()
   saved = ref.rgb2y
   ref.rgb2y = po.rgb2y   # un-fused float64 (this container's BLAS fuses: see the oracle)
   try:
     want_proc = ref.atari(additional_discount=0.99, max_abs_reward=clip,
                           num_action_repeats=repeats, num_pooled_frames=pooled,
-                          zero_discount_on_life_loss=life_loss)
+                          zero_discount_on_life_loss=life_loss, grayscaling=gray)
   finally:
     ref.rgb2y = saved
   got_proc = processors.AtariPreprocessor(
-      0.99, clip, (84, 84), repeats, pooled, life_loss, 4, True,
-      observation_pipeline=OraclePixels(pooled, 4))
+      0.99, clip, (84, 84), repeats, pooled, life_loss, 4, gray,
+      observation_pipeline=OraclePixels(pooled, 4, grayscaling=gray))
   stream = random_episodes(np.random.RandomState(seed), 120)
   want = drive(want_proc, stream)
   got = drive(got_proc, stream)

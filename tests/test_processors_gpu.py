@@ -83,6 +83,41 @@ def test_other_geometries(in_shape, out_shape, stack):
     assert (got[..., 0] == po.pooled_frame([a], out_shape)).all()
 
 
+@pytest.mark.parametrize('device_obs', [False, True])
+def test_grayscaling_false_keeps_rgb_bands(device_obs):
+  """atari(grayscaling=False) (processors.py:429,495): pooled RGB frame -> PIL mode
+  "RGB" resize (each band on its own) -> stack on a new last axis: observations
+  [84, 84, 3, 4], bit-exact against the oracle (itself checked against PIL) on episode
+  streams with FIRST / LAST / reset cycles; already-gray [H, W] frames still work."""
+  stream = tp.random_episodes(np.random.RandomState(7), 90)
+  dev = processors.atari(grayscaling=False, device_observations=device_obs)
+  ref = processors.AtariPreprocessor(
+      grayscaling=False, observation_pipeline=tp.OraclePixels(2, 4, grayscaling=False))
+  got, want = tp.drive(dev, stream), tp.drive(ref, stream)
+  n = 0
+  for g, w in zip(got, want):
+    if g is not None and device_obs:
+      g = g._replace(observation=g.observation.cpu().numpy())
+    assert tp.same_timestep(g, w)
+    if g is not None:
+      assert g.observation.shape == (84, 84, 3, 4) and g.observation.dtype == np.uint8
+      n += 1
+  assert n > 15
+  # one frame, by hand: bands differ, each equals the single-band resize of its band
+  rs = np.random.RandomState(3)
+  a = rs.randint(0, 256, (210, 160, 3), dtype=np.uint8)
+  pipe = processors.ObservationPipeline((84, 84), 1, 2, False)
+  out = pipe([a])
+  for c in range(3):
+    np.testing.assert_array_equal(out[:, :, c, 0], po.resize_bilinear(np.ascontiguousarray(a[:, :, c])))
+  assert (out[..., 1] == 0).all() and (out[:, :, 0, 0] != out[:, :, 1, 0]).any()
+  gpipe = processors.ObservationPipeline((84, 84), 1, 1, False)
+  g2 = rs.randint(0, 256, (210, 160), dtype=np.uint8)
+  np.testing.assert_array_equal(gpipe([g2])[..., 0], po.resize_bilinear(g2))
+  with pytest.raises(ValueError, match='frames must be uint8'):
+    processors.ObservationPipeline((84, 84), 1, 1, True)([g2])
+
+
 def test_rgb2y_all_colours_and_resize_processor():
   r, g, b = np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing='ij')
   arr = np.stack([r, g, b], -1).astype(np.uint8).reshape(4096, 4096, 3)
