@@ -679,13 +679,6 @@ def main():
   # (round 1 had these inside the timed window: at the driver's --steps 20 the
   # first-use costs of torch.distributed / ReplicaStats / the .cpu() reads were
   # 75 % of the measurement)
-  # one hipGraph per slot of the replay's sample ring: capture them all now so
-  # that no --warmup value can leave a capture inside the timed region
-  prime = replay.SAMPLE_RING_DEPTH
-  if args.prime_steps >= 0:
-    prime = args.prime_steps
-  for _ in range(prime):
-    step()
   # the statistics path once, end to end (allocations, first-use kernels, the
   # all-reduce's communicator set-up, the two device->host reads)
   dry = dz_dist.ReplicaStats(device)
@@ -693,6 +686,16 @@ def main():
   dry.all_reduce()
   stats = dz_dist.ReplicaStats(device)
   torch.cuda.synchronize()
+  # Untimed priming steps, directly in front of the warm-up (nothing idles the GPU in
+  # between): every ring slot / graph is touched, and the chip reaches its steady state
+  # -- the first ~30 steps after an idle period run ~4 % slower each (clock ramp-up; the
+  # per-step spans of a kernel trace fall from 172 to 163 us), which a 20-step window
+  # would otherwise measure instead of the step.  `sustained` reports the long-run rate.
+  prime = max(replay.SAMPLE_RING_DEPTH, 64)
+  if args.prime_steps >= 0:
+    prime = args.prime_steps
+  for _ in range(prime):
+    step()
 
   for _ in range(args.warmup):
     step()
