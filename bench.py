@@ -245,6 +245,7 @@ def dense_kernel_work(b, g, a=NUM_ACTIONS):
                             2 * b * (12800 + 5184) * 4)
   w['conv1_wgrad'] = (f(256, 32, b * 400), b * 28224 + b * 12800 * 4)
   w['rmsprop'] = (0.0, 7.0 * p_ref * 4)  # read g,p,mu,nu; write p,mu,nu
+  w['finalize+rmsprop'] = w['rmsprop']   # RMSProp rides in the finalize launch (+ the next sample in fused mode)
   return w
 
 
@@ -298,9 +299,10 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
   cap, b = args.capacity, args.batch
   T = replay_lib.Transition(None, None, None, None, None)
   out = {}
+  fused = args.mode == 'fused'   # sample(k+1) rides in step k's optimiser launch (eager)
 
   def run(name, replay, learner, step, work, desc):
-    learner.use_graphs = args.other_graphs
+    learner.use_graphs = args.other_graphs and not fused
     for _ in range(max(warmup, replay.SAMPLE_RING_DEPTH)):
       step()
     torch.cuda.synchronize()
@@ -316,7 +318,8 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
          'replay_samples_per_sec': round(steps / dt * b, 1), 'dtype': 'f32',
          'config': dict(desc, replay_capacity=cap, global_batch=b,
                         num_actions=NUM_ACTIONS,
-                        launch='eager' if not args.other_graphs else
+                        mode=args.mode,
+                        launch='eager' if (fused or not args.other_graphs) else
                                'hipGraph replay (learner) + 1 eager sample launch')}
     if prof_steps > 0:
       learner.use_graphs = False
@@ -333,9 +336,16 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
                                 eps=0.01 / 32 ** 2), b, seed=args.seed,
       device=device)
 
+  nxt = [None]
+
   def step_dqn():
-    t, _ = rep.sample_device(b)
-    ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, None)
+    if not fused:
+      t, _ = rep.sample_device(b)
+      ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, None)
+      return
+    t, _ = nxt[0] if nxt[0] is not None else rep.sample_device(b)
+    desc, nxt[0] = rep.prepare_next_sample(b)
+    ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, None, next_sample=desc)
 
   out['dqn_uniform_1m'] = run(
       'DQN + uniform replay', rep, ln, step_dqn, dense_kernel_work(b, 2),
@@ -359,11 +369,16 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
                                 eps=(0.01 / 32 ** 2) * (1.0 / 4) ** 2), b,
       seed=args.seed, device=device)
 
+  nxt2 = [None]
+
   def step_prio():
-    sm = rep.sample_device(b)
+    sm = nxt2[0] if (fused and nxt2[0] is not None) else rep.sample_device(b)
     t = sm.transitions
+    desc = None
+    if fused:
+      desc, nxt2[0] = rep.prepare_next_sample(b)
     ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, sm.weights32,
-            priority_sink=rep.priority_sink(sm.ids))
+            priority_sink=rep.priority_sink(sm.ids), next_sample=desc)
 
   out['double_q_prioritized_1m'] = run(
       'double-Q + prioritized replay', rep, ln, step_prio, dense_kernel_work(b, 3),

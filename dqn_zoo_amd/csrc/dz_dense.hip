@@ -244,6 +244,9 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
   }
 
   bool rms_in_finalize = false;
+  bool next_sample_done = false;
+  if (a->next_sample)
+    DZ_REQUIRE((phases & DZ_PHASE_BACKWARD) && (phases & DZ_PHASE_OPTIMIZER));
   bool norm_fused = false;  // this call's backward phase left the norm partials (Adam)
   int n_final = 0;   // fused-norm partials left by this call's backward phase (Adam)
   if (phases & DZ_PHASE_BACKWARD) {
@@ -382,9 +385,19 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
         if (!q_fused) { J.rms.lo4[1] = L.fc2_w >> 2; J.rms.n4[1] = ((int64_t)kHid * ld2) >> 2; }
         J.rms.flat_blocks = 1024;
       }
-      hipLaunchKernelGGL(finalize_grads_kernel,
-                         dim3(acc + J.c_tiles[0] + J.c_tiles[1] + J.o_tiles + J.rms.flat_blocks + presum),
-                         dim3(256), 0, s, J);
+      const unsigned fin_blocks = acc + J.c_tiles[0] + J.c_tiles[1] + J.o_tiles + J.rms.flat_blocks + presum;
+      if (a->next_sample && rms_in_finalize) {
+        // RMSProp lives in this launch: it also carries sample(k+1) + gather(k+1) (the
+        // write-back, if any, rode in conv3's backward launch above)
+        SampleGatherParams q;
+        unsigned sgb = 0;
+        rc = sample_gather_from_desc(a->next_sample, q, &sgb);
+        if (rc) return rc;
+        hipLaunchKernelGGL(finalize_grads_sg_kernel, dim3(sgb + fin_blocks), dim3(256), 0, s, J, q, sgb);
+        next_sample_done = true;
+      } else {
+        hipLaunchKernelGGL(finalize_grads_kernel, dim3(fin_blocks), dim3(256), 0, s, J);
+      }
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, rms_in_finalize ? "finalize+rmsprop" : "finalize_grads");
     }
@@ -405,10 +418,22 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
         DZ_PROF(s, "grad_sumsq");
         nparts = kNormBlocks;
       }
-      hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
-                         a->opt_m, a->opt_v, (long)(L.param_count >> 2),
-                         ws + L.ws_norm_part, nparts, a->opt_count, a->losses, wts, B,
-                         sc, a->lr, a->decay_or_b1, a->b2, a->eps, a->max_norm);
+      if (a->next_sample) {
+        SampleGatherParams q;
+        unsigned sgb = 0;
+        rc = sample_gather_from_desc(a->next_sample, q, &sgb);
+        if (rc) return rc;
+        hipLaunchKernelGGL(adam_sg_kernel, dim3(sgb + 1536), dim3(256), 0, s, a->online, a->grad,
+                           a->opt_m, a->opt_v, (long)(L.param_count >> 2),
+                           ws + L.ws_norm_part, nparts, a->opt_count, a->losses, wts, B,
+                           sc, a->lr, a->decay_or_b1, a->b2, a->eps, a->max_norm, DerivedGrad{}, q, sgb);
+        next_sample_done = true;
+      } else {
+        hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad,
+                           a->opt_m, a->opt_v, (long)(L.param_count >> 2),
+                           ws + L.ws_norm_part, nparts, a->opt_count, a->losses, wts, B,
+                           sc, a->lr, a->decay_or_b1, a->b2, a->eps, a->max_norm);
+      }
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "adam");
     } else if (!rms_in_finalize) {
@@ -419,6 +444,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       DZ_PROF(s, "rmsprop");
     }
   }
+  DZ_REQUIRE(!a->next_sample || next_sample_done);
   return DZ_OK;
 }
 

@@ -222,10 +222,22 @@ struct FinalizeJobs {
   int32_t* bump_count = nullptr;    // optax count_inc, done here when the optimiser follows
   RmsApply rms;                     // p == nullptr: off
 };
+__device__ __forceinline__ void finalize_grads_block(const FinalizeJobs& J, unsigned b);
 __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
+  finalize_grads_block(J, blockIdx.x);
+}
+// The same launch with the NEXT step's replay sample + gather as its first sg_blocks
+// blocks (dense learners whose optimiser lives in this launch: RMSProp; see
+// adam_sg_kernel for the Adam learners).
+__global__ __launch_bounds__(256) void finalize_grads_sg_kernel(FinalizeJobs J, SampleGatherParams sg,
+                                                                unsigned sg_blocks) {
+  if (blockIdx.x < sg_blocks) { SampleGatherSide::run(sg, blockIdx.x); return; }
+  finalize_grads_block(J, blockIdx.x - sg_blocks);
+}
+__device__ __forceinline__ void finalize_grads_block(const FinalizeJobs& J, unsigned b) {
   __shared__ float red[4][64];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  unsigned b = blockIdx.x;
+  const unsigned b_in = b;   // this block's index in the partial list
   if (b == 0 && threadIdx.x == 0 && J.bump_count) *J.bump_count = *J.bump_count + 1;
   float v = 0.f;
   if (b < J.r_end[2]) {
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
     }
     if (J.sumsq) {
       o = dz_wave_sum(o * o);
-      if (l == 0) J.sumsq[blockIdx.x] = o;
+      if (l == 0) J.sumsq[b_in] = o;
     }
     return;
   }
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
     }
     if (J.sumsq) {
       sq = dz_wave_sum(sq);
-      if (l == 0) J.sumsq[blockIdx.x] = sq;
+      if (l == 0) J.sumsq[b_in] = sq;
     }
     return;
   }
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
       if (J.rms.p) dz_rms_apply_at(J.rms, J.o_out + i, s);
       if (J.sumsq) {
         const float sq = dz_wave_sum(s * s);
-        if (l == 0) J.sumsq[blockIdx.x] = sq;
+        if (l == 0) J.sumsq[b_in] = sq;
       }
     }
     return;
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
     if (l == 0) red[0][w] = v;
     __syncthreads();
     if (threadIdx.x == 0)
-      J.sumsq[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      J.sumsq[b_in] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
   }
 }
 

@@ -448,26 +448,12 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     if (a->next_sample) {
       // sample(k+1) + gather(k+1) as the first blocks of this launch (write-back(k) was
       // carried by the conv3 backward launch above)
-      const dz_next_sample_t* ns = a->next_sample;
       DZ_REQUIRE((phases & DZ_PHASE_BACKWARD) && !prio_pending);
-      DZ_REQUIRE(ns->ids_out && ns->n > 0 && ns->n <= kMaxHostDraws && ns->pos_h &&
-                 ns->u_target_h && ns->u_mix_h && ns->fields && ns->num_fields > 0 &&
-                 ns->num_fields <= DZ_MAX_FIELDS);
-      DZ_REQUIRE(ns->args.node && dz_is_pow2(ns->args.cap_pow2) && ns->args.capacity > 0 &&
-                 ns->args.capacity <= ns->args.cap_pow2 && ns->args.size > 0 &&
-                 ns->args.size <= ns->args.capacity && ns->args.t >= ns->args.size);
-      SampleGatherParams q;
-      q.a = ns->args;
-      for (int i = 0; i < kMaxHostDraws; ++i) {
-        const int j = i < ns->n ? i : 0;
-        q.hd.pos[i] = ns->pos_h[j]; q.hd.u_target[i] = ns->u_target_h[j]; q.hd.u_mix[i] = ns->u_mix_h[j];
-      }
-      for (int i = 0; i < ns->num_fields; ++i)
-        DZ_REQUIRE(ns->fields[i].src && ns->fields[i].dst && ns->fields[i].row_bytes > 0);
       // (chunk caps 1..64 and 1024..2048 optimiser blocks all measure within +-1 %)
-      const unsigned sgb = sample_gather_plan(q, ns->fields, ns->num_fields, ns->n, 256);
-      q.ids_out = ns->ids_out; q.probs_out = ns->probs_out; q.weights_out = ns->weights_out;
-      q.weights32_out = ns->weights32_out; q.status = ns->status;
+      SampleGatherParams q;
+      unsigned sgb = 0;
+      rc = sample_gather_from_desc(a->next_sample, q, &sgb);
+      if (rc) return rc;
       hipLaunchKernelGGL(adam_sg_kernel, dim3(sgb + (unsigned)kAdamBlocksSG), dim3(256), 0, s,
                          a->online, a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
                          ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,

@@ -532,7 +532,16 @@ __device__ __forceinline__ void sample_gather_block(const SampleGatherParams& q,
   __shared__ double s_max;
   __shared__ int64_t s_slot;
   __shared__ int64_t s_ti[kMaxHostDraws];
+  // q.a.node == null: UNIFORM replay (replay.py:44-117, 141-175): element b is the id at
+  // position hd.pos[b] of the swap-remove list (closed form), no tree, no weights
+  const bool uniform = q.a.node == nullptr;
   if (blk == 0) {
+    if (uniform) {
+      if ((int)threadIdx.x < q.n && q.ids_out)
+        q.ids_out[threadIdx.x] = id_at_position(q.hd.pos[threadIdx.x & (kMaxHostDraws - 1)],
+                                                q.a.capacity, q.a.t);
+      return;
+    }
     prioritized_sample_body<1, 16>(q.a, q.hd, q.n, q.ids_out, nullptr, q.probs_out,
                                    q.weights_out, q.weights32_out, q.status, s_red, s_max, s_ti);
     return;
@@ -543,7 +552,11 @@ __device__ __forceinline__ void sample_gather_block(const SampleGatherParams& q,
   if ((int)blk >= q.first[DZ_MAX_FIELDS]) return;
   const int rel = (int)blk - q.first[fi], chunks = q.chunks[fi];
   const int b = rel / chunks, c = rel - b * chunks;
-  if (threadIdx.x < 16) {  // 16 lanes walk the element's descent, 4 levels per round trip
+  if (uniform) {
+    if (threadIdx.x == 0)
+      s_slot = dz_mod(id_at_position(q.hd.pos[b & (kMaxHostDraws - 1)], q.a.capacity, q.a.t),
+                      q.a.capacity);
+  } else if (threadIdx.x < 16) {  // 16 lanes walk the element's descent, 4 levels per round trip
     const double root = q.a.node[1];
     bool bad;
     const int64_t ti = sample_tree_index<1, 16>(q.a, q.hd, b, root, root == 0.0, bad, threadIdx.x);
@@ -565,6 +578,33 @@ __device__ __forceinline__ void sample_gather_block(const SampleGatherParams& q,
       dst[i] = src[i];
   }
 }
+// dz_next_sample_t (a learner step's `next_sample`) -> the 256-thread block list.
+// args.node == NULL selects the uniform replay (positions only).
+static inline int sample_gather_from_desc(const dz_next_sample_t* ns, SampleGatherParams& q,
+                                          unsigned* blocks) {
+  DZ_REQUIRE(ns && ns->ids_out && ns->n > 0 && ns->n <= kMaxHostDraws && ns->pos_h &&
+             ns->fields && ns->num_fields > 0 && ns->num_fields <= DZ_MAX_FIELDS);
+  const bool uniform = ns->args.node == nullptr;
+  DZ_REQUIRE(uniform || (ns->u_target_h && ns->u_mix_h && dz_is_pow2(ns->args.cap_pow2) &&
+                         ns->args.capacity <= ns->args.cap_pow2));
+  DZ_REQUIRE(ns->args.capacity > 0 && ns->args.size > 0 && ns->args.size <= ns->args.capacity &&
+             ns->args.t >= ns->args.size);
+  q.a = ns->args;
+  for (int i = 0; i < kMaxHostDraws; ++i) {
+    const int j = i < ns->n ? i : 0;
+    q.hd.pos[i] = ns->pos_h[j];
+    DZ_REQUIRE(q.hd.pos[i] >= 0 && q.hd.pos[i] < ns->args.size);
+    q.hd.u_target[i] = uniform ? 0.0 : ns->u_target_h[j];
+    q.hd.u_mix[i] = uniform ? 0.0 : ns->u_mix_h[j];
+  }
+  for (int i = 0; i < ns->num_fields; ++i)
+    DZ_REQUIRE(ns->fields[i].src && ns->fields[i].dst && ns->fields[i].row_bytes > 0);
+  *blocks = sample_gather_plan(q, ns->fields, ns->num_fields, ns->n, 256);
+  q.ids_out = ns->ids_out; q.probs_out = ns->probs_out; q.weights_out = ns->weights_out;
+  q.weights32_out = ns->weights32_out; q.status = ns->status;
+  return DZ_OK;
+}
+
 // The same blocks as extra blocks of a learner launch (256-thread workgroups).
 struct SampleGatherSide {
   typedef SampleGatherParams Params;

@@ -549,9 +549,11 @@ class DenseLearner:
     return self.ws[off:off + count]
 
   def step(self, s_tm1, a_tm1, r_t, discount_t, s_t, weights=None,
-           phases: int = _lib.PHASE_ALL, priority_sink=None) -> None:
+           phases: int = _lib.PHASE_ALL, priority_sink=None, next_sample=None) -> None:
     """`priority_sink`: see RainbowLearner.step (the |td| priorities go into the
-    replay's sum tree inside the backward launches)."""
+    replay's sum tree inside the backward launches).  `next_sample`: descriptor from
+    the replay's `prepare_next_sample` -- the optimiser launch carries the NEXT step's
+    sample + gather (full step, eager launches; RainbowLearner.step)."""
     b = self.batch_size
     check_batch(b, s_tm1, a_tm1, r_t, discount_t, s_t, weights)
     a = _lib.DenseArgs()
@@ -596,11 +598,17 @@ class DenseLearner:
         raise ValueError('priority_sink needs the backward phase in this call')
       (a.prio_node, a.prio_cap_pow2, a.prio_capacity, a.prio_ids, a.prio_exponent,
        a.prio_max_seen, a.prio_status) = priority_sink
+    if next_sample is not None:
+      if phases & (_lib.PHASE_BACKWARD | _lib.PHASE_OPTIMIZER) != (
+          _lib.PHASE_BACKWARD | _lib.PHASE_OPTIMIZER):
+        raise ValueError('next_sample needs the backward and optimiser phases in this call')
+      a.next_sample = ctypes.addressof(next_sample)
     stream = _lib.stream_ptr(self.device)
     enqueue = lambda: _lib.check(self._lib.dz_dense_learn(
         ctypes.byref(a), phases, stream), 'dz_dense_learn')
-    if not (bool(stream) if self.use_graphs is None else self.use_graphs):
-      enqueue()
+    if next_sample is not None or not (
+        bool(stream) if self.use_graphs is None else self.use_graphs):
+      enqueue()   # (next_sample: its draws are by-value kernel arguments -- no graph)
       return
     # every argument is a pointer or a constant of this object: the launches of
     # one call signature are captured once and replayed (as jax.jit does)

@@ -495,7 +495,7 @@ class TransitionReplay(_ReplayBase):
 
   SAMPLE_RING_DEPTH = 4
 
-  def sample_device(self, size: int):
+  def sample_device(self, size: int, prepare_only: bool = False):
     """Pipelined sample: (structure of device tensors, ids tensor).  For batches
     <= 64 this is ONE launch: the `randint` draws travel in the kernel arguments,
     the kernel maps positions to ids and gathers the rows (outputs live in a ring
@@ -524,10 +524,37 @@ class TransitionReplay(_ReplayBase):
     self._sample_ring_pos += 1
     pos = np.ascontiguousarray(self._random_state.randint(self._size, size=size),
                                dtype=np.int64)
+    if prepare_only:
+      return arr, outs, ids, pos
     _lib.check(_lib.load().dz_replay_sample_uniform(
         arr, len(self._ring.fields), pos.ctypes.data, size, self._t, self._size,
         self._capacity, ids.data_ptr(), self._stream()), 'dz_replay_sample_uniform')
     return outs, ids
+
+  def prepare_next_sample(self, size: int):
+    """The NEXT `sample_device(size)` as a descriptor for `DenseLearner.step(
+    next_sample=...)` (see PrioritizedTransitionReplay.prepare_next_sample): the
+    `randint` draws are made now, the ring slot reserved; returns
+    `(descriptor, (structure of device tensors, ids))`.  A uniform sample does not
+    depend on the learner step at all, only on the store: valid while nothing is added
+    in between."""
+    if size > 64:
+      raise ValueError('prepare_next_sample handles batches <= 64')
+    arr, outs, ids, pos = self.sample_device(size, prepare_only=True)
+    d = _lib.NextSample()
+    d.args.node = None              # uniform replay: no tree
+    d.args.capacity = self._capacity
+    d.args.size = self._size
+    d.args.t = self._t
+    d.pos_h = pos.ctypes.data
+    d.fields = ctypes.cast(arr, ctypes.c_void_p)
+    d.num_fields = len(self._ring.fields)
+    d.n = size
+    d.ids_out = ids.data_ptr()
+    d.status = self._status.word.data_ptr()
+    d._keep = (pos, arr)            # the descriptor points into these
+    self._prepared = (self._t, (outs, ids))
+    return d, (outs, ids)
 
   def sample(self, size: int) -> ReplayStructure:
     """Samples a batch uniformly with replacement (replay.py:157-163)."""

@@ -516,6 +516,11 @@ typedef struct {
   double prio_exponent;
   double* prio_max_seen;
   uint32_t* prio_status;
+  /* Optional, as dz_rainbow_args_t::next_sample (full step only): the NEXT step's replay
+   * sample + gather rides in this step's optimiser launch.  next_sample->args.node == NULL
+   * selects the UNIFORM replay (TransitionReplay: positions -> ids -> rows; no tree,
+   * `u_*_h`, `probs_out`, `weights*_out` unused).                                      */
+  const dz_next_sample_t* next_sample;
 } dz_dense_args_t;
 
 int dz_dense_learn(const dz_dense_args_t* args, int phases, dz_stream_t stream);
