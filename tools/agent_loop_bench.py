@@ -62,6 +62,8 @@ def main():
       transition_accumulator=replay_lib.NStepTransitionAccumulator(3), replay=rep,
       batch_size=32, min_replay_capacity_fraction=0.005, learn_period=4,
       target_network_update_period=2000, rng_key=1)
+  if len(sys.argv) > 3 and sys.argv[3] == 'eager-learn':
+    ag._learner.use_graphs = False   # learner launches eager, acting applies still from graphs  # pylint: disable=protected-access
   # instrument
   acc = {'act': 0.0, 'add': 0.0, 'learn': 0.0}
   def wrap(obj, name, key):
