@@ -24,7 +24,7 @@ src, dst = os.path.join(root, 'gpurun_out', tag), os.path.join(root, 'profiles')
 
 # bench mark name -> substring of the kernel's demangled name
 KERNELS = {
-    'adam': 'adam_kernel', 'adam+next_sample': 'adam_sg_kernel',
+    'adam': 'adam_', 'adam+next_sample': 'adam_',
     'fc1_fwd': 'dz_fc_stream_fwd3', 'fc1_dgrad+wgrad': 'dz_mfma_gemm2_occ<FcWgradOp',
     'conv1_fwd': 'ConvFwdOp<1, 84', 'conv2_fwd': 'dz_mfma_gemm<ConvFwdOp<0, 20, 20',
     'conv3_fwd': 'dz_mfma_gemm<ConvFwdOp<0, 9, 9', 'fc2_fwd': 'dz_mfma_gemm<FcFwdOp',
