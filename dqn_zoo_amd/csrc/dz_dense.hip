@@ -245,8 +245,12 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
 
   bool rms_in_finalize = false;
   bool next_sample_done = false;
-  if (a->next_sample)
+  if (a->next_sample) {
     DZ_REQUIRE((phases & DZ_PHASE_BACKWARD) && (phases & DZ_PHASE_OPTIMIZER));
+    // a prioritized sample must follow THIS step's write-back into the same tree
+    // (prioritized/agent.py:187-206)
+    DZ_REQUIRE(!a->next_sample->args.node || a->prio_node == a->next_sample->args.node);
+  }
   bool norm_fused = false;  // this call's backward phase left the norm partials (Adam)
   int n_final = 0;   // fused-norm partials left by this call's backward phase (Adam)
   if (phases & DZ_PHASE_BACKWARD) {

@@ -205,6 +205,12 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   DZ_REQUIRE(a && a->online && a->target && a->ws && a->noise && a->support);
   DZ_REQUIRE(a->s_tm1 && a->s_t && a->a_tm1 && a->r_t && a->discount_t && a->weights);
   DZ_REQUIRE(a->losses && a->priorities);
+  if (a->next_sample) {   // checked before anything is enqueued
+    DZ_REQUIRE((phases & DZ_PHASE_BACKWARD) && (phases & DZ_PHASE_OPTIMIZER));
+    // a prioritized sample must follow THIS step's write-back into the same tree
+    // (rainbow/agent.py:181-198: update_priorities, then the next sample)
+    DZ_REQUIRE(!a->next_sample->args.node || a->prio_node == a->next_sample->args.node);
+  }
   dz_rainbow_layout_t L;
   int rc = dz_rainbow_layout(a->num_actions, a->num_atoms, a->batch, &L);
   if (rc != DZ_OK) return rc;

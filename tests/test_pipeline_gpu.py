@@ -145,6 +145,24 @@ def test_dense_fused_next_sample_is_bit_identical_to_sequential(kind):
   assert np.isfinite(a[1]).all() and len({tuple(x[0]) for x in a[0]}) == 8
 
 
+def test_next_sample_needs_the_write_back_of_the_same_step():
+  """A prioritized next_sample without this step's priority_sink would sample BEFORE the
+  write-back the reference performs first (rainbow/agent.py:194-198): refused."""
+  import bench
+  args = types.SimpleNamespace(capacity=256, batch=32)
+  replay, learner, _ = bench.build_workload(args, torch.device('cuda', 0), seed=5)
+  learner.use_graphs = False
+  s = replay.sample_device(32)
+  t = s.transitions
+  desc, _ = replay.prepare_next_sample(32)
+  with pytest.raises(ValueError):
+    learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32, next_sample=desc)
+  with pytest.raises(ValueError):   # and it needs the whole step in one call
+    learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32, phases=2,
+                 priority_sink=replay.priority_sink(s.ids), next_sample=desc)
+  torch.cuda.synchronize()
+
+
 def test_pipelined_target_sync_matches_sequential():
   """sync_target() between two pipelined steps: the prefetched target apply used
   the OLD parameters and is redone in line -- same bits as the sequential loop."""
