@@ -559,6 +559,26 @@ static inline int dz_launch_gemm_side(const typename Op::Params& p, dim3 g,
   return DZ_OK;
 }
 
+// A contraction with `side_blocks` side-job workgroups FIRST in the grid (they are
+// dispatched before the contraction's and may use its LDS block as scratch).
+template <class Op, class Side>
+__global__ __launch_bounds__(256) void dz_mfma_gemm_side_first(typename Op::Params p, dim3 g,
+                                                               typename Side::Params sp,
+                                                               unsigned side_blocks) {
+  __shared__ __attribute__((aligned(16))) float smem[DzGemmSmem<Op>::ELEMS];
+  if (blockIdx.x < side_blocks) Side::run(sp, blockIdx.x, smem, (int)sizeof(smem));
+  else dz_gemm_body<Op>(p, dz_unflatten(blockIdx.x - side_blocks, g), smem);
+}
+template <class Op, class Side>
+static inline int dz_launch_gemm_side_first(const typename Op::Params& p, dim3 g,
+                                            const typename Side::Params& sp,
+                                            unsigned side_blocks, hipStream_t s) {
+  hipLaunchKernelGGL((dz_mfma_gemm_side_first<Op, Side>), dim3(dz_count(g) + side_blocks),
+                     dim3(256), 0, s, p, g, sp, side_blocks);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
+
 // Two contractions plus a side job (see dz_mfma_gemm_side).
 template <class OpA, class OpB, class Side>
 __global__ __launch_bounds__(256) void dz_mfma_gemm2_side(typename OpA::Params pa, dim3 ga,

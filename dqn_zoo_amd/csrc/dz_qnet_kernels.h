@@ -5,6 +5,7 @@
 #pragma once
 
 #include "dz_fc_stream.h"
+#include "dz_gram.h"
 #include "dz_sumtree_dev.h"
 
 namespace {
@@ -362,8 +363,16 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
     const double* __restrict__ d_t, const float* __restrict__ weights,
     const float* __restrict__ support, float* __restrict__ dout2,
     float* __restrict__ losses, float* __restrict__ priorities,
-    float* __restrict__ q_sel_out, float* __restrict__ target_out, HeadPre pre) {
+    float* __restrict__ q_sel_out, float* __restrict__ target_out, HeadPre pre,
+    GramX gram = GramX{}) {
   extern __shared__ float s_rows[];  // PRE: [3][ld]
+  // workgroups beyond the batch: the wide layer's input Grams (dz_gram.h), which need
+  // nothing this kernel computes and run on CUs it leaves idle
+  if ((int)blockIdx.x >= B) {
+    __shared__ dz_d4 s_gram[3 * 64];
+    dz_gram_x_block(gram, blockIdx.x - (unsigned)B, s_gram);
+    return;
+  }
   __shared__ float s_p[64];
   __shared__ float s_z[64];
   __shared__ float s_q[256];         // selector q-values (A <= 256)
@@ -606,6 +615,46 @@ __device__ __forceinline__ void adam_elem(float& P, float G, float& M, float& V,
 // scalars in all blocks) instead of waiting on a one-block "scalars" launch
 // (that launch cost ~5 us + a ~2 us gap for 2 KB of work); block 0 publishes
 // the scalars (global norm, bias corrections, clip flag, mean weighted loss).
+struct AdamScalars { float gn, bc1, bc2; bool pass; };
+__device__ __forceinline__ AdamScalars adam_scalars(const float* __restrict__ part, int nparts,
+                                                    const int32_t* __restrict__ count, float b1,
+                                                    float b2, float max_norm, float* red) {
+  // thread t sums part[t], part[t+256], ... in that order; 8 clamped loads are in
+  // flight per round (a plain loop serialises one L2 round trip per partial, and
+  // every block of this one-wave launch pays that chain before its first byte);
+  // out-of-range slots add +0 to a non-negative sum: no change
+  float s = 0.f;
+  for (int base = 0; base < nparts; base += 8 * 256) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = base + j * 256 + (int)threadIdx.x;
+      const float y = part[min(i, nparts - 1)];
+      x[j] = i < nparts ? y : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += x[j];
+  }
+  s = dz_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  AdamScalars o;
+  o.gn = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+  const int c = *count;  // already incremented (finalize / sumsq_kernel)
+  o.bc1 = 1.0f - powf(b1, (float)c); o.bc2 = 1.0f - powf(b2, (float)c);
+  o.pass = !(max_norm > 0.f && !(o.gn < max_norm));
+  return o;
+}
+__device__ __forceinline__ void adam_publish(const AdamScalars& o, float* __restrict__ sc,
+                                             const float* __restrict__ losses,
+                                             const float* __restrict__ weights, int B) {
+  sc[DZ_SC_GNORM] = o.gn; sc[DZ_SC_BC1] = o.bc1; sc[DZ_SC_BC2] = o.bc2;
+  sc[DZ_SC_CLIP] = o.pass ? 1.f : 0.f;
+  float l = 0.f;
+  for (int i = 0; i < B; ++i) l += losses[i] * weights[i];
+  sc[DZ_SC_LOSS] = l / (float)B;
+}
+
 // Optimiser block `bid` of `nblk` (the kernels below map their grids onto these).
 __device__ __forceinline__ void adam_body(
     unsigned bid, unsigned nblk,
@@ -636,36 +685,10 @@ __device__ __forceinline__ void adam_body(
   long ip = (long)bid * 256 + threadIdx.x;
   Elem cur;
   load(min(ip, n4 - 1), cur);  // clamped, unconditional (no exec-mask block)
-  // thread t sums part[t], part[t+256], ... in that order; 8 clamped loads are in
-  // flight per round (a plain loop serialises one L2 round trip per partial, and
-  // every block of this one-wave launch pays that chain before its first byte);
-  // out-of-range slots add +0 to a non-negative sum: no change
-  float s = 0.f;
-  for (int base = 0; base < nparts; base += 8 * 256) {
-    float x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int i = base + j * 256 + (int)threadIdx.x;
-      const float y = part[min(i, nparts - 1)];
-      x[j] = i < nparts ? y : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += x[j];
-  }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  const float gn = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-  const int c = *count;  // already incremented (sumsq_kernel)
-  const float bc1 = 1.0f - powf(b1, (float)c), bc2 = 1.0f - powf(b2, (float)c);
-  const bool pass = !(max_norm > 0.f && !(gn < max_norm));
-  if (bid == 0 && threadIdx.x == 0) {
-    sc[DZ_SC_GNORM] = gn; sc[DZ_SC_BC1] = bc1; sc[DZ_SC_BC2] = bc2;
-    sc[DZ_SC_CLIP] = pass ? 1.f : 0.f;
-    float l = 0.f;
-    for (int i = 0; i < B; ++i) l += losses[i] * weights[i];
-    sc[DZ_SC_LOSS] = l / (float)B;
-  }
+  const AdamScalars sc0 = adam_scalars(part, nparts, count, b1, b2, max_norm, red);
+  const float gn = sc0.gn, bc1 = sc0.bc1, bc2 = sc0.bc2;
+  const bool pass = sc0.pass;
+  if (bid == 0 && threadIdx.x == 0) adam_publish(sc0, sc, losses, weights, B);
   while (ip < n4) {
     const long inext = ip + stride;
     Elem nxt;

@@ -15,6 +15,7 @@
 // Roofline notes per kernel are in DESIGN.md.
 #include "dz_sumtree_dev.h"
 #include "dz_torso.h"
+#include "dz_fc1_onfly.h"
 
 namespace {
 
@@ -36,7 +37,7 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
                            const float* const* prm, const float* const* nz,
                            const uint8_t* const* in, float* ws, hipStream_t s,
                            const NoiseParams* resample = nullptr,
-                           bool skip_fc2_epilogue = false, bool stop_after_fc1 = false,
+                             bool skip_fc2_epilogue = false, bool stop_after_fc1 = false,
                            int32_t* bump = nullptr) {
   int rc = DZ_OK;
   const int NA = L.num_actions * L.num_atoms;
@@ -241,6 +242,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   NoiseParams nq = {const_cast<float*>(a->noise), Gf * (long)L.noise_stride, a->noise_seed,
                     (uint64_t)0x5eed, a->adam_count, 3 * (long)L.noise_stride, 0};
   if (do_nets && a->resample_noise) DZ_REQUIRE(a->adam_count);
+  // fc1's weight gradient formed inside the optimiser (dz_fc1_onfly.h): when this ONE call
+  // runs the loss, the backward pass and the optimiser, and nobody asked to keep the
+  // gradient vector complete
+  const bool onfly = do_loss && (phases & DZ_PHASE_BACKWARD) && (phases & DZ_PHASE_OPTIMIZER) &&
+                     !a->keep_all_grads && B <= 32;
+  // (Gram partials of the layer input: the head of the conv weight-gradient slab buffer,
+  // idle between the previous step's finalize and this step's conv backward launches)
+  double* gram_part = (double*)(ws + ((L.ws_wgrad_part + 7) & ~(int64_t)7));
   if (do_nets) {
     const uint8_t* in[kG] = {a->s_tm1, a->s_t, a->s_t};
     rc = rainbow_forward(L, H, Gf, B, prm, nz, in, ws, s,
@@ -249,22 +258,29 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   }
   if (do_loss) {
     {
+      GramX gx;
+      if (onfly) {
+        gx.x = ws + L.ws_feat; gx.M = B; gx.K = kFlat;
+        gx.eps_in[0] = nz[0] + L.n_adv1_in; gx.eps_in[1] = nz[0] + L.n_val1_in;
+        gx.part = gram_part;
+      }
+      const unsigned hb = (unsigned)B + (onfly ? (unsigned)kGramXBlocks : 0u);
       HeadPre pre = {};
       if (fuse) {
         pre.part = ws + L.ws_fc2_part; pre.S = kFc2Splits; pre.rows = Gf * B;
         for (int g = 0; g < kG; ++g) { pre.prm[g] = prm[g]; pre.nz[g] = nz[g]; }
         pre.b_sig = L.fc2_sig_b; pre.eps_out = (int)L.n_fc2_out;
         if (tgt_pre) { pre.part2 = a->tgt_part; pre.rows2 = B; }
-        hipLaunchKernelGGL(rainbow_head_loss_kernel<1>, dim3(B), dim3(256),
+        hipLaunchKernelGGL(rainbow_head_loss_kernel<1>, dim3(hb), dim3(256),
                            (size_t)3 * ld2 * sizeof(float), s, ws + L.ws_fc2_out, ld2, NAp, B,
                            A, K, 1, 1, 2, a->a_tm1, a->r_t, a->discount_t, a->weights,
                            a->support, ws + L.ws_dout2, a->losses, a->priorities,
-                           ws + L.ws_q_sel, ws + L.ws_target_probs, pre);
+                           ws + L.ws_q_sel, ws + L.ws_target_probs, pre, gx);
       } else {
-        hipLaunchKernelGGL(rainbow_head_loss_kernel<0>, dim3(B), dim3(256), 0, s,
+        hipLaunchKernelGGL(rainbow_head_loss_kernel<0>, dim3(hb), dim3(256), 0, s,
                            ws + L.ws_fc2_out, ld2, NAp, B, A, K, 1, 1, 2, a->a_tm1, a->r_t,
                            a->discount_t, a->weights, a->support, ws + L.ws_dout2, a->losses,
-                           a->priorities, ws + L.ws_q_sel, ws + L.ws_target_probs, pre);
+                           a->priorities, ws + L.ws_q_sel, ws + L.ws_target_probs, pre, gx);
       }
     }
     DZ_LAUNCH_CHECK();
@@ -275,7 +291,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   // fc1 sigma-weight gradient: derived inside Adam instead of stored and re-read,
   // when this one call both produces and consumes it
   const bool derive_sig = (phases & DZ_PHASE_BACKWARD) && (phases & DZ_PHASE_OPTIMIZER) &&
-                          !a->keep_all_grads;
+                          !a->keep_all_grads && !onfly;
   auto fc1_wgrad_params = [&](FcWgradParams& w) {
     w.x = ws + L.ws_feat; w.ldx = kFlat; w.dy = nullptr; w.ldy = 1024; w.M = B;
     w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc1h[0]; w.head[1] = fc1h[1];
@@ -355,9 +371,21 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       // ONE launch for the 25.7 MB weight read and the 12.9 MB gradient write, the
       // weight-gradient blocks first (15 us vs 14 + 14 back to back)
       // (compiled for 5 waves per SIMD: 1323 workgroups then find 1280 co-resident slots instead of 1024)
-      rc = dz_launch_gemm2_occ<FcWgradOp<2, 2, 1, 2, kS_dh1>, FcDgradOp<1, 2, 2, 1, 1, 1, 2, kS_dh1>, 5>(
-          w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), d,
-          dim3(kFlat / 64, (B + 31) / 32, kFc1DgradSplits), s);
+      if (onfly) {
+        // no weight-gradient workgroups; eight side blocks materialise dh1 and leave the
+        // layer's squared gradient norm in the fc1 slots (GramDSide)
+        GramD gd;
+        gd.dyp = w.dyp; gd.M = B; gd.eps_out = nz[0] + L.n_fc1_out; gd.gx_part = gram_part;
+        gd.dot_out = sq_slots + fc2_slots;
+        static_assert(DzGemmSmem<FcDgradOp<1, 2, 2, 1, 1, 1, 2, kS_dh1>>::ELEMS >= 32 * GramDSide::kLd,
+                      "GramDSide's tile lives in the contraction's LDS block");
+        rc = dz_launch_gemm_side_first<FcDgradOp<1, 2, 2, 1, 1, 1, 2, kS_dh1>, GramDSide>(
+            d, dim3(kFlat / 64, (B + 31) / 32, kFc1DgradSplits), gd, GramDSide::kBlocks, s);
+      } else {
+        rc = dz_launch_gemm2_occ<FcWgradOp<2, 2, 1, 2, kS_dh1>, FcDgradOp<1, 2, 2, 1, 1, 1, 2, kS_dh1>, 5>(
+            w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), d,
+            dim3(kFlat / 64, (B + 31) / 32, kFc1DgradSplits), s);
+      }
       if (rc) return rc;
       DZ_PROF(s, "fc1_dgrad+wgrad");
       hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0,
@@ -375,7 +403,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       const dim3 gw(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), gd(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1);
       // (with the next step's sample riding in the optimiser launch the write-back must
       // be complete BEFORE that launch: it stays here)
-      const bool prio_in_adam = (phases & DZ_PHASE_OPTIMIZER) != 0 && !a->next_sample;
+      const bool prio_in_adam = (phases & DZ_PHASE_OPTIMIZER) != 0 && !a->next_sample && !onfly;
       if (prio_pending && !prio_in_adam) {
         // The sum-tree priority write-back rides in this launch as one extra block:
         // it needs only the loss kernel's priorities and nothing here reads the tree.
@@ -421,10 +449,12 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       J.c[1] = {ws + L.ws_dout2, B, ld2, ld2, nullptr, nz[0] + L.n_fc2_out,
                 grad + L.fc2_sig_b};
       J.c_tiles[0] = 16; J.c_tiles[1] = (unsigned)((ld2 + 63) / 64);
-      const unsigned presum = (unsigned)((fc2_slots + fc1_slots + 1023) / 1024);
+      const unsigned presum =
+          (unsigned)((fc2_slots + (onfly ? GramDSide::kBlocks : fc1_slots) + 1023) / 1024);
       n_final = (int)(acc + J.c_tiles[0] + J.c_tiles[1] + presum);
       DZ_REQUIRE(n_final <= kNormFinal);
-      J.sumsq = sq_final; J.presum_src = sq_slots; J.presum_n = fc2_slots + fc1_slots;
+      J.sumsq = sq_final; J.presum_src = sq_slots;
+      J.presum_n = fc2_slots + (onfly ? GramDSide::kBlocks : fc1_slots);
       J.bump_count = (phases & DZ_PHASE_OPTIMIZER) ? a->adam_count : nullptr;
       hipLaunchKernelGGL(finalize_grads_kernel, dim3((unsigned)n_final), dim3(256), 0, s, J);
       DZ_LAUNCH_CHECK();
@@ -451,15 +481,38 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       dg.eps_out = nz[0] + L.n_fc1_out;
       dg.on = 1;
     }
+    // sample(k+1) + gather(k+1) as the first blocks of this launch (write-back(k) was
+    // carried by the conv3 backward launch above)
+    SampleGatherParams q = {};
+    unsigned sgb = 0;
     if (a->next_sample) {
-      // sample(k+1) + gather(k+1) as the first blocks of this launch (write-back(k) was
-      // carried by the conv3 backward launch above)
       DZ_REQUIRE((phases & DZ_PHASE_BACKWARD) && !prio_pending);
       // (chunk caps 1..64 and 1024..2048 optimiser blocks all measure within +-1 %)
-      SampleGatherParams q;
-      unsigned sgb = 0;
       rc = sample_gather_from_desc(a->next_sample, q, &sgb);
       if (rc) return rc;
+    }
+    if (onfly) {
+      Fc1OnFly of;
+      of.feat = ws + L.ws_feat; of.dh1 = ws + L.ws_dh1; of.B = B;
+      of.mu_b = (unsigned)(L.fc1_mu_w * 4); of.sig_b = (unsigned)(L.fc1_sig_w * 4);
+      of.ld = L.fc1_ld;
+      of.eps_in0 = nz[0] + L.n_adv1_in; of.eps_in1 = nz[0] + L.n_val1_in;
+      of.eps_out = nz[0] + L.n_fc1_out;
+      // the stored gradient covers everything but the two fc1 matrices
+      const long mat = (long)kFlat * L.fc1_ld;
+      DZ_REQUIRE(L.fc1_mu_w < L.fc1_sig_w && (L.fc1_sig_w + mat) * 4 < ((int64_t)1 << 32));
+      AdamRanges rg;
+      rg.lo[0] = 0; rg.n[0] = L.fc1_mu_w >> 2;
+      rg.lo[1] = (L.fc1_mu_w + mat) >> 2; rg.n[1] = (L.fc1_sig_w - (L.fc1_mu_w + mat)) >> 2;
+      rg.lo[2] = (L.fc1_sig_w + mat) >> 2; rg.n[2] = (L.param_count - (L.fc1_sig_w + mat)) >> 2;
+      DZ_REQUIRE(!prio_pending);   // (carried by the conv3 backward launch)
+      hipLaunchKernelGGL(adam_onfly_kernel, dim3(adam_onfly_blocks(sgb)), dim3(256), 0, s,
+                         a->online, a->grad, a->adam_m, a->adam_v, ws + L.ws_norm_part, nparts,
+                         a->adam_count, a->losses, a->weights, B, sc, a->lr, a->b1, a->b2, a->eps,
+                         a->max_norm, of, rg, q, sgb);
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, a->next_sample ? "adam+next_sample" : "adam");
+    } else if (a->next_sample) {
       hipLaunchKernelGGL(adam_sg_kernel, dim3(sgb + (unsigned)kAdamBlocksSG), dim3(256), 0, s,
                          a->online, a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
                          ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,

@@ -193,10 +193,11 @@ def test_full_step_vs_oracle_update():
 
 @pytest.mark.parametrize('max_norm', [10.0, 1e-3])
 def test_derived_sigma_gradient_is_bit_identical(max_norm):
-  """Default full step (the fc1 sigma-weight gradient is never stored: the
-  optimiser derives it from the mu-weight gradient and the noise) == step with
-  every gradient block materialised: parameters and both Adam moments bit for
-  bit."""
+  """A step split into two calls (forward | backward + optimiser) stores fc1's mu-weight
+  gradient and never its sigma-weight gradient: the optimiser derives it from the mu
+  gradient and the noise.  == the same split step with every gradient block
+  materialised: parameters and both Adam moments bit for bit."""
+  from dqn_zoo_amd import _lib
   A, B = 6, 32
   online, target, batch, w, noises = _problem(A, B, 13)
   dev = _dev_batch(batch, w)
@@ -205,7 +206,8 @@ def test_derived_sigma_gradient_is_bit_identical(max_norm):
     ln = _learner(A, B, online, target, noises, max_norm=max_norm)
     ln.keep_all_grads = keep
     for _ in range(3):
-      ln.step(*dev, resample_noise=False)
+      ln.step(*dev, resample_noise=False, phases=_lib.PHASE_FORWARD)
+      ln.step(*dev, resample_noise=False, phases=_lib.PHASE_BACKWARD | _lib.PHASE_OPTIMIZER)
     torch.cuda.synchronize()
     lns.append(ln)
   a, b = lns
@@ -217,6 +219,46 @@ def test_derived_sigma_gradient_is_bit_identical(max_norm):
   for k in ('conv1/w', 'conv3/b', 'adv1/mu/b', 'val1/sigma/b', 'adv2/mu/w', 'val2/sigma/w'):
     np.testing.assert_array_equal(ga[k], gb[k])
   assert np.abs(gb['adv1/mu/w']).max() > 0 and np.abs(gb['adv1/sigma/w']).max() > 0
+
+
+@pytest.mark.parametrize('max_norm,B', [(10.0, 32), (1e-3, 32), (0.05, 7)])
+def test_fc1_gradient_formed_in_the_optimiser_matches_the_stored_gradient(max_norm, B):
+  """The one-call step never stores fc1's weight gradient (dz_fc1_onfly.h: every
+  element is formed from the L2-resident factors inside the optimiser, the layer's share
+  of the global norm comes from two Gram matrices on the f64 matrix pipe).  Against the
+  step with every gradient block materialised: the same global norm to float32 rounding
+  -- also under a binding clip, where the norm scales every update -- and the same
+  parameters and moments up to the rounding order of the 32-term sums (one-call: batch
+  index ascending in one FMA chain; stored: MFMA partial sums)."""
+  A = 6
+  online, target, batch, w, noises = _problem(A, B, 13)
+  dev = _dev_batch(batch, w)
+  lns, norms = [], []
+  for keep in (False, True):
+    ln = _learner(A, B, online, target, noises, max_norm=max_norm)
+    ln.keep_all_grads = keep
+    gn = []
+    for _ in range(4):
+      ln.step(*dev, resample_noise=False)
+      gn.append(ln.scalars()['gnorm'])
+    torch.cuda.synchronize()
+    lns.append(ln)
+    norms.append(gn)
+  a, b = lns
+  np.testing.assert_allclose(norms[0], norms[1], rtol=2e-6)
+  assert a.scalars()['unclipped'] == b.scalars()['unclipped']
+  lr = a.opt.learning_rate
+  for x, y, tol in ((a.online, b.online, 2e-3 * lr), (a.adam_m, b.adam_m, None),
+                    (a.adam_v, b.adam_v, None)):
+    x, y = x.cpu().numpy(), y.cpu().numpy()
+    if tol is None:
+      np.testing.assert_allclose(x, y, rtol=2e-4, atol=1e-7 * np.abs(y).max())
+    else:
+      assert np.abs(x - y).max() <= tol, np.abs(x - y).max() / lr
+  # the fc1 matrices did move
+  pa = a.get_params('online')
+  assert np.abs(pa['adv1/mu/w'] - online['adv1/mu/w']).max() > 0
+  assert np.abs(pa['val1/sigma/w'] - online['val1/sigma/w']).max() > 0
 
 
 def test_device_noise_distribution():

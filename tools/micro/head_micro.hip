@@ -46,6 +46,20 @@ int main() {
   auto nopre = [&]() { hipLaunchKernelGGL(rainbow_head_loss_kernel<0>, dim3(B), dim3(256), 0, 0,
       out, ld, NAp, B, A, K, 1, 1, 2, a, r, d, w, support, dout, losses, prio, qsel, tprob, pre); };
   auto empty = [&]() { hipLaunchKernelGGL(empty32, dim3(B), dim3(256), 0, 0); };
+  // the wide layer's input Grams as extra workgroups of the same launch (dz_gram.h)
+  float *feat, *ein; double* gpart;
+  CK(hipMalloc(&feat, 32 * 3136 * 4)); CK(hipMalloc(&ein, 2 * 3136 * 4));
+  CK(hipMalloc(&gpart, (size_t)3 * 7 * 4 * 64 * 4 * 8));
+  std::vector<float> hf(32 * 3136); for (auto& v : hf) v = ((rand() % 2001) - 1000) / 1000.f;
+  CK(hipMemcpy(feat, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(ein, hf.data(), 2 * 3136 * 4, hipMemcpyHostToDevice));
+  GramX gx; gx.x = feat; gx.M = 32; gx.K = 3136; gx.eps_in[0] = ein; gx.eps_in[1] = ein + 3136; gx.part = gpart;
+  auto with_gram = [&]() { hipLaunchKernelGGL(rainbow_head_loss_kernel<1>, dim3(B + kGramXBlocks), dim3(256), (size_t)3 * ld * 4, 0,
+      out, ld, NAp, B, A, K, 1, 1, 2, a, r, d, w, support, dout, losses, prio, qsel, tprob, pre, gx); };
+  auto gram_only = [&]() { hipLaunchKernelGGL(rainbow_head_loss_kernel<1>, dim3(kGramXBlocks), dim3(256), (size_t)3 * ld * 4, 0,
+      out, ld, NAp, 0, A, K, 1, 1, 2, a, r, d, w, support, dout, losses, prio, qsel, tprob, pre, gx); };
+  printf("head_loss<1> + 84 Gram WGs %.2f us\n", time_us(with_gram));
+  printf("84 Gram WGs alone          %.2f us\n", time_us(gram_only));
   printf("empty 32-WG launch         %.2f us\n", time_us(empty));
   printf("head_loss<1> (fold slabs)  %.2f us\n", time_us(full));
   printf("head_loss<0> (no fold)     %.2f us\n", time_us(nopre));
