@@ -6,8 +6,8 @@
 // L2-resident factors at the moment the optimiser needs it.  Three pieces:
 //   * dz_gram_x_block (dz_gram.h): Grams of the layer input, side job of the loss
 //     kernel's launch;
-//   * GramDSide (here): side job (16 blocks) of the input-gradient launch -- materialises
-//     dh1 = relu'(h1) * sum of the fc2 input-gradient slabs, forms its Grams and the
+//   * GramDSide (here): side job (16 blocks) of the input-gradient launch -- forms the
+//     Grams of dh1 (left finished by fc2's backward launch: FcDgradParams::fold_*) and the
 //     layer's contribution to the global gradient norm  <X X^T, D D^T>  (both
 //     parameter matrices, per head), one non-negative float per block into the
 //     fused-norm slots;
@@ -90,6 +90,9 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
   const float gn = dz_sgpr(sc0.gn), bc1 = dz_sgpr(sc0.bc1), bc2 = dz_sgpr(sc0.bc2);
   const bool pass = __builtin_amdgcn_readfirstlane((int)sc0.pass) != 0;
   const unsigned rstep = (unsigned)(T::RP * q.ld) * 4u;
+  // (One pass over the batch for all seven rows -- 28 accumulators, the dh1 strip read
+  // once instead of seven times, LDS reads -69 % -- measured 35.1 us against 33.3: the
+  // rows' streams then start only after the whole product.)
   // (The optimiser arithmetic is not free here -- wave64 on a 16-lane SIMD, ~11
   // instructions per IEEE division, two waves per SIMD: an approximate-arithmetic build
   // measured 30.3 us against 33.3 -- but skipping the divisions that are exact no-ops,
@@ -138,7 +141,7 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
 }
 
 struct GramD {
-  DyParts dyp;             // fc2's input-gradient slabs + the ReLU mask; out = dh1 [M][1024]
+  const float* dh1 = nullptr;   // [M][1024], finished (folded + masked by fc2's backward launch)
   int M = 0;
   const float* eps_out = nullptr;   // [1024]
   const double* gx_part = nullptr;  // GramX::part
@@ -151,16 +154,13 @@ struct GramDSide {
     const int h = (int)blk / (kBlocks / 2), n0 = (int)blk * kCols;   // head, first column of [0, 1024)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
     const dz_d4* gp = (const dz_d4*)q.gx_part;
-    // dh1 tile [32][kCols]: folded from the slabs, kept in LDS, written out for the
-    // optimiser and the bias column sums
+    // dh1 tile [32][kCols] into LDS
 #pragma unroll
     for (int r = 0; r < kCols / 32; ++r) {
       const int e = tid + 256 * r, b = e / (kCols / 4), cc = e % (kCols / 4);
-      const long o = (long)min(b, q.M - 1) * 1024 + n0 + 4 * cc;
-      float4 v = dz_dy_parts4<kS_dh1>(q.dyp, o);
+      float4 v = *(const float4*)(q.dh1 + (unsigned)(min(b, q.M - 1) * 1024 + n0 + 4 * cc));
       if (b >= q.M) v = dz_f4zero();
       *(float4*)(smem + b * kLd + 4 * cc) = v;
-      if (b < q.M) *(float4*)(q.dyp.out + o) = v;
     }
     __syncthreads();
     const float* ta = smem + ((wave >> 1) * 16 + i) * kLd + 4 * kq;

@@ -16,6 +16,7 @@
 #include "dz_sumtree_dev.h"
 #include "dz_torso.h"
 #include "dz_fc1_onfly.h"
+#include "dz_row_dgrad.h"
 
 namespace {
 
@@ -24,6 +25,27 @@ namespace {
 constexpr int kFc1Splits = 32;       // fc1 forward k-splits (98 rows each)
 constexpr int kFc1DgradSplits = 12;  // fc1 input-gradient k-splits: 11 slabs of 6 single-chunk stages (17.9 us; 16 x 4: 19.2; 10 x 7: 19.6)
 constexpr int kFc2Splits = 8;        // fc2 forward k-splits
+// The two noisy linear layers' input gradients as row-owning weight streams
+// (dz_row_dgrad.h), used by the one-call step (dz_fc1_onfly.h):
+//   fc1: 448 workgroups x 7 rows behind the sixteen Gram side blocks;
+//   fc2: 128 workgroups x 4 rows in front of the fc2 weight-gradient contraction; dh1
+//        leaves that launch finished (summed over n, ReLU-masked) -- no slabs to fold.
+constexpr int kDgBlocks = 448, kDg2Blocks = 128;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fc1_dgrad_rows_kernel(RowDgrad q, GramD gd) {
+  __shared__ __attribute__((aligned(16))) float lds[kRdLdsFloats];
+  static_assert(kRdLdsFloats >= 32 * GramDSide::kLd, "GramDSide's tile");
+  if (blockIdx.x < (unsigned)GramDSide::kBlocks) { GramDSide::run(gd, blockIdx.x, lds, (int)sizeof(lds)); return; }
+  row_dgrad_block<2, 2, true, 4>(q, blockIdx.x - GramDSide::kBlocks, lds);
+}
+template <int NJ0>   // 256-column chunks of the advantage head
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fc2_bwd_rows_kernel(FcWgradParams w, dim3 gw, RowDgrad q) {
+  constexpr int SM = DzGemmSmem<FcWg>::ELEMS > kRdLdsFloats ? DzGemmSmem<FcWg>::ELEMS : kRdLdsFloats;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  if (blockIdx.x < (unsigned)q.nblocks) row_dgrad_block<NJ0, 1, false, 4>(q, blockIdx.x, smem);
+  else dz_gemm_body<FcWg>(w, dz_unflatten(blockIdx.x - q.nblocks, gw), smem);
+}
 constexpr int kAdamBlocks = 2048;    // grid-stride Adam launch width (8 blocks per CU)
 constexpr int kAdamBlocksSG = 1536;  // with ~550 sample+gather blocks in front: 6 per CU, so that the whole launch is co-resident
 
@@ -351,6 +373,27 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       }
       const dim3 gd(kHid / FcDg::BN, (B + 31) / 32, s_dh1);
       typedef FcDgradOp<1, 2, 2, 4, 1, 1, 1> FcDg1;  // noisy == 1 at compile time
+      if (onfly) {
+        // the input gradient as a row-owning stream over both heads' [512][N] matrices:
+        // dh1 = relu'(h1) * (dout2_adv . Wadv^T | dout2_val . Wval^T), finished
+        RowDgrad q = {};
+        q.params = a->online; q.noise = nz[0]; q.head[0] = fc2h[0]; q.head[1] = fc2h[1];
+        q.dy = ws + L.ws_dout2; q.ldy = ld2; q.mask = ws + L.ws_h1; q.out = ws + L.ws_dh1;
+        q.ldo = 1024; q.out_col[0] = 0; q.out_col[1] = 512; q.same_out = 0;
+        q.M = B; q.K = kHid; q.nblocks = kDg2Blocks;
+        const int nj0 = (NA + 255) / 256;
+        DZ_REQUIRE(nj0 >= 1 && nj0 <= 4 && K <= 256 && row_dgrad_max_rows(q) * (nj0 + 1) <= 32);
+        const dim3 gw((NA + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 2);
+        const dim3 grid(kDg2Blocks + dz_count(gw));
+        switch (nj0) {
+          case 1: hipLaunchKernelGGL(fc2_bwd_rows_kernel<1>, grid, dim3(256), 0, s, w, gw, q); break;
+          case 2: hipLaunchKernelGGL(fc2_bwd_rows_kernel<2>, grid, dim3(256), 0, s, w, gw, q); break;
+          case 3: hipLaunchKernelGGL(fc2_bwd_rows_kernel<3>, grid, dim3(256), 0, s, w, gw, q); break;
+          default: hipLaunchKernelGGL(fc2_bwd_rows_kernel<4>, grid, dim3(256), 0, s, w, gw, q); break;
+        }
+        DZ_LAUNCH_CHECK();
+        rc = DZ_OK;
+      } else
       rc = dz_launch_gemm3<FcWg, FcDg1, FcDg1>(
           w, dim3((NA + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 2), d[0], gd, d[1], gd, s);
       if (rc) return rc;
@@ -372,15 +415,22 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       // weight-gradient blocks first (15 us vs 14 + 14 back to back)
       // (compiled for 5 waves per SIMD: 1323 workgroups then find 1280 co-resident slots instead of 1024)
       if (onfly) {
-        // no weight-gradient workgroups; eight side blocks materialise dh1 and leave the
-        // layer's squared gradient norm in the fc1 slots (GramDSide)
-        GramD gd;
-        gd.dyp = w.dyp; gd.M = B; gd.eps_out = nz[0] + L.n_fc1_out; gd.gx_part = gram_part;
-        gd.dot_out = sq_slots + fc2_slots;
-        static_assert(DzGemmSmem<FcDgradOp<1, 2, 2, 1, 1, 1, 2, kS_dh1>>::ELEMS >= 32 * GramDSide::kLd,
-                      "GramDSide's tile lives in the contraction's LDS block");
-        rc = dz_launch_gemm_side_first<FcDgradOp<1, 2, 2, 1, 1, 1, 2, kS_dh1>, GramDSide>(
-            d, dim3(kFlat / 64, (B + 31) / 32, kFc1DgradSplits), gd, GramDSide::kBlocks, s);
+        // no weight-gradient workgroups: sixteen side blocks leave the layer's squared
+        // gradient norm in the fc1 slots (GramDSide), the input gradient is one row-owning
+        // weight stream (no slabs, no reduce launch)
+        GramD gdp;
+        gdp.dh1 = ws + L.ws_dh1; gdp.M = B; gdp.eps_out = nz[0] + L.n_fc1_out;
+        gdp.gx_part = gram_part; gdp.dot_out = sq_slots + fc2_slots;
+        RowDgrad q = {};
+        q.params = a->online; q.noise = nz[0]; q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
+        q.dy = ws + L.ws_dh1; q.ldy = 1024; q.mask = ws + L.ws_feat; q.out = ws + L.ws_dfeat;
+        q.ldo = kFlat; q.out_col[0] = 0; q.out_col[1] = 0; q.same_out = 1;
+        q.M = B; q.K = kFlat; q.nblocks = kDgBlocks;
+        static_assert((kFlat + kDgBlocks - 1) / kDgBlocks * 4 <= 32, "rows x jobs per workgroup");
+        hipLaunchKernelGGL(fc1_dgrad_rows_kernel, dim3(GramDSide::kBlocks + kDgBlocks), dim3(256),
+                           0, s, q, gdp);
+        DZ_LAUNCH_CHECK();
+        rc = DZ_OK;
       } else {
         rc = dz_launch_gemm2_occ<FcWgradOp<2, 2, 1, 2, kS_dh1>, FcDgradOp<1, 2, 2, 1, 1, 1, 2, kS_dh1>, 5>(
             w, dim3(512 / FcWg::BN, kFlat / FcWg::BM, 2), d,
@@ -388,11 +438,13 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       }
       if (rc) return rc;
       DZ_PROF(s, "fc1_dgrad+wgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0,
-                         s, ws + L.ws_dfeat_part, kFc1DgradSplits, (long)B * kFlat,
-                         ws + L.ws_feat, ws + L.ws_dfeat);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "dfeat_reduce");
+      if (!onfly) {
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0,
+                           s, ws + L.ws_dfeat_part, kFc1DgradSplits, (long)B * kFlat,
+                           ws + L.ws_feat, ws + L.ws_dfeat);
+        DZ_LAUNCH_CHECK();
+        DZ_PROF(s, "dfeat_reduce");
+      }
     }
     {  // conv3: weight+bias gradient partials + input gradient (relu(conv2) mask)
       ConvWgradParams w;

@@ -1,0 +1,188 @@
+// Input gradient of a noisy linear layer with a small batch (M <= 32) as a ROW-OWNING
+// weight stream:
+//     dX[b][k] = relu'(x[b][k]) * sum_n dY[b][n] * W_eff[k][n],
+//     W_eff[k][n] = Wmu[k][n] + Wsig[k][n] * (eps_in[k] * eps_out[n])        (networks.py:168-176)
+// The reduction index n is the CONTIGUOUS one in memory, so it cannot be the K dimension
+// of an MFMA without a transposing stage; the tile-GEMM form (global -> registers -> LDS
+// -> MFMA, split over n into slabs + a fold) read fc1's 25.7 MB of weights at 2.7 TB/s and
+// needed 10.4 + 4.8 us (contraction + reduce launch).  Here a workgroup OWNS whole rows k:
+// a wave streams up to 256 columns of a row as one float4 per lane per matrix (1 KB
+// contiguous per instruction), keeps its four columns of dY for all 32 batch rows in
+// registers (128 VGPRs, as PAIRS of batch rows: the multiply-adds are v_pk_fma_f32),
+// and reduces the 32 partial sums across the wave with the gfx950 lane-swap instructions
+// (v_permlane32_swap / v_permlane16_swap: one swap + one add halve two registers into
+// one -- a transposed butterfly).  No split over n, no slabs, no reduce launch, the ReLU
+// mask in the epilogue.
+//
+// A "job" is one chunk of <= 256 columns of one head; a row's jobs go to the workgroup's
+// four waves round-robin (fc1: 2 heads x 2 chunks = one job per wave; fc2 with 6 actions:
+// 2 + 1 jobs).  The heads either add into ONE output (fc1: both read the same input) or
+// own one output block each (fc2: adv | val halves of the hidden layer).
+// ref: rainbow/agent.py:112-118 (jax.grad through the network), networks.py:150-180.
+#pragma once
+#include "dz_qnet_ops.h"
+
+namespace {
+struct RowDgrad {
+  const float* params;
+  const float* noise;
+  FcHead head[2];         // w_mu, w_sig, ldw, N (columns), eps_in (per row), eps_out (per column),
+                          // out_off = column offset of the head's dY
+  const float* dy; int ldy;     // [M][ldy]
+  const float* mask;      // [M][ldo] post-ReLU activation of the layer input
+  float* out;             // [M][ldo]
+  int ldo;
+  int out_col[2];         // output column of row 0, per head
+  int same_out;           // 1: both heads add into out_col[0] + k; 0: head h owns out_col[h] + k
+  int M, K;               // batch rows (<= 32), weight rows
+  int nblocks;            // row-owning workgroups (rows are split as evenly as K allows)
+};
+constexpr int kRdLdsFloats = 32 * 256;   // rows-per-workgroup x jobs <= 32
+
+typedef float dz_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dz_dpp_xor8(float v) {   // lane l <- lane l ^ 8
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+      0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+}
+// v_permlane32_swap: a's lanes 32..63 <-> b's lanes 0..31; v_permlane16_swap: a's odd
+// 16-lane rows <-> b's even rows (checked on hardware: tools/micro/sw_test).  Inline
+// assembly: this compiler's __builtin_amdgcn_permlane{16,32}_swap loses the second result
+// when both feed one add (it emitted v_add vdst, vdst), and inline assembly is opaque to
+// the hazard recogniser -- hence the explicit wait states around each group of four.
+#define DZ_SWAP4(INSN, A0, A1, A2, A3, B0, B1, B2, B3)                                        \
+  asm volatile("s_nop 1\n\t" INSN " %0, %4\n\t" INSN " %1, %5\n\t" INSN " %2, %6\n\t" INSN        \
+               " %3, %7\n\ts_nop 1"                                                            \
+               : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(B0), "+v"(B1), "+v"(B2), "+v"(B3))
+__device__ __forceinline__ void dz_swap32x4(dz_f2& a0, dz_f2& a1, dz_f2& b0, dz_f2& b1) {
+  float x0 = a0.x, x1 = a0.y, x2 = a1.x, x3 = a1.y, y0 = b0.x, y1 = b0.y, y2 = b1.x, y3 = b1.y;
+  DZ_SWAP4("v_permlane32_swap_b32", x0, x1, x2, x3, y0, y1, y2, y3);
+  a0.x = x0; a0.y = x1; a1.x = x2; a1.y = x3; b0.x = y0; b0.y = y1; b1.x = y2; b1.y = y3;
+}
+__device__ __forceinline__ void dz_swap16x4(dz_f2& a0, dz_f2& a1, dz_f2& b0, dz_f2& b1) {
+  float x0 = a0.x, x1 = a0.y, x2 = a1.x, x3 = a1.y, y0 = b0.x, y1 = b0.y, y2 = b1.x, y3 = b1.y;
+  DZ_SWAP4("v_permlane16_swap_b32", x0, x1, x2, x3, y0, y1, y2, y3);
+  a0.x = x0; a0.y = x1; a1.x = x2; a1.y = x3; b0.x = y0; b0.y = y1; b1.x = y2; b1.y = y3;
+}
+
+static inline int row_dgrad_jobs(const RowDgrad& q) {
+  return (q.head[0].N + 255) / 256 + (q.head[1].N + 255) / 256;
+}
+static inline int row_dgrad_max_rows(const RowDgrad& q) { return (q.K + q.nblocks - 1) / q.nblocks; }
+
+// `lds`: kRdLdsFloats floats.  P = rows in flight per wave.
+// NJ0 / NJ1: column chunks of head 0 / head 1 (compile time: the job count shapes the
+// LDS indexing and, with at most four jobs, removes the job loop); SAME = same_out.
+template <int NJ0, int NJ1, bool SAME, int P = 2>
+__device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk, float* lds) {
+  constexpr bool ONE = NJ0 + NJ1 <= 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k0 = (int)(((long)blk * q.K) / q.nblocks), k1 = (int)(((long)(blk + 1) * q.K) / q.nblocks);
+  const int nrows = k1 - k0;
+  constexpr int nj0 = NJ0, nj = NJ0 + NJ1, nout = SAME ? 1 : 2;
+  // the ReLU mask of this thread's outputs (epilogue), requested now
+  constexpr int NO = 2;   // outputs per thread: nrows * 32 * nout <= 512
+  float mk[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    const int o = min(tid + 256 * j, nrows * 32 * nout - 1);
+    const int sel = o >= nrows * 32 ? 1 : 0, r = (o - sel * nrows * 32) >> 5, b = min(o & 31, q.M - 1);
+    mk[j] = q.mask[(long)b * q.ldo + (sel ? q.out_col[1] : q.out_col[0]) + k0 + r];
+  }
+  for (int job = wave; job < nj; job += ONE ? 1 << 20 : 4) {   // (wave-uniform)
+    const bool h1 = job >= nj0;
+    const int c0 = ((h1 ? job - nj0 : job) << 8) + 4 * lane;      // this lane's first column
+    const int N = dz_val(h1, q.head[1].N, q.head[0].N), ldw = dz_val(h1, q.head[1].ldw, q.head[0].ldw);
+    const int cc = min(c0, ldw - 4);                                // clamped (pitch is a multiple of 4)
+    // (uniform base + 32-bit byte offset: SGPR-base addressing, no 64-bit lane addresses)
+    const char* __restrict__ wmu = (const char*)(q.params + dz_val(h1, q.head[1].w_mu, q.head[0].w_mu));
+    const char* __restrict__ wsg = (const char*)(q.params + dz_val(h1, q.head[1].w_sig, q.head[0].w_sig));
+    const float* __restrict__ ein = q.noise + dz_val(h1, q.head[1].eps_in, q.head[0].eps_in);
+    float4 pm[P], ps[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const unsigned o = (unsigned)(min(k0 + u, k1 - 1) * ldw + cc) * 4u;
+      pm[u] = *(const float4*)(wmu + o); ps[u] = *(const float4*)(wsg + o);
+    }
+    // this lane's four columns of dY, all batch rows, as pairs of batch rows; columns
+    // beyond the head's N (and lanes beyond the chunk) contribute zeros
+    const char* dyp = (const char*)(q.dy + dz_val(h1, q.head[1].out_off, q.head[0].out_off));
+    const float v0 = c0 < N ? 1.f : 0.f, v1 = c0 + 1 < N ? 1.f : 0.f;
+    const float v2 = c0 + 2 < N ? 1.f : 0.f, v3 = c0 + 3 < N ? 1.f : 0.f;
+    dz_f2 D[16][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float4 d0 = *(const float4*)(dyp + (unsigned)(min(2 * i, q.M - 1) * q.ldy + cc) * 4u);
+      const float4 d1 = *(const float4*)(dyp + (unsigned)(min(2 * i + 1, q.M - 1) * q.ldy + cc) * 4u);
+      const float m0 = 2 * i < q.M ? 1.f : 0.f, m1 = 2 * i + 1 < q.M ? 1.f : 0.f;
+      D[i][0] = dz_f2{d0.x * (m0 * v0), d1.x * (m1 * v0)}; D[i][1] = dz_f2{d0.y * (m0 * v1), d1.y * (m1 * v1)};
+      D[i][2] = dz_f2{d0.z * (m0 * v2), d1.z * (m1 * v2)}; D[i][3] = dz_f2{d0.w * (m0 * v3), d1.w * (m1 * v3)};
+    }
+    const float4 eo = *(const float4*)(q.noise + dz_val(h1, q.head[1].eps_out, q.head[0].eps_out) + cc);
+#pragma unroll 1
+    for (int r = 0; r < nrows; r += P) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        if (r + u < nrows) {   // (wave-uniform)
+          const float4 cm = pm[u], cs = ps[u];
+          {
+            const unsigned o = (unsigned)(min(k0 + r + u + P, k1 - 1) * ldw + cc) * 4u;
+            pm[u] = *(const float4*)(wmu + o); ps[u] = *(const float4*)(wsg + o);
+          }
+          const float e = ein[k0 + r + u];
+          const float w0 = __builtin_fmaf(cs.x, e * eo.x, cm.x), w1 = __builtin_fmaf(cs.y, e * eo.y, cm.y);
+          const float w2 = __builtin_fmaf(cs.z, e * eo.z, cm.z), w3 = __builtin_fmaf(cs.w, e * eo.w, cm.w);
+          dz_f2 a[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            dz_f2 t = D[i][0] * w0;
+            t = __builtin_elementwise_fma(D[i][1], dz_f2{w1, w1}, t);
+            t = __builtin_elementwise_fma(D[i][2], dz_f2{w2, w2}, t);
+            a[i] = __builtin_elementwise_fma(D[i][3], dz_f2{w3, w3}, t);
+          }
+          // transposed butterfly over lane bits 5, 4, 3: 32 -> 16 -> 8 -> 4 values per
+          // lane (a[i] = batch rows 2i, 2i+1)
+#pragma unroll
+          for (int i = 0; i < 8; i += 2) { dz_swap32x4(a[i], a[i + 1], a[i + 8], a[i + 9]); }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) a[i] += a[i + 8];
+#pragma unroll
+          for (int i = 0; i < 4; i += 2) { dz_swap16x4(a[i], a[i + 1], a[i + 4], a[i + 5]); }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[i] += a[i + 4];
+          const bool hi8 = (lane & 8) != 0;
+          float4 v;
+          float* V = (float*)&v;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const dz_f2 own = hi8 ? a[i + 2] : a[i], oth = hi8 ? a[i] : a[i + 2];
+            V[2 * i] = own.x + dz_dpp_xor8(oth.x); V[2 * i + 1] = own.y + dz_dpp_xor8(oth.y);
+          }
+          // lane l now holds batch rows 4 (l >> 3) + {0..3}, summed over the 8 lanes that
+          // share l & 7
+          *(float4*)(lds + (((r + u) * nj + job) * 8 + (lane & 7)) * 32 + 4 * (lane >> 3)) = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    const int o = tid + 256 * j;
+    if (o < nrows * 32 * nout) {
+      const int sel = o >= nrows * 32 ? 1 : 0, r = (o - sel * nrows * 32) >> 5, b = o & 31;
+      // this output's jobs (ascending), eight lane groups each
+      const int j0 = SAME ? 0 : (sel ? nj0 : 0), j1 = SAME ? nj : (sel ? nj : nj0);
+      float s = 0.f;
+      for (int jb = j0; jb < j1; ++jb) {
+        float x[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) x[g] = lds[((r * nj + jb) * 8 + g) * 32 + b];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += x[g];
+      }
+      if (b < q.M)
+        q.out[(long)b * q.ldo + (sel ? q.out_col[1] : q.out_col[0]) + k0 + r] = mk[j] > 0.f ? s : 0.f;
+    }
+  }
+}
+}  // namespace
