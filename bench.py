@@ -80,6 +80,10 @@ def parse_args():
                   help='two-stream mode that runs only write-back/sample/gather ahead')
   ap.add_argument('--prime-steps', type=int, default=-1,
                   help='untimed steps before the warm-up (default: one per ring slot)')
+  ap.add_argument('--stored-gradients', action='store_true',
+                  help='keep every gradient block in memory (learner.keep_all_grads: the '
+                       'stored-gradient form of the step, for A/B against the default, '
+                       'which forms fc1\'s weight gradient inside the optimiser)')
   ap.add_argument('--host-scope-events', action='store_true',
                   help='two-stream mode with default (system-fence) events instead of '
                        'device-scope ones (measurement aid)')
@@ -134,6 +138,7 @@ def build_workload(args, device, seed):
   net = networks.RainbowNetwork(NUM_ACTIONS, support, 0.1)
   learner = learner_lib.RainbowLearner(net, learner_lib.AdamConfig(), b,
                                        seed=seed, device=device)
+  learner.keep_all_grads = bool(getattr(args, 'stored_gradients', False))
   torch.cuda.synchronize(device)
   return replay, learner, None
 

@@ -598,15 +598,24 @@ struct DerivedGrad {
   int on;
 };
 
+// a / b for a divisor shared by the whole launch, given rb = 1.0f / b (IEEE): quotient
+// estimate, exact residual, one correction (Markstein) -- 3 instructions instead of the
+// ~11 of the IEEE expansion, the correctly rounded quotient whenever the quotient and the
+// residual are normal numbers.
+__device__ __forceinline__ float dz_div_by(float a, float b, float rb) {
+  const float q = a * rb;
+  return __builtin_fmaf(__builtin_fmaf(-q, b, a), rb, q);
+}
 // One element of clip_by_global_norm + adam + apply_updates (the single
 // definition every optimiser path inlines, so that all of them round alike).
 __device__ __forceinline__ void adam_elem(float& P, float G, float& M, float& V, bool pass,
                                           float gn, float bc1, float bc2, float lr, float b1,
                                           float b2, float eps, float max_norm) {
-  const float gj = pass ? G : (G / gn) * max_norm;
+  const float rg = 1.0f / gn, r1 = 1.0f / bc1, r2 = 1.0f / bc2;   // (uniform: hoisted)
+  const float gj = pass ? G : dz_div_by(G, gn, rg) * max_norm;
   M = (1.0f - b1) * gj + b1 * M;
   V = (1.0f - b2) * (gj * gj) + b2 * V;
-  const float upd = (M / bc1) / (sqrtf(V / bc2) + eps);
+  const float upd = dz_div_by(M, bc1, r1) / (sqrtf(dz_div_by(V, bc2, r2)) + eps);
   P = P + (-lr) * upd;
 }
 

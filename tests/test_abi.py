@@ -109,3 +109,51 @@ def test_div255_identity():
   y2 = (r.astype(np.float64) * np.float64(rc) + y.astype(np.float64)).astype(np.float32)
   assert (y != true).any()          # the plain reciprocal multiply is NOT exact
   np.testing.assert_array_equal(y2, true)
+
+
+import numpy as np  # noqa: E402
+
+
+def _rn32(x):
+  """Fraction -> nearest float32 (ties to even), normal range, exact integer arithmetic."""
+  from fractions import Fraction
+  if x == 0:
+    return np.float32(0.0)
+  s = -1 if x < 0 else 1
+  x = abs(x)
+  e = x.numerator.bit_length() - x.denominator.bit_length() - 24
+  while x / Fraction(2) ** e >= 2 ** 24:
+    e += 1
+  while x / Fraction(2) ** e < 2 ** 23:
+    e -= 1
+  y = x / Fraction(2) ** e
+  n = y.numerator // y.denominator
+  rem = y - n
+  if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and n % 2 == 1):
+    n += 1
+  return np.float32(s * float(n) * 2.0 ** e)   # n <= 2^24 and the power: exact in float64
+
+
+def test_div_by_uniform_divisor_is_the_ieee_quotient():
+  """dz_div_by (csrc/dz_qnet_kernels.h; Adam's M / bc1, V / bc2, G / gnorm):
+  q = a * fl(1/b); q' = fma(fma(-q, b, a), fl(1/b), q) is the correctly rounded a / b
+  (optax: mu_hat = mu / bc1 ...), checked with exact rational arithmetic on the divisors
+  an optimiser run produces (bias corrections of every early step, a spread of later
+  ones, gradient norms) against moments from 1e-30 to 1e3."""
+  from fractions import Fraction
+  rs = np.random.RandomState(0)
+  divisors = [np.float32(1.0) - np.float32(0.9) ** np.float32(c) for c in range(1, 60)]
+  divisors += [np.float32(1.0) - np.float32(0.999) ** np.float32(c) for c in (1, 2, 3, 7, 50, 333, 2500, 9000)]
+  divisors += list(rs.uniform(0.01, 30.0, 40).astype(np.float32))
+  bad = 0
+  for b in divisors:
+    b = np.float32(b)
+    rb = np.float32(1.0) / b
+    for a in (10.0 ** rs.uniform(-30, 3, 60) * rs.choice([-1.0, 1.0], 60)).astype(np.float32):
+      q = np.float32(a * rb)
+      r = _rn32(Fraction(float(a)) - Fraction(float(q)) * Fraction(float(b)))
+      got = _rn32(Fraction(float(q)) + Fraction(float(r)) * Fraction(float(rb)))
+      want = _rn32(Fraction(float(a)) / Fraction(float(b)))
+      assert want == np.float32(a / b)          # (numpy's division is the IEEE one)
+      bad += got != want
+  assert bad == 0
