@@ -214,20 +214,32 @@ def kernel_work(b, a=NUM_ACTIONS, k=NUM_ATOMS):
   # weight gradient + input gradient of a layer are ONE fused launch
   w['fc1_wgrad'] = (f(3136, 1024, b), 2 * 3136 * 1024 * 4)     # write dW mu,sigma
   w['fc1_dgrad'] = (2 * f(b, 3136, 1024), 2 * 3136 * 1024 * 4)  # read W mu,sigma
-  w['fc1_dgrad+wgrad'] = (w['fc1_wgrad'][0] + f(b, 3136, 1024),
-                          w['fc1_wgrad'][1] + w['fc1_dgrad'][1])  # W_eff: depth N
-  w['fc2_wgrad+dgrad'] = (f(512, na + k, b) + 2 * f(b, 1024, (na + k) / 2.0),
+  # (the one-call step never stores fc1's weight gradient: this launch is the input gradient
+  # against W_eff, depth N, a row-owning weight stream -- csrc/dz_row_dgrad.h)
+  w['fc1_dgrad+wgrad'] = (f(b, 3136, 1024), w['fc1_dgrad'][1])
+  w['fc2_wgrad+dgrad'] = (f(512, na + k, b) + f(b, 1024, (na + k) / 2.0),
                           2 * 2 * 512 * (na + k) * 4)
   w['conv3_wgrad+dgrad'] = (f(576, 64, b * 49) + f(b * 81, 64, 576),
                             2 * b * (5184 + 3136) * 4)
   w['conv2_wgrad+dgrad'] = (f(512, 64, b * 81) + f(b * 400, 32, 256),
                             2 * b * (12800 + 5184) * 4)
   w['conv1_wgrad'] = (f(256, 32, b * 400), b * 28224 + b * 12800 * 4)
-  w['adam'] = (0.0, 7.0 * p_ref * 4)           # read g,p,m,v; write p,m,v
+  # SURVEY.md 8d's figure: read g,p,m,v; write p,m,v.  (The launch itself moves less: it
+  # forms fc1's 2 x 3.2 M gradient entries from L2-resident factors instead of reading
+  # them -- ADAM_BYTES_MOVED, reported next to `achieved` as `achieved_moved`.)
+  w['adam'] = (0.0, 7.0 * p_ref * 4)
   # fused mode: the next step's sample + gather (2 x 32 states read and written) rides along
   w['adam+next_sample'] = (0.0, 7.0 * p_ref * 4 + 2.0 * b * (2 * 28224 + 20))
   w['grad_sumsq'] = (0.0, 1.0 * p_ref * 4)
   return w
+
+
+def adam_bytes_moved(a=NUM_ACTIONS, k=NUM_ATOMS):
+  """HBM bytes the Rainbow optimiser launch actually has to move: p, m, v read and written
+  for every parameter, the stored gradient only outside the two fc1 matrices."""
+  na = a * k
+  p_ref = 77984 + 2 * (3136 * 512 * 2 + 1024) + (512 * na * 2 + na) + (512 * k * 2 + k)
+  return 6.0 * p_ref * 4 + (p_ref - 2 * 3136 * 1024) * 4
 
 
 def dense_kernel_work(b, g, a=NUM_ACTIONS):
@@ -460,6 +472,13 @@ def measure_roofline(step, prof_steps, batch):
     out['frac'] = out['achieved'] / out['peak']
     out['achieved'] = round(out['achieved'], 3)
     out['frac'] = round(out['frac'], 4)
+    if dom.startswith('adam'):
+      moved = adam_bytes_moved() + (nbytes - work['adam'][1])
+      out['bytes_moved'] = moved
+      out['achieved_moved'] = round(moved / avg[dom] / 1e9, 3)
+      out['note'] = ('achieved = SURVEY 8d algorithmic bytes (7 words per parameter) / time; '
+                     'achieved_moved = the bytes this launch has to move (fc1\'s weight gradient '
+                     'is formed in the launch, not read) / time')
   util, util_tag = pmc_mfma_util()
   table = {}
   for k2, v in sorted(avg.items(), key=lambda kv: -kv[1]):

@@ -237,7 +237,7 @@ __device__ __forceinline__ void adam_flat_ranges(unsigned bid, unsigned nblk, co
 // 36.6 us, 16 x 128 34.3, 32 x 128 34.6, 56 x 128 33.2, 112 x 64 33.0; the next rows'
 // streams requested before the current arithmetic 33.8 (no gain: the arithmetic is the
 // exposed part, see adam_fc1_block).
-constexpr int kOfC = 128, kOfIT = 7, kOfFlatBlocks = 64;
+constexpr int kOfC = 64, kOfIT = 7, kOfFlatBlocks = 64;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void adam_onfly_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

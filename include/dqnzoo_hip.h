@@ -336,10 +336,17 @@ typedef struct {
   double prio_exponent;
   double* prio_max_seen;
   uint32_t* prio_status;
-  /* 0 (default): when a call runs backward AND optimiser, the fc1 sigma-weight
-   * gradient (12.85 MB) is not written to `grad`: the optimiser re-derives it
-   * from the mu-weight gradient and the noise, bit-identically (saves the write).  1: every
-   * gradient block is materialised in `grad` (inspection, tests).             */
+  /* 0 (default): `grad` is not a complete gradient vector after the call.
+   *   - A call that runs the loss, the backward pass AND the optimiser (batch <= 32)
+   *     writes NEITHER of fc1's two weight-gradient blocks (2 x 12.85 MB): the optimiser
+   *     forms each entry from the layer's input and output gradient at the moment it
+   *     updates the weight, and the blocks' share of the global norm comes from Gram
+   *     matrices (same mathematics, float32 rounding order of the 32-term batch sums
+   *     apart from the stored form).
+   *   - A call that runs backward + optimiser without the loss (a step split over several
+   *     calls), or a batch > 32, stores fc1's mu-weight gradient and derives the sigma
+   *     block in the optimiser (bit-identical to storing it).
+   * 1: every gradient block is materialised in `grad` (inspection, tests, A/B).       */
   int32_t keep_all_grads;
   int32_t pad_;
   /* Optional precomputed target apply (software pipelining across steps): when

@@ -25,13 +25,13 @@ src, dst = os.path.join(root, 'gpurun_out', tag), os.path.join(root, 'profiles')
 # bench mark name -> substring of the kernel's demangled name
 KERNELS = {
     'adam': 'adam_', 'adam+next_sample': 'adam_',
-    'fc1_fwd': 'dz_fc_stream_fwd3', 'fc1_dgrad+wgrad': 'dz_mfma_gemm2_occ<FcWgradOp',
+    'fc1_fwd': 'dz_fc_stream_fwd3', 'fc1_dgrad+wgrad': 'fc1_dgrad_rows_kernel',
     'conv1_fwd': 'ConvFwdOp<1, 84', 'conv2_fwd': 'dz_mfma_gemm<ConvFwdOp<0, 20, 20',
     'conv3_fwd': 'dz_mfma_gemm<ConvFwdOp<0, 9, 9', 'fc2_fwd': 'dz_mfma_gemm<FcFwdOp',
-    'fc2_wgrad+dgrad': 'dz_mfma_gemm3<FcWgradOp',
+    'fc2_wgrad+dgrad': 'fc2_bwd_rows_kernel',
     'conv3_wgrad+dgrad': 'ConvWgradOp<0, 9, 9', 'conv2_wgrad+dgrad': 'ConvWgradOp<0, 20, 20',
     'conv1_wgrad': 'dz_mfma_gemm<ConvWgradOp<1, 84', 'head_loss': 'rainbow_head_loss_kernel',
-    'fc1_epilogue': 'fc_epilogue_kernel', 'dfeat_reduce': 'reduce_parts_kernel',
+    'fc1_epilogue': 'fc_epilogue_kernel',
     'finalize_grads': 'finalize_grads_kernel',
     'sample+gather': 'prioritized_sample_gather_kernel',
 }
@@ -103,7 +103,7 @@ doc = {
                'bytes that crossed the L2\'s memory side.',
     'fetch_calibration': factors, 'kernels': {}}
 pattern_of = {'adam': 'float4_flat', 'fc1_fwd': 'dword_per_lane',
-              'fc1_dgrad+wgrad': 'float4_per_lane_tiles'}
+              'fc1_dgrad+wgrad': 'float4_flat'}
 for key in ('adam', 'fc1_fwd', 'fc1_dgrad+wgrad', 'conv1_fwd', 'conv2_fwd', 'conv3_fwd'):
   f, w = find(fetch, KERNELS[key]), find(write, KERNELS[key])
   if f is None or w is None:
