@@ -16,7 +16,9 @@ def main():
   for r in rows:
     r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
   rows.sort(key=lambda r: r['s'])
-  adam = [i for i, r in enumerate(rows) if 'adam_' in r['Kernel_Name'] and 'kernel' in r['Kernel_Name']]
+  import os
+  marker = os.environ.get('DZ_STEP_MARKER', 'adam_')   # last kernel of a step (dense RMSProp learners: finalize_grads)
+  adam = [i for i, r in enumerate(rows) if marker in r['Kernel_Name'] and 'kernel' in r['Kernel_Name']]
   if len(adam) < n + 1:
     n = len(adam) - 1
   a, b = adam[-n - 1], adam[-1]
