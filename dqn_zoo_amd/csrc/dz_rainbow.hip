@@ -382,7 +382,9 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         q.ldo = 1024; q.out_col[0] = 0; q.out_col[1] = 512; q.same_out = 0;
         q.M = B; q.K = kHid; q.nblocks = kDg2Blocks;
         const int nj0 = (NA + 255) / 256;
-        DZ_REQUIRE(nj0 >= 1 && nj0 <= 4 && K <= 256 && row_dgrad_max_rows(q) * (nj0 + 1) <= 32);
+        // (LDS: rows x jobs x 256 floats <= 32 KB; epilogue: two outputs per thread)
+        DZ_REQUIRE(nj0 >= 1 && nj0 <= 4 && K <= 256 && row_dgrad_max_rows(q) * (nj0 + 1) <= 32 &&
+                   row_dgrad_max_rows(q) * 32 * 2 <= 512);
         const dim3 gw((NA + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 2);
         const dim3 grid(kDg2Blocks + dz_count(gw));
         switch (nj0) {
@@ -426,7 +428,8 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         q.dy = ws + L.ws_dh1; q.ldy = 1024; q.mask = ws + L.ws_feat; q.out = ws + L.ws_dfeat;
         q.ldo = kFlat; q.out_col[0] = 0; q.out_col[1] = 0; q.same_out = 1;
         q.M = B; q.K = kFlat; q.nblocks = kDgBlocks;
-        static_assert((kFlat + kDgBlocks - 1) / kDgBlocks * 4 <= 32, "rows x jobs per workgroup");
+        static_assert((kFlat + kDgBlocks - 1) / kDgBlocks * 4 <= 32 &&
+                      (kFlat + kDgBlocks - 1) / kDgBlocks * 32 <= 512, "rows x jobs per workgroup");
         hipLaunchKernelGGL(fc1_dgrad_rows_kernel, dim3(GramDSide::kBlocks + kDgBlocks), dim3(256),
                            0, s, q, gdp);
         DZ_LAUNCH_CHECK();
