@@ -4,10 +4,25 @@
 //   groups: g0 = online(s_tm1) [gradient], g1 = target(s_t), g2 = online(s_t)
 //   (double-Q selector only).
 #include "dz_torso.h"
+#include "dz_row_dgrad.h"
 
 namespace {
 constexpr int kS_dfc1 = 32;   // fc1 forward k-splits (100 rows each: dz_fc_stream_fwd3<0, 50>)
 constexpr int kMaxS_ddh1 = 32; // fc2 input-gradient k-splits grow with the head width (QR: 3618 outputs)
+// fc1's input gradient as a row-owning weight stream (dz_row_dgrad.h) in front of the
+// layer's weight-gradient contraction, for the learners whose forward phase already left
+// dh1 finished (the narrow Q heads): no split over the reduction, no slabs, no reduce
+// launch.  256 workgroups x 12-13 rows, two jobs per row (512 columns), two row groups:
+// with the stream's 218 VGPRs a CU holds two workgroups, so the 392 one-stage
+// weight-gradient workgroups pass through the second slot while the 256 streams run.
+constexpr int kDenseDgBlocks = 256;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void dense_fc1_bwd_rows_kernel(FcWgradParams w, dim3 gw, RowDgrad q) {
+  constexpr int SM = DzGemmSmem<FcWg>::ELEMS > kRdLdsFloats ? DzGemmSmem<FcWg>::ELEMS : kRdLdsFloats;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  if (blockIdx.x < (unsigned)q.nblocks) row_dgrad_block<2, 0, true, 4, false>(q, blockIdx.x, smem);
+  else dz_gemm_body<FcWg>(w, dz_unflatten(blockIdx.x - q.nblocks, gw), smem);
+}
 constexpr int kS_ddfeat = 8;  // fc1 input-gradient k-splits (FcDgradOp<1,2,2,1>): 8 x 4 stages (16 x 2: +1.5 us)
 }
 
@@ -319,7 +334,22 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       d1.part = ws + L.ws_dfeat_part; d1.ldo = kFlat; d1.K = kFlat; d1.x_off = 0;
       // weight gradient and input gradient in ONE launch (as in dz_rainbow.hip)
       const dim3 gw(kHid / FcWg::BN, kFlat / FcWg::BM, 1), gdd(kFlat / 64, (B + 31) / 32, kS_ddfeat);
-      if (fold) {
+      const bool rows = q_fused && B <= 32;   // dh1 is finished: row-owning stream
+      if (rows) {
+        RowDgrad q = {};
+        q.params = a->online; q.noise = nullptr; q.head[0] = h1; q.head[1] = h1;
+        q.head[0].out_off = 0; q.head[1].N = 0;
+        q.dy = ws + L.ws_dh1; q.ldy = kHid; q.mask = ws + L.ws_feat; q.out = ws + L.ws_dfeat;
+        q.ldo = kFlat; q.out_col[0] = 0; q.out_col[1] = 0; q.same_out = 1;
+        q.M = B; q.K = kFlat; q.nblocks = kDenseDgBlocks;
+        static_assert(kHid == 512, "two 256-column jobs per row");
+        static_assert((kFlat + kDenseDgBlocks - 1) / kDenseDgBlocks * 2 <= 32 &&
+                      (kFlat + kDenseDgBlocks - 1) / kDenseDgBlocks * 32 <= 512, "rows x jobs per workgroup");
+        hipLaunchKernelGGL(dense_fc1_bwd_rows_kernel, dim3(kDenseDgBlocks + dz_count(gw)), dim3(256), 0, s,
+                           w1, gw, q);
+        DZ_LAUNCH_CHECK();
+        rc = DZ_OK;
+      } else if (fold) {
         w1.dyp.part = ws + L.ws_fc1_part; w1.dyp.stride = (long)B * kHid;
         w1.dyp.mask = ws + L.ws_h1; w1.dyp.out = ws + L.ws_dh1;
         d1.dyp = w1.dyp; d1.dyp.out = nullptr;
@@ -330,11 +360,13 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       }
       if (rc) return rc;
       DZ_PROF(s, "fc1_wgrad+dgrad");
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0, s,
-                         ws + L.ws_dfeat_part, kS_ddfeat, (long)B * kFlat, ws + L.ws_feat,
-                         ws + L.ws_dfeat);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "dfeat_reduce");
+      if (!rows) {
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kFlat + 63) / 64), dim3(256), 0, s,
+                           ws + L.ws_dfeat_part, kS_ddfeat, (long)B * kFlat, ws + L.ws_feat,
+                           ws + L.ws_dfeat);
+        DZ_LAUNCH_CHECK();
+        DZ_PROF(s, "dfeat_reduce");
+      }
     }
     ReduceJob conv_jobs[3];
     const TorsoBufs T = {L.conv_w, L.conv_b, ws + L.ws_act1, ws + L.ws_act2, ws + L.ws_feat};

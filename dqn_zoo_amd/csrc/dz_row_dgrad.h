@@ -72,9 +72,13 @@ static inline int row_dgrad_max_rows(const RowDgrad& q) { return (q.K + q.nblock
 // `lds`: kRdLdsFloats floats.  P = rows in flight per wave.
 // NJ0 / NJ1: column chunks of head 0 / head 1 (compile time: the job count shapes the
 // LDS indexing and, with at most four jobs, removes the job loop); SAME = same_out.
-template <int NJ0, int NJ1, bool SAME, int P = 2>
+// NOISY = false: plain linear layer (W_eff = W: no sigma matrix, no noise).
+// With one or two jobs per row the four waves form 4 / jobs ROW GROUPS (group g takes rows
+// g, g + groups, ...), so that no wave idles.
+template <int NJ0, int NJ1, bool SAME, int P = 2, bool NOISY = true>
 __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk, float* lds) {
   constexpr bool ONE = NJ0 + NJ1 <= 4;
+  constexpr int GROUPS = NJ0 + NJ1 <= 2 ? 4 / (NJ0 + NJ1) : 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k0 = (int)(((long)blk * q.K) / q.nblocks), k1 = (int)(((long)(blk + 1) * q.K) / q.nblocks);
   const int nrows = k1 - k0;
@@ -88,7 +92,9 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
     const int sel = o >= nrows * 32 ? 1 : 0, r = (o - sel * nrows * 32) >> 5, b = min(o & 31, q.M - 1);
     mk[j] = q.mask[(long)b * q.ldo + (sel ? q.out_col[1] : q.out_col[0]) + k0 + r];
   }
-  for (int job = wave; job < nj; job += ONE ? 1 << 20 : 4) {   // (wave-uniform)
+  const int grp = GROUPS > 1 ? wave / nj : 0;
+  const int myrows = (nrows - grp + GROUPS - 1) / GROUPS;   // rows k0 + grp + GROUPS * i
+  for (int job = GROUPS > 1 ? wave % nj : wave; job < nj; job += ONE ? 1 << 20 : 4) {   // (wave-uniform)
     const bool h1 = job >= nj0;
     const int c0 = ((h1 ? job - nj0 : job) << 8) + 4 * lane;      // this lane's first column
     const int N = dz_val(h1, q.head[1].N, q.head[0].N), ldw = dz_val(h1, q.head[1].ldw, q.head[0].ldw);
@@ -100,8 +106,9 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
     float4 pm[P], ps[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) {
-      const unsigned o = (unsigned)(min(k0 + u, k1 - 1) * ldw + cc) * 4u;
-      pm[u] = *(const float4*)(wmu + o); ps[u] = *(const float4*)(wsg + o);
+      const unsigned o = (unsigned)(min(k0 + grp + GROUPS * u, k1 - 1) * ldw + cc) * 4u;
+      pm[u] = *(const float4*)(wmu + o);
+      if (NOISY) ps[u] = *(const float4*)(wsg + o);
     }
     // this lane's four columns of dY, all batch rows, as pairs of batch rows; columns
     // beyond the head's N (and lanes beyond the chunk) contribute zeros
@@ -117,20 +124,26 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
       D[i][0] = dz_f2{d0.x * (m0 * v0), d1.x * (m1 * v0)}; D[i][1] = dz_f2{d0.y * (m0 * v1), d1.y * (m1 * v1)};
       D[i][2] = dz_f2{d0.z * (m0 * v2), d1.z * (m1 * v2)}; D[i][3] = dz_f2{d0.w * (m0 * v3), d1.w * (m1 * v3)};
     }
-    const float4 eo = *(const float4*)(q.noise + dz_val(h1, q.head[1].eps_out, q.head[0].eps_out) + cc);
+    float4 eo = dz_f4zero();
+    if (NOISY) eo = *(const float4*)(q.noise + dz_val(h1, q.head[1].eps_out, q.head[0].eps_out) + cc);
 #pragma unroll 1
-    for (int r = 0; r < nrows; r += P) {
+    for (int i0 = 0; i0 < myrows; i0 += P) {
 #pragma unroll
       for (int u = 0; u < P; ++u) {
-        if (r + u < nrows) {   // (wave-uniform)
-          const float4 cm = pm[u], cs = ps[u];
+        if (i0 + u < myrows) {   // (wave-uniform)
+          const int r = grp + GROUPS * (i0 + u);   // row of the workgroup
+          const float4 cm = pm[u], cs = NOISY ? ps[u] : dz_f4zero();
           {
-            const unsigned o = (unsigned)(min(k0 + r + u + P, k1 - 1) * ldw + cc) * 4u;
-            pm[u] = *(const float4*)(wmu + o); ps[u] = *(const float4*)(wsg + o);
+            const unsigned o = (unsigned)(min(k0 + r + GROUPS * P, k1 - 1) * ldw + cc) * 4u;
+            pm[u] = *(const float4*)(wmu + o);
+            if (NOISY) ps[u] = *(const float4*)(wsg + o);
           }
-          const float e = ein[k0 + r + u];
-          const float w0 = __builtin_fmaf(cs.x, e * eo.x, cm.x), w1 = __builtin_fmaf(cs.y, e * eo.y, cm.y);
-          const float w2 = __builtin_fmaf(cs.z, e * eo.z, cm.z), w3 = __builtin_fmaf(cs.w, e * eo.w, cm.w);
+          float w0 = cm.x, w1 = cm.y, w2 = cm.z, w3 = cm.w;
+          if (NOISY) {
+            const float e = ein[k0 + r];
+            w0 = __builtin_fmaf(cs.x, e * eo.x, cm.x); w1 = __builtin_fmaf(cs.y, e * eo.y, cm.y);
+            w2 = __builtin_fmaf(cs.z, e * eo.z, cm.z); w3 = __builtin_fmaf(cs.w, e * eo.w, cm.w);
+          }
           dz_f2 a[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
@@ -159,7 +172,7 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
           }
           // lane l now holds batch rows 4 (l >> 3) + {0..3}, summed over the 8 lanes that
           // share l & 7
-          *(float4*)(lds + (((r + u) * nj + job) * 8 + (lane & 7)) * 32 + 4 * (lane >> 3)) = v;
+          *(float4*)(lds + ((r * nj + job) * 8 + (lane & 7)) * 32 + 4 * (lane >> 3)) = v;
         }
       }
     }
