@@ -34,7 +34,7 @@ int main() {
   const double MB = P * 4 / 1e6;
 #define RUN(RG, W, label) { auto f = [&]() { hipLaunchKernelGGL((rmw<RG, W>), dim3(2048), dim3(256), 0, 0, p, m, v, g, n4); }; \
     const float t = time_us(f); const double mb = (3 + RG + W) * MB; \
-    printf("%-34s %6.1f MB  %6.2f us  %.2f TB/s\n", label, mb, t, mb / t / 1e6 * 1e6 / 1e6); }
+    printf("%-34s %6.1f MB  %6.2f us  %.2f TB/s\n", label, mb, t, mb / t); }
   RUN(0, 0, "read p,m,v");
   RUN(1, 0, "read g,p,m,v");
   RUN(0, 1, "read p,m,v  write p");
