@@ -94,8 +94,10 @@ class RainbowLearner:
     # replay each distinct call signature from a hipGraph: True / False, or None =
     # automatically whenever the current stream allows capture (any non-default stream)
     self.use_graphs = None
-    # False: a full step does not store the fc1 sigma-weight gradient (Adam derives it
-    # from the mu-weight gradient and the noise); True: `grad` holds every block
+    # False: a one-call step (loss + backward + optimiser, batch <= 32) stores NEITHER of
+    # fc1's weight-gradient blocks -- the optimiser forms their entries from the layer's
+    # input and output gradient (csrc/dz_fc1_onfly.h) -- and a split step stores only the
+    # mu block; True: `grad` holds every block (inspection, tests, A/B)
     self.keep_all_grads = False
     # inference (acting) side: own workspace + one noise block, so that an
     # apply never aliases the buffers of an enqueued learner step.
