@@ -17,8 +17,10 @@ __device__ __forceinline__ bool finite_nonneg(double v) {
   return (v >= 0.0) && (v < __builtin_inf());  // false for NaN, -x, +inf
 }
 
+// (the word may live in pinned host memory -- the Python layer polls it there for free --
+// hence the system scope; nothing on the device ever reads it)
 __device__ __forceinline__ void raise(uint32_t* status, uint32_t bit) {
-  if (status) atomicOr(status, bit);
+  if (status) __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Shared body of SumTree.set for one workgroup.  `leaf[i]` are tree indices in

@@ -87,11 +87,15 @@ class DenseAgent(parts.Agent):
     if self._replay.size >= self._min_replay_capacity:
       if self._frame_t % self._learn_period == 0:
         self._learn()
+        # a NaN/inf/negative priority or weight flagged by an earlier step's kernels
+        # (sticky word in pinned host memory: a plain load, nothing is awaited)
+        self._replay.poll_status()
       if self._frame_t % self._target_network_update_period == 0:
         self._learner.sync_target()
         # the reference raises at the offending call when a priority or weight
         # goes NaN/inf/negative (replay.py:233-242,281-282); here those land in a
-        # sticky device word, polled once per target period (one host sync)
+        # sticky word; polled without waiting at every learner step, and definitively
+        # (one host sync) once per target period
         self._replay.check_status()
     if isinstance(action, parts.PendingAction):
       # the frame's device work is queued; wait for the acting launches only

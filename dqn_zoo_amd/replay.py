@@ -83,16 +83,35 @@ def _raise_status(bits):
 
 
 class _Status:
-  """Sticky device status word shared by the kernels of one object."""
+  """Sticky status word shared by the kernels of one object.
+
+  The word lives in PINNED HOST memory (device-visible under the same address): kernels
+  only ever touch it on the error path -- one system-scope atomic OR, no kernel reads it --
+  so the host can look at it whenever it likes without enqueueing or waiting for anything.
+  `poll()` is that look (a plain load of host memory; raises as soon as a flag has landed,
+  i.e. at most a few enqueued steps after the offending kernel ran); `check()` first waits
+  for everything enqueued on the device and is therefore definitive."""
 
   def __init__(self, device):
-    self.word = torch.zeros(1, dtype=torch.int32, device=device)
+    self._device = device
+    self.word = torch.zeros(1, dtype=torch.int32).pin_memory()
+    self._np = self.word.numpy()
+
+  def _take(self):
+    bits = int(self._np[0])
+    if bits:
+      torch.cuda.synchronize(self._device)   # let every flag of the failing step land
+      bits = int(self._np[0])
+      self._np[0] = 0
+      _raise_status(bits)
+
+  def poll(self):
+    if self._np[0]:
+      self._take()
 
   def check(self):
-    bits = int(self.word.item())  # synchronises
-    if bits:
-      self.word.zero_()
-      _raise_status(bits)
+    torch.cuda.synchronize(self._device)
+    self._take()
 
 
 # --------------------------------------------------------------------------- #
@@ -429,10 +448,18 @@ class _ReplayBase(Generic[ReplayStructure]):
     """Synchronises and raises what the reference would have raised at the
     offending call (ValueError for NaN/inf/negative priorities or non-finite
     importance weights, replay.py:233-242,281-282) if any pipelined kernel
-    flagged it in the sticky device status word since the last check.  The
-    agents poll this at every target-network sync, so a diverged run stops
-    within one target period instead of training on NaNs."""
+    flagged it in the sticky status word since the last check (definitive: waits for
+    everything enqueued).  The agents call this at every target-network sync and the
+    non-blocking `poll_status()` at every learner step."""
     self._status.check()
+
+  def poll_status(self) -> None:
+    """The same without waiting for the device: a load of the (pinned host) status
+    word.  Raises once a flag written by an already-executed kernel has landed; costs
+    nothing otherwise -- the agents call it at every learner step, so a diverged run
+    stops a few enqueued steps after the offending kernel instead of at the next
+    target-network sync."""
+    self._status.poll()
 
   def _allocate_fields(self, shapes, np_dtypes):
     """(Re-)allocates the field arrays; cached sample slots hold raw pointers

@@ -223,22 +223,28 @@ def test_async_acting_path_matches_oracle_and_replays_from_a_graph():
     torch.cuda.set_stream(prev)
 
 
-def test_diverged_priorities_stop_the_run_at_the_next_target_sync():
-  """NaN / negative priorities raise ValueError in the reference's
-  SumTree.set (replay.py:281-282).  Here they land in a sticky device status
-  word; the agents poll it at every target-network sync."""
-  ag, rep = _make_agent(target_period=8, min_frac=0.004, learn_period=1)
+def test_diverged_priorities_stop_the_run_within_a_few_steps():
+  """ADVICE r1 / VERDICT r2: NaN / negative priorities raise ValueError in the
+  reference's SumTree.set (replay.py:281-282) at the offending call.  Here they land in a
+  sticky status word in pinned host memory that the agents look at (a plain load, no
+  synchronisation) at every learner step, and definitively at every target-network sync:
+  the run stops a few enqueued steps after the offending kernel, long before the next
+  target sync (period 1000 here)."""
+  ag, rep = _make_agent(target_period=1000, min_frac=0.004, learn_period=1)
   env = SyntheticEnv(2, episode_length=100)
   ts = env.reset()
   ag.reset()
   for _ in range(9):
     ts = env.step(ag.step(ts))
+  rep.poll_status()   # nothing flagged so far
   # poison the priorities of the next write-back the way a diverged loss would
   ids = rep.sample_device(4).ids
   rep.update_priorities(ids, torch.full((4,), float('nan'), device='cuda'))
   with pytest.raises(ValueError, match='finite and positive'):
-    for _ in range(9):   # at most one target period later
+    for _ in range(12):
       ts = env.step(ag.step(ts))
+  # the word is clear again and the definitive check agrees
+  rep.check_status()
 
 
 def test_scalar_dtypes_are_canonicalised_on_insert():
