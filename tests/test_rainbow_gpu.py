@@ -222,7 +222,8 @@ def test_derived_sigma_gradient_is_bit_identical(max_norm):
 
 
 @pytest.mark.parametrize('max_norm,B,A', [(10.0, 32, 6), (1e-3, 32, 6), (0.05, 7, 6),
-                                          (10.0, 32, 18), (10.0, 20, 3), (10.0, 32, 11)])
+                                          (10.0, 32, 18), (10.0, 20, 3), (10.0, 32, 11),
+                                          (10.0, 1, 6), (10.0, 2, 4)])
 def test_fc1_gradient_formed_in_the_optimiser_matches_the_stored_gradient(max_norm, B, A):
   """The one-call step never stores fc1's weight gradient (dz_fc1_onfly.h: every
   element is formed from the L2-resident factors inside the optimiser, the layer's share
