@@ -23,6 +23,23 @@ void dense_fc1_bwd_rows_kernel(FcWgradParams w, dim3 gw, RowDgrad q) {
   if (blockIdx.x < (unsigned)q.nblocks) row_dgrad_block<2, 0, true, 4, false>(q, blockIdx.x, smem);
   else dz_gemm_body<FcWg>(w, dz_unflatten(blockIdx.x - q.nblocks, gw), smem);
 }
+// The second layer's input gradient the same way (wide heads: C51, QR-DQN; up to 16 chunks of
+// 256 outputs): 128 workgroups x 4 rows in front of that layer's weight-gradient
+// contraction; dh1 leaves the launch finished (summed over the outputs, ReLU-masked), so
+// nothing has to fold slabs and fc1's stream above can read it.
+constexpr int kDenseDg2Blocks = 128;
+template <int NJ0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void dense_fc2_bwd_rows_kernel(FcWgradParams w, dim3 gw, RowDgrad q) {
+  constexpr int SM = DzGemmSmem<FcWg>::ELEMS > kRdLdsFloats ? DzGemmSmem<FcWg>::ELEMS : kRdLdsFloats;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  if (blockIdx.x < (unsigned)q.nblocks) row_dgrad_block<NJ0, 0, true, 4, false>(q, blockIdx.x, smem);
+  else dz_gemm_body<FcWg>(w, dz_unflatten(blockIdx.x - q.nblocks, gw), smem);
+}
+template <int NJ0>
+static inline void launch_dense_fc2_rows(const FcWgradParams& w, dim3 gw, const RowDgrad& q, hipStream_t s) {
+  hipLaunchKernelGGL(dense_fc2_bwd_rows_kernel<NJ0>, dim3(q.nblocks + dz_count(gw)), dim3(256), 0, s, w, gw, q);
+}
 constexpr int kS_ddfeat = 8;  // fc1 input-gradient k-splits (FcDgradOp<1,2,2,1>): 8 x 4 stages (16 x 2: +1.5 us)
 }
 
@@ -302,18 +319,43 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       // the usual head (s_dh1 == kS_dh1): the slabs go to the idle fc1 forward slab
       // buffer and are summed + ReLU-masked by the loaders of the fc1 backward launch
       // (DyParts, as in dz_rainbow.hip): no dh1 reduction launch
-      const bool fold = !q_fused && s_dh1 == kS_dh1 &&
+      // wide heads, one batch tile: the input gradient as a row-owning stream (dh1 finished)
+      const int nj2 = (N + 255) / 256;
+      const bool rows2 = !q_fused && B <= 32 && nj2 <= 16;
+      const bool fold = !rows2 && !q_fused && s_dh1 == kS_dh1 &&
                         (int64_t)kS_dh1 * B * kHid <= (int64_t)kS_dfc1 * G * B * kHid;
       d.part = fold ? ws + L.ws_fc1_part : ws + L.ws_dfeat_part;
       d.ldo = kHid; d.K = kHid; d.x_off = 0;
-      if (!q_fused) {
+      if (rows2) {
+        RowDgrad q = {};
+        q.params = a->online; q.noise = nullptr; q.head[0] = h2; q.head[1] = h2;
+        q.head[0].out_off = 0; q.head[1].N = 0;
+        q.dy = ws + L.ws_dout; q.ldy = ld2; q.mask = ws + L.ws_h1; q.out = ws + L.ws_dh1;
+        q.ldo = kHid; q.out_col[0] = 0; q.out_col[1] = 0; q.same_out = 1;
+        q.M = B; q.K = kHid; q.nblocks = kDenseDg2Blocks;
+        static_assert(kHid / kDenseDg2Blocks * 4 <= 32, "rows x jobs per workgroup");
+        const dim3 gw2((N + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 1);
+        switch (nj2) {
+          case 1: launch_dense_fc2_rows<1>(w, gw2, q, s); break;
+          case 2: launch_dense_fc2_rows<2>(w, gw2, q, s); break;
+          case 3: launch_dense_fc2_rows<3>(w, gw2, q, s); break;
+          case 4: launch_dense_fc2_rows<4>(w, gw2, q, s); break;
+          default:   // wider: run-time job count, as many rows per workgroup as the LDS block holds
+            q.nblocks = (kHid + 32 / nj2 - 1) / (32 / nj2);
+            DZ_REQUIRE(row_dgrad_max_rows(q) * nj2 <= 32);
+            launch_dense_fc2_rows<0>(w, gw2, q, s);
+            break;
+        }
+        DZ_LAUNCH_CHECK();
+        DZ_PROF(s, "fc2_wgrad+dgrad");
+      } else if (!q_fused) {
         rc = dz_launch_gemm2<FcWg, FcDgradOp<1, 2, 2, 4, 1, 1, 0>>(
             w, dim3((N + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 1), d,
             dim3(kHid / FcDg::BN, (B + 31) / 32, s_dh1), s);
         if (rc) return rc;
         DZ_PROF(s, "fc2_wgrad+dgrad");
       }
-      if (!fold && !q_fused) {
+      if (!fold && !q_fused && !rows2) {
         hipLaunchKernelGGL(reduce_parts_kernel, dim3((B * kHid + 63) / 64), dim3(256), 0, s,
                            ws + L.ws_dfeat_part, s_dh1, (long)B * kHid, ws + L.ws_h1,
                            ws + L.ws_dh1);
@@ -334,7 +376,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       d1.part = ws + L.ws_dfeat_part; d1.ldo = kFlat; d1.K = kFlat; d1.x_off = 0;
       // weight gradient and input gradient in ONE launch (as in dz_rainbow.hip)
       const dim3 gw(kHid / FcWg::BN, kFlat / FcWg::BM, 1), gdd(kFlat / 64, (B + 31) / 32, kS_ddfeat);
-      const bool rows = q_fused && B <= 32;   // dh1 is finished: row-owning stream
+      const bool rows = (q_fused || rows2) && B <= 32;   // dh1 is finished: row-owning stream
       if (rows) {
         RowDgrad q = {};
         q.params = a->online; q.noise = nullptr; q.head[0] = h1; q.head[1] = h1;

@@ -80,12 +80,16 @@ static inline int row_dgrad_max_rows(const RowDgrad& q) { return (q.K + q.nblock
 // g, g + groups, ...), so that no wave idles.
 template <int NJ0, int NJ1, bool SAME, int P = 2, bool NOISY = true>
 __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk, float* lds) {
-  constexpr bool ONE = NJ0 + NJ1 <= 4;
-  constexpr int GROUPS = NJ0 + NJ1 <= 2 ? 4 / (NJ0 + NJ1) : 1;
+  // NJ0 == 0: the job count is a run-time value (head 0 only; more registers, for the
+  // rare very wide heads)
+  constexpr bool RT = NJ0 == 0;
+  constexpr bool ONE = !RT && NJ0 + NJ1 <= 4;
+  constexpr int GROUPS = (!RT && NJ0 + NJ1 <= 2) ? 4 / (NJ0 + NJ1) : 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k0 = (int)(((long)blk * q.K) / q.nblocks), k1 = (int)(((long)(blk + 1) * q.K) / q.nblocks);
   const int nrows = k1 - k0;
-  constexpr int nj0 = NJ0, nj = NJ0 + NJ1, nout = SAME ? 1 : 2;
+  const int nj0 = RT ? (q.head[0].N + 255) >> 8 : NJ0, nj = nj0 + NJ1;
+  constexpr int nout = SAME ? 1 : 2;
   // the ReLU mask of this thread's outputs (epilogue), requested now
   constexpr int NO = 2;   // outputs per thread: nrows * 32 * nout <= 512
   float mk[NO];

@@ -270,6 +270,16 @@ def test_distributional_dense_step(kind):
   assert int(ln.opt_count.item()) == 1
 
 
+@pytest.mark.parametrize('kind,actions', [('c51', 11), ('c51', 18), ('qr', 18), ('qr', 3)])
+def test_distributional_dense_step_other_head_widths(kind, actions, monkeypatch):
+  """The second layer's input gradient is a row-owning stream over 256-output chunks
+  (csrc/dz_row_dgrad.h): 561 / 918 outputs = 3 / 4 chunks (compile-time job counts), 3618
+  = 15 chunks (run-time job count, two rows per workgroup), 603 = 3."""
+  import sys
+  monkeypatch.setattr(sys.modules[__name__], 'A', actions)
+  test_distributional_dense_step(kind)
+
+
 def test_dense_apply_and_shared_bias():
   from dqn_zoo_amd import learner as ll
   rs, online, target, ln = _make('double_dqn', 'double_q', ll.RmsPropConfig(), 30)
