@@ -32,11 +32,20 @@ constexpr int kFc2Splits = 8;        // fc2 forward k-splits
 //        leaves that launch finished (summed over n, ReLU-masked) -- no slabs to fold.
 constexpr int kDgBlocks = 448, kDg2Blocks = 128;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void fc1_dgrad_rows_kernel(RowDgrad q, GramD gd) {
+void fc1_dgrad_rows_kernel(RowDgrad q, GramD gd, PrioUpdateParams prio) {
   __shared__ __attribute__((aligned(16))) float lds[kRdLdsFloats];
   static_assert(kRdLdsFloats >= 32 * GramDSide::kLd, "GramDSide's tile");
-  if (blockIdx.x < (unsigned)GramDSide::kBlocks) { GramDSide::run(gd, blockIdx.x, lds, (int)sizeof(lds)); return; }
-  row_dgrad_block<2, 2, true, 4>(q, blockIdx.x - GramDSide::kBlocks, lds);
+  static_assert(sizeof(lds) >= sizeof(WbScratch), "the write-back's LDS walk");
+  unsigned bid = blockIdx.x;
+  if (bid < (unsigned)GramDSide::kBlocks) { GramDSide::run(gd, bid, lds, (int)sizeof(lds)); return; }
+  bid -= GramDSide::kBlocks;
+  // optional: the sum-tree priority write-back as one more side block (it needs only the
+  // loss kernel's priorities; this launch's 218-VGPR allocation covers its LDS walk)
+  if (prio.node) {
+    if (bid == 0) { PrioUpdateSideFast::run(prio, 0, lds, (int)sizeof(lds)); return; }
+    bid -= 1;
+  }
+  row_dgrad_block<2, 2, true, 4>(q, bid, lds);
 }
 template <int NJ0>   // 256-column chunks of the advantage head
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -430,8 +439,13 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         q.M = B; q.K = kFlat; q.nblocks = kDgBlocks;
         static_assert((kFlat + kDgBlocks - 1) / kDgBlocks * 4 <= 32 &&
                       (kFlat + kDgBlocks - 1) / kDgBlocks * 32 <= 512, "rows x jobs per workgroup");
-        hipLaunchKernelGGL(fc1_dgrad_rows_kernel, dim3(GramDSide::kBlocks + kDgBlocks), dim3(256),
-                           0, s, q, gdp);
+        // the sum-tree priority write-back rides HERE in the one-call step (same-box A/B:
+        // conv3's backward launch 11.3 -> 10.2 us without it, this launch 12.7 -> 12.8)
+        const bool carry_prio = prio_pending;
+        hipLaunchKernelGGL(fc1_dgrad_rows_kernel,
+                           dim3(GramDSide::kBlocks + kDgBlocks + (carry_prio ? 1 : 0)), dim3(256),
+                           0, s, q, gdp, carry_prio ? prio_q : PrioUpdateParams{});
+        if (carry_prio) prio_pending = false;
         DZ_LAUNCH_CHECK();
         rc = DZ_OK;
       } else {
