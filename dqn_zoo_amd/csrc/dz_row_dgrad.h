@@ -109,7 +109,8 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
     // (uniform base + 32-bit byte offset: SGPR-base addressing, no 64-bit lane addresses)
     const char* __restrict__ wmu = (const char*)(q.params + dz_val(h1, q.head[1].w_mu, q.head[0].w_mu));
     const char* __restrict__ wsg = (const char*)(q.params + dz_val(h1, q.head[1].w_sig, q.head[0].w_sig));
-    const float* __restrict__ ein = q.noise + dz_val(h1, q.head[1].eps_in, q.head[0].eps_in);
+    const float* __restrict__ ein =
+        NOISY ? q.noise + dz_val(h1, q.head[1].eps_in, q.head[0].eps_in) : nullptr;
     float4 pm[P], ps[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) {
