@@ -7,17 +7,19 @@
 //   * dz_gram_x_block (dz_gram.h): Grams of the layer input, side job of the loss
 //     kernel's launch;
 //   * GramDSide (here): side job (16 blocks) of the input-gradient launch -- forms the
-//     Grams of dh1 (left finished by fc2's backward launch: FcDgradParams::fold_*) and the
-//     layer's contribution to the global gradient norm  <X X^T, D D^T>  (both
-//     parameter matrices, per head), one non-negative float per block into the
-//     fused-norm slots;
-//   * adam_onfly_kernel (here): the optimiser; a workgroup owns a 56 x 128 tile of
-//     the mu AND sigma matrices, keeps the 32 x 128 strip of dh1 and the 56 x 32 tile
-//     of X in LDS, and forms every gradient element (32 FMAs) right before its update.
-//     The rest of the parameter vector (convs, biases, fc2: 4 % of it) is streamed from
-//     the stored gradient by 64 more blocks of the same launch.
-// Step time 166.5 -> 159 us (the backward launch loses its 784 weight-gradient
-// workgroups, 14.4 -> 9.6 us; the optimiser moves 166 MB instead of 192, 33.8 -> 30.7 us).
+//     Grams of dh1 (left finished by fc2's backward launch: its input gradient is a
+//     row-owning stream, dz_row_dgrad.h) and the layer's contribution to the global
+//     gradient norm  <X X^T, D D^T>  (both parameter matrices, per head), one non-negative
+//     float per block into the fused-norm slots;
+//   * adam_onfly_kernel (here): the optimiser; a workgroup owns a 112 x 64 tile of the mu
+//     AND sigma matrices, keeps the 32 x 64 strip of dh1 and the 112 x 32 tile of X in
+//     LDS, and forms every gradient element (32 FMAs) right before its update.  The rest
+//     of the parameter vector (convs, biases, fc2: 4 % of it) is streamed from the stored
+//     gradient by 64 more blocks of the same launch.
+// Step 166.5 -> 160 us with the input gradients as row-owning streams: the
+// backward launch loses its 784 weight-gradient workgroups and its reduce launch (14.4 +
+// 4.8 -> 12.4 us); the optimiser itself moves 166 MB instead of 192 MB in the same 32 us
+// -- a bare read-modify-write stream of that traffic takes 30.3 us (tools/micro/rmw_micro).
 // ref: rainbow/agent.py:112-127 (grad + optimizer.update), networks.py:150-180 (the layer).
 #pragma once
 #include "dz_qnet_kernels.h"
