@@ -92,13 +92,12 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
   const float gn = dz_sgpr(sc0.gn), bc1 = dz_sgpr(sc0.bc1), bc2 = dz_sgpr(sc0.bc2);
   const bool pass = __builtin_amdgcn_readfirstlane((int)sc0.pass) != 0;
   const unsigned rstep = (unsigned)(T::RP * q.ld) * 4u;
-  // (One pass over the batch for all seven rows -- 28 accumulators, the dh1 strip read
-  // once instead of seven times, LDS reads -69 % -- measured 35.1 us against 33.3: the
-  // rows' streams then start only after the whole product.)
-  // (The optimiser arithmetic is not free here -- wave64 on a 16-lane SIMD, ~11
-  // instructions per IEEE division, two waves per SIMD: an approximate-arithmetic build
-  // measured 30.3 us against 33.3 -- but skipping the divisions that are exact no-ops,
-  // the unused clip scaling and x / bc1 once bc1 == 1.0f, measured the same 33.3.)
+  // Measured alternatives (optimiser role alone; this form 31.9 us, a bare read-modify-write
+  // stream of the same 165 MB 30.3 us): one pass over the batch for all seven rows (28
+  // accumulators, LDS reads -69 %) 35.1 us -- the rows' streams then start only after the
+  // whole product; the next rows' streams requested before the current arithmetic 33.8;
+  // an approximate-arithmetic build 30.3; skipping the divisions that are exact no-ops
+  // (unused clip scaling, x / bc1 once bc1 == 1.0f): no change.
   {
 #pragma unroll 1
     for (int it = 0; it < IT; ++it) {
