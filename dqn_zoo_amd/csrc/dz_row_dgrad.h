@@ -40,7 +40,12 @@ struct RowDgrad {
   int M, K;               // batch rows (<= 32), weight rows
   int nblocks;            // row-owning workgroups (rows are split as evenly as K allows)
 };
-constexpr int kRdLdsFloats = 32 * 256;   // rows-per-workgroup x jobs <= 32
+// LDS: [row][job][lane group 0..7][32 batch rows + 4]: the +4 skews the eight groups over
+// the banks (a lane writes one float4 at group * 36 + 4 * (lane >> 3); without it the
+// eight lanes served per cycle hit the same four banks: 704 k conflict cycles per fc1
+// launch in the SQ counters).  rows-per-workgroup x jobs <= 32.
+constexpr int kRdGroup = 36;
+constexpr int kRdLdsFloats = 32 * 8 * kRdGroup;
 
 typedef float dz_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dz_dpp_xor8(float v) {   // lane l <- lane l ^ 8
@@ -168,7 +173,7 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
             dz_f2 t = a[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) t += a[i];
-            *(float4*)(lds + ((r * nj + job) * 8 + (lane & 7)) * 32 + 4 * (lane >> 3)) = dz_f4(t.x, t.y, t.x, t.y);
+            *(float4*)(lds + ((r * nj + job) * 8 + (lane & 7)) * kRdGroup + 4 * (lane >> 3)) = dz_f4(t.x, t.y, t.x, t.y);
             continue;
           }
           // transposed butterfly over lane bits 5, 4, 3: 32 -> 16 -> 8 -> 4 values per
@@ -191,7 +196,7 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
           }
           // lane l now holds batch rows 4 (l >> 3) + {0..3}, summed over the 8 lanes that
           // share l & 7
-          *(float4*)(lds + ((r * nj + job) * 8 + (lane & 7)) * 32 + 4 * (lane >> 3)) = v;
+          *(float4*)(lds + ((r * nj + job) * 8 + (lane & 7)) * kRdGroup + 4 * (lane >> 3)) = v;
         }
       }
     }
@@ -208,7 +213,7 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
       for (int jb = j0; jb < j1; ++jb) {
         float x[8];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) x[g] = lds[((r * nj + jb) * 8 + g) * 32 + b];
+        for (int g = 0; g < 8; ++g) x[g] = lds[((r * nj + jb) * 8 + g) * kRdGroup + b];
 #pragma unroll
         for (int g = 0; g < 8; ++g) s += x[g];
       }
