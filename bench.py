@@ -58,35 +58,31 @@ def parse_args():
   ap.add_argument('--other-configs', type=int, default=1,
                   help='also measure BASELINE configs 2 and 3 (DQN + uniform replay; '
                        'double-Q + prioritized) after the headline (0 disables)')
-  ap.add_argument('--mode', default='fused', choices=('fused', 'sequential', 'two-stream'),
+  ap.add_argument('--mode', default='fused', choices=('fused', 'sequential'),
                   help="how the steps are enqueued.  'sequential': sample launch, then the "
                        "learner step with the write-back inside Adam -- what Rainbow._learn "
                        "enqueues per learn period.  'fused' (default): the same operations in "
                        "the same order, but the replay is static between two learner steps "
                        "here, so sample(k+1)+gather(k+1) ride in step k's optimiser launch "
                        "(after write-back(k)): one launch fewer on the dependent chain.  "
-                       "'two-stream': write-back, sample AND the target network's apply for "
-                       "step k+1 on a side stream under backward(k) "
-                       "(dqn_zoo_amd/pipeline.py; measured slower, DESIGN.md 6b).  All three "
-                       "are bit-identical (tests/test_pipeline_gpu.py)")
+                       "Both are bit-identical (tests/test_fused_step_gpu.py); the sequential "
+                       "form's rate is reported in the same JSON line as `agent_form`")
   ap.add_argument('--graphs', action='store_true',
-                  help='replay the learner launches from hipGraphs (sequential / two-stream '
-                       'modes; measured 3 %% slower than eager launches for this step, kept '
+                  help='replay the learner launches from hipGraphs (sequential mode; '
+                       'measured 3 %% slower than eager launches for this step, kept '
                        'for host-bound callers such as the agent loop)')
   ap.add_argument('--no-graphs', action='store_true', help='(default now; accepted for old scripts)')
   ap.add_argument('--sequential', action='store_true', help="same as --mode sequential")
   ap.add_argument('--fused-sample', action='store_true', help="same as --mode fused")
-  ap.add_argument('--replay-only-prefetch', action='store_true',
-                  help='two-stream mode that runs only write-back/sample/gather ahead')
   ap.add_argument('--prime-steps', type=int, default=-1,
                   help='untimed steps before the warm-up (default: one per ring slot)')
   ap.add_argument('--stored-gradients', action='store_true',
                   help='keep every gradient block in memory (learner.keep_all_grads: the '
                        'stored-gradient form of the step, for A/B against the default, '
                        'which forms fc1\'s weight gradient inside the optimiser)')
-  ap.add_argument('--host-scope-events', action='store_true',
-                  help='two-stream mode with default (system-fence) events instead of '
-                       'device-scope ones (measurement aid)')
+  ap.add_argument('--agent-form-steps', type=int, default=1000,
+                  help='steps of the sequential form (what Rainbow._learn enqueues) timed '
+                       'after the headline window for `agent_form` (0 disables)')
   return ap.parse_args()
 
 
@@ -150,12 +146,14 @@ def make_step(replay, learner, batch, fused_write_back=True, fused_next_sample=F
   fused_next_sample: the replay is static between steps, so sample(k+1) + gather(k+1)
   ride in step k's optimiser launch (after write-back(k), which moves into an earlier
   backward launch): same operations, same order, one launch fewer on the chain."""
-  nxt = [None]
+  primed = [False]
 
   def step_fused():
-    s = nxt[0] if nxt[0] is not None else replay.sample_device(batch)
+    # (take_prepared() refuses a batch prepared before the replay changed)
+    s = replay.take_prepared() if primed[0] else replay.sample_device(batch)
     t = s.transitions
-    desc, nxt[0] = replay.prepare_next_sample(batch)
+    desc, _ = replay.prepare_next_sample(batch)
+    primed[0] = True
     learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
                  priority_sink=replay.priority_sink(s.ids), next_sample=desc)
 
@@ -172,25 +170,6 @@ def make_step(replay, learner, batch, fused_write_back=True, fused_next_sample=F
       learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32)
       replay.update_priorities(s.ids, learner.priorities)
 
-  return step
-
-
-def make_step_pipelined(replay, learner, batch, device, device_scope_events=True,
-                        prefetch_target=True):
-  """The same steps, software-pipelined across steps on two HIP streams
-  (dqn_zoo_amd/pipeline.py): write-back(k), sample+gather(k+1) and the TARGET
-  network's apply for batch k+1 run on a side stream underneath backward(k) and
-  Adam(k); the main stream carries only the two online applies, the loss, the
-  backward pass and the optimiser.  Bit-identical to the sequential step."""
-  from dqn_zoo_amd import pipeline
-  loop = pipeline.PipelinedRainbowLoop(replay, learner, batch,
-                                       device_scope_events=device_scope_events,
-                                       prefetch_target=prefetch_target)
-
-  def step():
-    return loop.step()
-
-  step.loop = loop
   return step
 
 
@@ -353,15 +332,16 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
                                 eps=0.01 / 32 ** 2), b, seed=args.seed,
       device=device)
 
-  nxt = [None]
+  primed = [False]
 
   def step_dqn():
     if not fused:
       t, _ = rep.sample_device(b)
       ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, None)
       return
-    t, _ = nxt[0] if nxt[0] is not None else rep.sample_device(b)
-    desc, nxt[0] = rep.prepare_next_sample(b)
+    t, _ = rep.take_prepared() if primed[0] else rep.sample_device(b)
+    desc, _ = rep.prepare_next_sample(b)
+    primed[0] = True
     ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, None, next_sample=desc)
 
   out['dqn_uniform_1m'] = run(
@@ -386,14 +366,15 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
                                 eps=(0.01 / 32 ** 2) * (1.0 / 4) ** 2), b,
       seed=args.seed, device=device)
 
-  nxt2 = [None]
+  primed2 = [False]
 
   def step_prio():
-    sm = nxt2[0] if (fused and nxt2[0] is not None) else rep.sample_device(b)
+    sm = rep.take_prepared() if (fused and primed2[0]) else rep.sample_device(b)
     t = sm.transitions
     desc = None
     if fused:
-      desc, nxt2[0] = rep.prepare_next_sample(b)
+      desc, _ = rep.prepare_next_sample(b)
+      primed2[0] = True
     ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, sm.weights32,
             priority_sink=rep.priority_sink(sm.ids), next_sample=desc)
 
@@ -706,12 +687,7 @@ def main():
   args.other_graphs = not args.no_graphs   # configs 2/3 keep hipGraph replay unless --no-graphs
   args.no_graphs = not args.graphs or args.mode == 'fused'
   learner.use_graphs = not args.no_graphs
-  if args.mode == 'two-stream':
-    step = make_step_pipelined(replay, learner, args.batch, device,
-                               device_scope_events=not args.host_scope_events,
-                               prefetch_target=not args.replay_only_prefetch)
-  else:
-    step = make_step(replay, learner, args.batch, fused_next_sample=args.mode == 'fused')
+  step = make_step(replay, learner, args.batch, fused_next_sample=args.mode == 'fused')
   seq_step = make_step(replay, learner, args.batch)
 
   # ---- setup that is NOT a step, all of it before the clock starts ----------
@@ -784,8 +760,7 @@ def main():
             'collective': 'rccl' if dist is not None else 'none (single process)',
             'host_cpus_rank0': len(cpus),
             'untimed_setup_steps': prime,
-            'mode': args.mode,
-            'streams': 'two (dqn_zoo_amd/pipeline.py)' if args.mode == 'two-stream' else 'one'},
+            'mode': args.mode, 'streams': 'one'},
     }
     if args.sustain_steps > 0:
       # the same loop over a window long enough that pipeline fill and host jitter do
@@ -799,6 +774,25 @@ def main():
       out['sustained'] = {'steps': args.sustain_steps,
                           'value': round(args.sustain_steps / ds, 2),
                           'ms_per_step': round(1e3 * ds / args.sustain_steps, 4)}
+    if args.agent_form_steps > 0:
+      # The form the drop-in agent enqueues per learn period (Rainbow._learn: a sample +
+      # gather launch, then the learner step with the write-back inside it) -- transitions
+      # are inserted between two learner steps there, so the next sample cannot ride in this
+      # step's optimiser launch.  Same loop, same store, same process.
+      for _ in range(32):
+        seq_step()
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      for _ in range(args.agent_form_steps):
+        seq_step()
+      torch.cuda.synchronize()
+      ds = time.perf_counter() - t1
+      out['agent_form'] = {
+          'what': 'sequential form of the same step, as Rainbow._learn enqueues it: '
+                  'dz_prioritized_sample_gather launch + dz_rainbow_learn',
+          'steps': args.agent_form_steps, 'value': round(args.agent_form_steps / ds, 2),
+          'unit': 'steps/s', 'ms_per_step': round(1e3 * ds / args.agent_form_steps, 4),
+          'launches': None}
     if args.prof_steps > 0:
       learner.use_graphs = False  # per-kernel events need eager launches
       prof_step = step if args.mode == 'fused' else seq_step

@@ -85,7 +85,7 @@ class RainbowArgs(ctypes.Structure):
       ('prio_node', c_vp), ('prio_cap_pow2', c_i64), ('prio_capacity', c_i64),
       ('prio_ids', c_vp), ('prio_exponent', c_f64), ('prio_max_seen', c_vp),
       ('prio_status', c_vp), ('keep_all_grads', c_i32), ('pad_', c_i32),
-      ('tgt_part', c_vp), ('tgt_noise', c_vp), ('next_sample', c_vp),
+      ('next_sample', c_vp),
   ]
 
 
@@ -189,12 +189,6 @@ SIGNATURES = {
                                  c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dz_rainbow_act': (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, ctypes.c_uint64,
                                ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'dz_rainbow_target_forward': (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp,
-                                          ctypes.c_uint64, c_vp, c_vp, c_vp]),
-    'dz_event_create': (c_int, [c_int, ctypes.POINTER(c_vp)]),
-    'dz_event_destroy': (c_int, [c_vp]),
-    'dz_event_record': (c_int, [c_vp, c_vp]),
-    'dz_stream_wait_event': (c_int, [c_vp, c_vp]),
     'dz_rainbow_graph_capture': (c_int, [ctypes.POINTER(RainbowArgs), c_int, c_vp,
                                          ctypes.POINTER(c_vp)]),
     'dz_atari_observation': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int,

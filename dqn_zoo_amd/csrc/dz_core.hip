@@ -85,31 +85,3 @@ extern "C" int dz_prof_read(int max_marks, float* ms_out, char* names_out) {
   }
   return n;
 }
-
-// ---- cross-stream ordering (pipelined step) ------------------------------------
-// hipEventDisableSystemFence: the waiter is another stream of the SAME device, so the
-// record needs no system-scope release (a full L2 write-back + host-visible fence per
-// hop otherwise); timing is off.
-extern "C" int dz_event_create(int device_scope, void** event_out) {
-  DZ_REQUIRE(event_out);
-  hipEvent_t e = nullptr;
-  DZ_HIP_CHECK(hipEventCreateWithFlags(
-      &e, hipEventDisableTiming | (device_scope ? hipEventDisableSystemFence : 0u)));
-  *event_out = (void*)e;
-  return DZ_OK;
-}
-extern "C" int dz_event_destroy(void* event) {
-  DZ_REQUIRE(event);
-  DZ_HIP_CHECK(hipEventDestroy((hipEvent_t)event));
-  return DZ_OK;
-}
-extern "C" int dz_event_record(void* event, dz_stream_t stream) {
-  DZ_REQUIRE(event);
-  DZ_HIP_CHECK(hipEventRecord((hipEvent_t)event, dz_s(stream)));
-  return DZ_OK;
-}
-extern "C" int dz_stream_wait_event(dz_stream_t stream, void* event) {
-  DZ_REQUIRE(event);
-  DZ_HIP_CHECK(hipStreamWaitEvent(dz_s(stream), (hipEvent_t)event, 0));
-  return DZ_OK;
-}

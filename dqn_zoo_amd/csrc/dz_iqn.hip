@@ -113,7 +113,7 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
     // 64x64 tiles, KT4, tiles in XCD-aware order (all column tiles of one A-row slab on
     // one XCD: the 77 MB activation crosses the fabric once instead of 8 times, +4 %).
     // Measured alternatives (removed): KT2 207 us vs 192; 2-4 accumulators per wave
-    // 258-325 us (141-256 VGPRs, occupancy 1-2): DESIGN.md 6b.
+    // 258-325 us (141-256 VGPRs, occupancy 1-2): EXPERIMENTS.md.
     rc = dz_launch_gemm_xcd<IqnLinOp<2, 2, 1, 4>>(p, dim3(kHid / 64, my, ap.G), s);
     if (rc) return rc;
     DZ_PROF(s, "fc1_fwd");

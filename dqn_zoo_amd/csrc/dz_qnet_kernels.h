@@ -348,11 +348,6 @@ struct HeadPre {
   int eps_out;         // its noise offset
   int plain_bias;      // 1: the bias at b_sig is an ordinary one (no noise factor): C51
   int groups;          // rows g*B + b formed per sample (0 = 3: Rainbow)
-  // Optional: group 2 (the target apply) comes from ANOTHER slab set -- the one
-  // dz_rainbow_target_forward left for this batch ([S][rows2][ld], row b) -- and
-  // `part` then holds groups 0 and 1 only (rows = 2B).  Same fold order: same bits.
-  const float* part2;
-  int rows2;
 };
 // Launch with 256 threads: the 4 waves share the selector's per-action softmaxes
 // (A of them, 3 wave reductions each); wave 0 alone runs the rest.
@@ -400,11 +395,9 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
       for (int e = 0; e < E; ++e) {
         const int i = min(base + (int)threadIdx.x + 256 * e, n - 1);
         const int g = i / ld, c = i - g * ld;
-        // (dz_val: selects on VALUES -- see FcDgradOp::locate)
-        const bool alt = pre.part2 != nullptr && g == 2;
-        const float* src = dz_val(alt, pre.part2, pre.part);
-        const long row = dz_val(alt, (long)b, (long)g * B + b);
-        const long rows = dz_val(alt, (long)pre.rows2, (long)pre.rows);
+        const float* src = pre.part;
+        const long row = (long)g * B + b;
+        const long rows = (long)pre.rows;
 #pragma unroll
         for (int sidx = 0; sidx < SMAX; ++sidx) {
           const float t = src[((long)min(sidx, pre.S - 1) * rows + row) * ld + c];
@@ -635,8 +628,14 @@ __device__ __forceinline__ float dz_div_by(float a, float b, float rb) {
 __device__ __forceinline__ void adam_elem(float& P, float G, float& M, float& V, bool pass,
                                           float gn, float bc1, float bc2, float lr, float b1,
                                           float b2, float eps, float max_norm) {
-  const float rg = 1.0f / gn, r1 = 1.0f / bc1, r2 = 1.0f / bc2;   // (uniform: hoisted)
-  const float gj = pass ? G : dz_div_by(G, gn, rg) * max_norm;
+  // (launch-uniform, hoisted.)  An overflowed norm: G / inf must be sign(G)*0 as IEEE division --
+  // and optax's clip -- give it; q = G * (1/inf) = 0 times b = inf in the residual would be NaN,
+  // so the pair (b, 1/b) becomes (0, 0): residual G, result fma(G, 0, +-0) = sign(G)*0, NaN for
+  // G = inf / NaN as the division.  A NaN norm stays NaN.
+  const bool gn_inf = gn == __builtin_inff();
+  const float gb = gn_inf ? 0.0f : gn;
+  const float rg = gn_inf ? 0.0f : 1.0f / gn, r1 = 1.0f / bc1, r2 = 1.0f / bc2;
+  const float gj = pass ? G : dz_div_by(G, gb, rg) * max_norm;
   M = (1.0f - b1) * gj + b1 * M;
   V = (1.0f - b2) * (gj * gj) + b2 * V;
   const float upd = dz_div_by(M, bc1, r1) / (sqrtf(dz_div_by(V, bc2, r2)) + eps);
@@ -823,15 +822,6 @@ struct NoiseSide {
   typedef NoiseParams Params;
   __device__ static void run(const Params& q, unsigned block) {
     noise_fill_at(q, (long)block * 256 + threadIdx.x);
-  }
-};
-
-// ++*p as one extra block of a launch (a device-side step counter advanced by the
-// LAST launch of a sequence whose FIRST launch read it).
-struct BumpSide {
-  struct Params { int32_t* p; };
-  __device__ static void run(const Params& q, unsigned block) {
-    if (block == 0 && threadIdx.x == 0) *q.p = *q.p + 1;
   }
 };
 

@@ -347,7 +347,7 @@ struct FcFwdOp {
     }
     return dz_sel4(ok, dz_mul4(v, dz_one_or4(sig, e)));
   }
-  static constexpr int SPLIT_STORE = 0;  // distributed epilogue measured slower for this Op
+  static constexpr int SPLIT_STORE = 0;  // distributed epilogue measured slower for this Op (EXPERIMENTS.md)
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc, unsigned rmask = 0xffffu) {
     const FcHead& hd = t.hd;
@@ -483,7 +483,7 @@ struct FcDgradOp {
     }
     return dz_scale4(v, L.sig ? e : 1.f);
   }
-  static constexpr int SPLIT_STORE = 0;  // distributed epilogue measured slower for this Op
+  static constexpr int SPLIT_STORE = 0;  // distributed epilogue measured slower for this Op (EXPERIMENTS.md)
   __device__ __forceinline__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc, unsigned rmask = 0xffffu) {
     const int col = t.n0 + wn * 32 + (lane & 31);
@@ -761,7 +761,7 @@ struct ConvDgradOp {
     const int kh = (t.z / S) + (tap / TS) * S, kw = (t.z % S) + (tap % TS) * S;
     return dz_ld4(p.w + ((long)(kh * KS + kw) * C + ci) * CO + co);
   }
-  static constexpr int SPLIT_STORE = 0;  // distributed epilogue measured slower for this Op
+  static constexpr int SPLIT_STORE = 0;  // distributed epilogue measured slower for this Op (EXPERIMENTS.md)
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc, unsigned rmask = 0xffffu) {
     const int ci = t.n0 + wn * 32 + (lane & 31);

@@ -1,17 +1,22 @@
 // Rainbow learner step on one MI355X (ref: rainbow/agent.py:85-121).
 //
-// Launch sequence (16 launches, all on the caller's stream, no host sync):
-//   forward : conv1 (+ the step's noise draw as a side job) conv2 conv3 (3 applies
-//             batched as groups) -> fc1 (noisy adv1|val1, one weight stream per
-//             parameter set, W_eff in registers, split-K) -> epilogue -> fc2 (noisy
-//             adv2, val2, split-K) -> head/loss (folds the fc2 slabs; dueling +
-//             softmax + double-Q selector + Cramer projection + cross-entropy +
-//             dlogits + priorities)
-//   backward: [fc2 wgrad | fc2 dgrad x2] -> reduce -> [fc1 wgrad | fc1 dgrad] ->
-//             reduce -> [conv3 wgrad | conv3 dgrad | sum-tree priority write-back]
-//             -> [conv2 wgrad | conv2 dgrad] -> conv1 wgrad -> finalize (conv
-//             partials, bias column sums, global-norm partials, step count)
-//   update  : Adam (folds the norm partials, clip, derives the fc1 sigma gradient)
+// Launch sequence of the one-call step at batch <= 32 (14 launches, all on the caller's
+// stream, no host sync; DESIGN.md 4 has the table):
+//   forward : conv1 (+ the step's noise draw as side blocks) -> conv2 -> conv3 (the 3
+//             applies batched as groups) -> fc1 (noisy adv1|val1: one weight stream per
+//             parameter set, W_eff in registers, split-K slabs) -> epilogue (fold + bias +
+//             ReLU) -> fc2 (noisy adv2, val2, split-K) -> head/loss (folds the fc2 slabs;
+//             dueling + softmax + double-Q selector + Cramer projection + cross-entropy +
+//             dlogits + priorities; side blocks: Gram matrices of fc1's input)
+//   backward: [fc2 input gradient as a row-owning stream | fc2 weight gradient] ->
+//             [Gram side blocks of dh1 | sum-tree priority write-back | fc1 input gradient
+//             as a row-owning stream] -> [conv3 wgrad | conv3 dgrad] -> [conv2 wgrad |
+//             conv2 dgrad] -> conv1 wgrad -> finalize (conv slabs, bias column sums,
+//             global-norm partials, step count)
+//   update  : Adam; forms fc1's mu and sigma weight gradients on the fly (dz_fc1_onfly.h)
+//             and, in the loop over a static replay, carries the next step's sample+gather
+// Other shapes of the call (split phases, batch > 32, keep_all_grads) store fc1's weight
+// gradient: [fc1 wgrad | fc1 dgrad] -> reduce, and Adam streams the stored vector.
 // Roofline notes per kernel are in DESIGN.md.
 #include "dz_sumtree_dev.h"
 #include "dz_torso.h"
@@ -21,7 +26,7 @@
 namespace {
 
 // Launch constants: the measured best on MI355X at B = 32 (the sweeps and the
-// alternatives that lost are in DESIGN.md 6b; the code that implemented them is gone).
+// alternatives that lost are in EXPERIMENTS.md; the code that implemented them is gone).
 constexpr int kFc1Splits = 32;       // fc1 forward k-splits (98 rows each)
 constexpr int kFc1DgradSplits = 12;  // fc1 input-gradient k-splits: 11 slabs of 6 single-chunk stages (17.9 us; 16 x 4: 19.2; 10 x 7: 19.6)
 constexpr int kFc2Splits = 8;        // fc2 forward k-splits
@@ -68,8 +73,7 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
                            const float* const* prm, const float* const* nz,
                            const uint8_t* const* in, float* ws, hipStream_t s,
                            const NoiseParams* resample = nullptr,
-                             bool skip_fc2_epilogue = false, bool stop_after_fc1 = false,
-                           int32_t* bump = nullptr) {
+                           bool skip_fc2_epilogue = false, bool stop_after_fc1 = false) {
   int rc = DZ_OK;
   const int NA = L.num_actions * L.num_atoms;
   const int ld2 = L.adv2_ld + L.val2_ld;
@@ -126,10 +130,7 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
     p.head[0] = fc2h[0]; p.head[1] = fc2h[1];
     p.part = ws + L.ws_fc2_part; p.ldo = ld2;
     const dim3 g2((NA + FcFwd::BN - 1) / FcFwd::BN, (B + 31) / 32, G * 2 * kFc2Splits);
-    if (bump)  // ++*bump by one extra block of this (last) launch: the first launch read it
-      rc = dz_launch_gemm_side<FcFwdOp<1, 2, 2, 4, 2>, BumpSide>(p, g2, BumpSide::Params{bump}, 1, s);
-    else
-      rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4, 2>>(p, g2, s);
+    rc = dz_launch_gemm<FcFwdOp<1, 2, 2, 4, 2>>(p, g2, s);
     if (rc) return rc;
     DZ_PROF(s, "fc2_fwd");
     if (skip_fc2_epilogue) return rc;  // the loss kernel folds the partial slabs itself
@@ -260,13 +261,8 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   const FcHead* fc2h = H.fc2h;
 
   if (g_dz_prof_on) dz_prof_begin(s);
-  // Precomputed target apply (dz_rainbow_target_forward, tgt_part): only the two
-  // online applies run here; the loss kernel folds group 2 from the other slab set.
-  const bool tgt_pre = a->tgt_part != nullptr;
-  const int Gf = tgt_pre ? 2 : kG;
-  if (tgt_pre) { DZ_REQUIRE(a->tgt_noise); nz[2] = a->tgt_noise; }
+  const int Gf = kG;
   const bool fuse = (size_t)3 * ld2 * sizeof(float) <= 48 * 1024;
-  DZ_REQUIRE(fuse || !tgt_pre);  // the slab hand-over lives in the fused loss kernel
   const bool do_nets = (phases & (DZ_PHASE_FORWARD | DZ_PHASE_FWD_NETS)) != 0;
   const bool do_loss = (phases & (DZ_PHASE_FORWARD | DZ_PHASE_FWD_LOSS)) != 0;
   // the step's noise: blocks [0, Gf) of 3 at stream position *adam_count * 3 * stride
@@ -301,7 +297,6 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         pre.part = ws + L.ws_fc2_part; pre.S = kFc2Splits; pre.rows = Gf * B;
         for (int g = 0; g < kG; ++g) { pre.prm[g] = prm[g]; pre.nz[g] = nz[g]; }
         pre.b_sig = L.fc2_sig_b; pre.eps_out = (int)L.n_fc2_out;
-        if (tgt_pre) { pre.part2 = a->tgt_part; pre.rows2 = B; }
         hipLaunchKernelGGL(rainbow_head_loss_kernel<1>, dim3(hb), dim3(256),
                            (size_t)3 * ld2 * sizeof(float), s, ws + L.ws_fc2_out, ld2, NAp, B,
                            A, K, 1, 1, 2, a->a_tm1, a->r_t, a->discount_t, a->weights,
@@ -691,37 +686,6 @@ extern "C" int dz_rainbow_apply(int num_actions, int num_atoms, int batch,
                      num_atoms, support, q_values_out, greedy_out, vmax_out, HeadPre{});
   DZ_LAUNCH_CHECK();
   return DZ_OK;
-}
-
-// The target network's apply run ahead of its consumer (header: dz_rainbow_args_t::
-// tgt_part).  Same launches as group 2 of the three-apply forward, tile for tile, so
-// the slabs -- and everything the loss kernel derives from them -- are bit-identical.
-extern "C" int dz_rainbow_target_forward(int num_actions, int num_atoms, int batch,
-                                         const float* target_params, const uint8_t* s_t,
-                                         float* noise, uint64_t noise_seed,
-                                         int32_t* step_counter, float* ws,
-                                         dz_stream_t stream) {
-  DZ_REQUIRE(target_params && s_t && noise && ws);
-  dz_rainbow_layout_t L;
-  int rc = dz_rainbow_layout(num_actions, num_atoms, batch, &L);
-  if (rc != DZ_OK) return rc;
-  hipStream_t s = dz_s(stream);
-  FwdHeads H;
-  make_heads(L, H);
-  const float* prm[kG] = {target_params, target_params, target_params};
-  const float* nz[kG] = {noise, noise, noise};
-  const uint8_t* in[kG] = {s_t, s_t, s_t};
-  const int ld2 = L.adv2_ld + L.val2_ld;
-  DZ_REQUIRE((size_t)3 * ld2 * sizeof(float) <= 48 * 1024);  // consumer folds the slabs
-  // block 2 of the consuming step's three noise blocks (dz_rainbow_learn's nq)
-  const NoiseParams nq = {noise, (long)L.noise_stride, noise_seed, (uint64_t)0x5eed,
-                          step_counter, 3 * (long)L.noise_stride, 2 * (long)L.noise_stride};
-  const bool prof = g_dz_prof_on;
-  g_dz_prof_on = false;  // marks belong to dz_rainbow_learn
-  rc = rainbow_forward(L, H, 1, batch, prm, nz, in, ws, s, step_counter ? &nq : nullptr,
-                       /*skip_fc2_epilogue=*/true, /*stop_after_fc1=*/false, step_counter);
-  g_dz_prof_on = prof;
-  return rc;
 }
 
 // The actor's apply (ref: rainbow/agent.py:125-131, 171-179): fresh noise from

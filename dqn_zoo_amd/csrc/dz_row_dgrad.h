@@ -21,9 +21,6 @@
 // ref: rainbow/agent.py:112-118 (jax.grad through the network), networks.py:150-180.
 #pragma once
 #include "dz_qnet_ops.h"
-#ifndef DZ_RD_ABL
-#define DZ_RD_ABL 0   /* ablation bits (tools/micro/dgrad_micro.hip only) */
-#endif
 
 namespace {
 struct RowDgrad {
@@ -131,11 +128,8 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
     dz_f2 D[16][4];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      float4 d0 = dz_f4(1.f, 1.f, 1.f, 1.f), d1 = d0;
-      if (!(DZ_RD_ABL & 1)) {
-        d0 = *(const float4*)(dyp + (unsigned)(min(2 * i, q.M - 1) * q.ldy + cc) * 4u);
-        d1 = *(const float4*)(dyp + (unsigned)(min(2 * i + 1, q.M - 1) * q.ldy + cc) * 4u);
-      }
+      const float4 d0 = *(const float4*)(dyp + (unsigned)(min(2 * i, q.M - 1) * q.ldy + cc) * 4u);
+      const float4 d1 = *(const float4*)(dyp + (unsigned)(min(2 * i + 1, q.M - 1) * q.ldy + cc) * 4u);
       const float m0 = 2 * i < q.M ? 1.f : 0.f, m1 = 2 * i + 1 < q.M ? 1.f : 0.f;
       D[i][0] = dz_f2{d0.x * (m0 * v0), d1.x * (m1 * v0)}; D[i][1] = dz_f2{d0.y * (m0 * v1), d1.y * (m1 * v1)};
       D[i][2] = dz_f2{d0.z * (m0 * v2), d1.z * (m1 * v2)}; D[i][3] = dz_f2{d0.w * (m0 * v3), d1.w * (m1 * v3)};
@@ -163,18 +157,10 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
           dz_f2 a[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            if (DZ_RD_ABL & 2) { a[i] = D[i][0] * (w0 + w1 + w2 + w3); continue; }
             dz_f2 t = D[i][0] * w0;
             t = __builtin_elementwise_fma(D[i][1], dz_f2{w1, w1}, t);
             t = __builtin_elementwise_fma(D[i][2], dz_f2{w2, w2}, t);
             a[i] = __builtin_elementwise_fma(D[i][3], dz_f2{w3, w3}, t);
-          }
-          if (DZ_RD_ABL & 4) {
-            dz_f2 t = a[0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) t += a[i];
-            *(float4*)(lds + ((r * nj + job) * 8 + (lane & 7)) * kRdGroup + 4 * (lane >> 3)) = dz_f4(t.x, t.y, t.x, t.y);
-            continue;
           }
           // transposed butterfly over lane bits 5, 4, 3: 32 -> 16 -> 8 -> 4 values per
           // lane (a[i] = batch rows 2i, 2i+1)

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kMaxBatch) void prioritized_update_kernel(PrioUpdat
   __shared__ double s_red[kMaxBatch / 64];
   prio_update_body(p, s_leaf, s_red);
 }
-// batches <= 256: the two-round-trip walk (launched with 256 threads)
+// batches <= kWbMaxBatch (255): the two-round-trip walk (launched with 256 threads)
 __global__ __launch_bounds__(256) void prioritized_update_fast_kernel(PrioUpdateParams p) {
   __shared__ WbScratch wb;
   PrioUpdateSideFast::run(p, 0, &wb, (int)sizeof(wb));
@@ -318,7 +318,7 @@ extern "C" int dz_prioritized_update(double* node, int64_t cap_pow2,
   dz_prof_pair(2, 0, dz_s(stream));
   const PrioUpdateParams q = {node, cap_pow2, capacity, size, t, ids, priorities, prio_is_f32,
                               exponent, n, max_seen, status, 1};
-  if (n <= 256 && cap_pow2 <= ((int64_t)1 << 31))
+  if (n <= kWbMaxBatch && cap_pow2 <= ((int64_t)1 << 31))
     hipLaunchKernelGGL(prioritized_update_fast_kernel, dim3(1), dim3(256), 0, dz_s(stream), q);
   else
     hipLaunchKernelGGL(prioritized_update_kernel, dim3(1), dim3(round_up_64(n)), 0,

@@ -48,7 +48,8 @@ __device__ void set_leaves_and_ancestors(double* node, int64_t cap, int64_t my_l
 }
 
 // The same result with TWO dependent trips to memory instead of one per level (a batch of
-// n <= 256 leaves, one workgroup of 256 threads, cap <= 2^31).
+// n <= 255 leaves -- partner indices are bytes and 0xFF means "none", so batch element
+// 255 must not exist -- one workgroup of 256 threads, cap <= 2^31).
 //   1. every thread requests the sibling of each node on its leaf's path -- up to 31
 //      independent loads, one round trip -- before anything is stored;
 //   2. one scan over the batch finds, per thread, the duplicates of its leaf (the LAST
@@ -63,11 +64,12 @@ __device__ void set_leaves_and_ancestors(double* node, int64_t cap, int64_t my_l
 // Each touched node ends up exactly fl(left + right) of its final children (IEEE addition
 // is commutative: operand order is immaterial), every duplicate of a leaf carries the last
 // duplicate's value: the tree is bit-identical to set_leaves_and_ancestors (tools/micro/
-// wb_micro.hip, tests/test_pipeline_gpu.py).  As a side block of a busy launch the
+// wb_micro.hip, tests/test_fused_step_gpu.py).  As a side block of a busy launch the
 // level-by-level form's 21 dependent round trips stretch to 15-30 us; this one does not.
 // (First version: an O(n) LDS scan for the sibling at EVERY level -- 1.3 us per level of
 // 64-bit compares, 33 us per call; the partner table makes the scan a one-off.)
 constexpr int kWbMaxLevels = 31;
+constexpr int kWbMaxBatch = 255;         // partner[][] holds j as a byte; 0xFF is the "no partner" mark
 struct WbScratch {                       // 14.3 KB; may alias a host kernel's idle LDS
   uint32_t x[256];                       // node index of the leaf (cap + leaf < 2^32)
   double v0[256];                        // leaf values (scan), then level values, ping ...
@@ -225,7 +227,7 @@ __device__ __forceinline__ void prio_update_body(const PrioUpdateParams& q, int6
       *max_seen = mm;
     }
   }
-  if (wb && n <= 256 && blockDim.x == 256 && cap <= ((int64_t)1 << 31)) {
+  if (wb && n <= kWbMaxBatch && blockDim.x == 256 && cap <= ((int64_t)1 << 31)) {
     __syncthreads();
     set_leaves_and_ancestors_fast(node, cap, leaf, v, active, n, *wb);
   } else {

@@ -19,7 +19,7 @@ struct TorsoBufs {
 // Forward launch shapes: the M dimension (3 applies x 32 images x output pixels)
 // gives 300-600 workgroups of the shapes in dz_qnet_kernels.h on 256 CUs (the
 // measured best of a sweep over 4-6 tile shapes per layer; XCD-ordered tiles made
-// no difference for these: DESIGN.md 6b).
+// no difference for these: EXPERIMENTS.md).
 template <class Op>
 inline int launch_conv_fwd(const ConvFwdParams& p, int CO, int G, int B, hipStream_t s) {
   return dz_launch_gemm<Op>(p, dim3(CO / Op::BN, G * Op::tiles_per_group(B), 1), s);

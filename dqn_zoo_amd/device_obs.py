@@ -29,10 +29,25 @@ def depth_for(accumulator, floor: int = 8) -> int:
   insert that reads it can still be queued: the insert enqueued at frame t-1 reads
   the observations of frames t-1 and t-1-n (n-step window), and `step()` waits only
   for the acting launches, so slot reuse must be at least n + 2 frames apart (one
-  spare frame on top).  n = 3 (Rainbow) fits the default 8; n = 7 would alias."""
-  window = getattr(accumulator, '_window', None)
-  n = getattr(window, 'maxlen', None) or 1
+  spare frame on top).  n = 3 (Rainbow) fits the default 8; n = 7 would alias.
+
+  The window is read from the accumulator's public `window_size` (this package's
+  accumulators), else from the deque the reference's `NStepTransitionAccumulator`
+  keeps (`_transitions`, replay.py:841).  An accumulator that tells neither (a wrapper,
+  a custom class) gets UNKNOWN_WINDOW_DEPTH slots -- 1.8 MB of pinned memory instead of
+  a silent fall-back to 8 that an n >= 6 window would alias."""
+  n = getattr(accumulator, 'window_size', None)
+  if n is None:
+    for name in ('_transitions', '_window'):
+      n = getattr(getattr(accumulator, name, None), 'maxlen', None)
+      if n is not None:
+        break
+  if n is None:
+    return max(int(floor), UNKNOWN_WINDOW_DEPTH)
   return max(int(floor), int(n) + 3)
+
+
+UNKNOWN_WINDOW_DEPTH = 64
 
 
 class ObservationCache:

@@ -285,58 +285,9 @@ class RainbowLearner:
     return self.ws[off:off + count]
 
   # -- the step -----------------------------------------------------------------
-  # -- the target apply, run ahead of its step -----------------------------------
-  def target_forward(self, s_t: torch.Tensor, resample_noise: bool = True,
-                     step_from: typing.Optional[torch.Tensor] = None) -> None:
-    """Enqueues target(s_t) for a sampled batch on the CURRENT stream, into buffers
-    of its own (ref: rainbow/agent.py:91-96: the target apply needs the target
-    parameters and the batch, never the running optimiser step).  The step that
-    consumes it is `step(..., target_pre=True)`, ordered after this call by the
-    caller (same stream, or an event).  Noise: drawn on the device at the stream
-    position the three-apply step would use (`resample_noise`), from a device
-    counter that must equal the optimiser count at the consuming step: pass
-    `step_from=self.adam_count` on the first call of a pipeline, afterwards every
-    call advances it by one.  resample_noise=False: `set_target_noise` values."""
-    b = self.batch_size
-    if not (isinstance(s_t, torch.Tensor) and s_t.dtype == torch.uint8 and
-            tuple(s_t.shape) == (b, 84, 84, 4) and s_t.is_contiguous()):
-      raise ValueError('s_t must be a contiguous uint8 device tensor [%d,84,84,4]' % b)
-    self._tgt_alloc()
-    if step_from is not None:
-      self._tgt_step.copy_(step_from)
-    stream = _lib.stream_ptr(self.device)
-    enqueue = lambda: _lib.check(self._lib.dz_rainbow_target_forward(
-        self.network.num_actions, self.network.num_atoms, b, self.target.data_ptr(),
-        s_t.data_ptr(), self._tgt_noise.data_ptr(), self._noise_seed,
-        self._tgt_step.data_ptr() if resample_noise else None,
-        self._tgt_ws.data_ptr(), stream), 'dz_rainbow_target_forward')
-    graphs = bool(stream) if self.use_graphs is None else self.use_graphs
-    if not graphs:
-      enqueue()
-      return
-    key = ('tgt', s_t.data_ptr(), bool(resample_noise))
-    g = self._graphs.get(key)
-    if g is None:
-      g = self._graphs[key] = _lib.capture_graph(stream, enqueue)
-    _lib.check(self._lib.dz_graph_launch(g, stream), 'dz_graph_launch')
-
-  def set_target_noise(self, noise: dict) -> None:
-    """Explicit noise block for `target_forward(resample_noise=False)`."""
-    self._tgt_alloc()
-    self._tgt_noise.copy_(torch.from_numpy(self.layout.pack_noise(noise)))
-
-  def _tgt_alloc(self) -> None:
-    if getattr(self, '_tgt_ws', None) is None:
-      L = self.layout
-      f32 = dict(dtype=torch.float32, device=self.device)
-      self._tgt_ws = torch.zeros(L.ws_count, **f32)
-      self._tgt_noise = torch.zeros(L.noise_stride, **f32)
-      self._tgt_step = torch.zeros(1, dtype=torch.int32, device=self.device)
-      self._tgt_part_ptr = self._tgt_ws.data_ptr() + 4 * int(L.c.ws_fc2_part)
-
   def step(self, s_tm1, a_tm1, r_t, discount_t, s_t, weights,
            phases: int = _lib.PHASE_ALL, resample_noise: bool = True,
-           priority_sink=None, target_pre: bool = False, next_sample=None) -> None:
+           priority_sink=None, next_sample=None) -> None:
     """Enqueues one learner step.  Inputs are device tensors exactly as
     `PrioritizedTransitionReplay.sample_device` returns them: uint8 states
     [B,84,84,4], int64 actions, float64 rewards/discounts, float32 weights.
@@ -346,9 +297,6 @@ class RainbowLearner:
     the step writes the new priorities into that replay's sum tree itself,
     inside its backward launches -- the caller then must NOT call
     `update_priorities` for this batch.  Needs PHASE_BACKWARD in `phases`.
-
-    `target_pre`: target(s_t) of this batch was computed by `target_forward`
-    (ordered before this call): only the two online applies run here.
 
     `next_sample` (descriptor from `PrioritizedTransitionReplay.prepare_next_sample`,
     with `priority_sink` and a full step): the optimiser launch carries the NEXT
@@ -370,7 +318,7 @@ class RainbowLearner:
       key = (s_tm1.data_ptr(), s_t.data_ptr(), a_tm1.data_ptr(), r_t.data_ptr(),
              discount_t.data_ptr(), weights.data_ptr(), phases,
              int(bool(resample_noise) and nets),
-             sink[0], sink[3], int(self.keep_all_grads), bool(target_pre))
+             sink[0], sink[3], int(self.keep_all_grads))
       g = self._graphs.get(key)
       if g is not None:
         _lib.check(self._lib.dz_graph_launch(g, stream), 'dz_graph_launch')
@@ -412,13 +360,6 @@ class RainbowLearner:
     a.resample_noise = int(bool(resample_noise) and nets)
     a.keep_all_grads = int(self.keep_all_grads)
     a.next_sample = None if next_sample is None else ctypes.addressof(next_sample)
-    if target_pre:
-      self._tgt_alloc()
-      a.tgt_part = self._tgt_part_ptr
-      a.tgt_noise = self._tgt_noise.data_ptr()
-    else:
-      a.tgt_part = None
-      a.tgt_noise = None
     if priority_sink is not None:
       if not phases & _lib.PHASE_BACKWARD:
         raise ValueError('priority_sink needs the backward phase in this call')
@@ -434,8 +375,7 @@ class RainbowLearner:
             'hipGraph capture needs a non-default stream: run the learner under '
             '`torch.cuda.stream(torch.cuda.Stream())` (bench.py does)')
       key = (a.s_tm1, a.s_t, a.a_tm1, a.r_t, a.discount_t, a.weights, phases,
-             a.resample_noise, a.prio_node, a.prio_ids, a.keep_all_grads,
-             bool(target_pre))
+             a.resample_noise, a.prio_node, a.prio_ids, a.keep_all_grads)
       g = self._graphs.get(key)
       if g is None:
         if self.use_graphs is None and len(self._graphs) >= self.MAX_AUTO_GRAPHS:

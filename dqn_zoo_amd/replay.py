@@ -583,6 +583,14 @@ class TransitionReplay(_ReplayBase):
     self._prepared = (self._t, (outs, ids))
     return d, (outs, ids)
 
+  def take_prepared(self):
+    """The `(structure of device tensors, ids)` a learner step produced from
+    `prepare_next_sample`'s descriptor; refuses it if the store changed in between."""
+    t, batch = self._prepared
+    if t != self._t:
+      raise RuntimeError('the replay changed between prepare_next_sample and its use')
+    return batch
+
   def sample(self, size: int) -> ReplayStructure:
     """Samples a batch uniformly with replacement (replay.py:157-163)."""
     outs, _ = self.sample_device(size)
@@ -1272,6 +1280,8 @@ class PrioritizedTransitionReplay(_ReplayBase):
 class TransitionAccumulator:
   """Accumulates timesteps into 1-step transitions (ref: replay.py:771-805)."""
 
+  window_size = 1   # frames between s_tm1 and s_t (device_obs.depth_for)
+
   def __init__(self):
     self.reset()
 
@@ -1313,6 +1323,11 @@ class NStepTransitionAccumulator:
   def __init__(self, n):
     self._window = collections.deque(maxlen=n)
     self.reset()
+
+  @property
+  def window_size(self) -> int:
+    """n: the largest number of frames between s_tm1 and s_t of an emitted transition."""
+    return self._window.maxlen
 
   def step(self, timestep_t, a_t) -> Iterable[Transition]:
     if timestep_t.first():

@@ -349,16 +349,6 @@ typedef struct {
    * 1: every gradient block is materialised in `grad` (inspection, tests, A/B).       */
   int32_t keep_all_grads;
   int32_t pad_;
-  /* Optional precomputed target apply (software pipelining across steps): when
-   * tgt_part != NULL the forward phase evaluates only the two ONLINE applies and the
-   * loss kernel takes target(s_t) from tgt_part -- the fc2 split-K slabs
-   * dz_rainbow_target_forward left in ITS workspace for this batch's s_t -- with
-   * tgt_noise the noise block that apply used.  The target network's apply depends
-   * only on the target parameters and on the sampled batch, never on this step's
-   * optimiser update (rainbow/agent.py:91-96), so it can run ahead on another
-   * stream.  Results are bit-identical to the three-apply form.                  */
-  const float* tgt_part;
-  const float* tgt_noise;
   /* Optional (needs DZ_PHASE_BACKWARD | DZ_PHASE_OPTIMIZER in the call): the sample +
    * gather of the NEXT step rides in this step's optimiser launch as extra blocks, and
    * the priority write-back (prio_*) moves into an EARLIER backward launch, so that
@@ -374,35 +364,11 @@ typedef struct {
 #define DZ_PHASE_BACKWARD 2  /* gradients into args->grad                     */
 #define DZ_PHASE_OPTIMIZER 4 /* global norm + clip + Adam into args->online   */
 #define DZ_PHASE_ALL 7
-/* the two halves of DZ_PHASE_FORWARD, for callers that put a cross-stream wait
- * (the precomputed target apply) between them                                 */
+/* the two halves of DZ_PHASE_FORWARD, for callers that enqueue them separately  */
 #define DZ_PHASE_FWD_NETS 8  /* the network applies up to the fc2 partial slabs */
 #define DZ_PHASE_FWD_LOSS 16 /* loss kernel (folds the slabs): losses, priorities, dlogits */
 
 int dz_rainbow_learn(const dz_rainbow_args_t* args, int phases, dz_stream_t stream);
-
-/* The target network's apply for a sampled batch, run AHEAD of the step that
- * consumes it (dz_rainbow_args_t::tgt_part): conv torso + noisy fc1 + noisy fc2 of
- * `target_params` on s_t, leaving the fc2 split-K slabs in `ws` (a workspace of
- * dz_rainbow_layout(.., batch).ws_count floats that no other enqueued work uses)
- * at offset ws_fc2_part; the consumer passes tgt_part = ws + ws_fc2_part.
- * Noise: if step_counter != NULL the block (noise_stride floats at `noise`) is first
- * drawn on the device at the stream position the three-apply step would use for
- * its target apply when *adam_count == *step_counter, and the last launch does
- * ++*step_counter (one consuming optimiser step per call); if NULL, `noise` is
- * read as given (parity runs).  ref: rainbow/agent.py:91-96, networks.py:224-261. */
-int dz_rainbow_target_forward(int num_actions, int num_atoms, int batch,
-                              const float* target_params, const uint8_t* s_t,
-                              float* noise, uint64_t noise_seed, int32_t* step_counter,
-                              float* ws, dz_stream_t stream);
-
-/* Cross-stream ordering for the pipelined step: events without timing;
- * device_scope != 0 also drops the system-scope fence of the record (the waiter is
- * another stream of the same GPU: no L2 write-back / host visibility needed).     */
-int dz_event_create(int device_scope, void** event_out);
-int dz_event_destroy(void* event);
-int dz_event_record(void* event, dz_stream_t stream);
-int dz_stream_wait_event(dz_stream_t stream, void* event);
 
 /* One network apply (inference): q_values_out[b][a] for `batch` uint8 states
  * with ONE noise block, plus optionally the greedy action (first maximum) and

@@ -1,8 +1,10 @@
-"""The two-stream, software-pipelined form of the step (dqn_zoo_amd/pipeline.py:
-write-back(k), sample(k+1) and the TARGET network's apply for batch k+1 on a side
-stream under backward(k)/Adam(k); two online applies on the main stream) and the
-hipGraph form must be BIT-IDENTICAL to the sequential single-stream three-apply
-step: same sampled ids, same losses, same parameters, same tree."""
+"""Forms of the learner step that must be BIT-IDENTICAL to the sequential eager step
+(sample launch, then the one-call update with the write-back inside it): the same step
+replayed from hipGraphs, the loop over a static replay whose NEXT sample + gather ride
+in this step's optimiser launch (`next_sample`), and the priority write-back carried by
+a backward launch (`priority_sink`) instead of a separate update -- same sampled ids,
+same losses, same parameters, same tree.  (The two-stream variant of the loop these
+tests once also covered measured slower and was removed: EXPERIMENTS.md.)"""
 
 import types
 
@@ -13,8 +15,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(pipelined, steps=12, graphs=False, sync_every_step=True, sync_target_at=(),
-         fused_sample=False, capacity=2048, stored_gradient=False):
+def _run(steps=12, graphs=False, sync_target_at=(), fused_sample=False, capacity=2048,
+         stored_gradient=False):
   import bench
   args = types.SimpleNamespace(capacity=capacity, batch=32)
   dev = torch.device('cuda', 0)
@@ -24,23 +26,13 @@ def _run(pipelined, steps=12, graphs=False, sync_every_step=True, sync_target_at
   torch.cuda.synchronize()
   prev = torch.cuda.current_stream(dev)
   torch.cuda.set_stream(torch.cuda.Stream(dev))
-  step = (bench.make_step_pipelined(replay, learner, 32, dev) if pipelined
-          else bench.make_step(replay, learner, 32, fused_next_sample=fused_sample))
-  losses, ids = [], []
+  step = bench.make_step(replay, learner, 32, fused_next_sample=fused_sample)
+  losses = []
   for k in range(steps):
     if k in sync_target_at:   # target <- online between two steps
-      (step.loop if pipelined else learner).sync_target()
-    if pipelined:
-      s = step()
-      # (the loss buffer is rewritten by the next step: read it before enqueueing more)
-      if sync_every_step:
-        torch.cuda.synchronize()
-      else:
-        torch.cuda.current_stream(dev).synchronize()   # main only; side keeps running
-      ids.append(s.ids.cpu().numpy().copy())
-    else:
-      step()
-      torch.cuda.synchronize()
+      learner.sync_target()
+    step()
+    torch.cuda.synchronize()
     losses.append(learner.losses.cpu().numpy().copy())
   replay.check_status()
   torch.cuda.synchronize()
@@ -51,28 +43,31 @@ def _run(pipelined, steps=12, graphs=False, sync_every_step=True, sync_target_at
           learner.target.cpu().numpy())
 
 
-def test_overlapped_steps_are_bit_identical_to_sequential():
-  """(The two-stream loop splits the step into three calls -- nets | loss | backward +
-  optimiser -- and a split step uses the STORED fc1 weight gradient; the one-call step
-  forms it inside the optimiser (dz_fc1_onfly.h), the same sums in another float32
-  order.  The two-stream comparisons therefore pin the stored form on both sides; the
-  graph replays of the one-call step are compared in its default form.)"""
-  ref = _run(pipelined=False)
-  ref_stored = _run(pipelined=False, stored_gradient=True)
-  for pipelined, graphs, sync in ((True, False, True), (False, True, True),
-                                  (True, True, True), (True, True, False)):
-    got = _run(pipelined, graphs=graphs, sync_every_step=sync, stored_gradient=pipelined)
-    want = ref_stored if pipelined else ref
-    np.testing.assert_array_equal(got[0], want[0])
-    np.testing.assert_array_equal(got[1], want[1])
-    # the pipelined loop has prefetched one extra sample but the tree only
-    # changes through write-backs, which are identical
-    np.testing.assert_array_equal(got[2], want[2])
-    assert got[3] == want[3]
+def test_graph_replay_and_gradient_forms():
+  """hipGraph replay of the one-call step == eager launches, bit for bit; the two forms
+  of the fc1 weight gradient (formed inside the optimiser, dz_fc1_onfly.h, vs stored)
+  are the same sums in another float32 order."""
+  ref = _run()
+  ref_stored = _run(stored_gradient=True)
+  for stored, want in ((False, ref), (True, ref_stored)):
+    got = _run(graphs=True, stored_gradient=stored)
+    for a, b in zip(got, want):
+      np.testing.assert_array_equal(a, b)
   assert np.isfinite(ref[0]).all() and ref[0].std() > 0
-  # the two forms of the fc1 gradient: same mathematics, float32 rounding apart
   np.testing.assert_allclose(ref[0], ref_stored[0], rtol=2e-5, atol=1e-6)
   np.testing.assert_allclose(ref[1], ref_stored[1], rtol=0, atol=2e-6)
+
+
+def test_fused_next_sample_with_target_syncs():
+  """sync_target() between steps of the fused loop: the carried sample does not depend
+  on either parameter set, so the loop equals the sequential one with the same syncs --
+  and differs from the loop without them."""
+  ref = _run(steps=9, sync_target_at=(3, 4, 7))
+  got = _run(steps=9, sync_target_at=(3, 4, 7), fused_sample=True)
+  for a, b in zip(got, ref):
+    np.testing.assert_array_equal(a, b)
+  plain = _run(steps=9)
+  assert (plain[0][:3] == ref[0][:3]).all() and (plain[0][3:] != ref[0][3:]).any()
 
 
 @pytest.mark.parametrize('capacity', [2048, 40])
@@ -82,8 +77,8 @@ def test_fused_next_sample_is_bit_identical_to_sequential(capacity):
   (through the losses), losses, parameters, tree and running max as the sequential
   step.  capacity 40 < batch: duplicate ids in every batch (last-wins) and shared
   tree paths from the leaves up."""
-  ref = _run(pipelined=False, capacity=capacity)
-  got = _run(pipelined=False, fused_sample=True, capacity=capacity)
+  ref = _run(capacity=capacity)
+  got = _run(fused_sample=True, capacity=capacity)
   for a, b in zip(got, ref):
     np.testing.assert_array_equal(a, b)
   assert np.isfinite(ref[0]).all() and ref[0].std() > 0
@@ -127,18 +122,19 @@ def test_dense_fused_next_sample_is_bit_identical_to_sequential(kind):
       ln = ll.DenseLearner(networks.DenseNetwork('double_dqn', A), 'double_q',
                            ll.RmsPropConfig(), B, seed=4)
     ln.use_graphs = False
-    nxt, out = None, []
+    primed, out = False, []
     for _ in range(8):
       if kind == 'double_q_prioritized':
-        sm = nxt if nxt is not None else rep.sample_device(B)
+        sm = rep.take_prepared() if primed else rep.sample_device(B)
         t, ids, w = sm.transitions, sm.ids, sm.weights32
         sink = rep.priority_sink(ids)
       else:
-        t, ids = nxt if nxt is not None else rep.sample_device(B)
+        t, ids = rep.take_prepared() if primed else rep.sample_device(B)
         w, sink = None, None
       desc = None
       if fused:
-        desc, nxt = rep.prepare_next_sample(B)
+        desc, _ = rep.prepare_next_sample(B)
+        primed = True
       ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, w, priority_sink=sink,
               next_sample=desc)
       torch.cuda.synchronize()
@@ -172,56 +168,6 @@ def test_next_sample_needs_the_write_back_of_the_same_step():
     learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32, phases=2,
                  priority_sink=replay.priority_sink(s.ids), next_sample=desc)
   torch.cuda.synchronize()
-
-
-def test_pipelined_target_sync_matches_sequential():
-  """sync_target() between two pipelined steps: the prefetched target apply used
-  the OLD parameters and is redone in line -- same bits as the sequential loop."""
-  ref = _run(pipelined=False, steps=9, sync_target_at=(3, 4, 7), stored_gradient=True)
-  for graphs in (False, True):
-    got = _run(pipelined=True, steps=9, graphs=graphs, sync_every_step=False,
-               sync_target_at=(3, 4, 7), stored_gradient=True)
-    for a, b in zip(got, ref):
-      np.testing.assert_array_equal(a, b)
-  # the sync matters: without it the losses differ from step 3 on
-  plain = _run(pipelined=False, steps=9, stored_gradient=True)
-  assert (plain[0][:3] == ref[0][:3]).all() and (plain[0][3:] != ref[0][3:]).any()
-
-
-def test_target_pre_equals_three_apply_step():
-  """One stream, no pipeline: target_forward(s_t) followed by step(target_pre=True)
-  gives the bits of the three-apply step, with device-drawn noise (the target block's
-  stream positions) over several optimiser steps, and with injected noise."""
-  from dqn_zoo_amd import learner as ll, networks
-  A, B = 5, 32
-  sup = np.linspace(-10, 10, 51).astype(np.float32)
-  rs = np.random.RandomState(0)
-  dev = torch.device('cuda', 0)
-  mk = lambda: ll.RainbowLearner(networks.RainbowNetwork(A, sup, 0.1), ll.AdamConfig(), B, seed=7)
-  la, lb = mk(), mk()
-  lb.target.add_(torch.from_numpy(rs.uniform(-0.05, 0.05, lb.target.numel()).astype(np.float32)).to(dev))
-  la.target.copy_(lb.target)
-  for ln in (la, lb):
-    ln.use_graphs = False
-  for it in range(4):
-    s_tm1 = torch.from_numpy(rs.randint(0, 256, (B, 84, 84, 4)).astype(np.uint8)).to(dev)
-    s_t = torch.from_numpy(rs.randint(0, 256, (B, 84, 84, 4)).astype(np.uint8)).to(dev)
-    a = torch.from_numpy(rs.randint(0, A, B).astype(np.int64)).to(dev)
-    r = torch.from_numpy(rs.randint(-1, 2, B).astype(np.float64)).to(dev)
-    d = torch.from_numpy((rs.randint(0, 2, B) * 0.97).astype(np.float64)).to(dev)
-    w = torch.from_numpy(rs.uniform(0.3, 1.0, B).astype(np.float32)).to(dev)
-    la.step(s_tm1, a, r, d, s_t, w)
-    lb.target_forward(s_t, step_from=lb.adam_count if it == 0 else None)
-    lb.step(s_tm1, a, r, d, s_t, w, target_pre=True)
-    torch.cuda.synchronize()
-    np.testing.assert_array_equal(la.losses.cpu().numpy(), lb.losses.cpu().numpy())
-    np.testing.assert_array_equal(la.priorities.cpu().numpy(), lb.priorities.cpu().numpy())
-    np.testing.assert_array_equal(la.online.cpu().numpy(), lb.online.cpu().numpy())
-    # the target block of the three-apply step's noise == the block target_forward drew
-    st = int(la.layout.noise_stride)
-    np.testing.assert_array_equal(la.noise[2 * st:3 * st].cpu().numpy(),
-                                  lb._tgt_noise.cpu().numpy())  # pylint: disable=protected-access
-  assert np.isfinite(la.losses.cpu().numpy()).all()
 
 
 def test_priority_sink_equals_separate_update():

@@ -160,6 +160,25 @@ def test_clip_and_adam_vs_oracle(max_norm):
     st = dict(count=st['count'], mu=m_dev, nu=v_dev)
 
 
+@pytest.mark.parametrize('keep_all', [False, True])
+def test_overflowed_global_norm_zeroes_the_update(keep_all):
+  """optax's clip_by_global_norm computes (g / g_norm) * max_norm; with a
+  float32 norm that overflowed to +inf every finite g becomes 0, Adam's moments decay
+  from zero and the parameters do not move.  The reciprocal form of the division must
+  not turn that into 0 * inf = NaN."""
+  A, B = 6, 32
+  online, target, batch, w, noises = _problem(A, B, 21)
+  ln = _learner(A, B, online, target, noises)
+  ln.keep_all_grads = keep_all
+  before = ln.params.clone()
+  ln.step(*_dev_batch(batch, (w * 1e25).astype(np.float32)), resample_noise=False)
+  torch.cuda.synchronize()
+  assert ln.scalars()['gnorm'] == np.inf
+  assert bool(torch.isfinite(ln.params).all())
+  assert torch.equal(ln.params, before)
+  assert float(ln.adam_m.abs().max()) == 0.0 and float(ln.adam_v.abs().max()) == 0.0
+
+
 def test_full_step_vs_oracle_update():
   """End-to-end: oracle rainbow_update vs device step, same inputs."""
   A, B = 6, 32

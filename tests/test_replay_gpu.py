@@ -280,6 +280,35 @@ def test_pipelined_sample_update_vs_oracle(rl, seed, cap, expo, usp):
                                 _bits(cpu.dist.tree.node))
 
 
+@pytest.mark.parametrize('batch', [64, 200, 255, 256, 300])
+@pytest.mark.parametrize('cap', [37, 700])
+def test_wide_batch_write_back_vs_oracle(rl, batch, cap):
+  """update_priorities(device ids) with up to 256+ ids, many of them duplicated (cap 37)
+  and all partner levels populated (cap 700): the two-round-trip walk serves n <= 255
+  (its partner table stores batch positions as bytes, 0xFF = none -- ADVICE r3: at
+  n == 256 position 255 collided with the mark), the level-by-level form the rest; both
+  must leave the oracle's tree, bit for bit."""
+  dev = rl.PrioritizedTransitionReplay(
+      cap, protocol.Item(None, None), 0.5, protocol.beta_schedule(cap), 1e-3, True,
+      np.random.RandomState(5))
+  cpu = ro.PrioritizedReplayOracle(cap, protocol.Item(None, None), 0.5,
+                                   protocol.beta_schedule(cap), 1e-3, True,
+                                   np.random.RandomState(5))
+  for t in range(cap + 5):
+    dev.add(protocol.Item(t, -t), 1.0)
+    cpu.add(protocol.Item(t, -t), 1.0)
+  prs = np.random.RandomState(batch * 1000 + cap)
+  for _ in range(6):
+    ids = prs.randint(5, cap + 5, size=batch).astype(np.int64)
+    ids[-1] = ids[0]                       # the last position always has a duplicate
+    p32 = np.abs(prs.standard_cauchy(batch)).astype(np.float32)
+    dev.update_priorities(torch.from_numpy(ids).cuda(), torch.from_numpy(p32).cuda())
+    cpu.update_priorities(ids, p32)
+    dev.check_status()
+    np.testing.assert_array_equal(_bits(dev.tree_storage.cpu().numpy()),
+                                  _bits(cpu.dist.tree.node))
+
+
 # ---- gather ------------------------------------------------------------------
 def test_gather_bytes_and_dtypes(rl):
   cap, batch = 300, 32

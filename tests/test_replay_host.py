@@ -160,3 +160,28 @@ def test_nstep_short_episode():
     out.append(list(acc.step(dm_env.TimeStep(st, 1.0, 1.0, i), 1.0)))
   assert [[(t.s_tm1, t.s_t) for t in o] for o in out] == [[], [],
                                                            [(0, 2), (1, 2)]]
+
+
+def test_observation_cache_depth_follows_the_n_step_window():
+  """device_obs.depth_for: slot reuse must be > n + 2 frames apart; the window comes
+  from the public `window_size`, from the reference accumulator's private deque, and
+  an accumulator that tells neither gets the conservative depth."""
+  import collections
+  from dqn_zoo_amd import device_obs
+  assert device_obs.depth_for(replay_lib.TransitionAccumulator()) == 8
+  assert device_obs.depth_for(replay_lib.NStepTransitionAccumulator(3)) == 8
+  assert device_obs.depth_for(replay_lib.NStepTransitionAccumulator(7)) == 10
+  assert replay_lib.NStepTransitionAccumulator(5).window_size == 5
+
+  class RefLike:   # the reference's attribute name (replay.py:841)
+    def __init__(self, n):
+      self._transitions = collections.deque(maxlen=n)
+
+  assert device_obs.depth_for(RefLike(20)) == 23
+
+  class Wrapper:
+    def __init__(self, inner):
+      self.inner = inner
+
+  assert device_obs.depth_for(Wrapper(replay_lib.NStepTransitionAccumulator(9))) == \
+      device_obs.UNKNOWN_WINDOW_DEPTH
