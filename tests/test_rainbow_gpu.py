@@ -170,12 +170,12 @@ def test_overflowed_global_norm_zeroes_the_update(keep_all):
   online, target, batch, w, noises = _problem(A, B, 21)
   ln = _learner(A, B, online, target, noises)
   ln.keep_all_grads = keep_all
-  before = ln.params.clone()
+  before = ln.online.clone()
   ln.step(*_dev_batch(batch, (w * 1e25).astype(np.float32)), resample_noise=False)
   torch.cuda.synchronize()
   assert ln.scalars()['gnorm'] == np.inf
-  assert bool(torch.isfinite(ln.params).all())
-  assert torch.equal(ln.params, before)
+  assert bool(torch.isfinite(ln.online).all())
+  assert torch.equal(ln.online, before)
   assert float(ln.adam_m.abs().max()) == 0.0 and float(ln.adam_v.abs().max()) == 0.0
 
 
