@@ -69,6 +69,14 @@ __device__ __forceinline__ float4 dz_load4_masked(const float* __restrict__ p,
   return v;
 }
 
+// What a masked-out loader slot READS (third loader rule, dz_qnet_ops.h): 16 zero bytes, or
+// (1, 0, 0, 0) for the bias row of a weight-gradient operand (as floats, and as the bytes
+// 255, 0, 0, 0 that the uint8 conversion turns into the same values).  Deliberately not
+// `const`: the compiler must not fold the load into a select on the loaded VALUE.
+__device__ __attribute__((aligned(16))) static float dz_page_zero[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) static float dz_page_one[4] = {1.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) static unsigned dz_page_u8one[4] = {255u, 0u, 0u, 0u};
+
 // Optional per-wave register tiling: an Op may define MI / NI (default 1): every
 // wave then owns MI x NI accumulators (a (32 MI) x (32 NI) output block), i.e.
 // MI*NI independent MFMA chains fed by MI + NI operand fragments -- twice the
@@ -86,6 +94,14 @@ template <class Op> struct DzNI<Op, decltype((void)Op::NI)> { static constexpr i
 // after issuing it (vmcnt(0) + v_cvt in the middle of the MFMA block: conv1 ISA).
 template <class Op, class = void> struct DzRaw16 { static constexpr int v = 0; };
 template <class Op> struct DzRaw16<Op, decltype((void)Op::A_RAW16)> { static constexpr int v = Op::A_RAW16; };
+// The same for RC A operands fed from uint8 (conv1's weight gradient): an Op with A_RAW4 = 1
+// provides  unsigned load_a_raw4(p, t, st, c, kk, rq)  (4 bytes = 4 consecutive rows) and
+// float4 cook4(unsigned); the 4 raw bytes wait in ONE register under the MFMAs.
+template <class Op, class = void> struct DzRaw4 { static constexpr int v = 0; };
+template <class Op> struct DzRaw4<Op, decltype((void)Op::A_RAW4)> { static constexpr int v = Op::A_RAW4; };
+// Optional: Op::PIN_LOADS = 1 keeps the next stage's global loads in front of the MFMA block.
+template <class Op, class = void> struct DzPinLoads { static constexpr int v = 0; };
+template <class Op> struct DzPinLoads<Op, decltype((void)Op::PIN_LOADS)> { static constexpr int v = Op::PIN_LOADS; };
 
 // Optional distributed epilogue (WK > 1, MI = NI = 1): an Op with SPLIT_STORE = 1
 // takes  store(p, t, wm, wn, lane, acc, rmask)  and stores only the accumulator
@@ -175,8 +191,18 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
   constexpr bool B_FULL = BT::SLOTS % 256 == 0;
 
   constexpr bool A_RAW = A_ROW16 && DzRaw16<Op>::v;
+  constexpr bool A_RAW4 = Op::A_LAYOUT == DZ_RC && DzRaw4<Op>::v;
   auto load_stage = [&](int st) {
-    if constexpr (A_RAW) {
+    if constexpr (A_RAW4) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int idx = tid + j * 256;
+        const int kidx = idx / (BM / 4), rq = idx % (BM / 4);
+        unsigned raw = 0u;
+        if (A_FULL || idx < AT::SLOTS) raw = Op::load_a_raw4(p, t, st, kidx >> 4, kidx & 15, rq);
+        ra[j].x = __builtin_bit_cast(float, raw);  // (.y .z .w stay unused)
+      }
+    } else if constexpr (A_RAW) {
 #pragma unroll
       for (int j = 0; j < NA / 4; ++j) {
         const int idx = tid + j * 256;
@@ -229,7 +255,16 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
   };
 
   auto store_stage = [&]() {
-    if constexpr (A_RAW) {
+    if constexpr (A_RAW4) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int idx = tid + j * 256;
+        const int kidx = idx / (BM / 4), rq = idx % (BM / 4);
+        if (A_FULL || idx < AT::SLOTS)
+          *(float4*)(As + (kidx >> 4) * AT::CHUNK + (kidx & 15) * BM + 4 * rq) =
+              Op::cook4(__builtin_bit_cast(unsigned, ra[j].x));
+      }
+    } else if constexpr (A_RAW) {
 #pragma unroll
       for (int j = 0; j < NA / 4; ++j) {
         const int idx = tid + j * 256;
@@ -301,6 +336,11 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
     store_stage();
     __syncthreads();
     if (st + 1 < t.st_end) load_stage(st + 1);  // in flight under the MFMAs
+    // (optionally pinned, Op::PIN_LOADS: in a fully unrolled stage loop the scheduler otherwise
+    // sinks these loads BELOW the MFMA block, next to the LDS writes that consume them --
+    // conv2 forward ISA, rounds 1-3 -- and the stage pays their whole latency behind its last
+    // MFMA.  Per Op, by measurement: conv2's backward pair runs 2.5 us SLOWER pinned)
+    if constexpr (DzPinLoads<Op>::v) __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {

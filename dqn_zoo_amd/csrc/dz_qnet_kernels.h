@@ -34,15 +34,15 @@ constexpr int kMaxSplitFc1 = 32;
 //                                                       WM WN WK KT
 using Conv1Fwd = ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 2, 1, 2, 2>;
 using Conv2Fwd = ConvFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4, 2>;
-using Conv3Fwd = ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4, 3>;
+using Conv3Fwd = ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4, 3, 0>;
 // acting (a handful of images: 7-13 workgroups, pure latency): conv1's whole K = 256 in ONE
 // stage instead of four (one memory round trip): 10.3 -> 6.8 us at batch 1.  (conv2 with 2 or 1
 // stages: 7.9 / 8.2 vs 8.15 us; conv3 with 2: 11.7 vs 8.3 -- left on the learner's shapes.)
 using Conv1FwdAct = ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 1, 1, 4, 4>;
 using Conv1Wg = ConvWgradOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 2, 1, 2, 2>;
-using Conv2Wg = ConvWgradOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 2, 2, 1, 2>;
+using Conv2Wg = ConvWgradOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 2, 2, 1, 2, 0>;
 using Conv3Wg = ConvWgradOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 2, 2, 1, 2>;
-using Conv2Dg = ConvDgradOp<20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4, 1>;
+using Conv2Dg = ConvDgradOp<20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4, 1, 0>;
 using Conv3Dg = ConvDgradOp<9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4, 3>;
 using FcFwd = FcFwdOp<1, 2, 2, 4>;
 using FcDg = FcDgradOp<1, 2, 2, 4>;

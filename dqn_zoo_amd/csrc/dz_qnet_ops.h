@@ -13,6 +13,15 @@
 // instead of ~15 us).  All operand rows are 16-byte aligned by construction
 // (leading dimensions are multiples of 4 floats), so loads are always float4.
 //
+// THIRD LOADER RULE (round 4): nothing in a loader may CONSUME a loaded value.  A select
+// on the value (`ok ? v : 0`), a conversion or a product placed behind the load is
+// scheduled right behind it, in front of the stage's MFMA block, with the `s_waitcnt
+// vmcnt` it needs: the stage then pays the full global-load latency before its first MFMA
+// (conv3 forward ISA: six `vmcnt` waits + 24 `v_cndmask` between the loads and the MFMAs;
+// the conv weight-gradient halves waited for ALL their loads).  Masked slots therefore
+// select on the ADDRESS -- they read dz_page_zero / dz_page_one (dz_gemm.h) -- and
+// conversions happen when the stage is written to LDS (DzRaw16 / DzRaw4).
+//
 // SECOND LOADER RULE: loaders never index a kernel-argument array with a runtime
 // value (p.in[g], p.head[h] ...).  The compiler turns that into a LOAD of the
 // pointer from the kernarg segment followed by s_waitcnt vmcnt(0) in front of
@@ -107,10 +116,19 @@ struct ConvFwdParams {
   int G;
 };
 
+// AM_ (all three convolution Ops): 1 = masked slots select on the ADDRESS (third loader rule)
+// and the next stage's loads are pinned in front of the MFMA block; 0 = the round-1..3 form
+// (select on the loaded value, scheduler's order).  Chosen per instantiation by measurement
+// (same box, us): conv1 fwd 14.0 -> 13.5, conv2 fwd 10.95 -> 10.15, conv3 bwd 10.1 -> 9.4,
+// conv1 wgrad 8.7 -> 7.6 with 1; conv3 fwd 10.9 -> 11.2 and conv2 bwd 10.7 -> 11.8 with 1
+// (those two keep 0): with two or three workgroups per CU a wave that waits for its loads
+// leaves the matrix pipe to its neighbours, so the exposed wait is not always the loss the
+// ISA suggests.
 template <int IN_U8, int H, int W, int C, int KS, int S, int OH, int OW, int CO,
-          int WM_, int WN_, int WK_, int KT_ = 1>
+          int WM_, int WN_, int WK_, int KT_ = 1, int AM_ = 1>
 struct ConvFwdOp {
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
+  static constexpr int PIN_LOADS = AM_;
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_RC;
   static constexpr int A_MAP = IN_U8 ? DZ_MAP_ROW16 : DZ_MAP_QUAD;
   static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
@@ -154,7 +172,9 @@ struct ConvFwdOp {
     const int k0 = st * BK + c * 16 + 4 * q;
     const int tap = k0 / C, ci = k0 % C;
     const int kh = tap / KS, kw = tap % KS;
-    return dz_sel4(ok, dz_ld4((const float*)t.in + off + ((long)kh * W + kw) * C + ci));
+    const float* src = (const float*)t.in + off + ((long)kh * W + kw) * C + ci;
+    if constexpr (AM_) return dz_ld4(ok ? src : dz_page_zero);
+    else return dz_sel4(ok, dz_ld4(src));
   }
   // deferred conversion (dz_gemm.h DzRaw16): the loader keeps the 16 raw bytes
   static constexpr int A_RAW16 = IN_U8;
@@ -163,8 +183,8 @@ struct ConvFwdOp {
     const bool ok = pixel_base(p, t, row, off);
     const int k0 = st * BK + c * 16;  // KS*C == 32 bytes per kernel row
     const int kh = k0 / 32, o = k0 % 32;
-    const uint4 raw = *(const uint4*)((const uint8_t*)t.in + off + (long)kh * W * C + o);
-    return make_uint4(ok ? raw.x : 0u, ok ? raw.y : 0u, ok ? raw.z : 0u, ok ? raw.w : 0u);
+    const uint8_t* src = (const uint8_t*)t.in + off + (long)kh * W * C + o;
+    return *(const uint4*)(ok ? src : (const uint8_t*)dz_page_zero);
   }
   __device__ static void cook16(uint4 raw, float4 (&v)[4]) {  // byte 0 -> 0/255 == 0.0f
     v[0] = dz_u8x4_to_unit(raw.x); v[1] = dz_u8x4_to_unit(raw.y);
@@ -191,7 +211,12 @@ struct ConvFwdOp {
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc, unsigned rmask = 0xffffu) {
     const int col = t.n0 + wn * 32 + (lane & 31);
-    const float b = t.bias[col];
+    float b = t.bias[col];
+    // the bias waited for ONCE, here: used first inside the conditional store blocks below, the
+    // compiler puts an `s_waitcnt vmcnt(0)` into every one of them, and from the second block on
+    // that wait is for the previous block's STORE (gfx950 counts stores in vmcnt): the wave's
+    // four row stores became four serial round trips
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(b));
     const int rows = p.B * OH * OW;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -632,9 +657,10 @@ struct ConvWgradParams {
 };
 
 template <int IN_U8, int H, int W, int C, int KS, int S, int OH, int OW, int CO,
-          int WM_, int WN_, int WK_, int KT_ = 1>
+          int WM_, int WN_, int WK_, int KT_ = 1, int AM_ = 1>
 struct ConvWgradOp {
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
+  static constexpr int PIN_LOADS = AM_;
   static constexpr int A_LAYOUT = DZ_RC, B_LAYOUT = DZ_RC, A_MAP = DZ_MAP_QUAD;
   static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   static constexpr int K = KS * KS * C;
@@ -666,18 +692,45 @@ struct ConvWgradOp {
     const int tap = kc / C, ci = kc % C;
     const int kh = tap / KS, kw = tap % KS;
     const long off = (((long)img * H + oh * S + kh) * W + ow * S + kw) * C + ci;
-    float4 v;
-    if (IN_U8) v = dz_u8x4_to_unit(*(const unsigned*)((const uint8_t*)p.in + off));
-    else v = dz_ld4((const float*)p.in + off);
-    // rows >= K: the bias row (value 1 at k == K) then zero padding
-    v = k < K ? v : dz_f4(k == K ? 1.f : 0.f, 0.f, 0.f, 0.f);
-    return dz_sel4(ml < rows, v);
+    // rows >= K: the bias row (value 1 at k == K) then zero padding; pixels beyond the
+    // batch: zero -- by ADDRESS (third loader rule)
+    // (dz_val: selects on VALUES; nested ?: here become branches with one load each)
+    const float* src = (const float*)p.in + off;
+    if constexpr (AM_) {
+      src = dz_val(k < K, src, dz_val(k == K, (const float*)dz_page_one, (const float*)dz_page_zero));
+      return dz_ld4(dz_val(ml < rows, src, (const float*)dz_page_zero));
+    } else {
+      float4 v = dz_ld4(src);
+      v = k < K ? v : dz_f4(k == K ? 1.f : 0.f, 0.f, 0.f, 0.f);
+      return dz_sel4(ml < rows, v);
+    }
   }
+  // uint8 input (conv1): the four raw bytes, converted when the stage is written to LDS
+  static constexpr int A_RAW4 = IN_U8;
+  __device__ static unsigned load_a_raw4(const Params& p, const Tile& t, int st, int c,
+                                         int kk, int rq) {
+    const int rows = p.B * OH * OW;
+    const int ml = st * BK + c * 16 + kk;
+    const int mc = min(ml, rows - 1);
+    const int img = mc / (OH * OW), pix = mc % (OH * OW);
+    const int oh = pix / OW, ow = pix % OW;
+    const int k = t.m0 + 4 * rq;
+    const int kc = min(k, K - 4);
+    const int tap = kc / C, ci = kc % C;
+    const int kh = tap / KS, kw = tap % KS;
+    const long off = (((long)img * H + oh * S + kh) * W + ow * S + kw) * C + ci;
+    const unsigned* src = (const unsigned*)((const uint8_t*)p.in + off);
+    src = dz_val(k < K, src, dz_val(k == K, (const unsigned*)dz_page_u8one, (const unsigned*)dz_page_zero));
+    return *dz_val(ml < rows, src, (const unsigned*)dz_page_zero);
+  }
+  __device__ static float4 cook4(unsigned raw) { return dz_u8x4_to_unit(raw); }
   __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
     const int rows = p.B * OH * OW;
     const int ml = st * BK + c * 16 + kk;
-    return dz_sel4(ml < rows, dz_ld4(p.dy + (long)min(ml, rows - 1) * CO + t.n0 + 4 * rq));
+    const float* src = p.dy + (long)min(ml, rows - 1) * CO + t.n0 + 4 * rq;
+    if constexpr (AM_) return dz_ld4(ml < rows ? src : dz_page_zero);
+    else return dz_sel4(ml < rows, dz_ld4(src));
   }
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
@@ -707,9 +760,10 @@ struct ConvDgradParams {
 };
 
 template <int H, int W, int C, int KS, int S, int OH, int OW, int CO,
-          int WM_, int WN_, int WK_, int KT_ = 1>
+          int WM_, int WN_, int WK_, int KT_ = 1, int AM_ = 1>
 struct ConvDgradOp {
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
+  static constexpr int PIN_LOADS = AM_;
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_KC, A_MAP = DZ_MAP_QUAD;
   static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
   static constexpr int TS = (KS + S - 1) / S;   // taps per dimension per class
@@ -751,7 +805,9 @@ struct ConvDgradOp {
     const int oh = (h - kh) / S, ow = (w - kw) / S;  // exact when h >= kh, w >= kw
     ok = ok & (h >= kh) & (w >= kw) & (oh < OH) & (ow < OW);
     const int ohc = min(max(oh, 0), OH - 1), owc = min(max(ow, 0), OW - 1);
-    return dz_sel4(ok, dz_ld4(p.dy + (((long)img * OH + ohc) * OW + owc) * CO + co));
+    const float* src = p.dy + (((long)img * OH + ohc) * OW + owc) * CO + co;
+    if constexpr (AM_) return dz_ld4(ok ? src : dz_page_zero);
+    else return dz_sel4(ok, dz_ld4(src));
   }
   __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {

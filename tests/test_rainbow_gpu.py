@@ -179,6 +179,46 @@ def test_overflowed_global_norm_zeroes_the_update(keep_all):
   assert float(ln.adam_m.abs().max()) == 0.0 and float(ln.adam_v.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('A,B,seed', [(6, 32, 31), (4, 20, 32)])
+def test_on_the_fly_fc1_gradient_elements_and_norm_share(A, B, seed):
+  """The DEFAULT step never stores fc1's two weight-gradient blocks: the optimiser forms
+  each element from the layer's input and output gradient (dz_fc1_onfly.h) and the blocks'
+  share of the global norm comes from Gram matrices on the f64 matrix pipe (GramDSide).
+  Both are read back directly here: with the clip out of reach the
+  first Adam step leaves m = (1 - b1) g and v = (1 - b2) g^2, element by element, and
+  gnorm^2 minus the stored blocks' sums of squares is the fc1 share.  Ground truth: the
+  float64 oracle."""
+  online, target, batch, w, noises = _problem(A, B, seed)
+  ln = _learner(A, B, online, target, noises, max_norm=1e9)
+  assert not ln.keep_all_grads
+  ln.step(*_dev_batch(batch, w), resample_noise=False)
+  torch.cuda.synchronize()
+  f64 = lambda t: {k: v.astype(np.float64) for k, v in t.items()}
+  _, _, g64, _ = qo.rainbow_loss_and_grads(
+      f64(online), f64(target), batch, w, [f64(n) for n in noises],
+      SUPPORT.astype(np.float64), A, np.float64)
+  m = ln.layout.unpack(ln.adam_m.cpu().numpy())
+  v = ln.layout.unpack(ln.adam_v.cpu().numpy())
+  fc1 = [k for k in g64 if k.split('/')[0] in ('adv1', 'val1') and k.endswith('/w')]
+  assert len(fc1) == 4
+  for k in fc1:
+    g_dev = m[k].astype(np.float64) / (1.0 - ln.opt.b1)
+    scale = np.abs(g64[k]).max()
+    assert np.abs(g_dev - g64[k]).max() / scale < 2e-6, k       # float32 sums of <= 32 terms
+    g2 = v[k].astype(np.float64) / (1.0 - ln.opt.b2)
+    np.testing.assert_allclose(g2, g64[k] ** 2, rtol=1e-5, atol=5e-6 * scale ** 2)
+  # the norm: whole vector, then the on-the-fly blocks' share alone
+  sc = ln.scalars()
+  gn64 = np.sqrt(sum(float((g ** 2).sum()) for g in g64.values()))
+  np.testing.assert_allclose(sc['gnorm'], gn64, rtol=1e-5)
+  stored = ln.layout.unpack(ln.grad.cpu().numpy())
+  other = sum(float((stored[k].astype(np.float64) ** 2).sum()) for k in g64 if k not in fc1)
+  share_dev = float(sc['gnorm']) ** 2 - other
+  share64 = sum(float((g64[k] ** 2).sum()) for k in fc1)
+  assert share64 > 0.05 * gn64 ** 2        # (a share that matters, so the difference is meaningful)
+  np.testing.assert_allclose(share_dev, share64, rtol=5e-5)
+
+
 def test_full_step_vs_oracle_update():
   """End-to-end: oracle rainbow_update vs device step, same inputs."""
   A, B = 6, 32
