@@ -21,7 +21,7 @@ constexpr int kMaxS_dfeat = 32;
 constexpr int kMaxS_fc2 = 8;
 // conv weight-gradient split-K counts.  kS_cw3 = 9 makes conv3's backward launch 90 + 162 = 252
 // workgroups: one round on 256 CUs (10 splits = 262 workgroups: 15.6 us; 9: 13.0; 8: 14.3 by events)
-constexpr int kS_cw1 = 50, kS_cw2 = 27, kS_cw3 = 9;
+constexpr int kS_cw1 = 50, kS_cw2 = 27, kS_cw3 = 9;   // (re-swept in round 4: 25/34/40/67 x 14/18/22/36 all slower)
 constexpr int kNormBlocks = 512;
 constexpr int kNormFinal = 4096;    // fused-norm partials: one per finalize block
 constexpr int kNormSlots = 12288;   // per-wave slots of the weight-gradient kernels
@@ -32,7 +32,10 @@ constexpr int kMaxSplitFc1 = 32;
 // conv geometries (networks.py:194-198)
 //                      U8  H   W   C  KS S  OH  OW  CO
 //                                                       WM WN WK KT
-using Conv1Fwd = ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 2, 1, 2, 2>;
+
+// (conv1: 1 200 workgroups of 32 rows, K over the four waves -- 12.6 vs 13.1 us for <2,1,2,2>
+// once its loader stopped waiting; round 4 re-sweep of six shapes per layer, tools/lib_ab.sh)
+using Conv1Fwd = ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 1, 1, 4, 1>;
 using Conv2Fwd = ConvFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4, 2>;
 using Conv3Fwd = ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4, 3, 0>;
 // acting (a handful of images: 7-13 workgroups, pure latency): conv1's whole K = 256 in ONE

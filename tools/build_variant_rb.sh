@@ -1,0 +1,10 @@
+#!/bin/bash
+# bash tools/build_variant_rb.sh <out.so> [-DFLAG=..]...  : recompiles dz_rainbow.hip ONLY with the extra
+# flags and links it with the other translation units' current objects (run python -m dqn_zoo_amd.build first)
+out=$1; shift
+R=/root/repo
+tmp=$(mktemp -d)
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -I $R/include "$@" -c $R/dqn_zoo_amd/csrc/dz_rainbow.hip -o $tmp/dz_rainbow.o 2>$tmp/err || { echo "FAILED $out"; grep -m3 error $tmp/err; rm -rf $tmp; exit 1; }
+objs=$(ls $R/dqn_zoo_amd/csrc/_obj/*.o | grep -v dz_rainbow.o)
+hipcc --offload-arch=gfx950 -shared -fPIC -o $out $tmp/dz_rainbow.o $objs && echo built $out
+rm -rf $tmp
