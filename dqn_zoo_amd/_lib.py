@@ -188,7 +188,7 @@ SIGNATURES = {
     'dz_rainbow_apply': (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                                  c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dz_rainbow_act': (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, ctypes.c_uint64,
-                               ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+                               ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dz_rainbow_graph_capture': (c_int, [ctypes.POINTER(RainbowArgs), c_int, c_vp,
                                          ctypes.POINTER(c_vp)]),
     'dz_atari_observation': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int,

@@ -35,11 +35,19 @@ constexpr int kFc2Splits = 8;        // fc2 forward k-splits
 //   fc1: 448 workgroups x 7 rows behind the sixteen Gram side blocks;
 //   fc2: 128 workgroups x 4 rows in front of the fc2 weight-gradient contraction; dh1
 //        leaves that launch finished (summed over n, ReLU-masked) -- no slabs to fold.
-constexpr int kDgBlocks = 448, kDg2Blocks = 128;
+#ifndef DZ_DGB
+#define DZ_DGB 448
+#endif
+#ifndef DZ_DGP
+#define DZ_DGP 4
+#endif
+constexpr int kDgBlocks = DZ_DGB, kDg2Blocks = 128;
+constexpr int kDgRows = (kFlat + kDgBlocks - 1) / kDgBlocks;          // weight rows per workgroup
+constexpr int kDgLds = kDgRows * 4 * 8 * kRdGroup > kRdLdsFloats ? kDgRows * 4 * 8 * kRdGroup : kRdLdsFloats;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fc1_dgrad_rows_kernel(RowDgrad q, GramD gd, PrioUpdateParams prio) {
-  __shared__ __attribute__((aligned(16))) float lds[kRdLdsFloats];
-  static_assert(kRdLdsFloats >= 32 * GramDSide::kLd, "GramDSide's tile");
+  __shared__ __attribute__((aligned(16))) float lds[kDgLds];
+  static_assert(kDgLds >= 32 * GramDSide::kLd, "GramDSide's tile");
   static_assert(sizeof(lds) >= sizeof(WbScratch), "the write-back's LDS walk");
   unsigned bid = blockIdx.x;
   if (bid < (unsigned)GramDSide::kBlocks) { GramDSide::run(gd, bid, lds, (int)sizeof(lds)); return; }
@@ -50,7 +58,7 @@ void fc1_dgrad_rows_kernel(RowDgrad q, GramD gd, PrioUpdateParams prio) {
     if (bid == 0) { PrioUpdateSideFast::run(prio, 0, lds, (int)sizeof(lds)); return; }
     bid -= 1;
   }
-  row_dgrad_block<2, 2, true, 4>(q, bid, lds);
+  row_dgrad_block<2, 2, true, DZ_DGP>(q, bid, lds);
 }
 template <int NJ0>   // 256-column chunks of the advantage head
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -73,7 +81,8 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
                            const float* const* prm, const float* const* nz,
                            const uint8_t* const* in, float* ws, hipStream_t s,
                            const NoiseParams* resample = nullptr,
-                           bool skip_fc2_epilogue = false, bool stop_after_fc1 = false) {
+                           bool skip_fc2_epilogue = false, bool stop_after_fc1 = false,
+                           const SampleGatherParams* sg = nullptr, unsigned sg_blocks = 0) {
   int rc = DZ_OK;
   const int NA = L.num_actions * L.num_atoms;
   const int ld2 = L.adv2_ld + L.val2_ld;
@@ -81,7 +90,7 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
   const FcHead* fc2h = H.fc2h;
   {
     const TorsoBufs T = {L.conv_w, L.conv_b, ws + L.ws_act1, ws + L.ws_act2, ws + L.ws_feat};
-    rc = torso_forward(T, G, B, prm, in, s, resample);
+    rc = torso_forward(T, G, B, prm, in, s, resample, sg, sg_blocks);
     if (rc) return rc;
   }
   {  // fc1: noisy adv1 | val1, split-K partials
@@ -432,11 +441,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         q.dy = ws + L.ws_dh1; q.ldy = 1024; q.mask = ws + L.ws_feat; q.out = ws + L.ws_dfeat;
         q.ldo = kFlat; q.out_col[0] = 0; q.out_col[1] = 0; q.same_out = 1;
         q.M = B; q.K = kFlat; q.nblocks = kDgBlocks;
-        static_assert((kFlat + kDgBlocks - 1) / kDgBlocks * 4 <= 32 &&
-                      (kFlat + kDgBlocks - 1) / kDgBlocks * 32 <= 512, "rows x jobs per workgroup");
+        static_assert(kDgRows * 32 <= 512, "two outputs per thread in the epilogue");
         // the sum-tree priority write-back rides HERE in the one-call step (same-box A/B:
         // conv3's backward launch 11.3 -> 10.2 us without it, this launch 12.7 -> 12.8)
+#ifdef DZ_PRIO_IN_CONV3
+        const bool carry_prio = false;
+#else
         const bool carry_prio = prio_pending;
+#endif
         hipLaunchKernelGGL(fc1_dgrad_rows_kernel,
                            dim3(GramDSide::kBlocks + kDgBlocks + (carry_prio ? 1 : 0)), dim3(256),
                            0, s, q, gdp, carry_prio ? prio_q : PrioUpdateParams{});
@@ -696,7 +708,7 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
                               uint64_t noise_counter, int32_t* step_counter,
                               const float* support, float* ws,
                               float* q_values_out, int32_t* greedy_out, float* vmax_out,
-                              dz_stream_t stream) {
+                              const dz_next_sample_t* next_sample, dz_stream_t stream) {
   DZ_REQUIRE(params && states && noise && support && ws && q_values_out);
   dz_rainbow_layout_t L;
   int rc = dz_rainbow_layout(num_actions, num_atoms, batch, &L);
@@ -710,12 +722,20 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
   const int ld2 = L.adv2_ld + L.val2_ld;
   const bool fuse = (size_t)ld2 * sizeof(float) <= 48 * 1024;
   const NoiseParams nq = {noise, (long)L.noise_stride, noise_seed, noise_counter, step_counter};
+  // the following learner step's sample + gather, as extra blocks of the conv2 launch
+  SampleGatherParams sgq = {};
+  unsigned sgb = 0;
+  if (next_sample) {
+    rc = sample_gather_from_desc(next_sample, sgq, &sgb);
+    if (rc) return rc;
+  }
   const bool prof = g_dz_prof_on;
   g_dz_prof_on = false;  // marks belong to dz_rainbow_learn
   // Few rows: the tail (fc1 epilogue + fc2 + q-values) is ONE launch that folds the
   // fc1 slabs itself (rainbow_act_tail_kernel): 5 launches per decision instead of 7.
   const bool tail = batch <= 8 && ld2 <= 1024 && num_atoms <= 64;
-  rc = rainbow_forward(L, H, 1, batch, prm, nz, in, ws, s, &nq, fuse, tail);
+  rc = rainbow_forward(L, H, 1, batch, prm, nz, in, ws, s, &nq, fuse, tail,
+                       next_sample ? &sgq : nullptr, sgb);
   g_dz_prof_on = prof;
   if (rc) return rc;
   if (tail) {

@@ -113,12 +113,17 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
     const char* __restrict__ wsg = (const char*)(q.params + dz_val(h1, q.head[1].w_sig, q.head[0].w_sig));
     const float* __restrict__ ein =
         NOISY ? q.noise + dz_val(h1, q.head[1].eps_in, q.head[0].eps_in) : nullptr;
+    // the row's noise factor travels WITH the row's weights, P rows ahead: requested in the
+    // iteration that uses it (rounds 1-3) it was one exposed memory round trip per row -- the
+    // ISA had `s_waitcnt vmcnt(2)` right behind the three loads of each row
     float4 pm[P], ps[P];
+    float pe[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) {
-      const unsigned o = (unsigned)(min(k0 + grp + GROUPS * u, k1 - 1) * ldw + cc) * 4u;
+      const int kr = min(k0 + grp + GROUPS * u, k1 - 1);
+      const unsigned o = (unsigned)(kr * ldw + cc) * 4u;
       pm[u] = *(const float4*)(wmu + o);
-      if (NOISY) ps[u] = *(const float4*)(wsg + o);
+      if (NOISY) { ps[u] = *(const float4*)(wsg + o); pe[u] = ein[kr]; }
     }
     // this lane's four columns of dY, all batch rows, as pairs of batch rows; columns
     // beyond the head's N (and lanes beyond the chunk) contribute zeros
@@ -142,17 +147,17 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
       for (int u = 0; u < P; ++u) {
         if (i0 + u < myrows) {   // (wave-uniform)
           const int r = grp + GROUPS * (i0 + u);   // row of the workgroup
-          const float4 cm = pm[u], cs = NOISY ? ps[u] : dz_f4zero();
-          {
-            const unsigned o = (unsigned)(min(k0 + r + GROUPS * P, k1 - 1) * ldw + cc) * 4u;
-            pm[u] = *(const float4*)(wmu + o);
-            if (NOISY) ps[u] = *(const float4*)(wsg + o);
-          }
-          float w0 = cm.x, w1 = cm.y, w2 = cm.z, w3 = cm.w;
+          // W_eff of THIS row and its 48 multiply-adds first, from the registers loaded P rows
+          // ago; only then (below, in front of the butterfly) are those registers re-requested
+          // for row r + P.  (Loads first, as in rounds 1-3, leaves the old values -- W_eff is
+          // formed in place -- live under the new ones: the new ones land in temporaries and are
+          // `v_mov`ed into the loop-carried registers at the end of the iteration, behind an
+          // `s_waitcnt vmcnt(0..2)`: one exposed memory round trip per row.)
+          float w0 = pm[u].x, w1 = pm[u].y, w2 = pm[u].z, w3 = pm[u].w;
           if (NOISY) {
-            const float e = ein[k0 + r];
-            w0 = __builtin_fmaf(cs.x, e * eo.x, cm.x); w1 = __builtin_fmaf(cs.y, e * eo.y, cm.y);
-            w2 = __builtin_fmaf(cs.z, e * eo.z, cm.z); w3 = __builtin_fmaf(cs.w, e * eo.w, cm.w);
+            const float e = pe[u];
+            w0 = __builtin_fmaf(ps[u].x, e * eo.x, w0); w1 = __builtin_fmaf(ps[u].y, e * eo.y, w1);
+            w2 = __builtin_fmaf(ps[u].z, e * eo.z, w2); w3 = __builtin_fmaf(ps[u].w, e * eo.w, w3);
           }
           dz_f2 a[16];
 #pragma unroll
@@ -162,6 +167,14 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
             t = __builtin_elementwise_fma(D[i][2], dz_f2{w2, w2}, t);
             a[i] = __builtin_elementwise_fma(D[i][3], dz_f2{w3, w3}, t);
           }
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            const int kr = min(k0 + r + GROUPS * P, k1 - 1);
+            const unsigned o = (unsigned)(kr * ldw + cc) * 4u;
+            pm[u] = *(const float4*)(wmu + o);
+            if (NOISY) { ps[u] = *(const float4*)(wsg + o); pe[u] = ein[kr]; }
+          }
+          __builtin_amdgcn_sched_barrier(0);
           // transposed butterfly over lane bits 5, 4, 3: 32 -> 16 -> 8 -> 4 values per
           // lane (a[i] = batch rows 2i, 2i+1)
 #pragma unroll

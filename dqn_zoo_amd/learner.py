@@ -164,13 +164,20 @@ class RainbowLearner:
     self._noise_counter += n
 
   def apply(self, states: torch.Tensor, which: str = 'online', noise=None,
-            resample_noise: bool = True, packed_out=None):
+            resample_noise: bool = True, packed_out=None, next_sample=None):
     """One network apply on uint8 states [B,84,84,4] (device tensor).
     Returns device tensors (q_values [B,A] f32, greedy action [B] i32,
-    max_a q [B] f32).  ref: rainbow/agent.py:125-131 (select_action)."""
+    max_a q [B] f32).  ref: rainbow/agent.py:125-131 (select_action).
+
+    `next_sample` (descriptor from `replay.prepare_next_sample`, fresh-noise acting
+    applies only): the replay sample + gather of the learner step that follows this
+    decision rides in the apply's second launch (dz_rainbow_act); launched eagerly."""
     stream = _lib.stream_ptr(self.device)
     params = self.online if which == 'online' else self.target
-    if packed_out is not None and noise is None and resample_noise and self.act_graphs and stream:
+    if next_sample is not None and not (noise is None and resample_noise):
+      raise ValueError('next_sample rides in the fresh-noise acting apply only')
+    if (packed_out is not None and noise is None and resample_noise and self.act_graphs and
+        stream and next_sample is None):
       # steady state of the agent loop: same observation slot, same result slot, same
       # parameters -> replay the captured launches, nothing to allocate
       # (the key carries shape and dtype: an address the allocator recycled for a
@@ -207,8 +214,10 @@ class RainbowLearner:
           a, self.network.num_atoms, b, params.data_ptr(), states.data_ptr(),
           self._act_noise.data_ptr(), self._noise_seed ^ 0xA5A5A5A5, 0,
           self._act_step.data_ptr(), self.support.data_ptr(), self._act_ws.data_ptr(),
-          q.data_ptr(), greedy.data_ptr(), vmax.data_ptr(), stream), 'dz_rainbow_act')
-      if (self.act_graphs and stream and packed_out is not None and
+          q.data_ptr(), greedy.data_ptr(), vmax.data_ptr(),
+          None if next_sample is None else ctypes.addressof(next_sample), stream),
+                                   'dz_rainbow_act')
+      if (self.act_graphs and stream and packed_out is not None and next_sample is None and
           len(self._act_graphs) < self.MAX_ACT_GRAPHS):
         # (a caller that hands over a fresh observation tensor per decision --
         # atari(device_observations=True) -- fills the cache with single-use graphs:
@@ -232,7 +241,7 @@ class RainbowLearner:
 
   ACT_RING = 8   # acting results in flight (pinned host words)
 
-  def apply_async(self, states: torch.Tensor):
+  def apply_async(self, states: torch.Tensor, next_sample=None):
     """Acting apply whose (greedy action, max q) pair is written by the kernel
     straight into pinned, device-mapped HOST memory: no device->host copy is
     enqueued and nothing synchronises here.  Returns `read() -> (action, value)`
@@ -246,7 +255,7 @@ class RainbowLearner:
     k = self._act_pos % self.ACT_RING
     self._act_pos += 1
     slot = self._act_host[k]
-    self.apply(states, packed_out=slot)
+    self.apply(states, packed_out=slot, next_sample=next_sample)
     ev = self._act_events[k]
     ev.record(_lib.current_stream(self.device))
 

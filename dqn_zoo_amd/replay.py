@@ -1066,6 +1066,7 @@ class PrioritizedTransitionReplay(_ReplayBase):
     return slot.sample
 
   SAMPLE_RING_DEPTH = 4
+  MAX_PREPARED_BATCH = 64   # draws of a prepared sample travel in kernel arguments
 
   def _ring_slot(self, size):
     ring = getattr(self, '_sample_ring', None)

@@ -390,13 +390,22 @@ int dz_rainbow_apply(int num_actions, int num_atoms, int batch, const float* par
  * the call can be captured once (dz_graph_capture_begin/end) and replayed per
  * decision.  greedy_out / vmax_out may point into pinned, device-mapped host
  * memory (the action is then on the host when the stream reaches that point).
+ * next_sample (nullable): the replay sample + gather of the learner step that FOLLOWS
+ * this decision (rainbow/agent.py:141-155: act, add, then -- every learn_period
+ * frames -- sample and learn) rides in the apply's second launch as extra blocks:
+ * exactly dz_prioritized_sample_gather / dz_replay_sample_uniform with these
+ * arguments.  The caller enqueues the frame's replay inserts BEFORE this call (the
+ * sample must see them; the apply does not read the replay) and then learns from the
+ * descriptor's buffers instead of sampling: one launch fewer per learn period, same
+ * ids, weights and rows.  The draws are by-value kernel arguments: such a call is
+ * not graph-capturable.
  * ref: rainbow/agent.py:125-131, 171-179 (select_action with a fresh key).    */
 int dz_rainbow_act(int num_actions, int num_atoms, int batch, const float* params,
                    const uint8_t* states, float* noise, uint64_t noise_seed,
                    uint64_t noise_counter, int32_t* step_counter,
                    const float* support, float* ws,
                    float* q_values_out, int32_t* greedy_out, float* vmax_out,
-                   dz_stream_t stream);
+                   const dz_next_sample_t* next_sample, dz_stream_t stream);
 
 /* hipGraph form of dz_rainbow_learn: captures the launches of one call (same
  * args, same phases; every pointer in `args` is baked in) on `stream` and

@@ -62,7 +62,7 @@ def main():
       transition_accumulator=replay_lib.NStepTransitionAccumulator(3), replay=rep,
       batch_size=32, min_replay_capacity_fraction=0.005, learn_period=4,
       target_network_update_period=2000, rng_key=1)
-  if len(sys.argv) > 3 and sys.argv[3] == 'eager-learn':
+  if 'eager-learn' in sys.argv[3:]:
     ag._learner.use_graphs = False   # learner launches eager, acting applies still from graphs  # pylint: disable=protected-access
   # instrument
   acc = {'act': 0.0, 'add': 0.0, 'learn': 0.0}
@@ -74,7 +74,13 @@ def main():
       acc[key] += time.perf_counter() - t0
       return r
     setattr(obj, name, g)
-  wrap(ag, '_act', 'act'); wrap(ag, '_learn', 'learn'); wrap(rep, add_name, 'add')
+  if hasattr(ag, '_act'):
+    wrap(ag, '_act', 'act')
+  else:   # Rainbow: the acting apply is enqueued inside step() (it may carry the sample)
+    wrap(ag._learner, 'apply_async', 'act')   # pylint: disable=protected-access
+  wrap(ag, '_learn', 'learn'); wrap(rep, add_name, 'add')
+  if 'nofuse' in sys.argv[3:]:
+    ag.fuse_sample_into_acting = False
   env = Env(3)
   loop = parts.run_loop(ag, env, max_steps_per_episode=0)
   for _ in range(1000):   # fill past min replay, warm up
@@ -92,6 +98,12 @@ def main():
             1e6 * acc['learn'] / frames,
             1e6 * (dt - sum(acc.values())) / frames))
   rep.check_status()
+  if 'json' in sys.argv[3:]:
+    import json
+    print(json.dumps({'agent': which, 'agent_steps_per_sec': round(frames / dt, 1),
+                      'us_per_agent_step': round(1e6 * dt / frames, 2), 'learn_period': 4,
+                      'learner_steps_per_sec': round(frames / dt / 4, 1),
+                      'sample_carried_by_acting_apply': bool(getattr(ag, 'fuse_sample_into_acting', False))}))
 
 
 if __name__ == '__main__':
