@@ -35,13 +35,11 @@ constexpr int kFc2Splits = 8;        // fc2 forward k-splits
 //   fc1: 448 workgroups x 7 rows behind the sixteen Gram side blocks;
 //   fc2: 128 workgroups x 4 rows in front of the fc2 weight-gradient contraction; dh1
 //        leaves that launch finished (summed over n, ReLU-masked) -- no slabs to fold.
-#ifndef DZ_DGB
-#define DZ_DGB 448
-#endif
-#ifndef DZ_DGP
-#define DZ_DGP 4
-#endif
-constexpr int kDgBlocks = DZ_DGB, kDg2Blocks = 128;
+// (round 4, with the pipelined row loop: 224 / 256 / 320 / 392 / 448 / 640 workgroups = 12.5 /
+// 13.4 / 13.5 / 12.3 / 12.4 / 13.9 us -- flat: the stream is bound by its vector arithmetic,
+// 170 instructions per row and wave of which 64 are the multiply-adds, not by the 128 KB of
+// dY every workgroup pulls or by how many rows share it)
+constexpr int kDgBlocks = 448, kDg2Blocks = 128;
 constexpr int kDgRows = (kFlat + kDgBlocks - 1) / kDgBlocks;          // weight rows per workgroup
 constexpr int kDgLds = kDgRows * 4 * 8 * kRdGroup > kRdLdsFloats ? kDgRows * 4 * 8 * kRdGroup : kRdLdsFloats;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -58,7 +56,7 @@ void fc1_dgrad_rows_kernel(RowDgrad q, GramD gd, PrioUpdateParams prio) {
     if (bid == 0) { PrioUpdateSideFast::run(prio, 0, lds, (int)sizeof(lds)); return; }
     bid -= 1;
   }
-  row_dgrad_block<2, 2, true, DZ_DGP>(q, bid, lds);
+  row_dgrad_block<2, 2, true, 4>(q, bid, lds);
 }
 template <int NJ0>   // 256-column chunks of the advantage head
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -444,11 +442,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         static_assert(kDgRows * 32 <= 512, "two outputs per thread in the epilogue");
         // the sum-tree priority write-back rides HERE in the one-call step (same-box A/B:
         // conv3's backward launch 11.3 -> 10.2 us without it, this launch 12.7 -> 12.8)
-#ifdef DZ_PRIO_IN_CONV3
-        const bool carry_prio = false;
-#else
         const bool carry_prio = prio_pending;
-#endif
         hipLaunchKernelGGL(fc1_dgrad_rows_kernel,
                            dim3(GramDSide::kBlocks + kDgBlocks + (carry_prio ? 1 : 0)), dim3(256),
                            0, s, q, gdp, carry_prio ? prio_q : PrioUpdateParams{});
