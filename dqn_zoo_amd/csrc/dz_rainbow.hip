@@ -22,6 +22,7 @@
 #include "dz_torso.h"
 #include "dz_fc1_onfly.h"
 #include "dz_row_dgrad.h"
+#include "dz_fc1_dgrad.h"
 
 namespace {
 
@@ -30,33 +31,31 @@ namespace {
 constexpr int kFc1Splits = 32;       // fc1 forward k-splits (98 rows each)
 constexpr int kFc1DgradSplits = 12;  // fc1 input-gradient k-splits: 11 slabs of 6 single-chunk stages (17.9 us; 16 x 4: 19.2; 10 x 7: 19.6)
 constexpr int kFc2Splits = 8;        // fc2 forward k-splits
-// The two noisy linear layers' input gradients as row-owning weight streams
-// (dz_row_dgrad.h), used by the one-call step (dz_fc1_onfly.h):
-//   fc1: 448 workgroups x 7 rows behind the sixteen Gram side blocks;
-//   fc2: 128 workgroups x 4 rows in front of the fc2 weight-gradient contraction; dh1
-//        leaves that launch finished (summed over n, ReLU-masked) -- no slabs to fold.
-// (round 4, with the pipelined row loop: 224 / 256 / 320 / 392 / 448 / 640 workgroups = 12.5 /
-// 13.4 / 13.5 / 12.3 / 12.4 / 13.9 us -- flat: the stream is bound by its vector arithmetic,
-// 170 instructions per row and wave of which 64 are the multiply-adds, not by the 128 KB of
-// dY every workgroup pulls or by how many rows share it)
-constexpr int kDgBlocks = 448, kDg2Blocks = 128;
-constexpr int kDgRows = (kFlat + kDgBlocks - 1) / kDgBlocks;          // weight rows per workgroup
-constexpr int kDgLds = kDgRows * 4 * 8 * kRdGroup > kRdLdsFloats ? kDgRows * 4 * 8 * kRdGroup : kRdLdsFloats;
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void fc1_dgrad_rows_kernel(RowDgrad q, GramD gd, PrioUpdateParams prio) {
-  __shared__ __attribute__((aligned(16))) float lds[kDgLds];
-  static_assert(kDgLds >= 32 * GramDSide::kLd, "GramDSide's tile");
+// The two noisy linear layers' input gradients in the one-call step (dz_fc1_onfly.h):
+//   fc1: on the matrix pipe, weights transposed through LDS by LDS-DMA (dz_fc1_dgrad.h): 196
+//        workgroups x 16 rows behind the sixteen Gram side blocks.  (Rounds 3-4 ran it as a
+//        row-owning VALU stream, dz_row_dgrad.h: 12.3-13.9 us whatever the launch shape -- 224
+//        ... 640 workgroups -- because its 170 vector instructions per row and wave, 64 of them
+//        the multiply-adds, were the bound; 10.75 us now.)
+//   fc2: row-owning stream (dz_row_dgrad.h), 128 workgroups x 4 rows in front of the fc2
+//        weight-gradient contraction; dh1 leaves that launch finished (summed over n,
+//        ReLU-masked) -- no slabs to fold.
+constexpr int kDg2Blocks = 128;
+// fc1's input gradient (dz_fc1_dgrad.h): one workgroup per 16 weight rows behind the side
+// blocks (Gram norms of dh1; optionally the sum-tree priority write-back).
+__global__ __launch_bounds__(256)
+void fc1_dgrad_mfma_kernel(Fc1DgradMfma q, GramD gd, PrioUpdateParams prio) {
+  __shared__ __attribute__((aligned(16))) float lds[kDmLdsFloats];
+  static_assert(kDmLdsFloats >= 32 * GramDSide::kLd, "GramDSide's tile");
   static_assert(sizeof(lds) >= sizeof(WbScratch), "the write-back's LDS walk");
   unsigned bid = blockIdx.x;
   if (bid < (unsigned)GramDSide::kBlocks) { GramDSide::run(gd, bid, lds, (int)sizeof(lds)); return; }
   bid -= GramDSide::kBlocks;
-  // optional: the sum-tree priority write-back as one more side block (it needs only the
-  // loss kernel's priorities; this launch's 218-VGPR allocation covers its LDS walk)
   if (prio.node) {
     if (bid == 0) { PrioUpdateSideFast::run(prio, 0, lds, (int)sizeof(lds)); return; }
     bid -= 1;
   }
-  row_dgrad_block<2, 2, true, 4>(q, bid, lds);
+  fc1_dgrad_mfma_block(q, bid, lds);
 }
 template <int NJ0>   // 256-column chunks of the advantage head
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -429,23 +428,25 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       // (compiled for 5 waves per SIMD: 1323 workgroups then find 1280 co-resident slots instead of 1024)
       if (onfly) {
         // no weight-gradient workgroups: sixteen side blocks leave the layer's squared
-        // gradient norm in the fc1 slots (GramDSide), the input gradient is one row-owning
-        // weight stream (no slabs, no reduce launch)
+        // gradient norm in the fc1 slots (GramDSide); the input gradient runs on the matrix
+        // pipe with the weights transposed through LDS (dz_fc1_dgrad.h: no slabs, no reduce
+        // launch)
         GramD gdp;
         gdp.dh1 = ws + L.ws_dh1; gdp.M = B; gdp.eps_out = nz[0] + L.n_fc1_out;
         gdp.gx_part = gram_part; gdp.dot_out = sq_slots + fc2_slots;
-        RowDgrad q = {};
-        q.params = a->online; q.noise = nz[0]; q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
-        q.dy = ws + L.ws_dh1; q.ldy = 1024; q.mask = ws + L.ws_feat; q.out = ws + L.ws_dfeat;
-        q.ldo = kFlat; q.out_col[0] = 0; q.out_col[1] = 0; q.same_out = 1;
-        q.M = B; q.K = kFlat; q.nblocks = kDgBlocks;
-        static_assert(kDgRows * 32 <= 512, "two outputs per thread in the epilogue");
         // the sum-tree priority write-back rides HERE in the one-call step (same-box A/B:
-        // conv3's backward launch 11.3 -> 10.2 us without it, this launch 12.7 -> 12.8)
+        // +0.8 us on this launch, +1.3 us on conv3's backward launch)
         const bool carry_prio = prio_pending;
-        hipLaunchKernelGGL(fc1_dgrad_rows_kernel,
-                           dim3(GramDSide::kBlocks + kDgBlocks + (carry_prio ? 1 : 0)), dim3(256),
-                           0, s, q, gdp, carry_prio ? prio_q : PrioUpdateParams{});
+        Fc1DgradMfma m = {};
+        m.params = a->online; m.noise = nz[0];
+        m.w_mu = L.fc1_mu_w; m.w_sig = L.fc1_sig_w; m.ldw = L.fc1_ld;
+        m.eps_in[0] = (int)L.n_adv1_in; m.eps_in[1] = (int)L.n_val1_in; m.eps_out = (int)L.n_fc1_out;
+        m.dy = ws + L.ws_dh1; m.ldy = 1024; m.mask = ws + L.ws_feat; m.out = ws + L.ws_dfeat;
+        m.ldo = kFlat; m.M = B; m.K = kFlat;
+        static_assert(kFlat % 16 == 0, "16 weight rows per workgroup");
+        hipLaunchKernelGGL(fc1_dgrad_mfma_kernel,
+                           dim3(GramDSide::kBlocks + kFlat / 16 + (carry_prio ? 1 : 0)), dim3(256),
+                           0, s, m, gdp, carry_prio ? prio_q : PrioUpdateParams{});
         if (carry_prio) prio_pending = false;
         DZ_LAUNCH_CHECK();
         rc = DZ_OK;
