@@ -127,6 +127,7 @@ class DenseArgs(ctypes.Structure):
       ('prio_node', c_vp), ('prio_cap_pow2', c_i64), ('prio_capacity', c_i64),
       ('prio_ids', c_vp), ('prio_exponent', c_f64), ('prio_max_seen', c_vp),
       ('prio_status', c_vp), ('next_sample', c_vp),
+      ('keep_all_grads', c_i32), ('pad2_', c_i32),
   ]
 
 

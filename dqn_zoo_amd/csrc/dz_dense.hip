@@ -283,6 +283,7 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
     // (prioritized/agent.py:187-206)
     DZ_REQUIRE(!a->next_sample->args.node || a->prio_node == a->next_sample->args.node);
   }
+  bool fc1_onfly = false;   // fc1's weight gradient is formed inside the RMSProp launch
   bool norm_fused = false;  // this call's backward phase left the norm partials (Adam)
   int n_final = 0;   // fused-norm partials left by this call's backward phase (Adam)
   if (phases & DZ_PHASE_BACKWARD) {
@@ -377,6 +378,10 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
       // weight gradient and input gradient in ONE launch (as in dz_rainbow.hip)
       const dim3 gw(kHid / FcWg::BN, kFlat / FcWg::BM, 1), gdd(kFlat / 64, (B + 31) / 32, kS_ddfeat);
       const bool rows = (q_fused || rows2) && B <= 32;   // dh1 is finished: row-owning stream
+      // fc1's weight gradient formed inside the RMSProp launch instead of stored (RmsOnFly):
+      // this ONE call runs backward + optimiser, nobody asked for the full gradient vector
+      fc1_onfly = rows && (phases & DZ_PHASE_OPTIMIZER) && a->optimizer != DZ_OPT_ADAM &&
+                  !a->keep_all_grads;
       if (rows) {
         RowDgrad q = {};
         q.params = a->online; q.noise = nullptr; q.head[0] = h1; q.head[1] = h1;
@@ -387,7 +392,8 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
         static_assert(kHid == 512, "two 256-column jobs per row");
         static_assert((kFlat + kDenseDgBlocks - 1) / kDenseDgBlocks * 2 <= 32 &&
                       (kFlat + kDenseDgBlocks - 1) / kDenseDgBlocks * 32 <= 512, "rows x jobs per workgroup");
-        hipLaunchKernelGGL(dense_fc1_bwd_rows_kernel, dim3(kDenseDgBlocks + dz_count(gw)), dim3(256), 0, s,
+        hipLaunchKernelGGL(dense_fc1_bwd_rows_kernel,
+                           dim3(kDenseDgBlocks + (fc1_onfly ? 0u : dz_count(gw))), dim3(256), 0, s,
                            w1, gw, q);
         DZ_LAUNCH_CHECK();
         rc = DZ_OK;
@@ -459,11 +465,17 @@ extern "C" int dz_dense_learn(const dz_dense_args_t* a, int phases, dz_stream_t 
         DZ_REQUIRE(a->opt_m && a->opt_v);
         J.rms.p = a->online; J.rms.mu = a->opt_m; J.rms.nu = a->opt_v; J.rms.grad = grad;
         J.rms.lr = a->lr; J.rms.decay = a->decay_or_b1; J.rms.eps = a->eps;
-        J.rms.lo4[0] = L.fc1_w >> 2; J.rms.n4[0] = ((int64_t)kFlat * L.fc1_ld) >> 2;
+        J.rms.lo4[0] = L.fc1_w >> 2; J.rms.n4[0] = fc1_onfly ? 0 : ((int64_t)kFlat * L.fc1_ld) >> 2;
         if (!q_fused) { J.rms.lo4[1] = L.fc2_w >> 2; J.rms.n4[1] = ((int64_t)kHid * ld2) >> 2; }
-        J.rms.flat_blocks = 1024;
+        J.rms.flat_blocks = J.rms.n4[0] + J.rms.n4[1] > 0 ? (fc1_onfly ? 256 : 1024) : 0;
+        if (fc1_onfly) {
+          J.of.feat = ws + L.ws_feat; J.of.dh1 = ws + L.ws_dh1; J.of.B = B;
+          J.of.w = L.fc1_w; J.of.ld = L.fc1_ld; J.of.blocks = kRofBlocks;
+          DZ_REQUIRE((L.fc1_w & 3) == 0 && (L.fc1_ld & 3) == 0);
+        }
       }
-      const unsigned fin_blocks = acc + J.c_tiles[0] + J.c_tiles[1] + J.o_tiles + J.rms.flat_blocks + presum;
+      const unsigned fin_blocks = acc + J.c_tiles[0] + J.c_tiles[1] + J.o_tiles + J.of.blocks +
+                                  J.rms.flat_blocks + presum;
       if (a->next_sample && rms_in_finalize) {
         // RMSProp lives in this launch: it also carries sample(k+1) + gather(k+1) (the
         // write-back, if any, rode in conv3's backward launch above)

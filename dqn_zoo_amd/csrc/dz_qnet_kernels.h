@@ -182,6 +182,73 @@ __device__ __forceinline__ void dz_rms_apply_at(const RmsApply& R, const float* 
   dz_rms_one(g, m, v, pp, R.lr, R.decay, R.eps);
   R.mu[idx] = m; R.nu[idx] = v; R.p[idx] = pp;
 }
+// The dense learners' wide layer (fc1: 3136 x 512) WITHOUT a stored weight gradient, as
+// Rainbow's (dz_fc1_onfly.h): G = X^T D has rank <= 32, its factors (X: 400 KB, D = dh1:
+// 64 KB) are L2-resident, the matrix is 6.4 MB -- written by 392 MFMA workgroups of the
+// backward launch and read back here.  A workgroup owns a 64-row x 64-column tile of the
+// matrix and its two RMSProp moments, keeps the 32 x 64 strip of dh1 and the 64 x 32 tile of
+// X in LDS and forms every gradient element (32 FMAs, batch ascending) right before its
+// update.  RMSProp has no global norm: nothing else is needed (the Adam dense learners keep
+// the stored form).  ref: dqn/agent.py:109-117, dqn/run_atari.py:205-210.
+struct RmsOnFly {
+  const float* feat = nullptr;   // [B][3136] input of the layer (online s_tm1 apply); nullptr: off
+  const float* dh1 = nullptr;    // [B][512]  d loss / d pre-activation, finished
+  int B = 0;
+  long w = 0; int ld = 0;        // the [3136][ld] matrix in the parameter vector (512 columns used)
+  unsigned blocks = 0;
+};
+constexpr int kRofC = 64, kRofIT = 4, kRofRP = 256 / (kRofC / 4), kRofR = kRofRP * kRofIT, kRofFS = 36;
+constexpr int kRofStrips = 512 / kRofC, kRofBlocks = (3136 / kRofR) * kRofStrips;   // 49 x 8
+constexpr int kRofLds = 32 * kRofC + kRofR * kRofFS;
+static_assert(3136 % kRofR == 0, "rows");
+__device__ __forceinline__ void rms_fc1_block(unsigned blk, const RmsOnFly& q, const RmsApply& R,
+                                              float* lds) {
+  float* s_dh1 = lds; float* s_ft = lds + 32 * kRofC;
+  const int strip = blk % kRofStrips, rg = blk / kRofStrips;
+  const int k0 = rg * kRofR, c0 = strip * kRofC;
+  const int tid = threadIdx.x, rl = tid / (kRofC / 4), c4 = tid % (kRofC / 4);
+#pragma unroll
+  for (int i = 0; i < kRofC / 32; ++i) {       // dh1 strip [32][C]
+    const int e = tid + 256 * i, b = e / (kRofC / 4), cc = e % (kRofC / 4);
+    const float4 d = *(const float4*)(q.dh1 + (unsigned)(min(b, q.B - 1) * 512 + c0 + 4 * cc));
+    *(float4*)(s_dh1 + b * kRofC + 4 * cc) = b < q.B ? d : dz_f4zero();
+  }
+#pragma unroll
+  for (int i = 0; i < (32 * kRofR + 255) / 256; ++i) {   // X tile [R][32 (+4)]
+    const int e = tid + 256 * i, b = e / kRofR, r = e % kRofR;
+    if (e < 32 * kRofR) {
+      const float f = q.feat[(unsigned)(min(b, q.B - 1) * 3136 + k0 + r)];
+      s_ft[r * kRofFS + b] = b < q.B ? f : 0.f;
+    }
+  }
+  long o = (q.w + (long)(k0 + rl) * q.ld + c0 + 4 * c4) >> 2;      // float4 index
+  const long rstep = ((long)kRofRP * q.ld) >> 2;
+  float4 pv = ((const float4*)R.p)[o], mv = ((const float4*)R.mu)[o], vv = ((const float4*)R.nu)[o];
+  __syncthreads();
+#pragma unroll 1
+  for (int it = 0; it < kRofIT; ++it) {
+    const float* ft = s_ft + (it * kRofRP + rl) * kRofFS;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+    for (int bq = 0; bq < 8; ++bq) {           // G[k][n] = sum_b x[b][k] dh1[b][n], b ascending
+      const float4 f = *(const float4*)(ft + 4 * bq);
+      const float fx[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 d = *(const float4*)(s_dh1 + (4 * bq + j) * kRofC + 4 * c4);
+        a0 = __builtin_fmaf(fx[j], d.x, a0); a1 = __builtin_fmaf(fx[j], d.y, a1);
+        a2 = __builtin_fmaf(fx[j], d.z, a2); a3 = __builtin_fmaf(fx[j], d.w, a3);
+      }
+    }
+    const float G[4] = {a0, a1, a2, a3};
+    float* P = (float*)&pv; float* M = (float*)&mv; float* V = (float*)&vv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dz_rms_one(G[j], M[j], V[j], P[j], R.lr, R.decay, R.eps);
+    ((float4*)R.mu)[o] = mv; ((float4*)R.nu)[o] = vv; ((float4*)R.p)[o] = pv;
+    o += rstep;
+    if (it + 1 < kRofIT) { pv = ((const float4*)R.p)[o]; mv = ((const float4*)R.mu)[o]; vv = ((const float4*)R.nu)[o]; }
+  }
+}
 __device__ __forceinline__ void dz_rms_flat(const RmsApply& R, unsigned fb) {
   // software-pipelined like rmsprop_kernel: the next element's loads (clamped,
   // unconditional) are issued before the current element's arithmetic
@@ -225,6 +292,7 @@ struct FinalizeJobs {
   int presum_n = 0;
   int32_t* bump_count = nullptr;    // optax count_inc, done here when the optimiser follows
   RmsApply rms;                     // p == nullptr: off
+  RmsOnFly of;                      // feat == nullptr: off; `of.blocks` tile blocks in front of the flat ones
 };
 __device__ __forceinline__ void finalize_grads_block(const FinalizeJobs& J, unsigned b);
 __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeJobs J) {
@@ -313,8 +381,16 @@ __device__ __forceinline__ void finalize_grads_block(const FinalizeJobs& J, unsi
     return;
   }
   b -= J.o_tiles;
+  if (J.of.feat) {   // fc1 tiles whose gradient is formed here (RMSProp dense learners)
+    if (b < J.of.blocks) {
+      __shared__ __attribute__((aligned(16))) float of_lds[kRofLds];
+      rms_fc1_block(b, J.of, J.rms, of_lds);
+      return;
+    }
+    b -= J.of.blocks;
+  }
   if (J.rms.p) {  // flat optimiser blocks (dense learners: no presum blocks)
-    dz_rms_flat(J.rms, b);
+    if (J.rms.flat_blocks) dz_rms_flat(J.rms, b);
     return;
   }
   // presum block

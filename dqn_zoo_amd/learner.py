@@ -471,6 +471,9 @@ class DenseLearner:
     self._act_batch = 0
     self._graphs = {}        # (input pointers, phases, sink) -> hipGraphExec
     self.use_graphs = None   # True / False / None = whenever the stream allows capture
+    # False (default): a full RMSProp step of a narrow-head learner never stores fc1's
+    # weight gradient (dz_dense_args_t::keep_all_grads); True materialises every block
+    self.keep_all_grads = False
 
   def get_params(self, which='online') -> dict:
     t = self.online if which == 'online' else self.target
@@ -544,6 +547,7 @@ class DenseLearner:
       a.eps, a.max_norm = self.opt.eps, 0.0
     a.grad_error_bound = self.grad_error_bound
     a.huber = self.huber_param
+    a.keep_all_grads = int(self.keep_all_grads)
     if priority_sink is not None:
       if not phases & _lib.PHASE_BACKWARD:
         raise ValueError('priority_sink needs the backward phase in this call')
@@ -564,7 +568,7 @@ class DenseLearner:
     # every argument is a pointer or a constant of this object: the launches of
     # one call signature are captured once and replayed (as jax.jit does)
     key = (a.s_tm1, a.s_t, a.a_tm1, a.r_t, a.discount_t, a.weights, phases,
-           a.prio_node, a.prio_ids)
+           a.prio_node, a.prio_ids, a.keep_all_grads)
     g = self._graphs.get(key)
     if g is None:
       if self.use_graphs is None and len(self._graphs) >= RainbowLearner.MAX_AUTO_GRAPHS:

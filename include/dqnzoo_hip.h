@@ -503,6 +503,12 @@ typedef struct {
    * selects the UNIFORM replay (TransitionReplay: positions -> ids -> rows; no tree,
    * `u_*_h`, `probs_out`, `weights*_out` unused).                                      */
   const dz_next_sample_t* next_sample;
+  /* 0 (default): a call that runs the backward pass AND the RMSProp optimiser at batch <= 32
+   * (narrow Q heads) does not write fc1's weight-gradient block (6.4 MB) into `grad`: the
+   * optimiser forms each entry from the layer's input and output gradient when it updates
+   * the weight (as dz_rainbow_args_t::keep_all_grads).  1: every block is materialised.    */
+  int32_t keep_all_grads;
+  int32_t pad2_;
 } dz_dense_args_t;
 
 int dz_dense_learn(const dz_dense_args_t* args, int phases, dz_stream_t stream);

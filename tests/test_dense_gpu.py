@@ -87,7 +87,9 @@ def test_dqn_family_step(kind):
   assert (np.abs(td) > 1.0).any() and (np.abs(td) < 1.0).any()
   g_dev = L.unpack(ln.grad.cpu().numpy())
   _check_grads(g_dev, g32, g64)
-  # centred RMSProp fed with the device gradients
+  # centred RMSProp fed with the device gradients (the stored-gradient form of the step:
+  # this loop reads the whole gradient vector back)
+  ln.keep_all_grads = True
   p, st = dict(online), qo.rmsprop_init(online)
   for it in range(2):
     ln.step(*_dev(batch), wd)
@@ -114,6 +116,7 @@ def test_rmsprop_inside_finalize_is_bit_identical_to_the_split_phases(kind):
   opt = ll.RmsPropConfig(learning_rate=0.00025, decay=0.95, eps=0.01 / 32 ** 2)
   rs, _, _, fused = _make(net, loss, opt, 11, grad_error_bound=1.0 / 32)
   _, _, _, split = _make(net, loss, opt, 11, grad_error_bound=1.0 / 32)
+  fused.keep_all_grads = True   # (the default forms fc1's gradient in the optimiser: next test)
   w = rs.uniform(0.2, 1.0, size=B).astype(np.float32) if kind == 'prioritized' else None
   wd = None if w is None else torch.from_numpy(w).cuda()
   for it in range(3):
@@ -125,6 +128,52 @@ def test_rmsprop_inside_finalize_is_bit_identical_to_the_split_phases(kind):
     for name in ('online', 'opt_m', 'opt_v', 'grad'):
       a, b = getattr(fused, name).cpu().numpy(), getattr(split, name).cpu().numpy()
       assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (it, name)
+
+@pytest.mark.parametrize('kind', ['dqn', 'prioritized'])
+def test_on_the_fly_fc1_gradient_in_rmsprop(kind):
+  """The DEFAULT full step of the RMSProp learners never stores fc1's weight gradient: the
+  optimiser launch forms each entry from the layer's input and dh1 (RmsOnFly).  Read back
+  directly: from a zero state the first step leaves mu = (1 - decay) g and nu = (1 - decay)
+  g^2 element by element -- against the float64 oracle -- and three steps stay within
+  float32 rounding of the stored-gradient form (same sums, another order)."""
+  from dqn_zoo_amd import learner as ll
+  net = 'dqn' if kind == 'dqn' else 'double_dqn'
+  loss = 'q' if kind == 'dqn' else 'double_q'
+  opt = ll.RmsPropConfig(learning_rate=0.00025, decay=0.95, eps=0.01 / 32 ** 2)
+  rs, online, target, fly = _make(net, loss, opt, 17, grad_error_bound=1.0 / 32)
+  _, _, _, stored = _make(net, loss, opt, 17, grad_error_bound=1.0 / 32)
+  stored.keep_all_grads = True
+  assert not fly.keep_all_grads
+  w = rs.uniform(0.2, 1.0, size=B).astype(np.float32) if kind == 'prioritized' else None
+  wd = None if w is None else torch.from_numpy(w).cuda()
+  batch = _batch(rs, scale_r=2.5)
+  fly.step(*_dev(batch), wd)
+  stored.step(*_dev(batch), wd)
+  torch.cuda.synchronize()
+  _, _, g64, _ = qo.dqn_family_loss_and_grads(kind, _f64(online), _f64(target), batch, w,
+                                              1.0 / 32, np.float64)
+  L = fly.layout
+  mu = L.unpack(fly.opt_m.cpu().numpy())
+  nu = L.unpack(fly.opt_v.cpu().numpy())
+  g = mu['fc1/w'].astype(np.float64) / (1.0 - opt.decay)
+  scale = np.abs(g64['fc1/w']).max()
+  assert np.abs(g - g64['fc1/w']).max() / scale < 2e-6
+  np.testing.assert_allclose(nu['fc1/w'].astype(np.float64) / (1.0 - opt.decay),
+                             g64['fc1/w'] ** 2, rtol=1e-5, atol=5e-6 * scale ** 2)
+  # the stored-gradient buffer of the default form holds no fc1 block (never written)
+  assert float(fly.grad[int(L.c.fc1_w):int(L.c.fc1_w) + 3136 * int(L.c.fc1_ld)].abs().max()) == 0.0
+  for it in range(2):
+    batch = _batch(rs, scale_r=2.5)
+    fly.step(*_dev(batch), wd)
+    stored.step(*_dev(batch), wd)
+  torch.cuda.synchronize()
+  for name in ('online', 'opt_m', 'opt_v'):
+    a, b = getattr(fly, name).cpu().numpy(), getattr(stored, name).cpu().numpy()
+    if name == 'online':   # an update is lr * g / sqrt(nu - mu^2 + eps): |.| <= lr / sqrt(eps) = 32 lr
+      np.testing.assert_allclose(a, b, rtol=0, atol=0.02 * opt.learning_rate)
+    else:
+      np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-9)
+
 
 def test_rmsprop_inside_finalize_two_flat_ranges():
   """33 actions: the second layer's weight gradient is written by the GEMM launch, so
@@ -143,6 +192,7 @@ def test_rmsprop_inside_finalize_two_flat_ranges():
     ln.set_params(target, 'target')
     lns.append(ln)
   fused, split = lns
+  fused.keep_all_grads = True   # (bit-identity is a property of the stored-gradient form)
   for it in range(2):
     b = [torch.from_numpy(x).cuda() for x in (
         rs.randint(0, 256, (batch, 84, 84, 4)).astype(np.uint8),
