@@ -97,6 +97,15 @@ template <class Op> struct DzRaw16<Op, decltype((void)Op::A_RAW16)> { static con
 // The same for RC A operands fed from uint8 (conv1's weight gradient): an Op with A_RAW4 = 1
 // provides  unsigned load_a_raw4(p, t, st, c, kk, rq)  (4 bytes = 4 consecutive rows) and
 // float4 cook4(unsigned); the 4 raw bytes wait in ONE register under the MFMAs.
+// Optional epilogue operands requested in the PROLOGUE: an Op with `struct Pre` and
+//   Pre prefetch(p, t, wm, wn, lane [, rmask])
+// gets `pre` as the last argument of store().  A bias or a ReLU mask first loaded inside
+// store() is a full memory round trip between the last MFMA and the first store (in-kernel
+// stamps, round 4: 0.7-1.0 us of every conv launch's "store" phase).
+template <class Op, class = void> struct DzHasPre { static constexpr int v = 0; };
+template <class Op> struct DzHasPre<Op, decltype((void)sizeof(typename Op::Pre))> { static constexpr int v = 1; };
+template <class Op, class = void> struct DzHasDbg { static constexpr int v = 0; };
+template <class Op> struct DzHasDbg<Op, decltype((void)Op::HAS_DBG)> { static constexpr int v = 1; };
 template <class Op, class = void> struct DzRaw4 { static constexpr int v = 0; };
 template <class Op> struct DzRaw4<Op, decltype((void)Op::A_RAW4)> { static constexpr int v = Op::A_RAW4; };
 // Optional: Op::PIN_LOADS = 1 keeps the next stage's global loads in front of the MFMA block.
@@ -169,6 +178,14 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
 
   typename Op::Tile t;  // DzTile + whatever the Op resolves once per workgroup
   if (!Op::tile(p, bid, t)) return;
+#ifdef DZ_GEMM_STAMPS
+  long long* dz_dbg = nullptr;
+  if constexpr (DzHasDbg<Op>::v) dz_dbg = p.dbg ? p.dbg + (long)(bid.x + bid.y * 4) * 8 : nullptr;
+#define DZ_GSTAMP(i) do { if (dz_dbg && threadIdx.x == 0) dz_dbg[i] = wall_clock64(); } while (0)
+#else
+#define DZ_GSTAMP(i) do {} while (0)
+#endif
+  DZ_GSTAMP(0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -179,6 +196,16 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
   const int half = lane >> 5;
   const int l31 = lane & 31;
 
+  // (the epilogue's row mask of the distributed store, known now)
+  constexpr unsigned kRpw = (WK > 1 && DzSplitStore<Op>::v && DzMI<Op>::v == 1 && DzNI<Op>::v == 1)
+                                ? 16 / WK : 16;
+  const unsigned my_rmask = kRpw == 16 ? 0xffffu : ((1u << kRpw) - 1u) << (wk * kRpw);
+  auto prefetch = [&]() {
+    if constexpr (DzHasPre<Op>::v) return Op::prefetch(p, t, wm, wn, lane, my_rmask);
+    else return 0;
+  };
+  auto pre = prefetch();
+  (void)pre;
   constexpr int A_ROW16 = (Op::A_LAYOUT == DZ_KC && Op::A_MAP == DZ_MAP_ROW16);
   constexpr int NA = A_ROW16 ? ((BM * CPS + 255) / 256) * 4 : AT::PER_THREAD;
   constexpr int NB = BT::PER_THREAD;
@@ -331,10 +358,12 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
       for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
   if (t.st_begin < t.st_end) load_stage(t.st_begin);
+  DZ_GSTAMP(1);
   for (int st = t.st_begin; st < t.st_end; ++st) {
     __syncthreads();  // everyone finished reading the previous stage
     store_stage();
     __syncthreads();
+    if (st == t.st_begin) DZ_GSTAMP(2);
     if (st + 1 < t.st_end) load_stage(st + 1);  // in flight under the MFMAs
     // (optionally pinned, Op::PIN_LOADS: in a fully unrolled stage loop the scheduler otherwise
     // sinks these loads BELOW the MFMA block, next to the LDS writes that consume them --
@@ -385,6 +414,7 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
     }
   }
 
+  DZ_GSTAMP(3);
   if constexpr (WK > 1 && DzSplitStore<Op>::v && MI == 1 && NI == 1) {
     __syncthreads();
     float* red = smem;   // [WK][WM*WN][16][64]
@@ -408,7 +438,10 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
         out[i] = v;
       }
     }
-    Op::store(p, t, wm, wn, lane, out, ((1u << RPW) - 1u) << (wk * RPW));
+    DZ_GSTAMP(4);
+    if constexpr (DzHasPre<Op>::v) Op::store(p, t, wm, wn, lane, out, ((1u << RPW) - 1u) << (wk * RPW), pre);
+    else Op::store(p, t, wm, wn, lane, out, ((1u << RPW) - 1u) << (wk * RPW));
+    DZ_GSTAMP(5);
     return;
   }
   if constexpr (WK > 1) {
@@ -445,7 +478,8 @@ __device__ __forceinline__ void dz_gemm_body(const typename Op::Params& p, const
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
-      Op::store(p, t, wm * MI + mi, wn * NI + ni, lane, acc[mi][ni]);
+      if constexpr (DzHasPre<Op>::v && MI == 1 && NI == 1) Op::store(p, t, wm, wn, lane, acc[mi][ni], 0xffffu, pre);
+      else Op::store(p, t, wm * MI + mi, wn * NI + ni, lane, acc[mi][ni]);
 }
 
 // C/D fragment coordinates of v_mfma_f32_32x32x2_f32 (cdna_hip_programming.md 3):

@@ -114,6 +114,7 @@ struct ConvFwdParams {
   float* out;                     // [G*B][OH][OW][CO]
   int B;                          // images per group
   int G;
+  long long* dbg = nullptr;       // (DZ_GEMM_STAMPS builds) per-workgroup wall-clock stamps
 };
 
 // AM_ (all three convolution Ops): 1 = masked slots select on the ADDRESS (third loader rule)
@@ -129,6 +130,7 @@ template <int IN_U8, int H, int W, int C, int KS, int S, int OH, int OW, int CO,
 struct ConvFwdOp {
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int PIN_LOADS = AM_;
+  static constexpr int HAS_DBG = 1;
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_RC;
   static constexpr int A_MAP = IN_U8 ? DZ_MAP_ROW16 : DZ_MAP_QUAD;
   static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
@@ -208,14 +210,20 @@ struct ConvFwdOp {
     return dz_ld4(t.w + (long)k * CO + t.n0 + 4 * rq);
   }
   static constexpr int SPLIT_STORE = 1;
+  // the bias of this lane's output column, requested in the prologue (dz_gemm.h DzHasPre)
+  struct Pre { float bias; };
+  __device__ static Pre prefetch(const Params& p, const Tile& t, int wm, int wn, int lane,
+                                 unsigned rmask) {
+    return Pre{t.bias[t.n0 + wn * 32 + (lane & 31)]};
+  }
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
-                               int lane, const f32x16& acc, unsigned rmask = 0xffffu) {
+                               int lane, const f32x16& acc, unsigned rmask, const Pre& pre) {
     const int col = t.n0 + wn * 32 + (lane & 31);
-    float b = t.bias[col];
-    // the bias waited for ONCE, here: used first inside the conditional store blocks below, the
-    // compiler puts an `s_waitcnt vmcnt(0)` into every one of them, and from the second block on
-    // that wait is for the previous block's STORE (gfx950 counts stores in vmcnt): the wave's
-    // four row stores became four serial round trips
+    float b = pre.bias;
+    // pinned as "available" once, here: used first inside the conditional store blocks below,
+    // the compiler puts an `s_waitcnt vmcnt(0)` into every one of them, and from the second
+    // block on that wait is for the previous block's STORE (gfx950 counts stores in vmcnt):
+    // the wave's four row stores became four serial round trips
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(b));
     const int rows = p.B * OH * OW;
 #pragma unroll
@@ -818,23 +826,28 @@ struct ConvDgradOp {
     return dz_ld4(p.w + ((long)(kh * KS + kw) * C + ci) * CO + co);
   }
   static constexpr int SPLIT_STORE = 0;  // distributed epilogue measured slower for this Op (EXPERIMENTS.md)
-  __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
-                               int lane, const f32x16& acc, unsigned rmask = 0xffffu) {
+  // the ReLU mask values (and addresses) of this wave's 16 output rows, requested in the
+  // prologue: loaded inside store() they were a memory round trip behind the last MFMA
+  struct Pre { unsigned o[16]; float mk[16]; };
+  __device__ static Pre prefetch(const Params& p, const Tile& t, int wm, int wn, int lane,
+                                 unsigned rmask) {
+    Pre pre;
     const int ci = t.n0 + wn * 32 + (lane & 31);
-    // all mask values of this wave's rows first (pixel() clamps, so every address is
-    // valid): loaded inside the store loop they are serial load -> wait -> store trips
-    unsigned o[16];
-    float mk[16];
-    bool ok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int img, h, w;
-      ok[r] = pixel(p, t, wm * 32 + dz_acc_row(r, lane), img, h, w) && ((rmask >> r) & 1u);
-      o[r] = (unsigned)(((img * H + h) * W + w) * C + ci);
-      mk[r] = ((rmask >> r) & 1u) ? p.act[o[r]] : 0.f;
+      const bool ok = pixel(p, t, wm * 32 + dz_acc_row(r, lane), img, h, w);   // (clamped: valid address)
+      pre.o[r] = (unsigned)(((img * H + h) * W + w) * C + ci);
+      pre.mk[r] = p.act[pre.o[r]];
+      if (!ok) pre.o[r] = 0xffffffffu;
     }
+    return pre;
+  }
+  __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
+                               int lane, const f32x16& acc, unsigned rmask, const Pre& pre) {
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      if (ok[r]) p.dx[o[r]] = mk[r] > 0.f ? acc[r] : 0.f;
+      if (pre.o[r] != 0xffffffffu && ((rmask >> r) & 1u))
+        p.dx[pre.o[r]] = pre.mk[r] > 0.f ? acc[r] : 0.f;
   }
 };

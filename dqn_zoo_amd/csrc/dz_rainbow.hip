@@ -87,7 +87,11 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
   const FcHead* fc2h = H.fc2h;
   {
     const TorsoBufs T = {L.conv_w, L.conv_b, ws + L.ws_act1, ws + L.ws_act2, ws + L.ws_feat};
-    rc = torso_forward(T, G, B, prm, in, s, resample, sg, sg_blocks);
+    long long* dbg = nullptr;
+#ifdef DZ_GEMM_STAMPS
+    if (G == 3) dbg = (long long*)(ws + L.ws_dfeat_part);
+#endif
+    rc = torso_forward(T, G, B, prm, in, s, resample, sg, sg_blocks, dbg);
     if (rc) return rc;
   }
   {  // fc1: noisy adv1 | val1, split-K partials

@@ -42,7 +42,8 @@ inline int launch_conv1_fwd(const ConvFwdParams& p, int G, int B, const NoisePar
 inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* prm,
                          const uint8_t* const* in, hipStream_t s,
                          const NoiseParams* side = nullptr,
-                         const SampleGatherParams* sg = nullptr, unsigned sg_blocks = 0) {
+                         const SampleGatherParams* sg = nullptr, unsigned sg_blocks = 0,
+                         long long* dbg = nullptr) {
   int rc;
   {
     ConvFwdParams p;
@@ -50,7 +51,7 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
       p.in[g] = in[g]; p.in_img_base[g] = 0;
       p.w[g] = prm[g] + T.conv_w[0]; p.bias[g] = prm[g] + T.conv_b[0];
     }
-    p.out = T.act1; p.B = B; p.G = G;
+    p.out = T.act1; p.B = B; p.G = G; p.dbg = dbg;
     rc = B <= 8 ? launch_conv1_fwd<Conv1FwdAct>(p, G, B, side, s)
                 : launch_conv1_fwd<Conv1Fwd>(p, G, B, side, s);
     if (rc) return rc;
@@ -62,7 +63,7 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
       p.in[g] = T.act1; p.in_img_base[g] = g * B;
       p.w[g] = prm[g] + T.conv_w[1]; p.bias[g] = prm[g] + T.conv_b[1];
     }
-    p.out = T.act2; p.B = B; p.G = G;
+    p.out = T.act2; p.B = B; p.G = G; p.dbg = dbg ? dbg + 65536 * 8 : nullptr;
     if (sg)
       rc = dz_launch_gemm_side<Conv2Fwd, SampleGatherSide>(
           p, dim3(64 / Conv2Fwd::BN, G * Conv2Fwd::tiles_per_group(B), 1), *sg, sg_blocks, s);
@@ -77,7 +78,7 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
       p.in[g] = T.act2; p.in_img_base[g] = g * B;
       p.w[g] = prm[g] + T.conv_w[2]; p.bias[g] = prm[g] + T.conv_b[2];
     }
-    p.out = T.feat; p.B = B; p.G = G;
+    p.out = T.feat; p.B = B; p.G = G; p.dbg = dbg ? dbg + 2 * 65536 * 8 : nullptr;
     rc = launch_conv_fwd<Conv3Fwd>(p, 64, G, B, s);
     if (rc) return rc;
     DZ_PROF(s, "conv3_fwd");
