@@ -320,6 +320,12 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
     if prof_steps > 0:
       learner.use_graphs = False
       e['roofline'] = roofline_of(profile_kernels(step, prof_steps), work)
+      # HBM bytes of the dominant launch from the committed PMC passes of this learner
+      # (tools/run_dense.py under --pmc FETCH_SIZE / WRITE_SIZE; profiles/r4_hbm_traffic.json)
+      doc, _ = _profile_json('hbm_traffic')
+      t = (doc or {}).get('dense', {}).get(desc.get('pmc_key'))
+      if t and e['roofline'].get('kernel', '').startswith('finalize'):
+        e['roofline']['traffic'] = t['hbm_bytes_corrected']
     return e
 
   # ---- configs[1]: DQN, NatureDQN net, uniform replay ------------------------
@@ -348,7 +354,7 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
       'DQN + uniform replay', rep, ln, step_dqn, dense_kernel_work(b, 2),
       {'workload': 'dqn learner step: uniform sample (positions -> ids -> gather, '
                    'one launch) + 2x NatureDQN apply + Q-learning loss + backward '
-                   '+ centred RMSProp', 'baseline_config': 1})
+                   '+ centred RMSProp', 'baseline_config': 1, 'pmc_key': 'dqn'})
   del rep, ln, step_dqn
   torch.cuda.empty_cache()
 
@@ -383,7 +389,7 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
       {'workload': 'prioritized-DQN learner step: sum-tree sample (exponent 0.6) + '
                    'IS weights + gather (one launch) + 3x NatureDQN apply (shared '
                    'bias) + double-Q loss + backward (+ |td| priority write-back as '
-                   'a side block) + centred RMSProp', 'baseline_config': 2})
+                   'a side block) + centred RMSProp', 'baseline_config': 2, 'pmc_key': 'double_q'})
   del rep, ln
   torch.cuda.empty_cache()
   return out
@@ -391,7 +397,7 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
 
 def _profile_json(name):
   """A committed profile table (profiles/r3_<name>.json, else the round-2 file)."""
-  for tag in ('r3', 'r2'):
+  for tag in ('r4', 'r3', 'r2'):
     try:
       with open(os.path.join(ROOT, 'profiles', '%s_%s.json' % (tag, name))) as f:
         return json.load(f), tag
@@ -793,6 +799,13 @@ def main():
           'steps': args.agent_form_steps, 'value': round(args.agent_form_steps / ds, 2),
           'unit': 'steps/s', 'ms_per_step': round(1e3 * ds / args.agent_form_steps, 4),
           'launches': None}
+    for which in ('rainbow', 'dqn'):   # the whole drop-in loop, from the committed session
+      doc, tag = _profile_json('agent_loop_' + which)
+      if doc:
+        out.setdefault('agent_loop', {})[which] = dict(
+            doc, source='profiles/%s_agent_loop_%s.json (tools/agent_loop_bench.py: act -> insert '
+                        '-> learn every 4th frame on a synthetic environment; NOT measured in '
+                        'this run)' % (tag, which))
     if args.prof_steps > 0:
       learner.use_graphs = False  # per-kernel events need eager launches
       prof_step = step if args.mode == 'fused' else seq_step

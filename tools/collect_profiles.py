@@ -18,14 +18,14 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r3'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r4'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, 'gpurun_out', tag), os.path.join(root, 'profiles')
 
 # bench mark name -> substring of the kernel's demangled name
 KERNELS = {
     'adam': 'adam_', 'adam+next_sample': 'adam_',
-    'fc1_fwd': 'dz_fc_stream_fwd3', 'fc1_dgrad+wgrad': 'fc1_dgrad_rows_kernel',
+    'fc1_fwd': 'dz_fc_stream_fwd3', 'fc1_dgrad+wgrad': 'fc1_dgrad_mfma_kernel',
     'conv1_fwd': 'ConvFwdOp<1, 84', 'conv2_fwd': 'dz_mfma_gemm<ConvFwdOp<0, 20, 20',
     'conv3_fwd': 'dz_mfma_gemm<ConvFwdOp<0, 9, 9', 'fc2_fwd': 'dz_mfma_gemm<FcFwdOp',
     'fc2_wgrad+dgrad': 'fc2_bwd_rows_kernel',
@@ -74,7 +74,10 @@ for name, out in (('bench.json', 'bench_line.json'), ('bench_40k.json', 'bench_l
 for name in ('kernel_stats_fused.csv', 'kernel_stats_sequential.csv',
              'kernel_step_summary_fused.txt', 'kernel_step_summary_sequential.txt',
              'pmc_sq_rainbow.txt', 'pmc_FETCH_SIZE.csv', 'pmc_WRITE_SIZE.csv',
-             'pmc_cal_FETCH_SIZE.csv', 'pmc_cal_WRITE_SIZE.csv'):
+             'pmc_cal_FETCH_SIZE.csv', 'pmc_cal_WRITE_SIZE.csv',
+             'pmc_dqn_FETCH_SIZE.csv', 'pmc_dqn_WRITE_SIZE.csv', 'pmc_double_q_FETCH_SIZE.csv',
+             'pmc_double_q_WRITE_SIZE.csv', 'agent_loop_rainbow.json', 'agent_loop_dqn.json',
+             'kernel_step_summary_double_q.txt'):
   p = os.path.join(src, name)
   if os.path.exists(p):
     shutil.copy(p, os.path.join(dst, '%s_%s' % (tag, name)))
@@ -114,6 +117,16 @@ for key in ('adam', 'fc1_fwd', 'fc1_dgrad+wgrad', 'conv1_fwd', 'conv2_fwd', 'con
       'fetch_factor': fac, 'hbm_bytes_corrected': None if fac is None else fac * f + w}
 w1 = find(write, KERNELS['fc1_fwd'])
 doc['write_check'] = {'fc1_fwd_slab_store_algorithmic': 12582912, 'WRITE_SIZE_reported': w1}
+# the dense learners' dominant launch (finalize + RMSProp): float4 streams
+doc['dense'] = {}
+for cfg in ('dqn', 'double_q'):
+  f = find(pmc_csv(os.path.join(src, 'pmc_%s_FETCH_SIZE.csv' % cfg)), 'finalize_grads')
+  w = find(pmc_csv(os.path.join(src, 'pmc_%s_WRITE_SIZE.csv' % cfg)), 'finalize_grads')
+  fac = factors.get('float4_flat')
+  if f is not None and w is not None and fac:
+    doc['dense'][cfg] = {'kernel': 'finalize_grads(_sg)_kernel (finalize + RMSProp)',
+                         'fetch_size_bytes_raw': f, 'write_size_bytes': w, 'fetch_factor': fac,
+                         'hbm_bytes_corrected': fac * f + w}
 json.dump(doc, open(os.path.join(dst, '%s_hbm_traffic.json' % tag), 'w'), indent=1)
 
 # ---- MFMA utilisation --------------------------------------------------------------

@@ -7,18 +7,18 @@
 # Outputs under gpurun_out/<tag>/ (python tools/collect_profiles.py <tag> copies the
 # summaries into profiles/).
 ulimit -c 0
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python $R/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err < /dev/null
 echo "bench rc=$?"
-timeout 600 python $R/bench.py --steps 40000 --warmup 500 --cpu-seconds 0 --other-configs 0 --prof-steps 0 --sustain-steps 0 > $OUT/bench_40k.json 2> $OUT/bench_40k.err < /dev/null
+timeout 600 python $R/bench.py --steps 40000 --warmup 500 --cpu-seconds 0 --other-configs 0 --prof-steps 0 --sustain-steps 0 --agent-form-steps 0 > $OUT/bench_40k.json 2> $OUT/bench_40k.err < /dev/null
 echo "bench 40k rc=$?"
 for mode in fused sequential; do
   rm -rf $OUT/kt
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py --mode $mode --steps 300 --warmup 50 --cpu-seconds 0 --prof-steps 0 --other-configs 0 --sustain-steps 0 > $OUT/kt_$mode.log 2>&1 < /dev/null
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py --mode $mode --steps 300 --warmup 50 --cpu-seconds 0 --prof-steps 0 --other-configs 0 --sustain-steps 0 --agent-form-steps 0 > $OUT/kt_$mode.log 2>&1 < /dev/null
   f=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats_$mode.csv
   t=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
   [ -n "$t" ] && python $R/tools/step_trace_summary.py "$t" 100 > $OUT/kernel_step_summary_$mode.txt 2>&1
@@ -51,6 +51,20 @@ for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/pmc
   fi
 done
+# the dense learners (BASELINE configs 2 and 3): the same two counters
+for cfg in dqn double_q; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $OUT/pmc
+    timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc -- python $R/tools/run_dense.py $cfg > $OUT/pmc_${cfg}_$c.log 2>&1 < /dev/null
+    f=$(find $OUT/pmc -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && pmc_table "$f" $c > $OUT/pmc_${cfg}_$c.csv
+    rm -rf $OUT/pmc
+  done
+done
+# the agent loop (act -> insert -> learn every 4th frame) and the dense learners' kernel trace
+python $R/tools/agent_loop_bench.py 6000 rainbow json 2>/dev/null | tail -1 > $OUT/agent_loop_rainbow.json
+python $R/tools/agent_loop_bench.py 6000 dqn json 2>/dev/null | tail -1 > $OUT/agent_loop_dqn.json
+bash $R/tools/dense_trace.sh 200 > $OUT/kernel_step_summary_double_q.txt 2>&1
 bash $R/tools/pmc_rainbow.sh > $OUT/pmc_sq_rainbow.txt 2>&1
 ls -la $OUT | tail -20
 head -3 $OUT/kernel_step_summary_fused.txt

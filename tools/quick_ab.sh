@@ -6,10 +6,10 @@ OUT=$R/gpurun_out/q
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for i in 1 2 3; do
-timeout 300 python $R/bench.py --steps 3000 --warmup 300 --cpu-seconds 0 --prof-steps 0 --other-configs 0 --sustain-steps 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'])"
+timeout 300 python $R/bench.py --steps 3000 --warmup 300 --cpu-seconds 0 --prof-steps 0 --other-configs 0 --sustain-steps 0 --agent-form-steps 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'])"
 done
 rm -rf $OUT/kt
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python $R/bench.py --steps 400 --warmup 50 --cpu-seconds 0 --prof-steps 0 --other-configs 0 --sustain-steps 0 > $OUT/kt.log 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python $R/bench.py --steps 400 --warmup 50 --cpu-seconds 0 --prof-steps 0 --other-configs 0 --sustain-steps 0 --agent-form-steps 0 > $OUT/kt.log 2>&1 < /dev/null
 t=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
 python $R/tools/step_trace_summary.py "$t" 200 | grep -E "last 200|busy|${1:-adam}" | cut -c1-130
 rm -rf $OUT/kt
