@@ -798,7 +798,7 @@ def main():
                   'dz_prioritized_sample_gather launch + dz_rainbow_learn',
           'steps': args.agent_form_steps, 'value': round(args.agent_form_steps / ds, 2),
           'unit': 'steps/s', 'ms_per_step': round(1e3 * ds / args.agent_form_steps, 4),
-          'launches': None}
+          'launches': 15}   # 1 sample+gather + 14 (profiles/*_kernel_step_summary_sequential.txt)
     for which in ('rainbow', 'dqn'):   # the whole drop-in loop, from the committed session
       doc, tag = _profile_json('agent_loop_' + which)
       if doc:
