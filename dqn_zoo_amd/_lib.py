@@ -69,7 +69,7 @@ class RainbowLayout(ctypes.Structure):
           'ws_fc1_part', 'ws_h1', 'ws_fc2_part', 'ws_fc2_out', 'ws_dout2',
           'ws_dh1', 'ws_dfeat_part', 'ws_dfeat', 'ws_dact2', 'ws_dact1',
           'ws_wgrad_part', 'ws_norm_part', 'ws_scalars', 'ws_q_sel',
-          'ws_target_probs', 'ws_colsum_part')])
+          'ws_target_probs', 'ws_colsum_part', 'ws_act_seams')])
 
 
 class RainbowArgs(ctypes.Structure):

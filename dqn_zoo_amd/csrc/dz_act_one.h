@@ -1,0 +1,513 @@
+// The Rainbow actor's decision for ONE observation as ONE launch
+// (ref: rainbow/agent.py:125-133,171-179 select_action -> network.apply on a batch of one;
+//  networks.py:186-204 torso, :137-178 noisy linear, :229-261 dueling C51 head).
+//
+// At one image the network is 15 MFLOP of convolution, a 25.7 MB weight stream (fc1's mu and
+// sigma) and 1.5 MB for the second layer -- five launches of 7-9 us each spent 41 us on it,
+// almost all of it launch floors and cold round trips in series.  Here 261 workgroups of one
+// launch take three roles and hand results to each other through write-through (sc1) stores,
+// drained `vmcnt`, relaxed agent-scope counters and sc1 loads (the cheap seam of
+// tools/micro/gridbar_micro.hip; no L2 write-back or invalidate anywhere):
+//
+//   torso  (25 workgroups)  conv1 -> conv2 -> conv3 with two 25/24-party barriers.  One workgroup
+//                           owns 16 output pixels (x 32 channels in conv1, x 16 channels in
+//                           conv2/conv3), its 4 waves split K; the input patch is copied once
+//                           into LDS (conv1: raw bytes over PCIe from the pinned observation
+//                           slot), A fragments are read from the patch, B fragments (weights)
+//                           were requested lane-wise straight into MFMA operand registers for
+//                           ALL three layers before the first wait; v_mfma_f32_16x16x4_f32.
+//   fc1    (224 workgroups) 28 K-splits x 8 column groups of the 3136 x 1024 layer: every thread
+//                           requests its 14 x 4 mu and sigma values at launch, draws the eps it
+//                           needs itself (dz_noise_at is a pure function of the stream position),
+//                           forms W_eff in registers and only then waits for the torso's feature
+//                           vector: the 25.7 MB stream runs UNDER the convolutions.
+//   tail   (12 workgroups)  the second noisy layer's column tiles (weights in registers from the
+//                           start), folds the 28 fc1 slabs, takes a ticket; the last one emits
+//                           q-values, greedy action and value (into pinned host memory) and
+//                           re-arms the counters.
+//
+// Dependencies only point from lower to higher block ids and the 25 torso workgroups are the
+// first to be dispatched, so the launch cannot deadlock whatever else occupies the chip.  Every
+// spin is bounded: a stuck seam sets a sticky word and the apply returns NaN q-values instead
+// of hanging the device.
+#pragma once
+
+#include "dz_qnet_kernels.h"
+
+namespace {
+
+typedef float act_f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kActTorsoBlocks = 25;   // conv1 pixel tiles (400 / 16)
+constexpr int kActConv2Blocks = 24;   // 6 pixel tiles x 4 channel tiles
+constexpr int kActConv3Blocks = 16;   // 4 pixel tiles x 4 channel tiles
+constexpr int kActFc1Splits = 28, kActFc1Rows = 112, kActFc1Blocks = kActFc1Splits * 8;
+constexpr int kActSpinLimit = 300000;
+constexpr int kActSeamWords = 64 * 16 + 16 * kActFc1Blocks;   // 16 lines + one 64-byte flag per fc1 workgroup
+constexpr int kActLdsFloats = 8 * 20 * 36 + 4 * 256;   // largest patch (conv2) + partial tiles
+static_assert(kActFc1Splits * kActFc1Rows == kFlat, "fc1 K-splits");
+
+#define DZ_ACT_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+// (tools builds, -DDZ_ACT_STAMPS) per-workgroup wall-clock stamps in the idle dfeat slab buffer
+#ifdef DZ_ACT_STAMPS
+#define ACT_STAMP(i) do { if (threadIdx.x == 0) p.dbg[blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define ACT_STAMP(i) do {} while (0)
+#endif
+
+struct ActOneParams {
+  const uint8_t* obs;                 // [84][84][4], device or pinned device-mapped host memory
+  const float* prm;
+  long conv_w[3], conv_b[3];
+  float* act1; float* act2; float* feat;
+  long fc1_mu_w, fc1_sig_w, fc1_mu_b, fc1_sig_b; int fc1_ld;
+  float* part;                        // [28][1024] fc1 slabs
+  float* noise; int n_noise;          // the apply's noise block, also written out (tests, state)
+  uint64_t seed, counter; const int32_t* step;
+  int n_eps_in[2]; int n_fc1_out;
+  FcHead head[2];                     // adv2, val2
+  long fc2_sig_b; int n_fc2_out;
+  int ld2, val_off, A, K;
+  const float* support;
+  float* fc2_out; float* q_out; int32_t* greedy_out; float* vmax_out;
+  int tiles0, tiles;
+  int32_t* bump;
+  // Seam words, 256 bytes apart (one poller population per line: 236 workgroups polling words of ONE
+  // line delayed every arrival on it by 3-5 us): line 0/1/2 conv1/conv2/conv3 arrivals, 3 generation,
+  // 4 tail tickets, 5 sticky failure, 8..15 fc1 arrivals per column group; from line 16 on one
+  // 64-byte flag per fc1 workgroup, set to generation + 1 by the torso's last arriver.  Zero in a
+  // fresh workspace; the last tail workgroup re-arms the counters and advances the generation.
+  unsigned* sync;
+  long long* dbg = nullptr;
+};
+
+// ---- seams -----------------------------------------------------------------------------------
+__device__ __forceinline__ void act_store(float* p, float v) { __hip_atomic_store(p, v, DZ_ACT_RLX); }
+__device__ __forceinline__ float act_load(const float* p) {
+  return __hip_atomic_load(p, DZ_ACT_RLX);
+}
+__device__ __forceinline__ float2 act_load2(const float* p) {   // 8-byte aligned
+  const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, DZ_ACT_RLX);
+  return make_float2(__builtin_bit_cast(float, (unsigned)(v & 0xffffffffull)),
+                     __builtin_bit_cast(float, (unsigned)(v >> 32)));
+}
+// all sc1 stores of the workgroup are in memory, then one arrival
+__device__ __forceinline__ void act_arrive(unsigned* w) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(w, 1u, DZ_ACT_RLX);
+}
+__device__ __forceinline__ unsigned* act_line(unsigned* sync, int i) { return sync + 64 * i; }
+__device__ __forceinline__ unsigned* act_flag(unsigned* sync, int f) { return sync + 64 * 16 + 16 * f; }
+// the whole workgroup waits until NW consecutive lines starting at w hold `target` (thread 0
+// polls); false: gave up
+template <int NW = 1>
+__device__ __forceinline__ bool act_wait(unsigned* w, unsigned target, unsigned* fail, int* s_ok) {
+  if (threadIdx.x == 0) {
+    int ok = 0;
+    for (int i = 0; i < kActSpinLimit; ++i) {
+      unsigned v[NW];
+#pragma unroll
+      for (int j = 0; j < NW; ++j) v[j] = __hip_atomic_load(w + 64 * j, DZ_ACT_RLX);   // one round trip
+      bool all = true;
+#pragma unroll
+      for (int j = 0; j < NW; ++j) all = all && v[j] == target;
+      if (all) { ok = 1; break; }
+      if ((i & 63) == 63 && __hip_atomic_load(fail, DZ_ACT_RLX)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) __hip_atomic_store(fail, 1u, DZ_ACT_RLX);
+    *s_ok = ok;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+// ---- torso -----------------------------------------------------------------------------------
+// 16x16x4 operand maps: A lane l = A[l & 15][l >> 4], B lane l = B[l >> 4][l & 15],
+// D lane l reg r = D[4 (l >> 4) + r][l & 15].  The k's of one MFMA step are ANY four k's as long
+// as both operands agree, so steps are chosen such that one 4-byte (conv1) or 16-byte (conv2/3)
+// LDS read per lane feeds four steps.
+__device__ __forceinline__ void act_partial_to_lds(float* red, int wave, int lane, const act_f4& a,
+                                                   const act_f4& b) {
+  float* d = red + wave * 256 + (4 * (lane >> 4)) * 16 + (lane & 15);
+  d[0] = a[0] + b[0]; d[16] = a[1] + b[1]; d[32] = a[2] + b[2]; d[48] = a[3] + b[3];
+}
+
+__device__ __forceinline__ void act_torso_block(const ActOneParams& p, int blk, float* lds, int* s_ok) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  float* red = lds + 8 * 20 * 36;
+  const float* W1 = p.prm + p.conv_w[0];
+  const float* W2 = p.prm + p.conv_w[1];
+  const float* W3 = p.prm + p.conv_w[2];
+  // conv1: wave = (channel tile, K half); step (tl, c): tap 4 (8 kh1 + tl) + kq, channel c
+  const int ct1 = wave & 1, kh1 = wave >> 1;
+  const int pt2 = min(blk >> 2, 5), ct2 = blk & 3;   // conv2: wave = kernel row
+  const int pt3 = min(blk >> 2, 3), ct3 = blk & 3;   // conv3: wave = 9 of the 36 (tap, 16-channel) pairs
+
+  ACT_STAMP(0);
+  const unsigned gen = *act_line(p.sync, 3);
+  // conv1's patch first (vector loads return in order): 12 input rows x 84 pixels x 4 bytes
+  const int p0c1 = 16 * blk, oy0c1 = p0c1 / 20;
+  unsigned raw[4];
+  {
+    const unsigned* src = (const unsigned*)p.obs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = min(tid + 256 * i, 1007);
+      raw[i] = src[min(4 * oy0c1 + idx / 84, 83) * 84 + idx % 84];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- every weight this workgroup will ever need, requested now -------------------------------
+  float b1[32], b2[32], b3[36];
+#pragma unroll
+  for (int tl = 0; tl < 8; ++tl)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int tap = 4 * (8 * kh1 + tl) + kq;
+      b1[4 * tl + c] = W1[(tap * 4 + c) * 32 + 16 * ct1 + n];
+    }
+#pragma unroll
+  for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = (4 * wave + kw) * 32 + 16 * g + 4 * kq + j;
+        b2[(kw * 2 + g) * 4 + j] = W2[k * 64 + 16 * ct2 + n];
+      }
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = 9 * wave + i;
+      const int k = (q >> 2) * 64 + 16 * (q & 3) + 4 * kq + j;
+      b3[4 * i + j] = W3[k * 64 + 16 * ct3 + n];
+    }
+  const float bias1a = p.prm[p.conv_b[0] + (tid & 15)], bias1b = p.prm[p.conv_b[0] + 16 + (tid & 15)];
+  const float bias2 = p.prm[p.conv_b[1] + 16 * ct2 + (tid & 15)];
+  const float bias3 = p.prm[p.conv_b[2] + 16 * ct3 + (tid & 15)];
+
+  // ---- conv1: pixels 16 blk .. 16 blk + 15, all 32 channels ------------------------------------
+  {
+    const int p0 = p0c1, oy0 = oy0c1;
+    unsigned* patch = (unsigned*)lds;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (tid + 256 * i < 1008) patch[tid + 256 * i] = raw[i];
+    __syncthreads();
+    ACT_STAMP(1);
+    const int pix = p0 + n, oy = pix / 20, ox = pix % 20;
+    unsigned a[8];
+#pragma unroll
+    for (int tl = 0; tl < 8; ++tl) {
+      const int T = 8 * kh1 + tl;
+      a[tl] = patch[(4 * (oy - oy0) + (T >> 1)) * 84 + 4 * ox + 4 * (T & 1) + kq];
+    }
+    act_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tl = 0; tl < 8; ++tl) {
+      const float4 v = dz_u8x4_to_unit(a[tl]);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, b1[4 * tl + 0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, b1[4 * tl + 1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, b1[4 * tl + 2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, b1[4 * tl + 3], acc1, 0, 0, 0);
+    }
+    act_partial_to_lds(red, wave, lane, acc0, acc1);
+    __syncthreads();
+    {   // wave (ct, kh): red[ct + 2 kh]; output element (m, channel 16 ct + n')
+      const int m = tid >> 4;
+      const float va = red[0 * 256 + tid] + red[2 * 256 + tid] + bias1a;
+      const float vb = red[1 * 256 + tid] + red[3 * 256 + tid] + bias1b;
+      act_store(p.act1 + (p0 + m) * 32 + (tid & 15), va > 0.f ? va : 0.f);
+      act_store(p.act1 + (p0 + m) * 32 + 16 + (tid & 15), vb > 0.f ? vb : 0.f);
+    }
+  }
+  act_arrive(act_line(p.sync, 0));
+  ACT_STAMP(2);
+  if (blk >= kActConv2Blocks) return;
+  if (!act_wait(act_line(p.sync, 0), kActTorsoBlocks, act_line(p.sync, 5), s_ok)) return;
+  ACT_STAMP(3);
+
+  // ---- conv2: pixels 16 pt2 .., channels 16 ct2 .. ------------------------------------------------
+  {
+    const int p0 = 16 * pt2, oy0 = p0 / 9;
+    float2 v[10];   // 8 input rows x 20 pixels x 32 channels, LDS pixel pitch 36
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int f = 2 * (tid + 256 * i);
+      const int r = f / 640, rem = f % 640;
+      v[i] = act_load2(p.act1 + (min(2 * oy0 + r, 19) * 20 + rem / 32) * 32 + (rem & 31));
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int f = 2 * (tid + 256 * i);
+      const int r = f / 640, rem = f % 640;
+      *(float2*)(lds + (r * 20 + rem / 32) * 36 + (rem & 31)) = v[i];
+    }
+    __syncthreads();
+    ACT_STAMP(4);
+    const int pix = min(p0 + n, 80), oy = pix / 9, ox = pix % 9;
+    float4 a[8];
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        a[kw * 2 + g] = *(const float4*)(lds + ((2 * (oy - oy0) + wave) * 20 + 2 * ox + kw) * 36 +
+                                         16 * g + 4 * kq);
+    act_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b2[4 * i + 0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b2[4 * i + 1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b2[4 * i + 2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b2[4 * i + 3], acc1, 0, 0, 0);
+    }
+    act_partial_to_lds(red, wave, lane, acc0, acc1);
+    __syncthreads();
+    {
+      const int m = tid >> 4;
+      const float s = ((red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid])) + bias2;
+      if (p0 + m < 81) act_store(p.act2 + (p0 + m) * 64 + 16 * ct2 + (tid & 15), s > 0.f ? s : 0.f);
+    }
+  }
+  act_arrive(act_line(p.sync, 1));
+  ACT_STAMP(5);
+  if (blk >= kActConv3Blocks) return;
+  if (!act_wait(act_line(p.sync, 1), kActConv2Blocks, act_line(p.sync, 5), s_ok)) return;
+  ACT_STAMP(6);
+
+  // ---- conv3: pixels 16 pt3 .., channels 16 ct3 .. ------------------------------------------------
+  {
+    const int p0 = 16 * pt3, oy0 = p0 / 7;
+    float2 v[7];    // 6 input rows x 9 pixels x 64 channels, LDS pixel pitch 68
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int f = min(2 * (tid + 256 * i), 3454);
+      const int r = f / 576, rem = f % 576;
+      v[i] = act_load2(p.act2 + (min(oy0 + r, 8) * 9 + rem / 64) * 64 + (rem & 63));
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int f = 2 * (tid + 256 * i);
+      const int r = f / 576, rem = f % 576;
+      if (f < 3456) *(float2*)(lds + (r * 9 + rem / 64) * 68 + (rem & 63)) = v[i];
+    }
+    __syncthreads();
+    ACT_STAMP(7);
+    const int pix = min(p0 + n, 48), oy = pix / 7, ox = pix % 7;
+    float4 a[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int q = 9 * wave + i, tap = q >> 2, g = q & 3;
+      a[i] = *(const float4*)(lds + (((oy - oy0) + tap / 3) * 9 + ox + tap % 3) * 68 + 16 * g + 4 * kq);
+    }
+    act_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b3[4 * i + 0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b3[4 * i + 1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b3[4 * i + 2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b3[4 * i + 3], acc1, 0, 0, 0);
+    }
+    act_partial_to_lds(red, wave, lane, acc0, acc1);
+    __syncthreads();
+    {
+      const int m = tid >> 4;
+      const float s = ((red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid])) + bias3;
+      if (p0 + m < 49) act_store(p.feat + (p0 + m) * 64 + 16 * ct3 + (tid & 15), s > 0.f ? s : 0.f);
+    }
+  }
+  // the last arriver tells every fc1 workgroup on that workgroup's own line
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0)
+    *s_ok = __hip_atomic_fetch_add(act_line(p.sync, 2), 1u, DZ_ACT_RLX) == (unsigned)kActConv3Blocks - 1;
+  __syncthreads();
+  if (*s_ok && tid < kActFc1Blocks) __hip_atomic_store(act_flag(p.sync, tid), gen + 1u, DZ_ACT_RLX);
+  ACT_STAMP(8);
+}
+
+// ---- fc1 -------------------------------------------------------------------------------------
+__device__ __forceinline__ void act_fc1_block(const ActOneParams& p, int fb, float* lds, int* s_ok) {
+  const int tid = threadIdx.x;
+  const int split = fb >> 3, cg = fb & 7, hsel = cg >> 2;
+  const int cq = tid & 31, kg = tid >> 5;
+  const int col = 128 * cg + 4 * cq, k0 = kActFc1Rows * split + 14 * kg;
+  ACT_STAMP(0);
+  const unsigned gen = *act_line(p.sync, 3);
+  float4 w[14], sg[14];
+  {
+    const float* wm = p.prm + p.fc1_mu_w + (long)k0 * p.fc1_ld + col;
+    const float* ws = p.prm + p.fc1_sig_w + (long)k0 * p.fc1_ld + col;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      w[j] = dz_ld4(wm + (long)j * p.fc1_ld);
+      sg[j] = dz_ld4(ws + (long)j * p.fc1_ld);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // this apply's position in the actor's noise stream; the block is also written out
+  const uint64_t base = p.counter + (uint64_t)(*p.step) * (uint64_t)p.n_noise;
+  {
+    const int i = fb * 256 + tid;
+    if (i < p.n_noise) p.noise[i] = dz_noise_at(p.seed, base + (uint64_t)i);
+  }
+  float eo[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) eo[c] = dz_noise_at(p.seed, base + (uint64_t)(p.n_fc1_out + col + c));
+  const int e_in = hsel ? p.n_eps_in[1] : p.n_eps_in[0];
+#pragma unroll
+  for (int j = 0; j < 14; ++j) {
+    const float ei = dz_noise_at(p.seed, base + (uint64_t)(e_in + k0 + j));
+    // W_eff = Wmu + Wsig * (eps_in[k] * eps_out[n])   (networks.py:168-176)
+    w[j].x = __builtin_fmaf(sg[j].x, ei * eo[0], w[j].x);
+    w[j].y = __builtin_fmaf(sg[j].y, ei * eo[1], w[j].y);
+    w[j].z = __builtin_fmaf(sg[j].z, ei * eo[2], w[j].z);
+    w[j].w = __builtin_fmaf(sg[j].w, ei * eo[3], w[j].w);
+  }
+  ACT_STAMP(1);
+  if (!act_wait(act_flag(p.sync, fb), gen + 1u, act_line(p.sync, 5), s_ok)) return;
+  ACT_STAMP(2);
+  float x[14];
+#pragma unroll
+  for (int j = 0; j < 14; ++j) x[j] = act_load(p.feat + k0 + j);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < 14; ++j) {
+    acc.x = __builtin_fmaf(x[j], w[j].x, acc.x); acc.y = __builtin_fmaf(x[j], w[j].y, acc.y);
+    acc.z = __builtin_fmaf(x[j], w[j].z, acc.z); acc.w = __builtin_fmaf(x[j], w[j].w, acc.w);
+  }
+  *(float4*)(lds + kg * 128 + 4 * cq) = acc;
+  __syncthreads();
+  ACT_STAMP(3);
+  if (tid < 128) {
+    const float s = ((lds[tid] + lds[128 + tid]) + (lds[256 + tid] + lds[384 + tid])) +
+                    ((lds[512 + tid] + lds[640 + tid]) + (lds[768 + tid] + lds[896 + tid]));
+    act_store(p.part + split * 1024 + 128 * cg + tid, s);
+  }
+  act_arrive(act_line(p.sync, 8 + cg));
+  ACT_STAMP(4);
+}
+
+// ---- tail ------------------------------------------------------------------------------------
+// As rainbow_act_tail_kernel (one row), with the noise drawn here and the slabs read after the
+// fc1 counter is full.
+__device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, float* lds, int* s_ok) {
+  float* s_h1 = lds;            // [512]
+  float* s_ein = lds + 512;     // [512]
+  float* s_red = lds + 1024;    // [8][32]
+  float* s_row = lds + 1280;    // [ld2 <= 1024]
+  float* s_q = lds + 2304;      // [64]
+  float* s_best = lds + 2368;
+  int* s_arg = (int*)(lds + 2369);
+  int* s_last = (int*)(lds + 2370);
+  const int tid = threadIdx.x;
+  ACT_STAMP(0);
+  const int hsel = tile >= p.tiles0 ? 1 : 0;
+  const FcHead hd = dz_pick_head(p.head, hsel);
+  const int c = tid & 31, kg = tid >> 5;
+  const int col = (tile - (hsel ? p.tiles0 : 0)) * 32 + c;   // within the head
+  const int colc = min(col, hd.ldw - 1);
+  float m[64], g[64];
+  {
+    const float* wmu = p.prm + hd.w_mu + (long)(kg * 64) * hd.ldw + colc;
+    const float* wsg = p.prm + hd.w_sig + (long)(kg * 64) * hd.ldw + colc;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) { m[j] = wmu[(long)j * hd.ldw]; g[j] = wsg[(long)j * hd.ldw]; }
+  }
+  float bm[2], bs[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int cc = hd.x_off + tid + 256 * e;
+    bm[e] = p.prm[p.fc1_mu_b + cc]; bs[e] = p.prm[p.fc1_sig_b + cc];
+  }
+  const float sbw = p.prm[p.fc2_sig_b + hd.out_off + colc];
+  __builtin_amdgcn_sched_barrier(0);
+  const uint64_t base = p.counter + (uint64_t)(*p.step) * (uint64_t)p.n_noise;
+  float be[2], ei[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    be[e] = dz_noise_at(p.seed, base + (uint64_t)(p.n_fc1_out + hd.x_off + tid + 256 * e));
+    ei[e] = dz_noise_at(p.seed, base + (uint64_t)(hd.eps_in + tid + 256 * e));
+  }
+  const float eo = dz_noise_at(p.seed, base + (uint64_t)(hd.eps_out + colc));
+  const float sb = sbw * dz_noise_at(p.seed, base + (uint64_t)(p.n_fc2_out + hd.out_off + colc));
+  ACT_STAMP(1);
+  if (!act_wait<4>(act_line(p.sync, 8 + 4 * hsel), kActFc1Splits, act_line(p.sync, 5), s_ok)) {
+    if (tile == 0 && tid == 0) {   // visible to the host: the decision is not a number
+      for (int a = 0; a < p.A; ++a) p.q_out[a] = __builtin_nanf("");
+      if (p.greedy_out) *p.greedy_out = 0;
+      if (p.vmax_out) *p.vmax_out = __builtin_nanf("");
+    }
+    return;
+  }
+  ACT_STAMP(2);
+  // ---- 1. h1 (this head's half): 28 slabs in slab order ------------------------------------------
+  float x[2][kActFc1Splits];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int j = 0; j < kActFc1Splits; ++j) x[e][j] = act_load(p.part + j * 1024 + hd.x_off + tid + 256 * e);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < kActFc1Splits; ++j) v += x[e][j];
+    const float h = v + bm[e] + bs[e] * be[e];
+    s_h1[tid + 256 * e] = h > 0.f ? h : 0.f;
+    s_ein[tid + 256 * e] = ei[e];
+  }
+  __syncthreads();
+  ACT_STAMP(3);
+  // ---- 2. this workgroup's 32 output columns ------------------------------------------------------
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const int k = kg * 64 + j;
+      acc = __builtin_fmaf(s_h1[k], __builtin_fmaf(g[j], s_ein[k] * eo, m[j]), acc);
+    }
+    s_red[kg * 32 + c] = acc;
+  }
+  __syncthreads();
+  if (tid < 32 && col < hd.ldw) {
+    const float o = (((s_red[c] + s_red[32 + c]) + (s_red[64 + c] + s_red[96 + c])) +
+                     ((s_red[128 + c] + s_red[160 + c]) + (s_red[192 + c] + s_red[224 + c]))) + sb;
+    act_store(p.fc2_out + hd.out_off + col, col < hd.N ? o : 0.f);
+  }
+  // ---- 3. ticket: the last workgroup finishes the row ---------------------------------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0)
+    *s_last = __hip_atomic_fetch_add(act_line(p.sync, 4), 1u, DZ_ACT_RLX) == (unsigned)p.tiles - 1;
+  __syncthreads();
+  ACT_STAMP(4);
+  if (!*s_last) return;
+  for (int i = tid; i < p.ld2; i += 256) s_row[i] = act_load(p.fc2_out + i);
+  __syncthreads();
+  if (tid == 0) {
+    // re-armed for the next apply (ordered by the kernel boundary; every poller has passed)
+    const unsigned gen = *act_line(p.sync, 3);
+    for (int i = 0; i < 16; ++i)
+      if (i != 3 && i != 5) __hip_atomic_store(act_line(p.sync, i), 0u, DZ_ACT_RLX);
+    __hip_atomic_store(act_line(p.sync, 3), gen + 1u, DZ_ACT_RLX);
+    if (p.bump) *p.bump = *p.bump + 1;
+  }
+  dz_q_from_row(s_row, p.A, p.K, p.val_off, p.support, p.q_out, p.greedy_out, p.vmax_out, s_q,
+                s_best, s_arg);
+  ACT_STAMP(5);
+}
+
+__global__ __launch_bounds__(256, 2) void rainbow_act_one_kernel(ActOneParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[kActLdsFloats];
+  __shared__ int s_ok;
+  const int b = blockIdx.x;
+  if (b < kActTorsoBlocks) act_torso_block(p, b, lds, &s_ok);
+  else if (b < kActTorsoBlocks + kActFc1Blocks) act_fc1_block(p, b - kActTorsoBlocks, lds, &s_ok);
+  else act_tail_block(p, b - kActTorsoBlocks - kActFc1Blocks, lds, &s_ok);
+}
+
+}  // namespace

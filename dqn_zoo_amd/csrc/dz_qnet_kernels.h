@@ -879,11 +879,10 @@ struct NoiseParams {
   float* out; long n; uint64_t seed; uint64_t counter; const int32_t* step;
   long step_mul = 0; long i0 = 0;
 };
-__device__ __forceinline__ void noise_fill_at(const NoiseParams& q, long i) {
-  if (i >= q.n) return;
-  uint64_t counter = q.counter + (uint64_t)q.i0;
-  if (q.step) counter += (uint64_t)(*q.step) * (uint64_t)(q.step_mul ? q.step_mul : q.n);  // per-step stream offset
-  const uint64_t h = mix64(mix64(q.seed) ^ mix64(counter + (uint64_t)i));
+// The value at stream position `pos` of seed `seed` (a pure function: any kernel can draw the
+// elements it needs itself instead of reading them from a buffer another launch filled).
+__device__ __forceinline__ float dz_noise_at(uint64_t seed, uint64_t pos) {
+  const uint64_t h = mix64(mix64(seed) ^ mix64(pos));
   // jax.random.truncated_normal: sqrt2 * erfinv(U(erf(lo/sqrt2), erf(hi/sqrt2)))
   const float u01 = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
   const float e = 0.9544997361036416f;  // erf(2/sqrt(2))
@@ -891,7 +890,16 @@ __device__ __forceinline__ void noise_fill_at(const NoiseParams& q, long i) {
   float x = 1.4142135623730951f * erfinvf(u);
   x = fminf(fmaxf(x, -2.0f), 2.0f);
   const float s = sqrtf(fabsf(x));
-  q.out[i] = x < 0.f ? -s : (x > 0.f ? s : 0.f);  // sign(x) * sqrt|x| (networks.py:144)
+  return x < 0.f ? -s : (x > 0.f ? s : 0.f);  // sign(x) * sqrt|x| (networks.py:144)
+}
+__device__ __forceinline__ uint64_t noise_base(const NoiseParams& q) {
+  uint64_t counter = q.counter + (uint64_t)q.i0;
+  if (q.step) counter += (uint64_t)(*q.step) * (uint64_t)(q.step_mul ? q.step_mul : q.n);  // per-step stream offset
+  return counter;
+}
+__device__ __forceinline__ void noise_fill_at(const NoiseParams& q, long i) {
+  if (i >= q.n) return;
+  q.out[i] = dz_noise_at(q.seed, noise_base(q) + (uint64_t)i);
 }
 __global__ void noise_fill_kernel(NoiseParams q) {
   noise_fill_at(q, (long)blockIdx.x * blockDim.x + threadIdx.x);
@@ -972,6 +980,53 @@ __global__ __launch_bounds__(PRE ? 256 : 64) void rainbow_q_values_kernel(
   if (k == 0) {
     if (greedy_out) greedy_out[b] = arg;
     if (vmax_out) vmax_out[b] = best;
+  }
+}
+
+// q-values, greedy action and its value of ONE finished fc2 row held in LDS (256 threads):
+// the 4 waves take the actions round-robin (3 wave reductions each).
+__device__ __forceinline__ void dz_q_from_row(const float* s_row, int A, int K, int val_off,
+                                              const float* __restrict__ support, float* q_out,
+                                              int32_t* greedy_out, float* vmax_out, float* s_q,
+                                              float* s_best, int* s_arg) {
+  const int tid = threadIdx.x;
+  const int k = tid & 63, wave = tid >> 6;
+  const bool on = k < K;
+  const float z = on ? support[k] : 0.f;
+  float mean_adv = 0.f;
+  for (int a = 0; a < A; ++a) mean_adv += on ? s_row[a * K + k] : 0.f;
+  mean_adv /= (float)A;
+  const float vv = on ? s_row[val_off + k] : 0.f;
+  for (int a0 = 0; a0 < A; a0 += 64) {        // A <= 256: 64 actions per round of s_q
+    for (int a = a0 + wave; a < min(A, a0 + 64); a += 4) {
+      const float lg = on ? (vv + s_row[a * K + k] - mean_adv) : -__builtin_inff();
+      const float mx = wave_max(lg);
+      const float e = on ? expf(lg - mx) : 0.f;
+      const float sm = wave_sum(e);
+      const float q = wave_sum((e / sm) * z);
+      if (k == 0) { s_q[a - a0] = q; q_out[a] = q; }
+    }
+    __syncthreads();
+    if (tid == 0) {   // first maximum, as jnp.argmax
+      float best = a0 ? *s_best : -__builtin_inff();
+      int arg = a0 ? *s_arg : 0;
+      for (int a = a0; a < min(A, a0 + 64); ++a)
+        if (s_q[a - a0] > best) { best = s_q[a - a0]; arg = a; }
+      *s_best = best; *s_arg = arg;
+      if (a0 + 64 >= A) {
+        // (action, value) adjacent and 8-byte aligned -- the acting slot in pinned host
+        // memory: ONE 8-byte store, so a host that polls the slot never sees half a pair
+        if (greedy_out && vmax_out == (float*)(greedy_out + 1) && ((uintptr_t)greedy_out & 7) == 0) {
+          const unsigned long long pr = (unsigned long long)(unsigned)arg |
+                                        ((unsigned long long)__builtin_bit_cast(unsigned, best) << 32);
+          *(volatile unsigned long long*)greedy_out = pr;
+        } else {
+          if (greedy_out) *greedy_out = arg;
+          if (vmax_out) *vmax_out = best;
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1097,37 +1152,9 @@ __global__ __launch_bounds__(256) void rainbow_act_tail_kernel(ActTailParams p) 
     p.tickets[row] = 0;   // ready for the next apply (ordered by the kernel boundary)
     if (p.bump && row == 0) *p.bump = *p.bump + 1;
   }
-  // q-values: the 4 waves take the actions round-robin (3 wave reductions each)
-  const int k = tid & 63, wave = tid >> 6;
-  const bool on = k < p.K;
-  const float z = on ? p.support[k] : 0.f;
-  float mean_adv = 0.f;
-  for (int a = 0; a < p.A; ++a) mean_adv += on ? s_row[a * p.K + k] : 0.f;
-  mean_adv /= (float)p.A;
-  const float vv = on ? s_row[p.val_off + k] : 0.f;
-  for (int a0 = 0; a0 < p.A; a0 += 64) {        // A <= 256: 64 actions per round of s_q
-    for (int a = a0 + wave; a < min(p.A, a0 + 64); a += 4) {
-      const float lg = on ? (vv + s_row[a * p.K + k] - mean_adv) : -__builtin_inff();
-      const float mx = wave_max(lg);
-      const float e = on ? expf(lg - mx) : 0.f;
-      const float sm = wave_sum(e);
-      const float q = wave_sum((e / sm) * z);
-      if (k == 0) { s_q[a - a0] = q; p.q_out[row * p.A + a] = q; }
-    }
-    __syncthreads();
-    if (tid == 0) {   // first maximum, as jnp.argmax
-      float best = a0 ? s_best : -__builtin_inff();
-      int arg = a0 ? s_arg : 0;
-      for (int a = a0; a < min(p.A, a0 + 64); ++a)
-        if (s_q[a - a0] > best) { best = s_q[a - a0]; arg = a; }
-      s_best = best; s_arg = arg;
-      if (a0 + 64 >= p.A) {
-        if (p.greedy_out) p.greedy_out[row] = arg;
-        if (p.vmax_out) p.vmax_out[row] = best;
-      }
-    }
-    __syncthreads();
-  }
+  dz_q_from_row(s_row, p.A, p.K, p.val_off, p.support, p.q_out + row * p.A,
+                p.greedy_out ? p.greedy_out + row : nullptr, p.vmax_out ? p.vmax_out + row : nullptr,
+                s_q, &s_best, &s_arg);
 }
 
 // rlax.q_learning / double_q_learning + clip_gradient + l2_loss (+ IS weights):

@@ -23,6 +23,7 @@
 #include "dz_fc1_onfly.h"
 #include "dz_row_dgrad.h"
 #include "dz_fc1_dgrad.h"
+#include "dz_act_one.h"
 
 namespace {
 
@@ -238,6 +239,7 @@ extern "C" int dz_rainbow_layout(int A, int K, int B, dz_rainbow_layout_t* L) {
   L->ws_scalars = take(16);
   L->ws_q_sel = take((int64_t)B * A);
   L->ws_target_probs = take((int64_t)B * K);
+  L->ws_act_seams = take(kActSeamWords);
   L->ws_count = w;
   return DZ_OK;
 }
@@ -727,6 +729,35 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
   if (next_sample) {
     rc = sample_gather_from_desc(next_sample, sgq, &sgb);
     if (rc) return rc;
+  }
+  // One observation: the whole decision is ONE launch (dz_act_one.h).
+  if (batch == 1 && !next_sample && ld2 <= 1024 && num_atoms <= 64 && step_counter) {
+    ActOneParams q;
+    q.obs = states; q.prm = params;
+    for (int i = 0; i < 3; ++i) { q.conv_w[i] = L.conv_w[i]; q.conv_b[i] = L.conv_b[i]; }
+    q.act1 = ws + L.ws_act1; q.act2 = ws + L.ws_act2; q.feat = ws + L.ws_feat;
+    q.fc1_mu_w = L.fc1_mu_w; q.fc1_sig_w = L.fc1_sig_w; q.fc1_mu_b = L.fc1_mu_b;
+    q.fc1_sig_b = L.fc1_sig_b; q.fc1_ld = L.fc1_ld;
+    q.part = ws + L.ws_fc1_part;
+    q.noise = noise; q.n_noise = (int)L.noise_stride; q.seed = noise_seed; q.counter = noise_counter;
+    q.step = step_counter;
+    q.n_eps_in[0] = (int)L.n_adv1_in; q.n_eps_in[1] = (int)L.n_val1_in; q.n_fc1_out = (int)L.n_fc1_out;
+    q.head[0] = H.fc2h[0]; q.head[1] = H.fc2h[1];
+    q.fc2_sig_b = L.fc2_sig_b; q.n_fc2_out = (int)L.n_fc2_out;
+    q.ld2 = ld2; q.val_off = L.adv2_ld; q.A = num_actions; q.K = num_atoms;
+    q.support = support; q.fc2_out = ws + L.ws_fc2_out;
+    q.q_out = q_values_out; q.greedy_out = greedy_out; q.vmax_out = vmax_out;
+    q.tiles0 = (L.adv2_ld + 31) / 32; q.tiles = q.tiles0 + (L.val2_ld + 31) / 32;
+    q.bump = step_counter;
+    q.sync = reinterpret_cast<unsigned*>(ws + L.ws_act_seams);   // zero in a fresh workspace, re-armed by the kernel
+#ifdef DZ_ACT_STAMPS
+    q.dbg = reinterpret_cast<long long*>(ws + L.ws_dfeat_part);
+#endif
+    static_assert(kMaxSplitFc1 * kG >= kActFc1Splits, "fc1 slab buffer holds the actor's 28 slabs");
+    hipLaunchKernelGGL(rainbow_act_one_kernel,
+                       dim3((unsigned)(kActTorsoBlocks + kActFc1Blocks + q.tiles)), dim3(256), 0, s, q);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
   }
   const bool prof = g_dz_prof_on;
   g_dz_prof_on = false;  // marks belong to dz_rainbow_learn

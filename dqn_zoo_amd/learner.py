@@ -147,7 +147,8 @@ class RainbowLearner:
   def _drop_act_graphs(self) -> None:
     graphs, self._act_graphs = getattr(self, '_act_graphs', {}), {}
     for g in graphs.values():
-      self._lib.dz_graph_destroy(g[0])
+      if g[0] is not None:
+        self._lib.dz_graph_destroy(g[0])
 
   def drop_graphs(self) -> None:
     graphs, self._graphs = self._graphs, {}
@@ -185,7 +186,10 @@ class RainbowLearner:
       g = self._act_graphs.get((states.data_ptr(), packed_out.data_ptr(), params.data_ptr(),
                                 states.shape, states.dtype))
       if g is not None:
-        _lib.check(self._lib.dz_graph_launch(g[0], stream), 'dz_graph_launch')
+        if g[0] is None:
+          g[4](stream)   # one launch: enqueued directly (a graph of one node costs more to launch)
+        else:
+          _lib.check(self._lib.dz_graph_launch(g[0], stream), 'dz_graph_launch')
         return g[1], g[2], g[3]
     assert states.dtype == torch.uint8 and states.is_contiguous()
     b = int(states.shape[0])
@@ -225,6 +229,16 @@ class RainbowLearner:
         key = (states.data_ptr(), packed_out.data_ptr(), params.data_ptr(),
                states.shape, states.dtype)
         q = self._act_q = torch.empty((b, a), dtype=torch.float32, device=self.device)
+        if b == 1 and self.act_direct:
+          fn, chk = self._lib.dz_rainbow_act, _lib.check
+          args = (a, self.network.num_atoms, b, params.data_ptr(), states.data_ptr(),
+                  self._act_noise.data_ptr(), self._noise_seed ^ 0xA5A5A5A5, 0,
+                  self._act_step.data_ptr(), self.support.data_ptr(), self._act_ws.data_ptr(),
+                  q.data_ptr(), greedy.data_ptr(), vmax.data_ptr(), None)
+          direct = lambda st: chk(fn(*args, st), 'dz_rainbow_act')
+          self._act_graphs[key] = (None, q, greedy, vmax, direct)   # the same cache, no graph
+          direct(stream)
+          return q, greedy, vmax
         g = self._act_graphs[key] = (_lib.capture_graph(stream, enqueue), q, greedy, vmax)
         _lib.check(self._lib.dz_graph_launch(g[0], stream), 'dz_graph_launch')
         return q, greedy, vmax
@@ -240,6 +254,9 @@ class RainbowLearner:
     return q, greedy, vmax
 
   ACT_RING = 8   # acting results in flight (pinned host words)
+  ACT_POLL_SPINS = 200000   # polled reads of the slot before falling back to a stream sync
+  poll_action_slot = True
+  act_direct = True   # the one-launch decision (batch 1) is enqueued directly, not from a hipGraph
 
   def apply_async(self, states: torch.Tensor, next_sample=None):
     """Acting apply whose (greedy action, max q) pair is written by the kernel
@@ -250,11 +267,32 @@ class RainbowLearner:
     b = int(states.shape[0])
     if getattr(self, '_act_host', None) is None or self._act_host.shape[2] != b:
       self._act_host = torch.empty((self.ACT_RING, 2, b), dtype=torch.int32).pin_memory()
+      self._act_host_np = self._act_host.numpy()   # the same pinned words, for the polled read
       self._act_events = [torch.cuda.Event() for _ in range(self.ACT_RING)]
       self._act_pos = 0
     k = self._act_pos % self.ACT_RING
     self._act_pos += 1
     slot = self._act_host[k]
+    if b == 1 and self.poll_action_slot:
+      # One observation: the decision kernel's last store is the (action, value) pair as ONE
+      # 8-byte word into this pinned slot.  The host marks the slot (action -1) before the
+      # enqueue and reads it with plain loads until the pair is there: no event to record, no
+      # completion signal to wait for (the wake-up after `Event.synchronize` cost more than the
+      # kernel's last phase).
+      words = self._act_host_np[k]
+      words[0, 0] = -1
+      self.apply(states, packed_out=slot, next_sample=next_sample)
+      device = self.device
+
+      def read_polled():
+        for _ in range(self.ACT_POLL_SPINS):
+          a = words[0, 0]
+          if a >= 0:
+            return int(a), float(words[1].view(np.float32)[0])
+        torch.cuda.current_stream(device).synchronize()   # stuck or very slow: the stream decides
+        return int(words[0, 0]), float(words[1].view(np.float32)[0])
+
+      return read_polled
     self.apply(states, packed_out=slot, next_sample=next_sample)
     ev = self._act_events[k]
     ev.record(_lib.current_stream(self.device))

@@ -264,6 +264,8 @@ typedef struct {
   int64_t ws_dout2, ws_dh1, ws_dfeat_part, ws_dfeat, ws_dact2, ws_dact1;
   int64_t ws_wgrad_part, ws_norm_part, ws_scalars, ws_q_sel, ws_target_probs;
   int64_t ws_colsum_part;
+  int64_t ws_act_seams;     /* counters and flags of the one-launch decision (dz_rainbow_act, batch 1): zero
+                             * when the workspace is created, owned by that kernel afterwards          */
 } dz_rainbow_layout_t;
 
 int dz_rainbow_layout(int num_actions, int num_atoms, int batch,

@@ -81,6 +81,9 @@ def main():
   wrap(ag, '_learn', 'learn'); wrap(rep, add_name, 'add')
   if 'nofuse' in sys.argv[3:]:
     ag.fuse_sample_into_acting = False
+  if which != 'dqn':   # A/B switches of the acting path (defaults: both on)
+    ag._learner.poll_action_slot = 'event-wait' not in sys.argv[3:]   # pylint: disable=protected-access
+    ag._learner.act_direct = 'act-graph' not in sys.argv[3:]          # pylint: disable=protected-access
   env = Env(3)
   loop = parts.run_loop(ag, env, max_steps_per_episode=0)
   for _ in range(1000):   # fill past min replay, warm up
