@@ -5,11 +5,16 @@
 // At one image the network is 15 MFLOP of convolution, a 25.7 MB weight stream (fc1's mu and
 // sigma) and 1.5 MB for the second layer -- five launches of 7-9 us each spent 41 us on it,
 // almost all of it launch floors and cold round trips in series.  Here 261 workgroups of one
-// launch take three roles and hand results to each other through write-through (sc1) stores,
-// drained `vmcnt`, relaxed agent-scope counters and sc1 loads (the cheap seam of
-// tools/micro/gridbar_micro.hip; no L2 write-back or invalidate anywhere):
+// launch take three roles and hand results to each other through write-through (sc1) stores and
+// sc1 loads (no L2 write-back or invalidate anywhere), and THE DATA IS ITS OWN FLAG: every
+// intermediate lives in a buffer that is all-zero-bits before its producers write it, producers
+// store -0.0f for a zero, and a consumer simply re-reads the values it needs until none of them is
+// +0.0f.  No arrival counter, no drained `vmcnt`, no second round trip for the payload (the first
+// version of this kernel did counter + flag + load: 23.0 us in-kernel; this form: see
+// EXPERIMENTS.md).  Two sets of buffers alternate by the parity of a generation word; the set of
+// the NEXT apply is cleared by idle workgroups of this one.
 //
-//   torso  (25 workgroups)  conv1 -> conv2 -> conv3 with two 25/24-party barriers.  One workgroup
+//   torso  (25 workgroups)  conv1 -> conv2 -> conv3.  One workgroup
 //                           owns 16 output pixels (x 32 channels in conv1, x 16 channels in
 //                           conv2/conv3), its 4 waves split K; the input patch is copied once
 //                           into LDS (conv1: raw bytes over PCIe from the pinned observation
@@ -42,8 +47,12 @@ constexpr int kActTorsoBlocks = 25;   // conv1 pixel tiles (400 / 16)
 constexpr int kActConv2Blocks = 24;   // 6 pixel tiles x 4 channel tiles
 constexpr int kActConv3Blocks = 16;   // 4 pixel tiles x 4 channel tiles
 constexpr int kActFc1Splits = 28, kActFc1Rows = 112, kActFc1Blocks = kActFc1Splits * 8;
-constexpr int kActSpinLimit = 300000;
-constexpr int kActSeamWords = 64 * 16 + 16 * kActFc1Blocks;   // 16 lines + one 64-byte flag per fc1 workgroup
+constexpr int kActSpinLimit = 200000;
+// one set of intermediates: act1 | act2 | feat | 28 fc1 slabs, padded to whole 256-float chunks
+constexpr int kActOffA1 = 0, kActOffA2 = 400 * 32, kActOffFeat = kActOffA2 + 81 * 64,
+              kActOffPart = kActOffFeat + kFlat, kActSetFloats = (kActOffPart + kActFc1Splits * 1024 + 255) & ~255;
+static_assert(kActSetFloats <= 256 * kActFc1Blocks, "one chunk of the next set per fc1 workgroup");
+constexpr int kActSeamWords = 64 * 8 + 2 * kActSetFloats;   // 8 lines (256 bytes apart) + the two sets
 constexpr int kActLdsFloats = 8 * 20 * 36 + 4 * 256;   // largest patch (conv2) + partial tiles
 static_assert(kActFc1Splits * kActFc1Rows == kFlat, "fc1 K-splits");
 
@@ -59,9 +68,7 @@ struct ActOneParams {
   const uint8_t* obs;                 // [84][84][4], device or pinned device-mapped host memory
   const float* prm;
   long conv_w[3], conv_b[3];
-  float* act1; float* act2; float* feat;
   long fc1_mu_w, fc1_sig_w, fc1_mu_b, fc1_sig_b; int fc1_ld;
-  float* part;                        // [28][1024] fc1 slabs
   float* noise; int n_noise;          // the apply's noise block, also written out (tests, state)
   uint64_t seed, counter; const int32_t* step;
   int n_eps_in[2]; int n_fc1_out;
@@ -72,11 +79,9 @@ struct ActOneParams {
   float* fc2_out; float* q_out; int32_t* greedy_out; float* vmax_out;
   int tiles0, tiles;
   int32_t* bump;
-  // Seam words, 256 bytes apart (one poller population per line: 236 workgroups polling words of ONE
-  // line delayed every arrival on it by 3-5 us): line 0/1/2 conv1/conv2/conv3 arrivals, 3 generation,
-  // 4 tail tickets, 5 sticky failure, 8..15 fc1 arrivals per column group; from line 16 on one
-  // 64-byte flag per fc1 workgroup, set to generation + 1 by the torso's last arriver.  Zero in a
-  // fresh workspace; the last tail workgroup re-arms the counters and advances the generation.
+  // Seam area (dz_rainbow_layout_t::ws_act_seams; zero in a fresh workspace, owned by this kernel):
+  // line 3 generation, line 4 tail tickets, line 5 sticky failure (lines are 256 bytes apart), then
+  // the two sets of intermediates.
   unsigned* sync;
   long long* dbg = nullptr;
 };
@@ -91,36 +96,29 @@ __device__ __forceinline__ float2 act_load2(const float* p) {   // 8-byte aligne
   return make_float2(__builtin_bit_cast(float, (unsigned)(v & 0xffffffffull)),
                      __builtin_bit_cast(float, (unsigned)(v >> 32)));
 }
-// all sc1 stores of the workgroup are in memory, then one arrival
-__device__ __forceinline__ void act_arrive(unsigned* w) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(w, 1u, DZ_ACT_RLX);
-}
+// a zero is stored as -0.0f: all-zero bits mean "not written yet"
+__device__ __forceinline__ float act_mark(float v) { return v == 0.f ? -0.f : v; }
+__device__ __forceinline__ bool act_missing(float v) { return __builtin_bit_cast(unsigned, v) == 0u; }
 __device__ __forceinline__ unsigned* act_line(unsigned* sync, int i) { return sync + 64 * i; }
-__device__ __forceinline__ unsigned* act_flag(unsigned* sync, int f) { return sync + 64 * 16 + 16 * f; }
-// the whole workgroup waits until NW consecutive lines starting at w hold `target` (thread 0
-// polls); false: gave up
-template <int NW = 1>
-__device__ __forceinline__ bool act_wait(unsigned* w, unsigned target, unsigned* fail, int* s_ok) {
-  if (threadIdx.x == 0) {
-    int ok = 0;
-    for (int i = 0; i < kActSpinLimit; ++i) {
-      unsigned v[NW];
-#pragma unroll
-      for (int j = 0; j < NW; ++j) v[j] = __hip_atomic_load(w + 64 * j, DZ_ACT_RLX);   // one round trip
-      bool all = true;
-#pragma unroll
-      for (int j = 0; j < NW; ++j) all = all && v[j] == target;
-      if (all) { ok = 1; break; }
-      if ((i & 63) == 63 && __hip_atomic_load(fail, DZ_ACT_RLX)) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (!ok) __hip_atomic_store(fail, 1u, DZ_ACT_RLX);
-    *s_ok = ok;
-  }
+__device__ __forceinline__ float* act_set(unsigned* sync, unsigned gen) {
+  return (float*)(sync + 64 * 8) + (gen & 1u) * kActSetFloats;
+}
+// Before the polling rounds: ONE thread watches ONE of the words the workgroup needs (224 x 256
+// threads re-reading 14 words each starved every other access of the chip: 38 us per decision).
+// The rounds that follow see the rest, written within a microsecond of it.
+__device__ __forceinline__ void act_watch(const float* word) {
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kActSpinLimit && act_missing(act_load(word)); ++i) __builtin_amdgcn_s_sleep(2);
   __syncthreads();
-  return *s_ok != 0;
+}
+// One polling round ends here: true = some thread still saw a missing value (go round again);
+// after kActSpinLimit rounds the sticky failure word is set and *give_up becomes true.
+__device__ __forceinline__ bool act_again(bool miss, int round, unsigned* fail, bool* give_up) {
+  const bool again = __syncthreads_or(miss ? 1 : 0) != 0;
+  *give_up = again && round >= kActSpinLimit;
+  if (*give_up && threadIdx.x == 0) __hip_atomic_store(fail, 1u, DZ_ACT_RLX);
+  if (again) __builtin_amdgcn_s_sleep(1);
+  return again && !*give_up;
 }
 
 // ---- torso -----------------------------------------------------------------------------------
@@ -134,7 +132,7 @@ __device__ __forceinline__ void act_partial_to_lds(float* red, int wave, int lan
   d[0] = a[0] + b[0]; d[16] = a[1] + b[1]; d[32] = a[2] + b[2]; d[48] = a[3] + b[3];
 }
 
-__device__ __forceinline__ void act_torso_block(const ActOneParams& p, int blk, float* lds, int* s_ok) {
+__device__ __forceinline__ void act_torso_block(const ActOneParams& p, int blk, float* lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, kq = lane >> 4;
   float* red = lds + 8 * 20 * 36;
@@ -148,6 +146,11 @@ __device__ __forceinline__ void act_torso_block(const ActOneParams& p, int blk, 
 
   ACT_STAMP(0);
   const unsigned gen = *act_line(p.sync, 3);
+  float* const set = act_set(p.sync, gen);
+  float* const act1 = set + kActOffA1; float* const act2 = set + kActOffA2;
+  float* const feat = set + kActOffFeat;
+  unsigned* const fail = act_line(p.sync, 5);
+  bool give_up;
   // conv1's patch first (vector loads return in order): 12 input rows x 84 pixels x 4 bytes
   const int p0c1 = 16 * blk, oy0c1 = p0c1 / 20;
   unsigned raw[4];
@@ -221,26 +224,34 @@ __device__ __forceinline__ void act_torso_block(const ActOneParams& p, int blk, 
       const int m = tid >> 4;
       const float va = red[0 * 256 + tid] + red[2 * 256 + tid] + bias1a;
       const float vb = red[1 * 256 + tid] + red[3 * 256 + tid] + bias1b;
-      act_store(p.act1 + (p0 + m) * 32 + (tid & 15), va > 0.f ? va : 0.f);
-      act_store(p.act1 + (p0 + m) * 32 + 16 + (tid & 15), vb > 0.f ? vb : 0.f);
+      act_store(act1 + (p0 + m) * 32 + (tid & 15), va > 0.f ? va : -0.f);
+      act_store(act1 + (p0 + m) * 32 + 16 + (tid & 15), vb > 0.f ? vb : -0.f);
     }
   }
-  act_arrive(act_line(p.sync, 0));
   ACT_STAMP(2);
   if (blk >= kActConv2Blocks) return;
-  if (!act_wait(act_line(p.sync, 0), kActTorsoBlocks, act_line(p.sync, 5), s_ok)) return;
-  ACT_STAMP(3);
+  __syncthreads();   // (the partial tiles and the patch are read; LDS is reused below)
 
   // ---- conv2: pixels 16 pt2 .., channels 16 ct2 .. ------------------------------------------------
   {
     const int p0 = 16 * pt2, oy0 = p0 / 9;
     float2 v[10];   // 8 input rows x 20 pixels x 32 channels, LDS pixel pitch 36
+    int round = 0;
+    bool miss;
+    act_watch(act1 + (min(2 * oy0 + 7, 19) * 20 + 19) * 32 + 31);
+    do {            // conv1's outputs are their own flags
+      miss = false;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const int f = 2 * (tid + 256 * i);
-      const int r = f / 640, rem = f % 640;
-      v[i] = act_load2(p.act1 + (min(2 * oy0 + r, 19) * 20 + rem / 32) * 32 + (rem & 31));
-    }
+      for (int i = 0; i < 10; ++i) {
+        const int f = 2 * (tid + 256 * i);
+        const int r = f / 640, rem = f % 640;
+        v[i] = act_load2(act1 + (min(2 * oy0 + r, 19) * 20 + rem / 32) * 32 + (rem & 31));
+      }
+#pragma unroll
+      for (int i = 0; i < 10; ++i) miss = miss || act_missing(v[i].x) || act_missing(v[i].y);
+    } while (act_again(miss, round++, fail, &give_up));
+    if (give_up) return;
+    ACT_STAMP(3);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const int f = 2 * (tid + 256 * i);
@@ -270,25 +281,33 @@ __device__ __forceinline__ void act_torso_block(const ActOneParams& p, int blk, 
     {
       const int m = tid >> 4;
       const float s = ((red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid])) + bias2;
-      if (p0 + m < 81) act_store(p.act2 + (p0 + m) * 64 + 16 * ct2 + (tid & 15), s > 0.f ? s : 0.f);
+      if (p0 + m < 81) act_store(act2 + (p0 + m) * 64 + 16 * ct2 + (tid & 15), s > 0.f ? s : -0.f);
     }
   }
-  act_arrive(act_line(p.sync, 1));
   ACT_STAMP(5);
   if (blk >= kActConv3Blocks) return;
-  if (!act_wait(act_line(p.sync, 1), kActConv2Blocks, act_line(p.sync, 5), s_ok)) return;
-  ACT_STAMP(6);
+  __syncthreads();
 
   // ---- conv3: pixels 16 pt3 .., channels 16 ct3 .. ------------------------------------------------
   {
     const int p0 = 16 * pt3, oy0 = p0 / 7;
     float2 v[7];    // 6 input rows x 9 pixels x 64 channels, LDS pixel pitch 68
+    int round = 0;
+    bool miss;
+    act_watch(act2 + (min(oy0 + 5, 8) * 9 + 8) * 64 + 63);
+    do {
+      miss = false;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int f = min(2 * (tid + 256 * i), 3454);
-      const int r = f / 576, rem = f % 576;
-      v[i] = act_load2(p.act2 + (min(oy0 + r, 8) * 9 + rem / 64) * 64 + (rem & 63));
-    }
+      for (int i = 0; i < 7; ++i) {
+        const int f = min(2 * (tid + 256 * i), 3454);
+        const int r = f / 576, rem = f % 576;
+        v[i] = act_load2(act2 + (min(oy0 + r, 8) * 9 + rem / 64) * 64 + (rem & 63));
+      }
+#pragma unroll
+      for (int i = 0; i < 7; ++i) miss = miss || act_missing(v[i].x) || act_missing(v[i].y);
+    } while (act_again(miss, round++, fail, &give_up));
+    if (give_up) return;
+    ACT_STAMP(6);
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int f = 2 * (tid + 256 * i);
@@ -317,27 +336,24 @@ __device__ __forceinline__ void act_torso_block(const ActOneParams& p, int blk, 
     {
       const int m = tid >> 4;
       const float s = ((red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid])) + bias3;
-      if (p0 + m < 49) act_store(p.feat + (p0 + m) * 64 + 16 * ct3 + (tid & 15), s > 0.f ? s : 0.f);
+      if (p0 + m < 49) act_store(feat + (p0 + m) * 64 + 16 * ct3 + (tid & 15), s > 0.f ? s : -0.f);
     }
   }
-  // the last arriver tells every fc1 workgroup on that workgroup's own line
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0)
-    *s_ok = __hip_atomic_fetch_add(act_line(p.sync, 2), 1u, DZ_ACT_RLX) == (unsigned)kActConv3Blocks - 1;
-  __syncthreads();
-  if (*s_ok && tid < kActFc1Blocks) __hip_atomic_store(act_flag(p.sync, tid), gen + 1u, DZ_ACT_RLX);
   ACT_STAMP(8);
 }
 
 // ---- fc1 -------------------------------------------------------------------------------------
-__device__ __forceinline__ void act_fc1_block(const ActOneParams& p, int fb, float* lds, int* s_ok) {
+__device__ __forceinline__ void act_fc1_block(const ActOneParams& p, int fb, float* lds) {
   const int tid = threadIdx.x;
   const int split = fb >> 3, cg = fb & 7, hsel = cg >> 2;
   const int cq = tid & 31, kg = tid >> 5;
   const int col = 128 * cg + 4 * cq, k0 = kActFc1Rows * split + 14 * kg;
   ACT_STAMP(0);
   const unsigned gen = *act_line(p.sync, 3);
+  float* const set = act_set(p.sync, gen);
+  const float* const feat = set + kActOffFeat;
+  // the NEXT apply's set (last read one apply ago) goes back to all-zero bits, a chunk per workgroup
+  if (fb * 256 < kActSetFloats) act_store(act_set(p.sync, gen + 1u) + fb * 256 + tid, 0.f);
   float4 w[14], sg[14];
   {
     const float* wm = p.prm + p.fc1_mu_w + (long)k0 * p.fc1_ld + col;
@@ -369,11 +385,21 @@ __device__ __forceinline__ void act_fc1_block(const ActOneParams& p, int fb, flo
     w[j].w = __builtin_fmaf(sg[j].w, ei * eo[3], w[j].w);
   }
   ACT_STAMP(1);
-  if (!act_wait(act_flag(p.sync, fb), gen + 1u, act_line(p.sync, 5), s_ok)) return;
-  ACT_STAMP(2);
   float x[14];
+  {
+    int round = 0;
+    bool miss, give_up;
+    act_watch(feat + k0 + 13);
+    do {            // conv3's outputs are their own flags
+      miss = false;
 #pragma unroll
-  for (int j = 0; j < 14; ++j) x[j] = act_load(p.feat + k0 + j);
+      for (int j = 0; j < 14; ++j) x[j] = act_load(feat + k0 + j);
+#pragma unroll
+      for (int j = 0; j < 14; ++j) miss = miss || act_missing(x[j]);
+    } while (act_again(miss, round++, act_line(p.sync, 5), &give_up));
+    if (give_up) return;
+  }
+  ACT_STAMP(2);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int j = 0; j < 14; ++j) {
@@ -386,16 +412,15 @@ __device__ __forceinline__ void act_fc1_block(const ActOneParams& p, int fb, flo
   if (tid < 128) {
     const float s = ((lds[tid] + lds[128 + tid]) + (lds[256 + tid] + lds[384 + tid])) +
                     ((lds[512 + tid] + lds[640 + tid]) + (lds[768 + tid] + lds[896 + tid]));
-    act_store(p.part + split * 1024 + 128 * cg + tid, s);
+    act_store(set + kActOffPart + split * 1024 + 128 * cg + tid, act_mark(s));
   }
-  act_arrive(act_line(p.sync, 8 + cg));
   ACT_STAMP(4);
 }
 
 // ---- tail ------------------------------------------------------------------------------------
 // As rainbow_act_tail_kernel (one row), with the noise drawn here and the slabs read after the
 // fc1 counter is full.
-__device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, float* lds, int* s_ok) {
+__device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, float* lds) {
   float* s_h1 = lds;            // [512]
   float* s_ein = lds + 512;     // [512]
   float* s_red = lds + 1024;    // [8][32]
@@ -416,7 +441,11 @@ __device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, 
     const float* wmu = p.prm + hd.w_mu + (long)(kg * 64) * hd.ldw + colc;
     const float* wsg = p.prm + hd.w_sig + (long)(kg * 64) * hd.ldw + colc;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) { m[j] = wmu[(long)j * hd.ldw]; g[j] = wsg[(long)j * hd.ldw]; }
+    for (int j = 0; j < 64; ++j) {   // (running pointers kept opaque: 128 precomputed addresses = 256 registers)
+      m[j] = *wmu; g[j] = *wsg;
+      wmu += hd.ldw; wsg += hd.ldw;
+      asm volatile("" : "+v"(wmu), "+v"(wsg));
+    }
   }
   float bm[2], bs[2];
 #pragma unroll
@@ -435,22 +464,48 @@ __device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, 
   }
   const float eo = dz_noise_at(p.seed, base + (uint64_t)(hd.eps_out + colc));
   const float sb = sbw * dz_noise_at(p.seed, base + (uint64_t)(p.n_fc2_out + hd.out_off + colc));
+  // W_eff of this thread's 64 k's, formed while the torso runs (64 registers instead of 128)
+  s_ein[tid] = ei[0]; s_ein[tid + 256] = ei[1];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    m[j] = __builtin_fmaf(g[j], s_ein[kg * 64 + j] * eo, m[j]);
+    asm volatile("" : "+v"(m[j]));   // formed HERE (the compiler otherwise sinks it below the wait and keeps g alive)
+  }
   ACT_STAMP(1);
-  if (!act_wait<4>(act_line(p.sync, 8 + 4 * hsel), kActFc1Splits, act_line(p.sync, 5), s_ok)) {
-    if (tile == 0 && tid == 0) {   // visible to the host: the decision is not a number
-      for (int a = 0; a < p.A; ++a) p.q_out[a] = __builtin_nanf("");
-      if (p.greedy_out) *p.greedy_out = 0;
-      if (p.vmax_out) *p.vmax_out = __builtin_nanf("");
+  // ---- 1. h1 (this head's half): 28 slabs in slab order; the slab values are their own flags ------
+  float x[2][kActFc1Splits];
+  {
+    const float* part = act_set(p.sync, *act_line(p.sync, 3)) + kActOffPart + hd.x_off + tid;
+    int round = 0;
+    bool miss, give_up;
+    act_watch(part + (kActFc1Splits - 1) * 1024);
+    do {
+      miss = false;
+      // (running pointer kept opaque: the slabs are 4 KB apart, beyond the immediate offset, and
+      // 56 addresses computed ahead of the loads cost 112 registers -- the kernel spilled)
+      const float* pp = part;
+#pragma unroll
+      for (int j = 0; j < kActFc1Splits; ++j) {
+        asm volatile("" : "+v"(pp));
+        x[0][j] = act_load(pp); x[1][j] = act_load(pp + 256);
+        pp += 1024;
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < kActFc1Splits; ++j) miss = miss || act_missing(x[e][j]);
+    } while (act_again(miss, round++, act_line(p.sync, 5), &give_up));
+    if (give_up) {
+      if (tile == 0 && tid == 0) {   // visible to the host: the decision is not a number
+        for (int a = 0; a < p.A; ++a) p.q_out[a] = __builtin_nanf("");
+        if (p.greedy_out) *p.greedy_out = 0;
+        if (p.vmax_out) *p.vmax_out = __builtin_nanf("");
+      }
+      return;
     }
-    return;
   }
   ACT_STAMP(2);
-  // ---- 1. h1 (this head's half): 28 slabs in slab order ------------------------------------------
-  float x[2][kActFc1Splits];
-#pragma unroll
-  for (int e = 0; e < 2; ++e)
-#pragma unroll
-    for (int j = 0; j < kActFc1Splits; ++j) x[e][j] = act_load(p.part + j * 1024 + hd.x_off + tid + 256 * e);
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     float v = 0.f;
@@ -458,7 +513,6 @@ __device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, 
     for (int j = 0; j < kActFc1Splits; ++j) v += x[e][j];
     const float h = v + bm[e] + bs[e] * be[e];
     s_h1[tid + 256 * e] = h > 0.f ? h : 0.f;
-    s_ein[tid + 256 * e] = ei[e];
   }
   __syncthreads();
   ACT_STAMP(3);
@@ -468,7 +522,7 @@ __device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, 
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
       const int k = kg * 64 + j;
-      acc = __builtin_fmaf(s_h1[k], __builtin_fmaf(g[j], s_ein[k] * eo, m[j]), acc);
+      acc = __builtin_fmaf(s_h1[k], m[j], acc);
     }
     s_red[kg * 32 + c] = acc;
   }
@@ -491,8 +545,7 @@ __device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, 
   if (tid == 0) {
     // re-armed for the next apply (ordered by the kernel boundary; every poller has passed)
     const unsigned gen = *act_line(p.sync, 3);
-    for (int i = 0; i < 16; ++i)
-      if (i != 3 && i != 5) __hip_atomic_store(act_line(p.sync, i), 0u, DZ_ACT_RLX);
+    __hip_atomic_store(act_line(p.sync, 4), 0u, DZ_ACT_RLX);
     __hip_atomic_store(act_line(p.sync, 3), gen + 1u, DZ_ACT_RLX);
     if (p.bump) *p.bump = *p.bump + 1;
   }
@@ -503,11 +556,10 @@ __device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, 
 
 __global__ __launch_bounds__(256, 2) void rainbow_act_one_kernel(ActOneParams p) {
   __shared__ __attribute__((aligned(16))) float lds[kActLdsFloats];
-  __shared__ int s_ok;
   const int b = blockIdx.x;
-  if (b < kActTorsoBlocks) act_torso_block(p, b, lds, &s_ok);
-  else if (b < kActTorsoBlocks + kActFc1Blocks) act_fc1_block(p, b - kActTorsoBlocks, lds, &s_ok);
-  else act_tail_block(p, b - kActTorsoBlocks - kActFc1Blocks, lds, &s_ok);
+  if (b < kActTorsoBlocks) act_torso_block(p, b, lds);
+  else if (b < kActTorsoBlocks + kActFc1Blocks) act_fc1_block(p, b - kActTorsoBlocks, lds);
+  else act_tail_block(p, b - kActTorsoBlocks - kActFc1Blocks, lds);
 }
 
 }  // namespace

@@ -735,10 +735,8 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
     ActOneParams q;
     q.obs = states; q.prm = params;
     for (int i = 0; i < 3; ++i) { q.conv_w[i] = L.conv_w[i]; q.conv_b[i] = L.conv_b[i]; }
-    q.act1 = ws + L.ws_act1; q.act2 = ws + L.ws_act2; q.feat = ws + L.ws_feat;
     q.fc1_mu_w = L.fc1_mu_w; q.fc1_sig_w = L.fc1_sig_w; q.fc1_mu_b = L.fc1_mu_b;
     q.fc1_sig_b = L.fc1_sig_b; q.fc1_ld = L.fc1_ld;
-    q.part = ws + L.ws_fc1_part;
     q.noise = noise; q.n_noise = (int)L.noise_stride; q.seed = noise_seed; q.counter = noise_counter;
     q.step = step_counter;
     q.n_eps_in[0] = (int)L.n_adv1_in; q.n_eps_in[1] = (int)L.n_val1_in; q.n_fc1_out = (int)L.n_fc1_out;
@@ -753,7 +751,6 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
 #ifdef DZ_ACT_STAMPS
     q.dbg = reinterpret_cast<long long*>(ws + L.ws_dfeat_part);
 #endif
-    static_assert(kMaxSplitFc1 * kG >= kActFc1Splits, "fc1 slab buffer holds the actor's 28 slabs");
     hipLaunchKernelGGL(rainbow_act_one_kernel,
                        dim3((unsigned)(kActTorsoBlocks + kActFc1Blocks + q.tiles)), dim3(256), 0, s, q);
     DZ_LAUNCH_CHECK();

@@ -28,7 +28,7 @@ for i in range(5):
   worst = max(worst, err)
   print('decision', i, 'max|q - oracle| %.2e' % err, 'max|q - multi-launch| %.2e' % err5,
         'greedy', int(g[0]), int(q_ref[0].argmax()), 'step', ln.act_step(),
-        'seam words', ln._act_ws[int(ln.network.layout(1).c.ws_act_seams):][:64 * 16:64]
+        'seam words', ln._act_ws[int(ln.network.layout(1).c.ws_act_seams):][:64 * 8:64]
         .view(torch.int32).tolist())
 assert worst < 2e-4, worst
 x = torch.randint(0, 256, (1, 84, 84, 4), dtype=torch.uint8, device='cuda')

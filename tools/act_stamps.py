@@ -23,10 +23,10 @@ def show(name, rows, labels):
   print(name)
   for i, l in enumerate(labels):
     print('   %-26s mean %6.2f  (%6.2f .. %6.2f)' % (l, r[:, i].mean(), r[:, i].min(), r[:, i].max()))
-show('torso, all 25', slice(0, 25), ['start', 'conv1 patch in LDS', 'conv1 stored + arrived'])
-show('torso, first 24', slice(0, 24), ['start', 'conv1 patch in LDS', 'conv1 arrived', 'barrier 1 passed', 'conv2 patch in LDS', 'conv2 arrived'])
-show('torso, first 16', slice(0, 16), ['start', 'p1', 'a1', 'b1', 'p2', 'conv2 arrived', 'barrier 2 passed', 'conv3 patch in LDS', 'conv3 arrived'])
-show('fc1, 224', slice(25, 249), ['start', 'W_eff formed', 'features seen', 'partials in LDS', 'slab stored + arrived'])
-show('tail, 12', slice(249, 261), ['start', 'weights requested, noise drawn', 'fc1 complete seen', 'h1 in LDS', 'ticket taken'])
+show('torso, all 25', slice(0, 25), ['start', 'conv1 patch in LDS', 'conv1 stored'])
+show('torso, first 24', slice(0, 24), ['start', 'conv1 patch in LDS', 'conv1 stored', 'conv1 outputs all seen', 'conv2 patch in LDS', 'conv2 stored'])
+show('torso, first 16', slice(0, 16), ['start', 'p1', 's1', 'seen1', 'p2', 'conv2 stored', 'conv2 outputs all seen', 'conv3 patch in LDS', 'conv3 stored'])
+show('fc1, 224', slice(25, 249), ['start', 'W_eff formed', 'features seen', 'partials in LDS', 'slab stored'])
+show('tail, 12', slice(249, 261), ['start', 'weights requested, noise drawn', 'slabs seen', 'h1 in LDS', 'ticket taken'])
 last = us[249:261, 5].max()
 print('last tail workgroup done: %.2f' % last)
