@@ -185,6 +185,43 @@ def test_get_state_set_state_roundtrip():
   assert rep2.size == rep.size and list(rep2.ids()) == list(rep.ids())
 
 
+@pytest.mark.parametrize('num_actions', [3, 6, 18])
+def test_one_launch_decision_vs_oracle_and_the_multi_launch_apply(num_actions):
+  """A batch of ONE observation with fresh noise is one launch (csrc/dz_act_one.h: torso, fc1
+  stream and tail as workgroup roles, intermediates that are their own flags, two alternating
+  sets).  Seven consecutive decisions -- every set used at least three times -- against the
+  oracle forward with the noise the kernel drew and wrote out, against the multi-launch apply on
+  the same noise, and the seam words left re-armed."""
+  from dqn_zoo_amd import learner, networks
+  rs = np.random.RandomState(17 + num_actions)
+  params = qo.init_params('rainbow', num_actions, rs)
+  for k in params:
+    if 'sigma' in k:
+      params[k] = (params[k] * 3).astype(np.float32)
+  ln = learner.RainbowLearner(networks.RainbowNetwork(num_actions, SUPPORT),
+                              learner.AdamConfig(), 8, params=params)
+  ln.act_graphs = False
+  seams = int(ln.network.layout(1).c.ws_act_seams)
+  for i in range(7):
+    x = rs.randint(0, 256, (1, 84, 84, 4)).astype(np.uint8)
+    if i == 3:
+      x[:] = 0          # all-zero activations are stored as -0.0f, never as "not written"
+    xd = torch.from_numpy(x).cuda()
+    q, greedy, vmax = ln.apply(xd)
+    torch.cuda.synchronize()
+    nz = ln.layout.unpack_noise(ln._act_noise.cpu().numpy())  # pylint: disable=protected-access
+    _, q_ref, _ = qo.rainbow_fwd(params, x, nz, SUPPORT, num_actions)
+    np.testing.assert_allclose(q.cpu().numpy(), q_ref, rtol=2e-4, atol=2e-5)
+    assert int(greedy[0]) == int(q_ref[0].argmax())
+    np.testing.assert_allclose(float(vmax[0]), q_ref[0].max(), rtol=2e-4, atol=2e-5)
+    q5, g5, _ = ln.apply(xd, noise=nz)       # stored noise: the multi-launch kernels
+    np.testing.assert_allclose(q.cpu().numpy(), q5.cpu().numpy(), rtol=0, atol=2e-6)
+    assert int(g5[0]) == int(greedy[0])
+    assert ln.act_step() == i + 1
+    words = ln._act_ws[seams:seams + 64 * 8:64].view(torch.int32).tolist()  # pylint: disable=protected-access
+    assert words[3] == i + 1 and words[4] == 0 and words[5] == 0, words
+
+
 def test_async_acting_path_matches_oracle_and_replays_from_a_graph():
   """`apply_async` (the agents' acting path): launches enqueued, (action, value)
   written by the kernel into pinned host memory, replayed from a hipGraph from
