@@ -110,7 +110,7 @@ class DenseLayout(ctypes.Structure):
           'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'ws_count', 'ws_act1', 'ws_act2',
           'ws_feat', 'ws_fc1_part', 'ws_h1', 'ws_fc2_part', 'ws_out', 'ws_dout',
           'ws_dh1', 'ws_dfeat_part', 'ws_dfeat', 'ws_dact2', 'ws_dact1',
-          'ws_wgrad_part', 'ws_norm_part', 'ws_scalars', 'ws_zeros')])
+          'ws_wgrad_part', 'ws_norm_part', 'ws_scalars', 'ws_zeros', 'ws_act_seams')])
 
 
 class DenseArgs(ctypes.Structure):
@@ -204,6 +204,7 @@ SIGNATURES = {
     'dz_dense_learn': (c_int, [ctypes.POINTER(DenseArgs), c_int, c_vp]),
     'dz_dense_apply': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                                c_vp, c_vp, c_vp, c_vp]),
+    'dz_dense_act': (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dz_iqn_layout': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int,
                               ctypes.POINTER(IqnLayout)]),
     'dz_iqn_learn': (c_int, [ctypes.POINTER(IqnArgs), c_int, c_vp]),

@@ -50,9 +50,10 @@ constexpr int kActFc1Splits = 28, kActFc1Rows = 112, kActFc1Blocks = kActFc1Spli
 constexpr int kActSpinLimit = 200000;
 // one set of intermediates: act1 | act2 | feat | 28 fc1 slabs, padded to whole 256-float chunks
 constexpr int kActOffA1 = 0, kActOffA2 = 400 * 32, kActOffFeat = kActOffA2 + 81 * 64,
-              kActOffPart = kActOffFeat + kFlat, kActSetFloats = (kActOffPart + kActFc1Splits * 1024 + 255) & ~255;
-static_assert(kActSetFloats <= 256 * kActFc1Blocks, "one chunk of the next set per fc1 workgroup");
-constexpr int kActSeamWords = 64 * 8 + 2 * kActSetFloats;   // 8 lines (256 bytes apart) + the two sets
+              kActOffPart = kActOffFeat + kFlat;
+constexpr int act_set_floats(int part_ld) { return (kActOffPart + kActFc1Splits * part_ld + 255) & ~255; }
+constexpr int act_seam_words(int part_ld) { return 64 * 8 + 2 * act_set_floats(part_ld); }   // 8 lines + two sets
+constexpr int kActSeamWords = act_seam_words(1024), kDenseActSeamWords = act_seam_words(512);
 constexpr int kActLdsFloats = 8 * 20 * 36 + 4 * 256;   // largest patch (conv2) + partial tiles
 static_assert(kActFc1Splits * kActFc1Rows == kFlat, "fc1 K-splits");
 
@@ -64,11 +65,24 @@ static_assert(kActFc1Splits * kActFc1Rows == kFlat, "fc1 K-splits");
 #define ACT_STAMP(i) do {} while (0)
 #endif
 
-struct ActOneParams {
+// What every role needs: the torso's inputs and the seam area.
+struct ActTorso {
   const uint8_t* obs;                 // [84][84][4], device or pinned device-mapped host memory
   const float* prm;
   long conv_w[3], conv_b[3];
-  long fc1_mu_w, fc1_sig_w, fc1_mu_b, fc1_sig_b; int fc1_ld;
+  // Seam area (dz_*_layout_t::ws_act_seams; zero in a fresh workspace, owned by these kernels):
+  // line 3 generation, line 4 tail tickets, line 5 sticky failure (lines are 256 bytes apart), then
+  // the two sets of intermediates: act1 | act2 | feat | 28 fc1 slabs of part_ld columns.
+  unsigned* sync;
+  int set_floats;                     // floats per set (a multiple of 256)
+  int ncg, part_ld;                   // fc1: column groups of 128, slab row length (128 ncg)
+  long fc1_mu_w; int fc1_ld;
+  long long* dbg = nullptr;
+};
+
+struct ActOneParams : ActTorso {      // Rainbow: noisy fc1 (adv | val), dueling C51 head
+  static constexpr bool NOISY = true;
+  long fc1_sig_w, fc1_mu_b, fc1_sig_b;
   float* noise; int n_noise;          // the apply's noise block, also written out (tests, state)
   uint64_t seed, counter; const int32_t* step;
   int n_eps_in[2]; int n_fc1_out;
@@ -79,11 +93,12 @@ struct ActOneParams {
   float* fc2_out; float* q_out; int32_t* greedy_out; float* vmax_out;
   int tiles0, tiles;
   int32_t* bump;
-  // Seam area (dz_rainbow_layout_t::ws_act_seams; zero in a fresh workspace, owned by this kernel):
-  // line 3 generation, line 4 tail tickets, line 5 sticky failure (lines are 256 bytes apart), then
-  // the two sets of intermediates.
-  unsigned* sync;
-  long long* dbg = nullptr;
+};
+
+struct DenseActParams : ActTorso {    // DQN-family: linear(512) + ReLU + linear(N <= 32)
+  static constexpr bool NOISY = false;
+  long fc1_b, fc2_w, fc2_b; int ld2, N, bias_shared;
+  unsigned long long* pairs_out;      // [N] {float q, float 1.0f}: one 8-byte store each
 };
 
 // ---- seams -----------------------------------------------------------------------------------
@@ -100,8 +115,8 @@ __device__ __forceinline__ float2 act_load2(const float* p) {   // 8-byte aligne
 __device__ __forceinline__ float act_mark(float v) { return v == 0.f ? -0.f : v; }
 __device__ __forceinline__ bool act_missing(float v) { return __builtin_bit_cast(unsigned, v) == 0u; }
 __device__ __forceinline__ unsigned* act_line(unsigned* sync, int i) { return sync + 64 * i; }
-__device__ __forceinline__ float* act_set(unsigned* sync, unsigned gen) {
-  return (float*)(sync + 64 * 8) + (gen & 1u) * kActSetFloats;
+__device__ __forceinline__ float* act_set(const ActTorso& p, unsigned gen) {
+  return (float*)(p.sync + 64 * 8) + (gen & 1u) * p.set_floats;
 }
 // Before the polling rounds: ONE thread watches ONE of the words the workgroup needs (224 x 256
 // threads re-reading 14 words each starved every other access of the chip: 38 us per decision).
@@ -132,7 +147,7 @@ __device__ __forceinline__ void act_partial_to_lds(float* red, int wave, int lan
   d[0] = a[0] + b[0]; d[16] = a[1] + b[1]; d[32] = a[2] + b[2]; d[48] = a[3] + b[3];
 }
 
-__device__ __forceinline__ void act_torso_block(const ActOneParams& p, int blk, float* lds) {
+__device__ __forceinline__ void act_torso_block(const ActTorso& p, int blk, float* lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, kq = lane >> 4;
   float* red = lds + 8 * 20 * 36;
@@ -146,7 +161,7 @@ __device__ __forceinline__ void act_torso_block(const ActOneParams& p, int blk, 
 
   ACT_STAMP(0);
   const unsigned gen = *act_line(p.sync, 3);
-  float* const set = act_set(p.sync, gen);
+  float* const set = act_set(p, gen);
   float* const act1 = set + kActOffA1; float* const act2 = set + kActOffA2;
   float* const feat = set + kActOffFeat;
   unsigned* const fail = act_line(p.sync, 5);
@@ -343,19 +358,25 @@ __device__ __forceinline__ void act_torso_block(const ActOneParams& p, int blk, 
 }
 
 // ---- fc1 -------------------------------------------------------------------------------------
-__device__ __forceinline__ void act_fc1_block(const ActOneParams& p, int fb, float* lds) {
+// P = ActOneParams (noisy, 8 column groups) or DenseActParams (plain, 4 column groups)
+template <class P>
+__device__ __forceinline__ void act_fc1_block(const P& p, int fb, int nfc1, float* lds) {
   const int tid = threadIdx.x;
-  const int split = fb >> 3, cg = fb & 7, hsel = cg >> 2;
+  const int split = fb / p.ncg, cg = fb % p.ncg;
   const int cq = tid & 31, kg = tid >> 5;
   const int col = 128 * cg + 4 * cq, k0 = kActFc1Rows * split + 14 * kg;
   ACT_STAMP(0);
   const unsigned gen = *act_line(p.sync, 3);
-  float* const set = act_set(p.sync, gen);
+  float* const set = act_set(p, gen);
   const float* const feat = set + kActOffFeat;
-  // the NEXT apply's set (last read one apply ago) goes back to all-zero bits, a chunk per workgroup
-  if (fb * 256 < kActSetFloats) act_store(act_set(p.sync, gen + 1u) + fb * 256 + tid, 0.f);
-  float4 w[14], sg[14];
+  // the NEXT apply's set (last read one apply ago) goes back to all-zero bits, 256 floats at a time
   {
+    float* const nxt = act_set(p, gen + 1u);
+    for (int c = fb * 256; c < p.set_floats; c += nfc1 * 256) act_store(nxt + c + tid, 0.f);
+  }
+  float4 w[14];
+  if constexpr (P::NOISY) {
+    float4 sg[14];
     const float* wm = p.prm + p.fc1_mu_w + (long)k0 * p.fc1_ld + col;
     const float* ws = p.prm + p.fc1_sig_w + (long)k0 * p.fc1_ld + col;
 #pragma unroll
@@ -363,26 +384,31 @@ __device__ __forceinline__ void act_fc1_block(const ActOneParams& p, int fb, flo
       w[j] = dz_ld4(wm + (long)j * p.fc1_ld);
       sg[j] = dz_ld4(ws + (long)j * p.fc1_ld);
     }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // this apply's position in the actor's noise stream; the block is also written out
-  const uint64_t base = p.counter + (uint64_t)(*p.step) * (uint64_t)p.n_noise;
-  {
-    const int i = fb * 256 + tid;
-    if (i < p.n_noise) p.noise[i] = dz_noise_at(p.seed, base + (uint64_t)i);
-  }
-  float eo[4];
+    __builtin_amdgcn_sched_barrier(0);
+    // this apply's position in the actor's noise stream; the block is also written out
+    const uint64_t base = p.counter + (uint64_t)(*p.step) * (uint64_t)p.n_noise;
+    {
+      const int i = fb * 256 + tid;
+      if (i < p.n_noise) p.noise[i] = dz_noise_at(p.seed, base + (uint64_t)i);
+    }
+    float eo[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) eo[c] = dz_noise_at(p.seed, base + (uint64_t)(p.n_fc1_out + col + c));
-  const int e_in = hsel ? p.n_eps_in[1] : p.n_eps_in[0];
+    for (int c = 0; c < 4; ++c) eo[c] = dz_noise_at(p.seed, base + (uint64_t)(p.n_fc1_out + col + c));
+    const int e_in = cg >= 4 ? p.n_eps_in[1] : p.n_eps_in[0];
 #pragma unroll
-  for (int j = 0; j < 14; ++j) {
-    const float ei = dz_noise_at(p.seed, base + (uint64_t)(e_in + k0 + j));
-    // W_eff = Wmu + Wsig * (eps_in[k] * eps_out[n])   (networks.py:168-176)
-    w[j].x = __builtin_fmaf(sg[j].x, ei * eo[0], w[j].x);
-    w[j].y = __builtin_fmaf(sg[j].y, ei * eo[1], w[j].y);
-    w[j].z = __builtin_fmaf(sg[j].z, ei * eo[2], w[j].z);
-    w[j].w = __builtin_fmaf(sg[j].w, ei * eo[3], w[j].w);
+    for (int j = 0; j < 14; ++j) {
+      const float ei = dz_noise_at(p.seed, base + (uint64_t)(e_in + k0 + j));
+      // W_eff = Wmu + Wsig * (eps_in[k] * eps_out[n])   (networks.py:168-176)
+      w[j].x = __builtin_fmaf(sg[j].x, ei * eo[0], w[j].x);
+      w[j].y = __builtin_fmaf(sg[j].y, ei * eo[1], w[j].y);
+      w[j].z = __builtin_fmaf(sg[j].z, ei * eo[2], w[j].z);
+      w[j].w = __builtin_fmaf(sg[j].w, ei * eo[3], w[j].w);
+    }
+  } else {
+    const float* wm = p.prm + p.fc1_mu_w + (long)k0 * p.fc1_ld + col;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) w[j] = dz_ld4(wm + (long)j * p.fc1_ld);
+    __builtin_amdgcn_sched_barrier(0);
   }
   ACT_STAMP(1);
   float x[14];
@@ -412,7 +438,7 @@ __device__ __forceinline__ void act_fc1_block(const ActOneParams& p, int fb, flo
   if (tid < 128) {
     const float s = ((lds[tid] + lds[128 + tid]) + (lds[256 + tid] + lds[384 + tid])) +
                     ((lds[512 + tid] + lds[640 + tid]) + (lds[768 + tid] + lds[896 + tid]));
-    act_store(set + kActOffPart + split * 1024 + 128 * cg + tid, act_mark(s));
+    act_store(set + kActOffPart + split * p.part_ld + 128 * cg + tid, act_mark(s));
   }
   ACT_STAMP(4);
 }
@@ -476,7 +502,7 @@ __device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, 
   // ---- 1. h1 (this head's half): 28 slabs in slab order; the slab values are their own flags ------
   float x[2][kActFc1Splits];
   {
-    const float* part = act_set(p.sync, *act_line(p.sync, 3)) + kActOffPart + hd.x_off + tid;
+    const float* part = act_set(p, *act_line(p.sync, 3)) + kActOffPart + hd.x_off + tid;
     int round = 0;
     bool miss, give_up;
     act_watch(part + (kActFc1Splits - 1) * 1024);
@@ -558,8 +584,95 @@ __global__ __launch_bounds__(256, 2) void rainbow_act_one_kernel(ActOneParams p)
   __shared__ __attribute__((aligned(16))) float lds[kActLdsFloats];
   const int b = blockIdx.x;
   if (b < kActTorsoBlocks) act_torso_block(p, b, lds);
-  else if (b < kActTorsoBlocks + kActFc1Blocks) act_fc1_block(p, b - kActTorsoBlocks, lds);
+  else if (b < kActTorsoBlocks + kActFc1Blocks) act_fc1_block(p, b - kActTorsoBlocks, kActFc1Blocks, lds);
   else act_tail_block(p, b - kActTorsoBlocks - kActFc1Blocks, lds);
+}
+
+// ---- dense head (DQN-family) -------------------------------------------------------------------
+// ONE workgroup: h1 = relu(slab sum + b1), q = h1 W2 + b2 (ref: networks.py:206-221, 120-134),
+// each q-value stored with a marker as one 8-byte word into the pinned slot the host polls.
+__device__ __forceinline__ void dense_act_tail_block(const DenseActParams& p, float* lds) {
+  float* s_h = lds;            // [512]
+  float* s_red = lds + 512;    // [8][32]
+  const int tid = threadIdx.x;
+  ACT_STAMP(0);
+  const int n = tid & 31, ks = tid >> 5, nc = min(n, p.N - 1);
+  float w[64];
+  {
+    const float* w2 = p.prm + p.fc2_w + (long)(ks * 64) * p.ld2 + nc;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {   // (running pointer kept opaque, see act_tail_block)
+      w[k] = *w2;
+      w2 += p.ld2;
+      asm volatile("" : "+v"(w2));
+    }
+  }
+  const float b1a = p.prm[p.fc1_b + tid], b1b = p.prm[p.fc1_b + 256 + tid];
+  const float b2 = p.prm[p.fc2_b + (p.bias_shared ? 0 : nc)];
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned gen = *act_line(p.sync, 3);
+  ACT_STAMP(1);
+  float x[2][kActFc1Splits];
+  {
+    const float* part = act_set(p, gen) + kActOffPart + tid;
+    int round = 0;
+    bool miss, give_up;
+    act_watch(part + (kActFc1Splits - 1) * 512);
+    do {
+      miss = false;
+      const float* pp = part;
+#pragma unroll
+      for (int j = 0; j < kActFc1Splits; ++j) {
+        asm volatile("" : "+v"(pp));
+        x[0][j] = act_load(pp); x[1][j] = act_load(pp + 256);
+        pp += 512;
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < kActFc1Splits; ++j) miss = miss || act_missing(x[e][j]);
+    } while (act_again(miss, round++, act_line(p.sync, 5), &give_up));
+    if (give_up) {   // visible to the host: the q-values are not numbers
+      if (tid < p.N)
+        p.pairs_out[tid] = 0x3f8000007fc00000ull;
+      return;
+    }
+  }
+  ACT_STAMP(2);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < kActFc1Splits; ++j) v += x[e][j];
+    const float h = v + (e ? b1b : b1a);
+    s_h[tid + 256 * e] = h > 0.f ? h : 0.f;
+  }
+  __syncthreads();
+  ACT_STAMP(3);
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) acc = __builtin_fmaf(s_h[ks * 64 + k], w[k], acc);
+    s_red[ks * 32 + n] = acc;
+  }
+  __syncthreads();
+  if (tid < 32 && tid < p.N) {
+    const float q = (((s_red[n] + s_red[32 + n]) + (s_red[64 + n] + s_red[96 + n])) +
+                     ((s_red[128 + n] + s_red[160 + n]) + (s_red[192 + n] + s_red[224 + n]))) + b2;
+    p.pairs_out[n] = (unsigned long long)__builtin_bit_cast(unsigned, q) | (0x3f800000ull << 32);
+  }
+  if (tid == 0) __hip_atomic_store(act_line(p.sync, 3), gen + 1u, DZ_ACT_RLX);   // next apply: the other set
+  ACT_STAMP(4);
+}
+
+constexpr int kDenseActFc1Blocks = kActFc1Splits * 4;
+__global__ __launch_bounds__(256, 2) void dense_act_one_kernel(DenseActParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[kActLdsFloats];
+  const int b = blockIdx.x;
+  if (b < kActTorsoBlocks) act_torso_block(p, b, lds);
+  else if (b < kActTorsoBlocks + kDenseActFc1Blocks)
+    act_fc1_block(p, b - kActTorsoBlocks, kDenseActFc1Blocks, lds);
+  else dense_act_tail_block(p, lds);
 }
 
 }  // namespace

@@ -5,6 +5,7 @@
 //   (double-Q selector only).
 #include "dz_torso.h"
 #include "dz_row_dgrad.h"
+#include "dz_act_one.h"
 
 namespace {
 constexpr int kS_dfc1 = 32;   // fc1 forward k-splits (100 rows each: dz_fc_stream_fwd3<0, 50>)
@@ -85,6 +86,7 @@ extern "C" int dz_dense_layout(int N, int shared_bias, int B, int G,
   L->ws_norm_part = take(kNormFinal + kNormSlots);   // fused-norm partials + per-wave slots
   L->ws_scalars = take(16);
   L->ws_zeros = take(kFlat + 1024);   // stands in for the (absent) noise vectors
+  L->ws_act_seams = take(kDenseActSeamWords);
   L->ws_count = w;
   return DZ_OK;
 }
@@ -572,5 +574,36 @@ extern "C" int dz_dense_apply(int num_actions, int num_outputs, int shared_bias,
                        greedy_out, vmax_out);
     DZ_LAUNCH_CHECK();
   }
+  return DZ_OK;
+}
+
+// The dense-head actor's decision for ONE observation as ONE launch (dz_act_one.h): narrow Q
+// heads only (num_outputs == num_actions <= 32: DQN, double-Q, prioritized;
+// ref: dqn/agent.py:121-131).  Every q-value lands in `pairs_out` (pinned, device-mapped host
+// memory or device memory) as ONE 8-byte word {float q, float 1.0f}: a host that cleared the
+// words before the call reads them with plain loads until all markers are set.
+extern "C" int dz_dense_act(int num_actions, int shared_bias, const float* params,
+                            const uint8_t* state, float* ws, void* pairs_out,
+                            dz_stream_t stream) {
+  DZ_REQUIRE(params && state && ws && pairs_out && num_actions > 0 && num_actions <= 32);
+  DZ_REQUIRE(((uintptr_t)pairs_out & 7) == 0);
+  dz_dense_layout_t L;
+  int rc = dz_dense_layout(num_actions, shared_bias, 1, 1, &L);
+  if (rc) return rc;
+  DenseActParams q;
+  q.obs = state; q.prm = params;
+  for (int i = 0; i < 3; ++i) { q.conv_w[i] = L.conv_w[i]; q.conv_b[i] = L.conv_b[i]; }
+  q.sync = reinterpret_cast<unsigned*>(ws + L.ws_act_seams);   // zero in a fresh workspace
+  q.set_floats = act_set_floats(512); q.ncg = 4; q.part_ld = 512;
+  q.fc1_mu_w = L.fc1_w; q.fc1_ld = L.fc1_ld;
+#ifdef DZ_ACT_STAMPS
+  q.dbg = reinterpret_cast<long long*>(ws + L.ws_dfeat_part);
+#endif
+  q.fc1_b = L.fc1_b; q.fc2_w = L.fc2_w; q.fc2_b = L.fc2_b; q.ld2 = L.fc2_ld;
+  q.N = num_actions; q.bias_shared = shared_bias;
+  q.pairs_out = (unsigned long long*)pairs_out;
+  hipLaunchKernelGGL(dense_act_one_kernel, dim3(kActTorsoBlocks + kDenseActFc1Blocks + 1), dim3(256),
+                     0, dz_s(stream), q);
+  DZ_LAUNCH_CHECK();
   return DZ_OK;
 }

@@ -748,6 +748,7 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
     q.tiles0 = (L.adv2_ld + 31) / 32; q.tiles = q.tiles0 + (L.val2_ld + 31) / 32;
     q.bump = step_counter;
     q.sync = reinterpret_cast<unsigned*>(ws + L.ws_act_seams);   // zero in a fresh workspace, re-armed by the kernel
+    q.set_floats = act_set_floats(1024); q.ncg = 8; q.part_ld = 1024;
 #ifdef DZ_ACT_STAMPS
     q.dbg = reinterpret_cast<long long*>(ws + L.ws_dfeat_part);
 #endif

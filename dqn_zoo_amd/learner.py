@@ -644,6 +644,47 @@ class DenseLearner:
                                device=self.device)
     self._act_batch = b
 
+  act_one_launch = True   # narrow Q heads: the decision is ONE launch, its slot is polled
+
+  def _q_async(self, states: torch.Tensor):
+    """`head_async` for narrow Q heads (dz_dense_act): one launch per decision, every
+    q-value lands in the pinned slot as an 8-byte {q, marker} word; the host clears the
+    words before the enqueue and `read()` polls the markers with plain loads -- no graph,
+    no event, no completion signal.  Falls back to a stream sync if the markers do not
+    show up."""
+    a = self.network.num_actions
+    if getattr(self, '_q_host', None) is None:
+      self._q_host = torch.zeros((self.ACT_RING, a, 2), dtype=torch.float32).pin_memory()
+      self._q_host_np = self._q_host.numpy()
+      self._q_pos = 0
+      self._q_calls = {}
+    if self._act_batch != 1:
+      self._realloc_act_ws(1)
+    k = self._q_pos % self.ACT_RING
+    self._q_pos += 1
+    words = self._q_host_np[k]
+    words[:] = 0.0
+    key = (states.data_ptr(), k, self._act_ws.data_ptr(), self.online.data_ptr())
+    call = self._q_calls.get(key)
+    if call is None:
+      if len(self._q_calls) > 4 * self.ACT_RING * 64:
+        self._q_calls.clear()
+      fn, chk = self._lib.dz_dense_act, _lib.check
+      args = (a, int(self.network.shared_bias), self.online.data_ptr(), states.data_ptr(),
+              self._act_ws.data_ptr(), self._q_host[k].data_ptr())
+      call = self._q_calls[key] = lambda st: chk(fn(*args, st), 'dz_dense_act')
+    call(_lib.stream_ptr(self.device))
+    device, marks, vals = self.device, words[:, 1], words[:, 0]
+
+    def read():
+      for _ in range(RainbowLearner.ACT_POLL_SPINS):
+        if marks.all():
+          return vals.copy()
+      torch.cuda.current_stream(device).synchronize()
+      return vals.copy()
+
+    return read
+
   def head_async(self, states: torch.Tensor):
     """Acting apply for ONE state: the head outputs go straight to a pinned host
     slot (the copy-out of dz_dense_apply targets it), nothing synchronises here, and
@@ -653,6 +694,8 @@ class DenseLearner:
     if int(states.shape[0]) != 1:
       raise ValueError('head_async takes one state')
     net = self.network
+    if self.act_one_launch and net.num_outputs == net.num_actions <= 32:
+      return self._q_async(states)
     if getattr(self, '_head_host', None) is None:
       self._head_host = torch.empty((self.ACT_RING, net.num_outputs),
                                     dtype=torch.float32).pin_memory()

@@ -463,6 +463,7 @@ typedef struct {
   int64_t ws_act1, ws_act2, ws_feat, ws_fc1_part, ws_h1, ws_fc2_part, ws_out;
   int64_t ws_dout, ws_dh1, ws_dfeat_part, ws_dfeat, ws_dact2, ws_dact1;
   int64_t ws_wgrad_part, ws_norm_part, ws_scalars, ws_zeros;
+  int64_t ws_act_seams;          /* one-launch decision (dz_dense_act): zero at creation, owned by it */
 } dz_dense_layout_t;
 
 /* groups: 2 (Q / categorical / quantile) or 3 (double-Q).                     */
@@ -522,6 +523,17 @@ int dz_dense_apply(int num_actions, int num_outputs, int shared_bias, int batch,
                    const float* params, const uint8_t* states, float* ws,
                    float* out, float* q_values_out, int32_t* greedy_out,
                    float* vmax_out, dz_stream_t stream);
+
+/* The actor's decision for ONE observation as ONE launch -- narrow Q heads only
+ * (num_outputs == num_actions <= 32: dqn/agent.py:121-131, double_q, prioritized).
+ * `ws`: a dz_dense_layout(num_actions, shared_bias, 1, 1) workspace, zero when created
+ * and used by nothing else in between (its ws_act_seams region belongs to this call).
+ * `pairs_out` (8-byte aligned; pinned device-mapped host memory or device memory):
+ * num_actions 8-byte words {float q, float 1.0f}, each written with ONE store -- a host
+ * that zeroed the words before the call may poll them with plain loads instead of
+ * waiting for the stream.                                                          */
+int dz_dense_act(int num_actions, int shared_bias, const float* params,
+                 const uint8_t* state, float* ws, void* pairs_out, dz_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  *  IQN learner step (ref: iqn/agent.py:176-232 loss_fn/update,
