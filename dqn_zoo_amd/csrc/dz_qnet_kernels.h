@@ -185,10 +185,13 @@ __device__ __forceinline__ void dz_rms_apply_at(const RmsApply& R, const float* 
 // The dense learners' wide layer (fc1: 3136 x 512) WITHOUT a stored weight gradient, as
 // Rainbow's (dz_fc1_onfly.h): G = X^T D has rank <= 32, its factors (X: 400 KB, D = dh1:
 // 64 KB) are L2-resident, the matrix is 6.4 MB -- written by 392 MFMA workgroups of the
-// backward launch and read back here.  A workgroup owns a 64-row x 64-column tile of the
-// matrix and its two RMSProp moments, keeps the 32 x 64 strip of dh1 and the 64 x 32 tile of
-// X in LDS and forms every gradient element (32 FMAs, batch ascending) right before its
-// update.  RMSProp has no global norm: nothing else is needed (the Adam dense learners keep
+// backward launch and read back here.  A workgroup owns a 16-row x 64-column tile of the
+// matrix and its two RMSProp moments (one float4 of each per thread, requested before anything
+// else), keeps the 32 x 64 strip of dh1 and the 16 x 32 tile of X in LDS and forms every
+// gradient element (32 FMAs, batch ascending) right before its update.  (Measured, same box:
+// 64-row tiles with one row group of loads ahead 10.52 k steps/s on BASELINE config 2; all four
+// row groups' loads up front 10.31 k -- 124 VGPRs for every role of the launch; 32-row tiles
+// 10.6 k; 16-row tiles, 1568 workgroups 10.98 k.)  RMSProp has no global norm: nothing else is needed (the Adam dense learners keep
 // the stored form).  ref: dqn/agent.py:109-117, dqn/run_atari.py:205-210.
 struct RmsOnFly {
   const float* feat = nullptr;   // [B][3136] input of the layer (online s_tm1 apply); nullptr: off
@@ -197,7 +200,7 @@ struct RmsOnFly {
   long w = 0; int ld = 0;        // the [3136][ld] matrix in the parameter vector (512 columns used)
   unsigned blocks = 0;
 };
-constexpr int kRofC = 64, kRofIT = 4, kRofRP = 256 / (kRofC / 4), kRofR = kRofRP * kRofIT, kRofFS = 36;
+constexpr int kRofC = 64, kRofIT = 1, kRofRP = 256 / (kRofC / 4), kRofR = kRofRP * kRofIT, kRofFS = 36;
 constexpr int kRofStrips = 512 / kRofC, kRofBlocks = (3136 / kRofR) * kRofStrips;   // 49 x 8
 constexpr int kRofLds = 32 * kRofC + kRofR * kRofFS;
 static_assert(3136 % kRofR == 0, "rows");
@@ -207,6 +210,17 @@ __device__ __forceinline__ void rms_fc1_block(unsigned blk, const RmsOnFly& q, c
   const int strip = blk % kRofStrips, rg = blk / kRofStrips;
   const int k0 = rg * kRofR, c0 = strip * kRofC;
   const int tid = threadIdx.x, rl = tid / (kRofC / 4), c4 = tid % (kRofC / 4);
+  const long o0 = (q.w + (long)(k0 + rl) * q.ld + c0 + 4 * c4) >> 2;      // float4 index
+  const long rstep = ((long)kRofRP * q.ld) >> 2;
+  // every parameter / moment load of the tile is in flight before the factors are staged (one
+  // iteration ahead left 48 bytes per thread in flight: 15.8 us for 51 MB)
+  float4 pv[kRofIT], mv[kRofIT], vv[kRofIT];
+#pragma unroll
+  for (int it = 0; it < kRofIT; ++it) {
+    const long o = o0 + it * rstep;
+    pv[it] = ((const float4*)R.p)[o]; mv[it] = ((const float4*)R.mu)[o]; vv[it] = ((const float4*)R.nu)[o];
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < kRofC / 32; ++i) {       // dh1 strip [32][C]
     const int e = tid + 256 * i, b = e / (kRofC / 4), cc = e % (kRofC / 4);
@@ -221,11 +235,8 @@ __device__ __forceinline__ void rms_fc1_block(unsigned blk, const RmsOnFly& q, c
       s_ft[r * kRofFS + b] = b < q.B ? f : 0.f;
     }
   }
-  long o = (q.w + (long)(k0 + rl) * q.ld + c0 + 4 * c4) >> 2;      // float4 index
-  const long rstep = ((long)kRofRP * q.ld) >> 2;
-  float4 pv = ((const float4*)R.p)[o], mv = ((const float4*)R.mu)[o], vv = ((const float4*)R.nu)[o];
   __syncthreads();
-#pragma unroll 1
+#pragma unroll
   for (int it = 0; it < kRofIT; ++it) {
     const float* ft = s_ft + (it * kRofRP + rl) * kRofFS;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -241,12 +252,11 @@ __device__ __forceinline__ void rms_fc1_block(unsigned blk, const RmsOnFly& q, c
       }
     }
     const float G[4] = {a0, a1, a2, a3};
-    float* P = (float*)&pv; float* M = (float*)&mv; float* V = (float*)&vv;
+    float* P = (float*)&pv[it]; float* M = (float*)&mv[it]; float* V = (float*)&vv[it];
 #pragma unroll
     for (int j = 0; j < 4; ++j) dz_rms_one(G[j], M[j], V[j], P[j], R.lr, R.decay, R.eps);
-    ((float4*)R.mu)[o] = mv; ((float4*)R.nu)[o] = vv; ((float4*)R.p)[o] = pv;
-    o += rstep;
-    if (it + 1 < kRofIT) { pv = ((const float4*)R.p)[o]; mv = ((const float4*)R.mu)[o]; vv = ((const float4*)R.nu)[o]; }
+    const long o = o0 + it * rstep;
+    ((float4*)R.mu)[o] = mv[it]; ((float4*)R.nu)[o] = vv[it]; ((float4*)R.p)[o] = pv[it];
   }
 }
 __device__ __forceinline__ void dz_rms_flat(const RmsApply& R, unsigned fb) {
