@@ -77,7 +77,7 @@ for name in ('kernel_stats_fused.csv', 'kernel_stats_sequential.csv',
              'pmc_cal_FETCH_SIZE.csv', 'pmc_cal_WRITE_SIZE.csv',
              'pmc_dqn_FETCH_SIZE.csv', 'pmc_dqn_WRITE_SIZE.csv', 'pmc_double_q_FETCH_SIZE.csv',
              'pmc_double_q_WRITE_SIZE.csv', 'agent_loop_rainbow.json', 'agent_loop_dqn.json',
-             'kernel_step_summary_double_q.txt'):
+             'kernel_step_summary_double_q.txt', 'act_decision.txt'):
   p = os.path.join(src, name)
   if os.path.exists(p):
     shutil.copy(p, os.path.join(dst, '%s_%s' % (tag, name)))

@@ -62,8 +62,10 @@ for cfg in dqn double_q; do
   done
 done
 # the agent loop (act -> insert -> learn every 4th frame) and the dense learners' kernel trace
-python $R/tools/agent_loop_bench.py 6000 rainbow json 2>/dev/null | tail -1 > $OUT/agent_loop_rainbow.json
-python $R/tools/agent_loop_bench.py 6000 dqn json 2>/dev/null | tail -1 > $OUT/agent_loop_dqn.json
+python $R/tools/agent_loop_bench.py 20000 rainbow json 2>/dev/null | tail -1 > $OUT/agent_loop_rainbow.json
+python $R/tools/agent_loop_bench.py 20000 dqn json 2>/dev/null | tail -1 > $OUT/agent_loop_dqn.json
+# the one-launch decision: parity print-out, back-to-back and per-decision latency, kernel durations
+bash $R/tools/act_prof.sh > $OUT/act_decision.txt 2>&1
 bash $R/tools/dense_trace.sh 200 > $OUT/kernel_step_summary_double_q.txt 2>&1
 bash $R/tools/pmc_rainbow.sh > $OUT/pmc_sq_rainbow.txt 2>&1
 ls -la $OUT | tail -20
