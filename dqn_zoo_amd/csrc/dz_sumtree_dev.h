@@ -574,9 +574,22 @@ __device__ __forceinline__ void sample_gather_block(const SampleGatherParams& q,
   char* dst = (char*)fd.dst + (int64_t)b * rb;
   if (dz_field_vec_ok(fd)) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const int64_t nvec = rb >> 4;
-    for (int64_t i = (int64_t)c * THREADS + threadIdx.x; i < nvec; i += (int64_t)chunks * THREADS)
-      ((u32x4*)dst)[i] = __builtin_nontemporal_load((const u32x4*)src + i);
+    const int64_t nvec = rb >> 4, step = (int64_t)chunks * THREADS;
+    // four 16-byte units per lane in flight (clamped, unconditional loads; stores behind them):
+    // a block of the side-job form (few fat chunks per row) copies its 16 KB in one round trip
+    for (int64_t i0 = (int64_t)c * THREADS + threadIdx.x; i0 < nvec; i0 += 4 * step) {
+      u32x4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t i = i0 + k * step;
+        v[k] = __builtin_nontemporal_load((const u32x4*)src + (i < nvec ? i : nvec - 1));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t i = i0 + k * step;
+        if (i < nvec) ((u32x4*)dst)[i] = v[k];
+      }
+    }
   } else {
     for (int64_t i = (int64_t)c * THREADS + threadIdx.x; i < rb; i += (int64_t)chunks * THREADS)
       dst[i] = src[i];
@@ -603,7 +616,15 @@ static inline int sample_gather_from_desc(const dz_next_sample_t* ns, SampleGath
   }
   for (int i = 0; i < ns->num_fields; ++i)
     DZ_REQUIRE(ns->fields[i].src && ns->fields[i].dst && ns->fields[i].row_bytes > 0);
-  *blocks = sample_gather_plan(q, ns->fields, ns->num_fields, ns->n, 256);
+  // side-job form: at most 4 chunks per row, four 16-byte units per lane (545 -> 289 blocks for a
+  // Rainbow batch).  Measured same-box: 64 / 4 / 2 / 1 chunks per row = 10.90 / 10.96 / 10.97 /
+  // 10.97 k steps/s on BASELINE config 2, 9.50-9.53 k on config 3, Rainbow 6.63 / 6.64 / 6.62 /
+  // 6.58 k: the block count is not what the side job costs its host (the descent's five dependent
+  // round trips are).
+#ifndef DZ_SG_SIDE_CHUNKS
+#define DZ_SG_SIDE_CHUNKS 4
+#endif
+  *blocks = sample_gather_plan(q, ns->fields, ns->num_fields, ns->n, 256, DZ_SG_SIDE_CHUNKS);
   q.ids_out = ns->ids_out; q.probs_out = ns->probs_out; q.weights_out = ns->weights_out;
   q.weights32_out = ns->weights32_out; q.status = ns->status;
   return DZ_OK;
