@@ -273,7 +273,11 @@ class RainbowLearner:
     k = self._act_pos % self.ACT_RING
     self._act_pos += 1
     slot = self._act_host[k]
-    if b == 1 and self.poll_action_slot:
+    lay = self.layout.c
+    # (the kernels that end in dz_q_from_row store the pair as one 8-byte word: dz_rainbow_act at
+    # batch <= 8 with a fc2 row of <= 1024 floats and <= 64 atoms -- every Atari action set)
+    if (b == 1 and self.poll_action_slot and int(lay.adv2_ld) + int(lay.val2_ld) <= 1024 and
+        self.network.num_atoms <= 64):
       # One observation: the decision kernel's last store is the (action, value) pair as ONE
       # 8-byte word into this pinned slot.  The host marks the slot (action -1) before the
       # enqueue and reads it with plain loads until the pair is there: no event to record, no
