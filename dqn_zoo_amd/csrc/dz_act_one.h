@@ -166,15 +166,17 @@ __device__ __forceinline__ void act_torso_block(const ActTorso& p, int blk, floa
   float* const feat = set + kActOffFeat;
   unsigned* const fail = act_line(p.sync, 5);
   bool give_up;
-  // conv1's patch first (vector loads return in order): 12 input rows x 84 pixels x 4 bytes
-  const int p0c1 = 16 * blk, oy0c1 = p0c1 / 20;
-  unsigned raw[4];
+  // conv1's patch first (vector loads return in order).  conv1's tile is a 4 x 4 SQUARE of output
+  // pixels (5 x 5 tiles): its input patch is 20 x 20 pixels x 4 bytes = 1.6 KB, 40 KB over PCIe for
+  // the whole image instead of the 100 KB that 16 consecutive pixels (12 full rows) cost
+  const int ty1 = blk / 5, tx1 = blk % 5;
+  unsigned raw[2];
   {
     const unsigned* src = (const unsigned*)p.obs;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = min(tid + 256 * i, 1007);
-      raw[i] = src[min(4 * oy0c1 + idx / 84, 83) * 84 + idx % 84];
+    for (int i = 0; i < 2; ++i) {
+      const int idx = min(tid + 256 * i, 399);
+      raw[i] = src[(16 * ty1 + idx / 20) * 84 + 16 * tx1 + idx % 20];
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -208,21 +210,18 @@ __device__ __forceinline__ void act_torso_block(const ActTorso& p, int blk, floa
   const float bias2 = p.prm[p.conv_b[1] + 16 * ct2 + (tid & 15)];
   const float bias3 = p.prm[p.conv_b[2] + 16 * ct3 + (tid & 15)];
 
-  // ---- conv1: pixels 16 blk .. 16 blk + 15, all 32 channels ------------------------------------
+  // ---- conv1: output pixels (4 ty1 + m / 4, 4 tx1 + m % 4), all 32 channels ------------------------
   {
-    const int p0 = p0c1, oy0 = oy0c1;
-    unsigned* patch = (unsigned*)lds;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (tid + 256 * i < 1008) patch[tid + 256 * i] = raw[i];
+    unsigned* patch = (unsigned*)lds;   // [20][20] dwords (the 64 lanes of an A read hit 64 banks)
+    patch[tid] = raw[0];
+    if (tid + 256 < 400) patch[tid + 256] = raw[1];
     __syncthreads();
     ACT_STAMP(1);
-    const int pix = p0 + n, oy = pix / 20, ox = pix % 20;
     unsigned a[8];
 #pragma unroll
     for (int tl = 0; tl < 8; ++tl) {
       const int T = 8 * kh1 + tl;
-      a[tl] = patch[(4 * (oy - oy0) + (T >> 1)) * 84 + 4 * ox + 4 * (T & 1) + kq];
+      a[tl] = patch[(4 * (n >> 2) + (T >> 1)) * 20 + 4 * (n & 3) + 4 * (T & 1) + kq];
     }
     act_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -237,10 +236,11 @@ __device__ __forceinline__ void act_torso_block(const ActTorso& p, int blk, floa
     __syncthreads();
     {   // wave (ct, kh): red[ct + 2 kh]; output element (m, channel 16 ct + n')
       const int m = tid >> 4;
+      const int pix = (4 * ty1 + (m >> 2)) * 20 + 4 * tx1 + (m & 3);
       const float va = red[0 * 256 + tid] + red[2 * 256 + tid] + bias1a;
       const float vb = red[1 * 256 + tid] + red[3 * 256 + tid] + bias1b;
-      act_store(act1 + (p0 + m) * 32 + (tid & 15), va > 0.f ? va : -0.f);
-      act_store(act1 + (p0 + m) * 32 + 16 + (tid & 15), vb > 0.f ? vb : -0.f);
+      act_store(act1 + pix * 32 + (tid & 15), va > 0.f ? va : -0.f);
+      act_store(act1 + pix * 32 + 16 + (tid & 15), vb > 0.f ? vb : -0.f);
     }
   }
   ACT_STAMP(2);
