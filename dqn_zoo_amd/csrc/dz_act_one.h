@@ -95,10 +95,11 @@ struct ActOneParams : ActTorso {      // Rainbow: noisy fc1 (adv | val), dueling
   int32_t* bump;
 };
 
-struct DenseActParams : ActTorso {    // DQN-family: linear(512) + ReLU + linear(N <= 32)
+struct DenseActParams : ActTorso {    // dense heads: linear(512) + ReLU + linear(N)
   static constexpr bool NOISY = false;
   long fc1_b, fc2_w, fc2_b; int ld2, N, bias_shared;
-  unsigned long long* pairs_out;      // [N] {float q, float 1.0f}: one 8-byte store each
+  int tiles;                          // tail workgroups: 32 output columns each
+  unsigned long long* pairs_out;      // [N] {float output, float 1.0f}: one 8-byte store each
 };
 
 // ---- seams -----------------------------------------------------------------------------------
@@ -588,15 +589,17 @@ __global__ __launch_bounds__(256, 2) void rainbow_act_one_kernel(ActOneParams p)
   else act_tail_block(p, b - kActTorsoBlocks - kActFc1Blocks, lds);
 }
 
-// ---- dense head (DQN-family) -------------------------------------------------------------------
-// ONE workgroup: h1 = relu(slab sum + b1), q = h1 W2 + b2 (ref: networks.py:206-221, 120-134),
-// each q-value stored with a marker as one 8-byte word into the pinned slot the host polls.
-__device__ __forceinline__ void dense_act_tail_block(const DenseActParams& p, float* lds) {
+// ---- dense heads (DQN, double-Q, prioritized: N = A; C51: N = 51 A; QR-DQN: N = 201 A) ------------
+// A workgroup per 32 output columns: h1 = relu(slab sum + b1) (every workgroup folds the 28 slabs
+// itself), out = h1 W2 + b2 (ref: networks.py:206-221, 120-134, 295-363), each output stored with a
+// marker as one 8-byte word into the pinned slot the host polls; the last workgroup (ticket)
+// advances the generation.
+__device__ __forceinline__ void dense_act_tail_block(const DenseActParams& p, int tile, float* lds) {
   float* s_h = lds;            // [512]
   float* s_red = lds + 512;    // [8][32]
   const int tid = threadIdx.x;
   ACT_STAMP(0);
-  const int n = tid & 31, ks = tid >> 5, nc = min(n, p.N - 1);
+  const int n = tid & 31, ks = tid >> 5, col = 32 * tile + n, nc = min(col, p.N - 1);
   float w[64];
   {
     const float* w2 = p.prm + p.fc2_w + (long)(ks * 64) * p.ld2 + nc;
@@ -632,9 +635,8 @@ __device__ __forceinline__ void dense_act_tail_block(const DenseActParams& p, fl
 #pragma unroll
         for (int j = 0; j < kActFc1Splits; ++j) miss = miss || act_missing(x[e][j]);
     } while (act_again(miss, round++, act_line(p.sync, 5), &give_up));
-    if (give_up) {   // visible to the host: the q-values are not numbers
-      if (tid < p.N)
-        p.pairs_out[tid] = 0x3f8000007fc00000ull;
+    if (give_up) {   // visible to the host: the outputs are not numbers
+      if (tid < 32 && col < p.N) p.pairs_out[col] = 0x3f8000007fc00000ull;
       return;
     }
   }
@@ -656,12 +658,18 @@ __device__ __forceinline__ void dense_act_tail_block(const DenseActParams& p, fl
     s_red[ks * 32 + n] = acc;
   }
   __syncthreads();
-  if (tid < 32 && tid < p.N) {
+  if (tid < 32 && col < p.N) {
     const float q = (((s_red[n] + s_red[32 + n]) + (s_red[64 + n] + s_red[96 + n])) +
                      ((s_red[128 + n] + s_red[160 + n]) + (s_red[192 + n] + s_red[224 + n]))) + b2;
-    p.pairs_out[n] = (unsigned long long)__builtin_bit_cast(unsigned, q) | (0x3f800000ull << 32);
+    p.pairs_out[col] = (unsigned long long)__builtin_bit_cast(unsigned, q) | (0x3f800000ull << 32);
   }
-  if (tid == 0) __hip_atomic_store(act_line(p.sync, 3), gen + 1u, DZ_ACT_RLX);   // next apply: the other set
+  // every tail workgroup has read the generation and the slabs once it takes its ticket: the last
+  // one re-arms the ticket and switches the next apply to the other set
+  if (tid == 0 &&
+      __hip_atomic_fetch_add(act_line(p.sync, 4), 1u, DZ_ACT_RLX) == (unsigned)p.tiles - 1) {
+    __hip_atomic_store(act_line(p.sync, 4), 0u, DZ_ACT_RLX);
+    __hip_atomic_store(act_line(p.sync, 3), gen + 1u, DZ_ACT_RLX);
+  }
   ACT_STAMP(4);
 }
 
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(256, 2) void dense_act_one_kernel(DenseActParams p)
   if (b < kActTorsoBlocks) act_torso_block(p, b, lds);
   else if (b < kActTorsoBlocks + kDenseActFc1Blocks)
     act_fc1_block(p, b - kActTorsoBlocks, kDenseActFc1Blocks, lds);
-  else dense_act_tail_block(p, lds);
+  else dense_act_tail_block(p, b - kActTorsoBlocks - kDenseActFc1Blocks, lds);
 }
 
 }  // namespace

@@ -577,18 +577,19 @@ extern "C" int dz_dense_apply(int num_actions, int num_outputs, int shared_bias,
   return DZ_OK;
 }
 
-// The dense-head actor's decision for ONE observation as ONE launch (dz_act_one.h): narrow Q
-// heads only (num_outputs == num_actions <= 32: DQN, double-Q, prioritized;
-// ref: dqn/agent.py:121-131).  Every q-value lands in `pairs_out` (pinned, device-mapped host
-// memory or device memory) as ONE 8-byte word {float q, float 1.0f}: a host that cleared the
-// words before the call reads them with plain loads until all markers are set.
-extern "C" int dz_dense_act(int num_actions, int shared_bias, const float* params,
+// The dense-head actor's decision for ONE observation as ONE launch (dz_act_one.h), any head
+// width (DQN / double-Q / prioritized: num_outputs = A; C51: 51 A; QR-DQN: 201 A;
+// ref: dqn/agent.py:121-131, c51/agent.py:118-126, qrdqn/agent.py:121-129).  Every head output
+// lands in `pairs_out` (pinned, device-mapped host memory or device memory) as ONE 8-byte word
+// {float value, float 1.0f}: a host that cleared the words before the call reads them with plain
+// loads until all markers are set, then forms the q-values as the reference's network does.
+extern "C" int dz_dense_act(int num_outputs, int shared_bias, const float* params,
                             const uint8_t* state, float* ws, void* pairs_out,
                             dz_stream_t stream) {
-  DZ_REQUIRE(params && state && ws && pairs_out && num_actions > 0 && num_actions <= 32);
+  DZ_REQUIRE(params && state && ws && pairs_out && num_outputs > 0);
   DZ_REQUIRE(((uintptr_t)pairs_out & 7) == 0);
   dz_dense_layout_t L;
-  int rc = dz_dense_layout(num_actions, shared_bias, 1, 1, &L);
+  int rc = dz_dense_layout(num_outputs, shared_bias, 1, 1, &L);
   if (rc) return rc;
   DenseActParams q;
   q.obs = state; q.prm = params;
@@ -600,9 +601,11 @@ extern "C" int dz_dense_act(int num_actions, int shared_bias, const float* param
   q.dbg = reinterpret_cast<long long*>(ws + L.ws_dfeat_part);
 #endif
   q.fc1_b = L.fc1_b; q.fc2_w = L.fc2_w; q.fc2_b = L.fc2_b; q.ld2 = L.fc2_ld;
-  q.N = num_actions; q.bias_shared = shared_bias;
+  q.N = num_outputs; q.bias_shared = shared_bias;
+  q.tiles = (num_outputs + 31) / 32;
   q.pairs_out = (unsigned long long*)pairs_out;
-  hipLaunchKernelGGL(dense_act_one_kernel, dim3(kActTorsoBlocks + kDenseActFc1Blocks + 1), dim3(256),
+  hipLaunchKernelGGL(dense_act_one_kernel,
+                     dim3((unsigned)(kActTorsoBlocks + kDenseActFc1Blocks + q.tiles)), dim3(256),
                      0, dz_s(stream), q);
   DZ_LAUNCH_CHECK();
   return DZ_OK;

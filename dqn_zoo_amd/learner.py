@@ -648,15 +648,16 @@ class DenseLearner:
                                device=self.device)
     self._act_batch = b
 
-  act_one_launch = True   # narrow Q heads: the decision is ONE launch, its slot is polled
+  act_one_launch = True   # the decision for one state is ONE launch, its slot is polled
 
   def _q_async(self, states: torch.Tensor):
-    """`head_async` for narrow Q heads (dz_dense_act): one launch per decision, every
-    q-value lands in the pinned slot as an 8-byte {q, marker} word; the host clears the
+    """`head_async` as ONE launch (dz_dense_act): every head output (A q-values, or the
+    51 A / 201 A distribution outputs of C51 / QR-DQN) lands in the pinned slot as an 8-byte
+    {value, marker} word; the host clears the
     words before the enqueue and `read()` polls the markers with plain loads -- no graph,
     no event, no completion signal.  Falls back to a stream sync if the markers do not
     show up."""
-    a = self.network.num_actions
+    a = self.network.num_outputs
     if getattr(self, '_q_host', None) is None:
       self._q_host = torch.zeros((self.ACT_RING, a, 2), dtype=torch.float32).pin_memory()
       self._q_host_np = self._q_host.numpy()
@@ -698,7 +699,7 @@ class DenseLearner:
     if int(states.shape[0]) != 1:
       raise ValueError('head_async takes one state')
     net = self.network
-    if self.act_one_launch and net.num_outputs == net.num_actions <= 32:
+    if self.act_one_launch:
       return self._q_async(states)
     if getattr(self, '_head_host', None) is None:
       self._head_host = torch.empty((self.ACT_RING, net.num_outputs),

@@ -524,15 +524,17 @@ int dz_dense_apply(int num_actions, int num_outputs, int shared_bias, int batch,
                    float* out, float* q_values_out, int32_t* greedy_out,
                    float* vmax_out, dz_stream_t stream);
 
-/* The actor's decision for ONE observation as ONE launch -- narrow Q heads only
- * (num_outputs == num_actions <= 32: dqn/agent.py:121-131, double_q, prioritized).
- * `ws`: a dz_dense_layout(num_actions, shared_bias, 1, 1) workspace, zero when created
+/* The actor's decision for ONE observation as ONE launch, any dense head (DQN / double-Q /
+ * prioritized: num_outputs = A, dqn/agent.py:121-131; C51: 51 A, c51/agent.py:118-126;
+ * QR-DQN: 201 A, qrdqn/agent.py:121-129).
+ * `ws`: a dz_dense_layout(num_outputs, shared_bias, 1, 1) workspace, zero when created
  * and used by nothing else in between (its ws_act_seams region belongs to this call).
  * `pairs_out` (8-byte aligned; pinned device-mapped host memory or device memory):
- * num_actions 8-byte words {float q, float 1.0f}, each written with ONE store -- a host
- * that zeroed the words before the call may poll them with plain loads instead of
- * waiting for the stream.                                                          */
-int dz_dense_act(int num_actions, int shared_bias, const float* params,
+ * num_outputs 8-byte words {float value, float 1.0f}, each written with ONE store -- a
+ * host that zeroed the words before the call may poll them with plain loads instead of
+ * waiting for the stream, and then forms q-values from the head outputs as the
+ * reference's network does (softmax expectation / quantile mean / identity).       */
+int dz_dense_act(int num_outputs, int shared_bias, const float* params,
                  const uint8_t* state, float* ws, void* pairs_out, dz_stream_t stream);
 
 /* ------------------------------------------------------------------------- *

@@ -330,17 +330,20 @@ def test_distributional_dense_step_other_head_widths(kind, actions, monkeypatch)
   test_distributional_dense_step(kind)
 
 
-@pytest.mark.parametrize('kind_net,actions', [('dqn', 6), ('double_dqn', 6), ('dqn', 18), ('double_dqn', 3)])
+@pytest.mark.parametrize('kind_net,actions', [('dqn', 6), ('double_dqn', 6), ('dqn', 18), ('double_dqn', 3),
+                                               ('c51', 6), ('c51', 18), ('qr', 6), ('qr', 18)])
 def test_one_launch_q_decision(kind_net, actions, monkeypatch):
-  """`head_async` for narrow Q heads is ONE launch (dz_dense_act, csrc/dz_act_one.h) whose
-  q-values land in a pinned slot as 8-byte {q, marker} words the host polls.  Nine decisions
+  """`head_async` is ONE launch (dz_dense_act, csrc/dz_act_one.h) whose head outputs -- A
+  q-values, or the 51 A / 201 A distribution outputs of C51 / QR-DQN (up to 114 tail
+  workgroups) -- land in a pinned slot as 8-byte {value, marker} words the host polls.  Nine decisions
   (more than the ring of slots, both sets of intermediates many times) against the oracle and
   the multi-launch apply; an all-zero observation; the shared fc2 bias of double_dqn."""
   import sys
   from dqn_zoo_amd import learner as ll
   monkeypatch.setattr(sys.modules[__name__], 'A', actions)
-  loss = 'q' if kind_net == 'dqn' else 'double_q'
-  rs, online, _, ln = _make(kind_net, loss, ll.RmsPropConfig(), 41 + actions)
+  loss = {'dqn': 'q', 'double_dqn': 'double_q', 'c51': 'categorical', 'qr': 'quantile'}[kind_net]
+  opt = ll.RmsPropConfig() if loss in ('q', 'double_q') else ll.AdamConfig()
+  rs, online, _, ln = _make(kind_net, loss, opt, 41 + actions)
   assert ln.act_one_launch
   for i in range(9):
     x = rs.randint(0, 256, (1, 84, 84, 4)).astype(np.uint8)
@@ -350,7 +353,7 @@ def test_one_launch_q_decision(kind_net, actions, monkeypatch):
     q = ln.head_async(xd)()
     ref, _ = qo.mlp_head_fwd(online, x)
     np.testing.assert_allclose(q, ref[0], rtol=2e-5, atol=2e-6)
-    out, _, _, _ = ln.apply(xd)
+    out = ln.apply(xd)[0]
     np.testing.assert_allclose(q, out.cpu().numpy()[0], rtol=0, atol=2e-6)
   seams = int(ln.network.layout(1, 1).c.ws_act_seams)
   words = ln._act_ws[seams:seams + 64 * 8:64].view(torch.int32).tolist()  # pylint: disable=protected-access
