@@ -19,7 +19,9 @@
 // Step 166.5 -> 160 us with the input gradients as row-owning streams: the
 // backward launch loses its 784 weight-gradient workgroups and its reduce launch (14.4 +
 // 4.8 -> 12.4 us); the optimiser itself moves 166 MB instead of 192 MB in the same 32 us
-// -- a bare read-modify-write stream of that traffic takes 30.3 us (tools/micro/rmw_micro).
+// -- a bare float4 read-modify-write stream of that traffic takes 24.65 us
+// (tools/micro/rmw2_micro.hip; round 3's 30.3 us came from a micro-benchmark the compiler had
+// narrowed to dword accesses), so ~5 us of the role's arithmetic are exposed: EXPERIMENTS.md.
 // ref: rainbow/agent.py:112-127 (grad + optimizer.update), networks.py:150-180 (the layer).
 #pragma once
 #include "dz_qnet_kernels.h"
@@ -92,8 +94,8 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
   const float gn = dz_sgpr(sc0.gn), bc1 = dz_sgpr(sc0.bc1), bc2 = dz_sgpr(sc0.bc2);
   const bool pass = __builtin_amdgcn_readfirstlane((int)sc0.pass) != 0;
   const unsigned rstep = (unsigned)(T::RP * q.ld) * 4u;
-  // Measured alternatives (optimiser role alone; this form 31.9 us, a bare read-modify-write
-  // stream of the same 165 MB 30.3 us): one pass over the batch for all seven rows (28
+  // Measured alternatives (optimiser role alone; this form 31.4-31.9 us, a bare float4
+  // read-modify-write stream of the same 165 MB 24.65 us): one pass over the batch for all seven rows (28
   // accumulators, LDS reads -69 %) 35.1 us -- the rows' streams then start only after the
   // whole product; the next rows' streams requested before the current arithmetic 33.8;
   // an approximate-arithmetic build 30.3; skipping the divisions that are exact no-ops
