@@ -38,6 +38,7 @@
 #pragma once
 
 #include "dz_qnet_kernels.h"
+#include "dz_sumtree_dev.h"
 
 namespace {
 
@@ -581,12 +582,19 @@ __device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, 
   ACT_STAMP(5);
 }
 
-__global__ __launch_bounds__(256, 2) void rainbow_act_one_kernel(ActOneParams p) {
+// `sg` / `sg_blocks`: optionally the replay sample + gather of the learner step that follows this
+// decision (dz_next_sample_t), as the LAST blocks of the grid: they read nothing the decision
+// writes, are dispatched behind its 261 workgroups and finish inside its 21 us; the host polls the
+// action slot, so they are not on the path to the action (they were, as blocks of the conv2 launch
+// of the multi-launch apply: EXPERIMENTS.md).
+__global__ __launch_bounds__(256, 2) void rainbow_act_one_kernel(ActOneParams p, SampleGatherParams sg,
+                                                              unsigned sg_blocks) {
   __shared__ __attribute__((aligned(16))) float lds[kActLdsFloats];
   const int b = blockIdx.x;
   if (b < kActTorsoBlocks) act_torso_block(p, b, lds);
   else if (b < kActTorsoBlocks + kActFc1Blocks) act_fc1_block(p, b - kActTorsoBlocks, kActFc1Blocks, lds);
-  else act_tail_block(p, b - kActTorsoBlocks - kActFc1Blocks, lds);
+  else if (b < kActTorsoBlocks + kActFc1Blocks + p.tiles) act_tail_block(p, b - kActTorsoBlocks - kActFc1Blocks, lds);
+  else SampleGatherSide::run(sg, (unsigned)(b - kActTorsoBlocks - kActFc1Blocks - p.tiles));
 }
 
 // ---- dense heads (DQN, double-Q, prioritized: N = A; C51: N = 51 A; QR-DQN: N = 201 A) ------------

@@ -731,7 +731,7 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
     if (rc) return rc;
   }
   // One observation: the whole decision is ONE launch (dz_act_one.h).
-  if (batch == 1 && !next_sample && ld2 <= 1024 && num_atoms <= 64 && step_counter) {
+  if (batch == 1 && ld2 <= 1024 && num_atoms <= 64 && step_counter) {
     ActOneParams q;
     q.obs = states; q.prm = params;
     for (int i = 0; i < 3; ++i) { q.conv_w[i] = L.conv_w[i]; q.conv_b[i] = L.conv_b[i]; }
@@ -753,7 +753,8 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
     q.dbg = reinterpret_cast<long long*>(ws + L.ws_dfeat_part);
 #endif
     hipLaunchKernelGGL(rainbow_act_one_kernel,
-                       dim3((unsigned)(kActTorsoBlocks + kActFc1Blocks + q.tiles)), dim3(256), 0, s, q);
+                       dim3((unsigned)(kActTorsoBlocks + kActFc1Blocks + q.tiles) + sgb), dim3(256), 0,
+                       s, q, sgq, sgb);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
   }

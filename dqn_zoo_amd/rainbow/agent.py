@@ -69,14 +69,15 @@ class Rainbow(parts.Agent):
     self._statistics = {'state_value': np.nan}
     self._obs = device_obs.ObservationCache(
         self._device, depth=device_obs.depth_for(transition_accumulator))
-    # True: in a learn frame the replay sample + gather ride in the acting apply's second
-    # launch (after the frame's inserts were enqueued) and `_learn` enqueues the 14 launches
-    # of the update alone -- bit-identical to the separate sample launch
-    # (tests/test_agent_gpu.py), one launch fewer per learn period, and MEASURED SLOWER in
-    # this loop (tools/agent_loop_bench.py: 7.93-8.01 k vs 8.17-8.23 k agent steps/s): the
-    # 545 extra blocks sit on the path to the action, which is what the loop waits for, and
-    # an apply that carries by-value draws cannot be replayed from its hipGraph.  Off by
-    # default; EXPERIMENTS.md.
+    # True: in a learn frame the replay sample + gather ride in the decision's launch as its LAST
+    # blocks (after the frame's inserts were enqueued) and `_learn` enqueues the 14 launches of
+    # the update alone -- bit-identical to the separate sample launch (tests/test_agent_gpu.py),
+    # one launch fewer per learn period, and MEASURED SLOWER in this loop
+    # (tools/agent_loop_bench.py, same box: 10.76-10.82 k vs 11.09-11.16 k agent steps/s; as blocks
+    # of the five-launch apply's conv2 launch in round 4's first form 7.93-8.01 k vs 8.17-8.23 k):
+    # the GPU saves the 9 us sample launch, but the host's part of the sample (RNG draws, the
+    # descriptor) moves IN FRONT of the decision's enqueue, which is what the loop waits for.
+    # Off by default; EXPERIMENTS.md.
     self.fuse_sample_into_acting = False
 
   # -- acting / stepping -------------------------------------------------------

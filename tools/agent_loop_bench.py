@@ -81,6 +81,8 @@ def main():
   wrap(ag, '_learn', 'learn'); wrap(rep, add_name, 'add')
   if 'nofuse' in sys.argv[3:]:
     ag.fuse_sample_into_acting = False
+  if 'fuse' in sys.argv[3:]:
+    ag.fuse_sample_into_acting = True
   if which != 'dqn':   # A/B switches of the acting path (defaults: both on)
     ag._learner.poll_action_slot = 'event-wait' not in sys.argv[3:]   # pylint: disable=protected-access
     ag._learner.act_direct = 'act-graph' not in sys.argv[3:]          # pylint: disable=protected-access
