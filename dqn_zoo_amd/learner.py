@@ -106,6 +106,7 @@ class RainbowLearner:
     self._act_noise = torch.zeros(L.noise_stride, **f32)
     self.act_graphs = True   # replay the acting apply from a hipGraph (apply_async)
     self._act_graphs = {}    # (state buffer, result slot, parameters) -> (graph, q, greedy, vmax)
+    self._act_fast = {}      # apply_async's steady state: -> (pre-bound enqueue, slot reader)
 
   # -- state ------------------------------------------------------------------
   def get_params(self, which='online') -> dict:
@@ -146,6 +147,7 @@ class RainbowLearner:
 
   def _drop_act_graphs(self) -> None:
     graphs, self._act_graphs = getattr(self, '_act_graphs', {}), {}
+    self._act_fast = {}
     for g in graphs.values():
       if g[0] is not None:
         self._lib.dz_graph_destroy(g[0])
@@ -285,17 +287,30 @@ class RainbowLearner:
       # kernel's last phase).
       words = self._act_host_np[k]
       words[0, 0] = -1
+      # steady state of an agent loop: the same observation slot, result slot and parameters as
+      # some earlier frame -> the pre-bound enqueue and the slot's reader, nothing else
+      fk = (states.data_ptr(), k, self.online.data_ptr(), states.shape)
+      fast = self._act_fast.get(fk) if next_sample is None else None
+      if fast is not None:
+        fast[0](_lib.stream_ptr(self.device))
+        return fast[1]
       self.apply(states, packed_out=slot, next_sample=next_sample)
       device = self.device
+      vals = words[1].view(np.float32)
 
       def read_polled():
         for _ in range(self.ACT_POLL_SPINS):
           a = words[0, 0]
           if a >= 0:
-            return int(a), float(words[1].view(np.float32)[0])
+            return int(a), float(vals[0])
         torch.cuda.current_stream(device).synchronize()   # stuck or very slow: the stream decides
-        return int(words[0, 0]), float(words[1].view(np.float32)[0])
+        return int(words[0, 0]), float(vals[0])
 
+      if next_sample is None:
+        g = self._act_graphs.get((states.data_ptr(), slot.data_ptr(), self.online.data_ptr(),
+                                  states.shape, states.dtype))
+        if g is not None and g[0] is None and states.dtype == torch.uint8:
+          self._act_fast[fk] = (g[4], read_polled)
       return read_polled
     self.apply(states, packed_out=slot, next_sample=next_sample)
     ev = self._act_events[k]
