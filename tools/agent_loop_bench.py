@@ -60,7 +60,8 @@ def main():
       network=networks.RainbowNetwork(A, SUPPORT, 0.1), support=SUPPORT,
       optimizer=learner.AdamConfig(),
       transition_accumulator=replay_lib.NStepTransitionAccumulator(3), replay=rep,
-      batch_size=32, min_replay_capacity_fraction=0.005, learn_period=4,
+      batch_size=32, min_replay_capacity_fraction=0.005,
+      learn_period=int(os.environ.get('LEARN_PERIOD', 4)),
       target_network_update_period=2000, rng_key=1)
   if 'eager-learn' in sys.argv[3:]:
     ag._learner.use_graphs = False   # learner launches eager, acting applies still from graphs  # pylint: disable=protected-access
