@@ -1,40 +1,46 @@
-// The Rainbow actor's decision for ONE observation as ONE launch
+// The actor's decision for ONE observation as ONE launch: Rainbow (rainbow_act_one_kernel) and the
+// dense-head agents (dense_act_one_kernel: DQN, double-Q, prioritized, C51, QR-DQN).
 // (ref: rainbow/agent.py:125-133,171-179 select_action -> network.apply on a batch of one;
-//  networks.py:186-204 torso, :137-178 noisy linear, :229-261 dueling C51 head).
+//  networks.py:186-204 torso, :137-178 noisy linear, :229-261 dueling C51 head, :206-221 / :295-363
+//  the dense heads; dqn/agent.py:121-131.)
 //
-// At one image the network is 15 MFLOP of convolution, a 25.7 MB weight stream (fc1's mu and
-// sigma) and 1.5 MB for the second layer -- five launches of 7-9 us each spent 41 us on it,
-// almost all of it launch floors and cold round trips in series.  Here 261 workgroups of one
-// launch take three roles and hand results to each other through write-through (sc1) stores and
-// sc1 loads (no L2 write-back or invalidate anywhere), and THE DATA IS ITS OWN FLAG: every
-// intermediate lives in a buffer that is all-zero-bits before its producers write it, producers
-// store -0.0f for a zero, and a consumer simply re-reads the values it needs until none of them is
-// +0.0f.  No arrival counter, no drained `vmcnt`, no second round trip for the payload (the first
-// version of this kernel did counter + flag + load: 23.0 us in-kernel; this form: see
-// EXPERIMENTS.md).  Two sets of buffers alternate by the parity of a generation word; the set of
-// the NEXT apply is cleared by idle workgroups of this one.
+// At one image the network is 15 MFLOP of convolution, a 25.7 MB weight stream (Rainbow's fc1 mu
+// and sigma) and 1.5 MB for the second layer -- five launches of 7-9 us each spent 41 us on it,
+// almost all of it launch floors and cold round trips in series.  Here the workgroups of one launch
+// take three roles and hand results to each other through write-through (sc1) stores and sc1 loads
+// (no L2 write-back or invalidate anywhere), and THE DATA IS ITS OWN FLAG: every intermediate lives
+// in a buffer that is all-zero bits before its producers write it, producers store -0.0f for a
+// zero, and a consumer re-reads the values it needs until none of them is +0.0f -- first ONE thread
+// watching ONE word, then whole-workgroup rounds.  No arrival counter, no drained `vmcnt`, no
+// fence, no second round trip for the payload (the first version of this kernel did counter + flag
+// + load: 23.0 us in-kernel against 21.5; EXPERIMENTS.md).  Two sets of buffers alternate by the
+// parity of a generation word; the set of the NEXT apply is cleared by fc1 workgroups of this one.
 //
-//   torso  (25 workgroups)  conv1 -> conv2 -> conv3.  One workgroup
-//                           owns 16 output pixels (x 32 channels in conv1, x 16 channels in
-//                           conv2/conv3), its 4 waves split K; the input patch is copied once
-//                           into LDS (conv1: raw bytes over PCIe from the pinned observation
-//                           slot), A fragments are read from the patch, B fragments (weights)
-//                           were requested lane-wise straight into MFMA operand registers for
-//                           ALL three layers before the first wait; v_mfma_f32_16x16x4_f32.
-//   fc1    (224 workgroups) 28 K-splits x 8 column groups of the 3136 x 1024 layer: every thread
-//                           requests its 14 x 4 mu and sigma values at launch, draws the eps it
-//                           needs itself (dz_noise_at is a pure function of the stream position),
-//                           forms W_eff in registers and only then waits for the torso's feature
-//                           vector: the 25.7 MB stream runs UNDER the convolutions.
-//   tail   (12 workgroups)  the second noisy layer's column tiles (weights in registers from the
-//                           start), folds the 28 fc1 slabs, takes a ticket; the last one emits
-//                           q-values, greedy action and value (into pinned host memory) and
-//                           re-arms the counters.
+//   torso  (25 workgroups)  conv1 -> conv2 -> conv3.  A workgroup owns 16 output pixels (a 4 x 4
+//                           square x 32 channels in conv1: 1.6 KB of the observation over PCIe per
+//                           workgroup; 16 consecutive pixels x 16 channels in conv2 / conv3), its 4
+//                           waves split K; the input patch is copied once into LDS, A fragments
+//                           are read from the patch (step order chosen so that one 4- or 16-byte
+//                           LDS read feeds four MFMAs), B fragments (weights) were requested
+//                           lane-wise straight into MFMA operand registers for ALL three layers
+//                           before the first wait; v_mfma_f32_16x16x4_f32.
+//   fc1    (224 / 112)      28 K-splits x 8 (Rainbow) or 4 (dense) column groups of 128: every
+//                           thread requests its 14 x 4 weights (mu and sigma) at launch, draws the
+//                           eps it needs itself (dz_noise_at is a pure function of the stream
+//                           position), forms W_eff in registers and only then waits for the
+//                           torso's feature vector: the weight stream runs UNDER the convolutions.
+//   tail   (12 / 1..114)    the second layer's 32-column tiles (weights in registers from the
+//                           start), fold the 28 fc1 slabs.  Rainbow: a ticket, the last workgroup
+//                           emits q-values, greedy action and value -- the pair as ONE 8-byte
+//                           store into the pinned slot the host polls.  Dense: every head output
+//                           as one 8-byte {value, marker} store.
+//   (Rainbow, optional)     the replay sample + gather of the learner step that follows, as the
+//                           last blocks of the grid (dz_next_sample_t).
 //
 // Dependencies only point from lower to higher block ids and the 25 torso workgroups are the
-// first to be dispatched, so the launch cannot deadlock whatever else occupies the chip.  Every
-// spin is bounded: a stuck seam sets a sticky word and the apply returns NaN q-values instead
-// of hanging the device.
+// first to be dispatched, so the launch cannot deadlock as long as 25 workgroups fit on the device
+// together.  Every spin is bounded: a stuck seam sets a sticky word and the decision comes back as
+// NaN instead of hanging the device.
 #pragma once
 
 #include "dz_qnet_kernels.h"
