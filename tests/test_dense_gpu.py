@@ -360,6 +360,30 @@ def test_one_launch_q_decision(kind_net, actions, monkeypatch):
   assert words[3] == 9 and words[5] == 0, words
 
 
+def test_dense_act_into_device_memory():
+  """dz_dense_act's {value, marker} words may also go to device memory (include/dqnzoo_hip.h);
+  called through the C ABI directly, twice on one workspace (both sets of intermediates)."""
+  from dqn_zoo_amd import _lib, learner as ll
+  rs, online, _, ln = _make('dqn', 'q', ll.RmsPropConfig(), 77)
+  lib = _lib.load()
+  ws = torch.zeros(ln.network.layout(1, 1).ws_count, dtype=torch.float32, device='cuda')
+  for _ in range(2):
+    x = rs.randint(0, 256, (1, 84, 84, 4)).astype(np.uint8)
+    xd = torch.from_numpy(x).cuda()
+    pairs = torch.zeros((A, 2), dtype=torch.float32, device='cuda')
+    _lib.check(lib.dz_dense_act(A, 0, ln.online.data_ptr(), xd.data_ptr(), ws.data_ptr(),
+                                pairs.data_ptr(), _lib.stream_ptr(ln.device)), 'dz_dense_act')
+    torch.cuda.synchronize()
+    got = pairs.cpu().numpy()
+    ref, _ = qo.mlp_head_fwd(online, x)
+    np.testing.assert_array_equal(got[:, 1], np.ones(A, np.float32))
+    np.testing.assert_allclose(got[:, 0], ref[0], rtol=2e-5, atol=2e-6)
+  # a misaligned slot is refused before anything is enqueued
+  bad = torch.zeros(2 * A + 1, dtype=torch.float32, device='cuda')[1:]
+  assert lib.dz_dense_act(A, 0, ln.online.data_ptr(), xd.data_ptr(), ws.data_ptr(),
+                          bad.data_ptr(), _lib.stream_ptr(ln.device)) != 0
+
+
 def test_dense_apply_and_shared_bias():
   from dqn_zoo_amd import learner as ll
   rs, online, target, ln = _make('double_dqn', 'double_q', ll.RmsPropConfig(), 30)
