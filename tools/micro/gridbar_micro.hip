@@ -7,6 +7,8 @@
 //   xcd/fence  : the same publish, XCD-hierarchical arrival (MI355X_MICROARCH.md
 //                "barrier-xcd"): per-XCC counter -> the XCC's last arriver bumps the top
 //                counter -> the top's last arriver bumps the generation of every XCC
+//   xcd/sc1+acq: payload stored write-through (sc1), every wave drains vmcnt, NO release fence;
+//                readers issue an agent-scope ACQUIRE fence and then PLAIN loads
 //   xcd/sc1    : payload stored write-through (sc1), every wave drains vmcnt, NO release
 //                fence; readers use sc1 loads, NO acquire fence (Guideline 16 R1)
 // Every spin is bounded: a stuck barrier aborts instead of hanging the box.
@@ -31,11 +33,11 @@ __device__ __forceinline__ bool spin_until(unsigned* w, unsigned target, Bar* b)
 // MODE 0: flat + fences; 1: hierarchical + fences; 2: hierarchical, no fences (sc1 payload)
 template <int MODE>
 __device__ __forceinline__ bool grid_barrier(Bar* b, unsigned nblocks, unsigned& my_gen, unsigned xcc) {
-  if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
+  if (MODE >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
   __syncthreads();
   bool ok = true;
   if (threadIdx.x == 0) {
-    if (MODE != 2) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (MODE < 2) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     const unsigned target = my_gen + 1;
     if (MODE == 0) {
       if (__hip_atomic_fetch_add(&b->count, 1u, RLX) == nblocks - 1) {
@@ -52,10 +54,11 @@ __device__ __forceinline__ bool grid_barrier(Bar* b, unsigned nblocks, unsigned&
         } else ok = spin_until(&b->xgen[xcc][0], target, b);
       } else ok = spin_until(&b->xgen[xcc][0], target, b);
     }
-    if (MODE != 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (MODE < 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   my_gen += 1;
   __syncthreads();
+  if (MODE == 3) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave, then plain loads
   return ok;
 }
 __global__ void census(Bar* b) { if (threadIdx.x == 0) atomicAdd(&b->xn[xcc_id() & 7][0], 1u); }
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void k(Bar* b, float* buf, int n, unsigned* ba
     if (WORK) {   // write my 4 KB
       for (int j = threadIdx.x; j < 1024; j += 256) {
         float* p = buf + (size_t)blockIdx.x * 1024 + j;
-        if (MODE == 2) __hip_atomic_store(p, (float)(it * 7 + j), RLX); else *p = (float)(it * 7 + j);
+        if (MODE >= 2) __hip_atomic_store(p, (float)(it * 7 + j), RLX); else *p = (float)(it * 7 + j);
       }
     }
     if (!grid_barrier<MODE>(b, nb, gen, xcc)) return;
@@ -110,5 +113,6 @@ int main(int argc, char** argv) {
   run<0>(G, b, buf, bad, "flat/fence");
   run<1>(G, b, buf, bad, "xcd/fence");
   run<2>(G, b, buf, bad, "xcd/sc1");
+  run<3>(G, b, buf, bad, "xcd/sc1+acq");
   return 0;
 }
