@@ -401,6 +401,14 @@ int dz_rainbow_apply(int num_actions, int num_atoms, int batch, const float* par
  * descriptor's buffers instead of sampling: one launch fewer per learn period, same
  * ids, weights and rows.  The draws are by-value kernel arguments: such a call is
  * not graph-capturable.
+ * batch == 1 with a step_counter (the agent's decision): the whole apply is ONE launch
+ * (csrc/dz_act_one.h); `ws` must have been all-zero when it was created and its
+ * ws_act_seams region must be touched by nothing else (the kernel keeps a generation
+ * word and two alternating sets of intermediates there).  With greedy_out and vmax_out
+ * adjacent and 8-byte aligned the pair is written with ONE 8-byte store: a host that set
+ * the action word to -1 before the call may poll it with plain loads.  next_sample then
+ * rides as the last blocks of that launch.  Every in-kernel wait is bounded: a failure
+ * returns NaN q-values and sets the sticky word at ws_act_seams + 5 * 64.
  * ref: rainbow/agent.py:125-131, 171-179 (select_action with a fresh key).    */
 int dz_rainbow_act(int num_actions, int num_atoms, int batch, const float* params,
                    const uint8_t* states, float* noise, uint64_t noise_seed,
