@@ -821,7 +821,7 @@ def main():
       del step, seq_step, replay, learner
       torch.cuda.empty_cache()
       out['other_configs'] = measure_other_configs(
-          args, device, steps=max(args.steps, 200), warmup=max(args.warmup, 20),
+          args, device, steps=max(args.steps, 1000), warmup=max(args.warmup, 50),
           prof_steps=min(args.prof_steps, 20))
     if world == 1 and args.cpu_seconds > 0:
       out['cpu_baseline'] = cpu_baseline(args, args.seed, args.cpu_seconds)
