@@ -83,6 +83,10 @@ def parse_args():
   ap.add_argument('--agent-form-steps', type=int, default=1000,
                   help='steps of the sequential form (what Rainbow._learn enqueues) timed '
                        'after the headline window for `agent_form` (0 disables)')
+  ap.add_argument('--agent-loop-frames', type=int, default=6000,
+                  help='frames of the whole drop-in loop (parts.run_loop: act -> insert -> learn '
+                       'every 4th frame; Rainbow and DQN agents on a synthetic environment) timed '
+                       'in THIS run for `agent_loop` (0 disables)')
   return ap.parse_args()
 
 
@@ -541,6 +545,94 @@ def measure_replay(replay, learner, batch, n=100):
               'capacity 1e6): dependent-load latency, not bytes'}
 
 
+class SyntheticFrames:
+  """A pre-processed environment (84x84x4 uint8 observations from a seeded pool, episodes of
+  `n` frames): what parts.run_loop drives the agents on in `agent_loop`."""
+
+  def __init__(self, seed, n=1000):
+    rs = np.random.RandomState(seed)
+    self.pool = rs.randint(0, 256, (64, 84, 84, 4)).astype(np.uint8)
+    self.rs, self.n, self.t = rs, n, 0
+
+  def _obs(self):
+    return self.pool[self.rs.randint(64)]
+
+  def reset(self):
+    from dqn_zoo_amd import dm_env_shim as dm_env
+    self.t = 0
+    return dm_env.restart(self._obs())
+
+  def step(self, action):
+    from dqn_zoo_amd import dm_env_shim as dm_env
+    self.t += 1
+    r = float(self.rs.randint(-1, 2))
+    if self.t == self.n:
+      return dm_env.termination(r, self._obs())
+    return dm_env.transition(r, self._obs(), 0.99)
+
+
+def make_loop_agent(which, learn_period=4, capacity=100000):
+  """The drop-in agents exactly as a run script builds them (rainbow/run_atari.py:196-262,
+  dqn/run_atari.py:180-236), on an identity preprocessor."""
+  from dqn_zoo_amd import learner as learner_lib, networks, parts, processors
+  from dqn_zoo_amd import replay as replay_lib
+  structure = replay_lib.Transition(None, None, None, None, None)
+  if which == 'dqn':
+    from dqn_zoo_amd.dqn import agent as dqn_lib
+    rep = replay_lib.TransitionReplay(capacity, structure, np.random.RandomState(1))
+    ag = dqn_lib.Dqn(
+        preprocessor=processors.Identity(), sample_network_input=np.zeros((84, 84, 4), np.uint8),
+        network=networks.DenseNetwork('dqn', NUM_ACTIONS), optimizer=learner_lib.RmsPropConfig(),
+        transition_accumulator=replay_lib.TransitionAccumulator(), replay=rep, batch_size=32,
+        exploration_epsilon=lambda t: 0.1, min_replay_capacity_fraction=0.005,
+        learn_period=learn_period, target_network_update_period=2000, rng_key=1,
+        grad_error_bound=1.0 / 32)
+    return ag, rep
+  from dqn_zoo_amd.rainbow import agent as rainbow_lib
+  support = np.linspace(-VMAX, VMAX, NUM_ATOMS).astype(np.float32)
+  rep = replay_lib.PrioritizedTransitionReplay(
+      capacity, structure, 0.5,
+      parts.LinearSchedule(begin_t=2000, end_t=10 ** 7, begin_value=0.4, end_value=1.0),
+      1e-3, True, np.random.RandomState(1))
+  ag = rainbow_lib.Rainbow(
+      preprocessor=processors.Identity(), sample_network_input=np.zeros((84, 84, 4), np.uint8),
+      network=networks.RainbowNetwork(NUM_ACTIONS, support, 0.1), support=support,
+      optimizer=learner_lib.AdamConfig(),
+      transition_accumulator=replay_lib.NStepTransitionAccumulator(3), replay=rep,
+      batch_size=32, min_replay_capacity_fraction=0.005, learn_period=learn_period,
+      target_network_update_period=2000, rng_key=1)
+  return ag, rep
+
+
+def measure_agent_loop(which, frames, learn_period=4, warm_frames=1000, setup=None, on_warm=None):
+  """Agent steps/s of the whole drop-in loop (ref: parts.py:70-122 run_loop driving
+  rainbow/agent.py:135-160 / dqn/agent.py:133-160): per frame the acting decision is awaited, the
+  transition inserted, and every `learn_period`-th frame a batch sampled and learned from."""
+  from dqn_zoo_amd import parts
+  ag, rep = make_loop_agent(which, learn_period)
+  if setup is not None:
+    setup(ag, rep)
+  loop = parts.run_loop(ag, SyntheticFrames(3), max_steps_per_episode=0)
+  for _ in range(warm_frames):   # past min replay; graphs captured, ring slots touched
+    next(loop)
+  torch.cuda.synchronize()
+  if on_warm is not None:
+    on_warm()
+  t0 = time.perf_counter()
+  for _ in range(frames):
+    next(loop)
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  rep.check_status()
+  out = {'agent': which, 'measured_in_run': True, 'frames': frames,
+         'agent_steps_per_sec': round(frames / dt, 1),
+         'us_per_agent_step': round(1e6 * dt / frames, 2), 'learn_period': learn_period,
+         'learner_steps_per_sec': round(frames / dt / learn_period, 1)}
+  del loop, ag, rep
+  torch.cuda.empty_cache()
+  return out
+
+
 def usable_cpus():
   """Host cores this process may actually use (affinity mask and cgroup CPU
   quota), which can be far fewer than os.cpu_count() inside a container."""
@@ -798,14 +890,8 @@ def main():
                   'dz_prioritized_sample_gather launch + dz_rainbow_learn',
           'steps': args.agent_form_steps, 'value': round(args.agent_form_steps / ds, 2),
           'unit': 'steps/s', 'ms_per_step': round(1e3 * ds / args.agent_form_steps, 4),
-          'launches': 15}   # 1 sample+gather + 14 (profiles/*_kernel_step_summary_sequential.txt)
-    for which in ('rainbow', 'dqn'):   # the whole drop-in loop, from the committed session
-      doc, tag = _profile_json('agent_loop_' + which)
-      if doc:
-        out.setdefault('agent_loop', {})[which] = dict(
-            doc, source='profiles/%s_agent_loop_%s.json (tools/agent_loop_bench.py: act -> insert '
-                        '-> learn every 4th frame on a synthetic environment; NOT measured in '
-                        'this run)' % (tag, which))
+          # counted from the library's event marks of this form + the sample + gather launch
+          'launches': len(profile_kernels(seq_step, 2)) + 1}
     if args.prof_steps > 0:
       learner.use_graphs = False  # per-kernel events need eager launches
       prof_step = step if args.mode == 'fused' else seq_step
@@ -823,6 +909,13 @@ def main():
       out['other_configs'] = measure_other_configs(
           args, device, steps=max(args.steps, 1000), warmup=max(args.warmup, 50),
           prof_steps=min(args.prof_steps, 20))
+    if world == 1 and args.agent_loop_frames > 0:
+      # the whole drop-in loop on this run's clock (the headline's store is gone by now)
+      if 'step' in dir():
+        del step, seq_step, replay, learner
+        torch.cuda.empty_cache()
+      out['agent_loop'] = {w: measure_agent_loop(w, args.agent_loop_frames)
+                           for w in ('rainbow', 'dqn')}
     if world == 1 and args.cpu_seconds > 0:
       out['cpu_baseline'] = cpu_baseline(args, args.seed, args.cpu_seconds)
       out['speedup_vs_cpu_baseline'] = round(

@@ -16,6 +16,9 @@ DZ_ERR_INVALID_ARG = -1
 DZ_ERR_HIP = -2
 DZ_ERR_UNSUPPORTED = -3
 
+ACT_FAILED = -2           # DZ_ACT_FAILED: the 'action' of a one-launch decision whose seams timed out
+ACT_FAILED_MARKER = 2.0   # DZ_ACT_FAILED_MARKER (dz_dense_act)
+
 ST_BAD_VALUE = 1
 ST_BAD_TARGET = 2
 ST_BAD_INDEX = 4
@@ -189,7 +192,7 @@ SIGNATURES = {
     'dz_rainbow_apply': (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                                  c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dz_rainbow_act': (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, ctypes.c_uint64,
-                               ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+                               ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dz_rainbow_graph_capture': (c_int, [ctypes.POINTER(RainbowArgs), c_int, c_vp,
                                          ctypes.POINTER(c_vp)]),
     'dz_atari_observation': (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int,
@@ -205,6 +208,7 @@ SIGNATURES = {
     'dz_dense_apply': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                                c_vp, c_vp, c_vp, c_vp]),
     'dz_dense_act': (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'dz_act_debug_spin_limit': (c_int, [c_int]),
     'dz_iqn_layout': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int,
                               ctypes.POINTER(IqnLayout)]),
     'dz_iqn_learn': (c_int, [ctypes.POINTER(IqnArgs), c_int, c_vp]),

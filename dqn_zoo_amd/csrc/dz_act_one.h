@@ -34,13 +34,19 @@
 //                           emits q-values, greedy action and value -- the pair as ONE 8-byte
 //                           store into the pinned slot the host polls.  Dense: every head output
 //                           as one 8-byte {value, marker} store.
-//   (Rainbow, optional)     the replay sample + gather of the learner step that follows, as the
-//                           last blocks of the grid (dz_next_sample_t).
 //
-// Dependencies only point from lower to higher block ids and the 25 torso workgroups are the
-// first to be dispatched, so the launch cannot deadlock as long as 25 workgroups fit on the device
-// together.  Every spin is bounded: a stuck seam sets a sticky word and the decision comes back as
-// NaN instead of hanging the device.
+// LIVENESS.  Dependencies only point from lower to higher block ids.  The launch relies on ONE
+// property of the dispatcher that HIP does not promise but every CDNA part has (and
+// MI355X_MICROARCH.md "Workgroup dispatch" describes): workgroups are handed to the XCDs round-robin
+// by linear id and every XCD starts its share in ascending id order.  Then the lowest-id unfinished
+// workgroup is either resident or the next one its XCD starts, whatever else occupies the chip (a
+// learner step on another stream delays the decision, it cannot block it): no co-residency of the
+// roles is needed for progress, only for speed.  If that property ever failed, a consumer would
+// spin on a producer that cannot start -- so EVERY spin is bounded (spin_limit rounds): a stuck
+// seam sets the sticky word (line 5), the workgroups still take their tickets (the counters
+// re-arm), and the decision comes back as action kActFailedAction with a NaN value / outputs
+// marked kActFailedMarker -- which the host-side readers turn into an exception after clearing
+// the seam area (learner.py) -- instead of hanging the device or returning a wrong action.
 #pragma once
 
 #include "dz_qnet_kernels.h"
@@ -54,7 +60,8 @@ constexpr int kActTorsoBlocks = 25;   // conv1 pixel tiles (400 / 16)
 constexpr int kActConv2Blocks = 24;   // 6 pixel tiles x 4 channel tiles
 constexpr int kActConv3Blocks = 16;   // 4 pixel tiles x 4 channel tiles
 constexpr int kActFc1Splits = 28, kActFc1Rows = 112, kActFc1Blocks = kActFc1Splits * 8;
-constexpr int kActSpinLimit = 200000;
+constexpr int kActFailedAction = -2;  // DZ_ACT_FAILED: the "action" of a decision whose seams timed out
+constexpr float kActFailedMarker = 2.0f;   // dense heads: the marker of an output of such a decision
 // one set of intermediates: act1 | act2 | feat | 28 fc1 slabs, padded to whole 256-float chunks
 constexpr int kActOffA1 = 0, kActOffA2 = 400 * 32, kActOffFeat = kActOffA2 + 81 * 64,
               kActOffPart = kActOffFeat + kFlat;
@@ -83,6 +90,8 @@ struct ActTorso {
   unsigned* sync;
   int set_floats;                     // floats per set (a multiple of 256)
   int ncg, part_ld;                   // fc1: column groups of 128, slab row length (128 ncg)
+  int spin_limit;                     // polling rounds per seam before giving up (g_dz_act_spin_limit;
+                                      // dz_act_debug_spin_limit lowers it to force the failure path)
   long fc1_mu_w; int fc1_ld;
   long long* dbg = nullptr;
 };
@@ -129,16 +138,17 @@ __device__ __forceinline__ float* act_set(const ActTorso& p, unsigned gen) {
 // Before the polling rounds: ONE thread watches ONE of the words the workgroup needs (224 x 256
 // threads re-reading 14 words each starved every other access of the chip: 38 us per decision).
 // The rounds that follow see the rest, written within a microsecond of it.
-__device__ __forceinline__ void act_watch(const float* word) {
+__device__ __forceinline__ void act_watch(const float* word, int limit) {
   if (threadIdx.x == 0)
-    for (int i = 0; i < kActSpinLimit && act_missing(act_load(word)); ++i) __builtin_amdgcn_s_sleep(2);
+    for (int i = 0; i < limit && act_missing(act_load(word)); ++i) __builtin_amdgcn_s_sleep(2);
   __syncthreads();
 }
 // One polling round ends here: true = some thread still saw a missing value (go round again);
-// after kActSpinLimit rounds the sticky failure word is set and *give_up becomes true.
-__device__ __forceinline__ bool act_again(bool miss, int round, unsigned* fail, bool* give_up) {
+// after `limit` rounds the sticky failure word is set and *give_up becomes true.
+__device__ __forceinline__ bool act_again(bool miss, int round, unsigned* fail, bool* give_up,
+                                          int limit) {
   const bool again = __syncthreads_or(miss ? 1 : 0) != 0;
-  *give_up = again && round >= kActSpinLimit;
+  *give_up = again && round >= limit;
   if (*give_up && threadIdx.x == 0) __hip_atomic_store(fail, 1u, DZ_ACT_RLX);
   if (again) __builtin_amdgcn_s_sleep(1);
   return again && !*give_up;
@@ -261,7 +271,7 @@ __device__ __forceinline__ void act_torso_block(const ActTorso& p, int blk, floa
     float2 v[10];   // 8 input rows x 20 pixels x 32 channels, LDS pixel pitch 36
     int round = 0;
     bool miss;
-    act_watch(act1 + (min(2 * oy0 + 7, 19) * 20 + 19) * 32 + 31);
+    act_watch(act1 + (min(2 * oy0 + 7, 19) * 20 + 19) * 32 + 31, p.spin_limit);
     do {            // conv1's outputs are their own flags
       miss = false;
 #pragma unroll
@@ -272,7 +282,7 @@ __device__ __forceinline__ void act_torso_block(const ActTorso& p, int blk, floa
       }
 #pragma unroll
       for (int i = 0; i < 10; ++i) miss = miss || act_missing(v[i].x) || act_missing(v[i].y);
-    } while (act_again(miss, round++, fail, &give_up));
+    } while (act_again(miss, round++, fail, &give_up, p.spin_limit));
     if (give_up) return;
     ACT_STAMP(3);
 #pragma unroll
@@ -317,7 +327,7 @@ __device__ __forceinline__ void act_torso_block(const ActTorso& p, int blk, floa
     float2 v[7];    // 6 input rows x 9 pixels x 64 channels, LDS pixel pitch 68
     int round = 0;
     bool miss;
-    act_watch(act2 + (min(oy0 + 5, 8) * 9 + 8) * 64 + 63);
+    act_watch(act2 + (min(oy0 + 5, 8) * 9 + 8) * 64 + 63, p.spin_limit);
     do {
       miss = false;
 #pragma unroll
@@ -328,7 +338,7 @@ __device__ __forceinline__ void act_torso_block(const ActTorso& p, int blk, floa
       }
 #pragma unroll
       for (int i = 0; i < 7; ++i) miss = miss || act_missing(v[i].x) || act_missing(v[i].y);
-    } while (act_again(miss, round++, fail, &give_up));
+    } while (act_again(miss, round++, fail, &give_up, p.spin_limit));
     if (give_up) return;
     ACT_STAMP(6);
 #pragma unroll
@@ -423,14 +433,14 @@ __device__ __forceinline__ void act_fc1_block(const P& p, int fb, int nfc1, floa
   {
     int round = 0;
     bool miss, give_up;
-    act_watch(feat + k0 + 13);
+    act_watch(feat + k0 + 13, p.spin_limit);
     do {            // conv3's outputs are their own flags
       miss = false;
 #pragma unroll
       for (int j = 0; j < 14; ++j) x[j] = act_load(feat + k0 + j);
 #pragma unroll
       for (int j = 0; j < 14; ++j) miss = miss || act_missing(x[j]);
-    } while (act_again(miss, round++, act_line(p.sync, 5), &give_up));
+    } while (act_again(miss, round++, act_line(p.sync, 5), &give_up, p.spin_limit));
     if (give_up) return;
   }
   ACT_STAMP(2);
@@ -509,11 +519,12 @@ __device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, 
   ACT_STAMP(1);
   // ---- 1. h1 (this head's half): 28 slabs in slab order; the slab values are their own flags ------
   float x[2][kActFc1Splits];
+  bool failed;
   {
     const float* part = act_set(p, *act_line(p.sync, 3)) + kActOffPart + hd.x_off + tid;
     int round = 0;
     bool miss, give_up;
-    act_watch(part + (kActFc1Splits - 1) * 1024);
+    act_watch(part + (kActFc1Splits - 1) * 1024, p.spin_limit);
     do {
       miss = false;
       // (running pointer kept opaque: the slabs are 4 KB apart, beyond the immediate offset, and
@@ -529,52 +540,56 @@ __device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, 
       for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int j = 0; j < kActFc1Splits; ++j) miss = miss || act_missing(x[e][j]);
-    } while (act_again(miss, round++, act_line(p.sync, 5), &give_up));
-    if (give_up) {
-      if (tile == 0 && tid == 0) {   // visible to the host: the decision is not a number
-        for (int a = 0; a < p.A; ++a) p.q_out[a] = __builtin_nanf("");
-        if (p.greedy_out) *p.greedy_out = 0;
-        if (p.vmax_out) *p.vmax_out = __builtin_nanf("");
-      }
-      return;
-    }
+    } while (act_again(miss, round++, act_line(p.sync, 5), &give_up, p.spin_limit));
+    // A stuck seam (workgroup-uniform): the sticky word is set; this workgroup still takes its
+    // ticket below, so that the ticket counter and the generation re-arm and the last workgroup
+    // can tell the host (the decision comes back as kActFailedAction / NaN, never as an action).
+    failed = give_up;
   }
   ACT_STAMP(2);
+  if (!failed) {
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    float v = 0.f;
+    for (int e = 0; e < 2; ++e) {
+      float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < kActFc1Splits; ++j) v += x[e][j];
-    const float h = v + bm[e] + bs[e] * be[e];
-    s_h1[tid + 256 * e] = h > 0.f ? h : 0.f;
-  }
-  __syncthreads();
-  ACT_STAMP(3);
-  // ---- 2. this workgroup's 32 output columns ------------------------------------------------------
-  {
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      const int k = kg * 64 + j;
-      acc = __builtin_fmaf(s_h1[k], m[j], acc);
+      for (int j = 0; j < kActFc1Splits; ++j) v += x[e][j];
+      const float h = v + bm[e] + bs[e] * be[e];
+      s_h1[tid + 256 * e] = h > 0.f ? h : 0.f;
     }
-    s_red[kg * 32 + c] = acc;
-  }
-  __syncthreads();
-  if (tid < 32 && col < hd.ldw) {
-    const float o = (((s_red[c] + s_red[32 + c]) + (s_red[64 + c] + s_red[96 + c])) +
-                     ((s_red[128 + c] + s_red[160 + c]) + (s_red[192 + c] + s_red[224 + c]))) + sb;
-    act_store(p.fc2_out + hd.out_off + col, col < hd.N ? o : 0.f);
+    __syncthreads();
+    ACT_STAMP(3);
+    // ---- 2. this workgroup's 32 output columns ----------------------------------------------------
+    {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        const int k = kg * 64 + j;
+        acc = __builtin_fmaf(s_h1[k], m[j], acc);
+      }
+      s_red[kg * 32 + c] = acc;
+    }
+    __syncthreads();
+    if (tid < 32 && col < hd.ldw) {
+      const float o = (((s_red[c] + s_red[32 + c]) + (s_red[64 + c] + s_red[96 + c])) +
+                       ((s_red[128 + c] + s_red[160 + c]) + (s_red[192 + c] + s_red[224 + c]))) + sb;
+      act_store(p.fc2_out + hd.out_off + col, col < hd.N ? o : 0.f);
+    }
   }
   // ---- 3. ticket: the last workgroup finishes the row ---------------------------------------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0)
-    *s_last = __hip_atomic_fetch_add(act_line(p.sync, 4), 1u, DZ_ACT_RLX) == (unsigned)p.tiles - 1;
+  if (tid == 0) {
+    int last = __hip_atomic_fetch_add(act_line(p.sync, 4), 1u, DZ_ACT_RLX) == (unsigned)p.tiles - 1;
+    // (a workgroup that gave up stored the sticky word before its ticket: the last one sees it)
+    if (last && __hip_atomic_load(act_line(p.sync, 5), DZ_ACT_RLX) != 0u) last = 2;
+    *s_last = last;
+  }
   __syncthreads();
   ACT_STAMP(4);
-  if (!*s_last) return;
-  for (int i = tid; i < p.ld2; i += 256) s_row[i] = act_load(p.fc2_out + i);
+  const int last = *s_last;
+  if (!last) return;
+  if (last == 1)
+    for (int i = tid; i < p.ld2; i += 256) s_row[i] = act_load(p.fc2_out + i);
   __syncthreads();
   if (tid == 0) {
     // re-armed for the next apply (ordered by the kernel boundary; every poller has passed)
@@ -583,24 +598,35 @@ __device__ __forceinline__ void act_tail_block(const ActOneParams& p, int tile, 
     __hip_atomic_store(act_line(p.sync, 3), gen + 1u, DZ_ACT_RLX);
     if (p.bump) *p.bump = *p.bump + 1;
   }
+  if (last == 2) {
+    // visible to the host: the decision is NOT an action.  The sticky word stays set until the
+    // host clears the seam area (RainbowLearner raises and resets), so every decision until
+    // then comes back like this one.
+    if (tid == 0) {
+      const float nan = __builtin_nanf("");
+      for (int a = 0; a < p.A; ++a) p.q_out[a] = nan;
+      if (p.greedy_out && p.vmax_out == (float*)(p.greedy_out + 1) && ((uintptr_t)p.greedy_out & 7) == 0) {
+        *(volatile unsigned long long*)p.greedy_out =
+            (unsigned long long)(unsigned)kActFailedAction |
+            ((unsigned long long)__builtin_bit_cast(unsigned, nan) << 32);
+      } else {
+        if (p.greedy_out) *p.greedy_out = kActFailedAction;
+        if (p.vmax_out) *p.vmax_out = nan;
+      }
+    }
+    return;
+  }
   dz_q_from_row(s_row, p.A, p.K, p.val_off, p.support, p.q_out, p.greedy_out, p.vmax_out, s_q,
                 s_best, s_arg);
   ACT_STAMP(5);
 }
 
-// `sg` / `sg_blocks`: optionally the replay sample + gather of the learner step that follows this
-// decision (dz_next_sample_t), as the LAST blocks of the grid: they read nothing the decision
-// writes, are dispatched behind its 261 workgroups and finish inside its 21 us; the host polls the
-// action slot, so they are not on the path to the action (they were, as blocks of the conv2 launch
-// of the multi-launch apply: EXPERIMENTS.md).
-__global__ __launch_bounds__(256, 2) void rainbow_act_one_kernel(ActOneParams p, SampleGatherParams sg,
-                                                              unsigned sg_blocks) {
+__global__ __launch_bounds__(256, 2) void rainbow_act_one_kernel(ActOneParams p) {
   __shared__ __attribute__((aligned(16))) float lds[kActLdsFloats];
   const int b = blockIdx.x;
   if (b < kActTorsoBlocks) act_torso_block(p, b, lds);
   else if (b < kActTorsoBlocks + kActFc1Blocks) act_fc1_block(p, b - kActTorsoBlocks, kActFc1Blocks, lds);
-  else if (b < kActTorsoBlocks + kActFc1Blocks + p.tiles) act_tail_block(p, b - kActTorsoBlocks - kActFc1Blocks, lds);
-  else SampleGatherSide::run(sg, (unsigned)(b - kActTorsoBlocks - kActFc1Blocks - p.tiles));
+  else act_tail_block(p, b - kActTorsoBlocks - kActFc1Blocks, lds);
 }
 
 // ---- dense heads (DQN, double-Q, prioritized: N = A; C51: N = 51 A; QR-DQN: N = 201 A) ------------
@@ -628,13 +654,15 @@ __device__ __forceinline__ void dense_act_tail_block(const DenseActParams& p, in
   const float b2 = p.prm[p.fc2_b + (p.bias_shared ? 0 : nc)];
   __builtin_amdgcn_sched_barrier(0);
   const unsigned gen = *act_line(p.sync, 3);
+  const unsigned sticky = *act_line(p.sync, 5);   // set by an earlier decision and not yet cleared by the host
   ACT_STAMP(1);
   float x[2][kActFc1Splits];
+  bool failed;
   {
     const float* part = act_set(p, gen) + kActOffPart + tid;
     int round = 0;
     bool miss, give_up;
-    act_watch(part + (kActFc1Splits - 1) * 512);
+    act_watch(part + (kActFc1Splits - 1) * 512, p.spin_limit);
     do {
       miss = false;
       const float* pp = part;
@@ -648,34 +676,39 @@ __device__ __forceinline__ void dense_act_tail_block(const DenseActParams& p, in
       for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int j = 0; j < kActFc1Splits; ++j) miss = miss || act_missing(x[e][j]);
-    } while (act_again(miss, round++, act_line(p.sync, 5), &give_up));
-    if (give_up) {   // visible to the host: the outputs are not numbers
-      if (tid < 32 && col < p.N) p.pairs_out[col] = 0x3f8000007fc00000ull;
-      return;
-    }
+    } while (act_again(miss, round++, act_line(p.sync, 5), &give_up, p.spin_limit));
+    failed = give_up || sticky != 0u;
   }
   ACT_STAMP(2);
+  if (failed) {
+    // visible to the host: the outputs are not numbers and carry the FAILED marker (2.0f); the
+    // ticket below still re-arms the counter and the generation
+    if (tid < 32 && col < p.N)
+      p.pairs_out[col] = 0x7fc00000ull |
+                         ((unsigned long long)__builtin_bit_cast(unsigned, kActFailedMarker) << 32);
+  } else {
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    float v = 0.f;
+    for (int e = 0; e < 2; ++e) {
+      float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < kActFc1Splits; ++j) v += x[e][j];
-    const float h = v + (e ? b1b : b1a);
-    s_h[tid + 256 * e] = h > 0.f ? h : 0.f;
-  }
-  __syncthreads();
-  ACT_STAMP(3);
-  {
-    float acc = 0.f;
+      for (int j = 0; j < kActFc1Splits; ++j) v += x[e][j];
+      const float h = v + (e ? b1b : b1a);
+      s_h[tid + 256 * e] = h > 0.f ? h : 0.f;
+    }
+    __syncthreads();
+    ACT_STAMP(3);
+    {
+      float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) acc = __builtin_fmaf(s_h[ks * 64 + k], w[k], acc);
-    s_red[ks * 32 + n] = acc;
-  }
-  __syncthreads();
-  if (tid < 32 && col < p.N) {
-    const float q = (((s_red[n] + s_red[32 + n]) + (s_red[64 + n] + s_red[96 + n])) +
-                     ((s_red[128 + n] + s_red[160 + n]) + (s_red[192 + n] + s_red[224 + n]))) + b2;
-    p.pairs_out[col] = (unsigned long long)__builtin_bit_cast(unsigned, q) | (0x3f800000ull << 32);
+      for (int k = 0; k < 64; ++k) acc = __builtin_fmaf(s_h[ks * 64 + k], w[k], acc);
+      s_red[ks * 32 + n] = acc;
+    }
+    __syncthreads();
+    if (tid < 32 && col < p.N) {
+      const float q = (((s_red[n] + s_red[32 + n]) + (s_red[64 + n] + s_red[96 + n])) +
+                       ((s_red[128 + n] + s_red[160 + n]) + (s_red[192 + n] + s_red[224 + n]))) + b2;
+      p.pairs_out[col] = (unsigned long long)__builtin_bit_cast(unsigned, q) | (0x3f800000ull << 32);
+    }
   }
   // every tail workgroup has read the generation and the slabs once it takes its ticket: the last
   // one re-arms the ticket and switches the next apply to the other set

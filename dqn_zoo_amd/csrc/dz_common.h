@@ -34,6 +34,10 @@ __host__ __device__ static inline int64_t dz_mod(int64_t a, int64_t b) {
   return r < 0 ? r + b : r;
 }
 
+// Polling rounds per seam of the one-launch decision kernels before a workgroup gives up
+// (dz_act_one.h; dz_act_debug_spin_limit).
+extern int g_dz_act_spin_limit;
+
 // ---- optional event profiler (dz_prof_*) ------------------------------------
 extern bool g_dz_prof_on;
 void dz_prof_begin(hipStream_t s);

@@ -7,6 +7,15 @@ extern "C" const char* dz_version(void) { return "dqnzoo_hip 0.1 (gfx950)"; }
 extern "C" int dz_last_hip_error(void) { return g_dz_last_hip_error; }
 extern "C" const char* dz_built_arch(void) { return "gfx950"; }
 
+// One-launch decision kernels (dz_act_one.h): polling rounds per seam before a workgroup gives
+// up.  200 000 rounds of >= 64 cycles are >= 5 ms: three orders of magnitude above a decision.
+int g_dz_act_spin_limit = 200000;
+extern "C" int dz_act_debug_spin_limit(int limit) {
+  const int old = g_dz_act_spin_limit;
+  if (limit >= 0) g_dz_act_spin_limit = limit;
+  return old;
+}
+
 extern "C" int dz_struct_size(int which) {
   switch (which) {
     case 0: return (int)sizeof(dz_field_t);

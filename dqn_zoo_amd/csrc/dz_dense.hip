@@ -596,6 +596,7 @@ extern "C" int dz_dense_act(int num_outputs, int shared_bias, const float* param
   for (int i = 0; i < 3; ++i) { q.conv_w[i] = L.conv_w[i]; q.conv_b[i] = L.conv_b[i]; }
   q.sync = reinterpret_cast<unsigned*>(ws + L.ws_act_seams);   // zero in a fresh workspace
   q.set_floats = act_set_floats(512); q.ncg = 4; q.part_ld = 512;
+  q.spin_limit = g_dz_act_spin_limit;
   q.fc1_mu_w = L.fc1_w; q.fc1_ld = L.fc1_ld;
 #ifdef DZ_ACT_STAMPS
   q.dbg = reinterpret_cast<long long*>(ws + L.ws_dfeat_part);

@@ -79,8 +79,7 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
                            const float* const* prm, const float* const* nz,
                            const uint8_t* const* in, float* ws, hipStream_t s,
                            const NoiseParams* resample = nullptr,
-                           bool skip_fc2_epilogue = false, bool stop_after_fc1 = false,
-                           const SampleGatherParams* sg = nullptr, unsigned sg_blocks = 0) {
+                           bool skip_fc2_epilogue = false, bool stop_after_fc1 = false) {
   int rc = DZ_OK;
   const int NA = L.num_actions * L.num_atoms;
   const int ld2 = L.adv2_ld + L.val2_ld;
@@ -92,7 +91,7 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
 #ifdef DZ_GEMM_STAMPS
     if (G == 3) dbg = (long long*)(ws + L.ws_dfeat_part);
 #endif
-    rc = torso_forward(T, G, B, prm, in, s, resample, sg, sg_blocks, dbg);
+    rc = torso_forward(T, G, B, prm, in, s, resample, dbg);
     if (rc) return rc;
   }
   {  // fc1: noisy adv1 | val1, split-K partials
@@ -709,7 +708,7 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
                               uint64_t noise_counter, int32_t* step_counter,
                               const float* support, float* ws,
                               float* q_values_out, int32_t* greedy_out, float* vmax_out,
-                              const dz_next_sample_t* next_sample, dz_stream_t stream) {
+                              dz_stream_t stream) {
   DZ_REQUIRE(params && states && noise && support && ws && q_values_out);
   dz_rainbow_layout_t L;
   int rc = dz_rainbow_layout(num_actions, num_atoms, batch, &L);
@@ -723,13 +722,6 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
   const int ld2 = L.adv2_ld + L.val2_ld;
   const bool fuse = (size_t)ld2 * sizeof(float) <= 48 * 1024;
   const NoiseParams nq = {noise, (long)L.noise_stride, noise_seed, noise_counter, step_counter};
-  // the following learner step's sample + gather, as extra blocks of the conv2 launch
-  SampleGatherParams sgq = {};
-  unsigned sgb = 0;
-  if (next_sample) {
-    rc = sample_gather_from_desc(next_sample, sgq, &sgb);
-    if (rc) return rc;
-  }
   // One observation: the whole decision is ONE launch (dz_act_one.h).
   if (batch == 1 && ld2 <= 1024 && num_atoms <= 64 && step_counter) {
     ActOneParams q;
@@ -749,12 +741,13 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
     q.bump = step_counter;
     q.sync = reinterpret_cast<unsigned*>(ws + L.ws_act_seams);   // zero in a fresh workspace, re-armed by the kernel
     q.set_floats = act_set_floats(1024); q.ncg = 8; q.part_ld = 1024;
+    q.spin_limit = g_dz_act_spin_limit;
 #ifdef DZ_ACT_STAMPS
     q.dbg = reinterpret_cast<long long*>(ws + L.ws_dfeat_part);
 #endif
     hipLaunchKernelGGL(rainbow_act_one_kernel,
-                       dim3((unsigned)(kActTorsoBlocks + kActFc1Blocks + q.tiles) + sgb), dim3(256), 0,
-                       s, q, sgq, sgb);
+                       dim3((unsigned)(kActTorsoBlocks + kActFc1Blocks + q.tiles)), dim3(256), 0,
+                       s, q);
     DZ_LAUNCH_CHECK();
     return DZ_OK;
   }
@@ -763,8 +756,7 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
   // Few rows: the tail (fc1 epilogue + fc2 + q-values) is ONE launch that folds the
   // fc1 slabs itself (rainbow_act_tail_kernel): 5 launches per decision instead of 7.
   const bool tail = batch <= 8 && ld2 <= 1024 && num_atoms <= 64;
-  rc = rainbow_forward(L, H, 1, batch, prm, nz, in, ws, s, &nq, fuse, tail,
-                       next_sample ? &sgq : nullptr, sgb);
+  rc = rainbow_forward(L, H, 1, batch, prm, nz, in, ws, s, &nq, fuse, tail);
   g_dz_prof_on = prof;
   if (rc) return rc;
   if (tail) {

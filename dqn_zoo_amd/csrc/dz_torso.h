@@ -36,14 +36,9 @@ inline int launch_conv1_fwd(const ConvFwdParams& p, int G, int B, const NoisePar
 // relu(conv3(relu(conv2(relu(conv1(u8/255)))))) for G groups; group g reads
 // images in[g] with parameters prm[g].  `side`: optional noise draw fused into
 // the conv1 launch.
-// `sg` / `sg_blocks`: optional replay sample + gather (dz_next_sample_t) carried by the
-// conv2 launch as extra blocks -- the actor's apply in a learn frame; neither reads the
-// other's data.
 inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* prm,
                          const uint8_t* const* in, hipStream_t s,
-                         const NoiseParams* side = nullptr,
-                         const SampleGatherParams* sg = nullptr, unsigned sg_blocks = 0,
-                         long long* dbg = nullptr) {
+                         const NoiseParams* side = nullptr, long long* dbg = nullptr) {
   int rc;
   {
     ConvFwdParams p;
@@ -64,11 +59,7 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
       p.w[g] = prm[g] + T.conv_w[1]; p.bias[g] = prm[g] + T.conv_b[1];
     }
     p.out = T.act2; p.B = B; p.G = G; p.dbg = dbg ? dbg + 65536 * 8 : nullptr;
-    if (sg)
-      rc = dz_launch_gemm_side<Conv2Fwd, SampleGatherSide>(
-          p, dim3(64 / Conv2Fwd::BN, G * Conv2Fwd::tiles_per_group(B), 1), *sg, sg_blocks, s);
-    else
-      rc = launch_conv_fwd<Conv2Fwd>(p, 64, G, B, s);
+    rc = launch_conv_fwd<Conv2Fwd>(p, 64, G, B, s);
     if (rc) return rc;
     DZ_PROF(s, "conv2_fwd");
   }

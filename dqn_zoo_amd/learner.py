@@ -9,6 +9,7 @@ library as raw device pointers; nothing is copied to the host unless asked.
 """
 
 import ctypes
+import time
 import typing
 
 import numpy as np
@@ -18,14 +19,25 @@ from dqn_zoo_amd import _lib
 from dqn_zoo_amd import networks
 
 
+class ActDecisionError(RuntimeError):
+  """A one-launch decision (dz_rainbow_act batch 1 / dz_dense_act) gave up on one of its
+  in-kernel seams (include/dqnzoo_hip.h: DZ_ACT_FAILED).  The workspace has been re-armed when
+  this is raised: the next decision starts from a clean seam area."""
+
+
 def read_packed_action(greedy: torch.Tensor, vmax: torch.Tensor):
   """Row 0 of (greedy int32 [B], vmax float32 [B]) that are views of ONE
   [2, B] int32 buffer: one 8*B-byte device->host copy instead of two syncs."""
   base = greedy._base if greedy._base is not None else None  # pylint: disable=protected-access
   if base is None or base.dim() != 2 or vmax.data_ptr() != base[1].data_ptr():
-    return int(greedy[0].item()), float(vmax[0].item())
-  h = base.cpu()
-  return int(h[0, 0]), float(h[1].view(torch.float32)[0])
+    a, v = int(greedy[0].item()), float(vmax[0].item())
+  else:
+    h = base.cpu()
+    a, v = int(h[0, 0]), float(h[1].view(torch.float32)[0])
+  if a == _lib.ACT_FAILED:
+    raise ActDecisionError('the one-launch decision gave up on a seam (DZ_ACT_FAILED): zero the '
+                           'ws_act_seams region of the acting workspace before the next decision')
+  return a, v
 
 
 def check_batch(b, s_tm1, a_tm1, r_t, discount_t, s_t, weights=None):
@@ -167,20 +179,14 @@ class RainbowLearner:
     self._noise_counter += n
 
   def apply(self, states: torch.Tensor, which: str = 'online', noise=None,
-            resample_noise: bool = True, packed_out=None, next_sample=None):
+            resample_noise: bool = True, packed_out=None):
     """One network apply on uint8 states [B,84,84,4] (device tensor).
     Returns device tensors (q_values [B,A] f32, greedy action [B] i32,
-    max_a q [B] f32).  ref: rainbow/agent.py:125-131 (select_action).
-
-    `next_sample` (descriptor from `replay.prepare_next_sample`, fresh-noise acting
-    applies only): the replay sample + gather of the learner step that follows this
-    decision rides in the apply's second launch (dz_rainbow_act); launched eagerly."""
+    max_a q [B] f32).  ref: rainbow/agent.py:125-131 (select_action)."""
     stream = _lib.stream_ptr(self.device)
     params = self.online if which == 'online' else self.target
-    if next_sample is not None and not (noise is None and resample_noise):
-      raise ValueError('next_sample rides in the fresh-noise acting apply only')
     if (packed_out is not None and noise is None and resample_noise and self.act_graphs and
-        stream and next_sample is None):
+        stream):
       # steady state of the agent loop: same observation slot, same result slot, same
       # parameters -> replay the captured launches, nothing to allocate
       # (the key carries shape and dtype: an address the allocator recycled for a
@@ -220,10 +226,8 @@ class RainbowLearner:
           a, self.network.num_atoms, b, params.data_ptr(), states.data_ptr(),
           self._act_noise.data_ptr(), self._noise_seed ^ 0xA5A5A5A5, 0,
           self._act_step.data_ptr(), self.support.data_ptr(), self._act_ws.data_ptr(),
-          q.data_ptr(), greedy.data_ptr(), vmax.data_ptr(),
-          None if next_sample is None else ctypes.addressof(next_sample), stream),
-                                   'dz_rainbow_act')
-      if (self.act_graphs and stream and packed_out is not None and next_sample is None and
+          q.data_ptr(), greedy.data_ptr(), vmax.data_ptr(), stream), 'dz_rainbow_act')
+      if (self.act_graphs and stream and packed_out is not None and
           len(self._act_graphs) < self.MAX_ACT_GRAPHS):
         # (a caller that hands over a fresh observation tensor per decision --
         # atari(device_observations=True) -- fills the cache with single-use graphs:
@@ -236,7 +240,7 @@ class RainbowLearner:
           args = (a, self.network.num_atoms, b, params.data_ptr(), states.data_ptr(),
                   self._act_noise.data_ptr(), self._noise_seed ^ 0xA5A5A5A5, 0,
                   self._act_step.data_ptr(), self.support.data_ptr(), self._act_ws.data_ptr(),
-                  q.data_ptr(), greedy.data_ptr(), vmax.data_ptr(), None)
+                  q.data_ptr(), greedy.data_ptr(), vmax.data_ptr())
           direct = lambda st: chk(fn(*args, st), 'dz_rainbow_act')
           self._act_graphs[key] = (None, q, greedy, vmax, direct)   # the same cache, no graph
           direct(stream)
@@ -256,11 +260,55 @@ class RainbowLearner:
     return q, greedy, vmax
 
   ACT_RING = 8   # acting results in flight (pinned host words)
-  ACT_POLL_SPINS = 200000   # polled reads of the slot before falling back to a stream sync
-  poll_action_slot = True
-  act_direct = True   # the one-launch decision (batch 1) is enqueued directly, not from a hipGraph
+  ACT_POLL_SECONDS = 2.0   # polled reads of the slot this long before falling back to a stream sync
+  last_act_fail = 0        # the sticky word found by the last reset
+  # (properties: toggling either drops the cached pre-bound enqueues and readers built for the
+  # other setting)
+  _poll_action_slot = True
+  _act_direct = True   # the one-launch decision (batch 1) is enqueued directly, not from a hipGraph
 
-  def apply_async(self, states: torch.Tensor, next_sample=None):
+  @property
+  def poll_action_slot(self):
+    return self._poll_action_slot
+
+  @poll_action_slot.setter
+  def poll_action_slot(self, v):
+    if bool(v) != self._poll_action_slot:
+      self._poll_action_slot = bool(v)
+      self._act_fast = {}
+
+  @property
+  def act_direct(self):
+    return self._act_direct
+
+  @act_direct.setter
+  def act_direct(self, v):
+    if bool(v) != self._act_direct:
+      self._act_direct = bool(v)
+      self._drop_act_graphs()
+
+  def act_seam_words(self):
+    """(generation, tickets, sticky failure) of the one-launch decision's seam area (synchronises)."""
+    if self._act_ws is None:
+      return (0, 0, 0)
+    off = int(self.network.layout(self._act_batch).c.ws_act_seams)
+    w = self._act_ws[off:off + 64 * 8:64].view(torch.int32).tolist()
+    return (w[3], w[4], w[5])
+
+  def _reset_act_seams(self) -> None:
+    """After a failed decision: waits for the device, records the sticky word and returns the
+    seam area (generation, tickets, sticky word, both sets of intermediates) to all-zero bits --
+    the state of a fresh workspace, from which the next decision is correct."""
+    torch.cuda.synchronize(self.device)
+    if self._act_ws is None:
+      return
+    lay = self.network.layout(self._act_batch).c
+    off = int(lay.ws_act_seams)
+    self.last_act_fail = int(self._act_ws[off + 5 * 64:off + 5 * 64 + 1].view(torch.int32).item())
+    self._act_ws[off:int(lay.ws_count)].zero_()
+    torch.cuda.synchronize(self.device)
+
+  def apply_async(self, states: torch.Tensor):
     """Acting apply whose (greedy action, max q) pair is written by the kernel
     straight into pinned, device-mapped HOST memory: no device->host copy is
     enqueued and nothing synchronises here.  Returns `read() -> (action, value)`
@@ -289,36 +337,62 @@ class RainbowLearner:
       words[0, 0] = -1
       # steady state of an agent loop: the same observation slot, result slot and parameters as
       # some earlier frame -> the pre-bound enqueue and the slot's reader, nothing else
-      fk = (states.data_ptr(), k, self.online.data_ptr(), states.shape)
-      fast = self._act_fast.get(fk) if next_sample is None else None
+      fk = (states.data_ptr(), k, self.online.data_ptr(), states.shape, _lib.stream_ptr(self.device))
+      fast = self._act_fast.get(fk)
       if fast is not None:
         fast[0](_lib.stream_ptr(self.device))
         return fast[1]
-      self.apply(states, packed_out=slot, next_sample=next_sample)
+      self.apply(states, packed_out=slot)
       device = self.device
       vals = words[1].view(np.float32)
 
-      def read_polled():
-        for _ in range(self.ACT_POLL_SPINS):
-          a = words[0, 0]
-          if a >= 0:
-            return int(a), float(vals[0])
-        torch.cuda.current_stream(device).synchronize()   # stuck or very slow: the stream decides
-        return int(words[0, 0]), float(vals[0])
+      enq_stream = _lib.current_stream(device)   # the stream THIS decision was enqueued on
+      owner = self
 
-      if next_sample is None:
-        g = self._act_graphs.get((states.data_ptr(), slot.data_ptr(), self.online.data_ptr(),
-                                  states.shape, states.dtype))
-        if g is not None and g[0] is None and states.dtype == torch.uint8:
-          self._act_fast[fk] = (g[4], read_polled)
+      def read_polled():
+        # plain loads of the pinned word; bounded by time (the GIL is held while spinning)
+        deadline = None
+        while True:
+          for _ in range(2000):
+            a = words[0, 0]
+            if a != -1:
+              break
+          if a != -1:
+            break
+          now = time.monotonic()
+          if deadline is None:
+            deadline = now + owner.ACT_POLL_SECONDS
+          elif now > deadline:
+            enq_stream.synchronize()   # stuck or very slow: the stream the kernel is on decides
+            a = words[0, 0]
+            break
+        if a < 0:
+          # DZ_ACT_FAILED (a seam of the decision kernel timed out: sticky word set) or the
+          # slot was never written: never hand the caller an action
+          owner._reset_act_seams()   # pylint: disable=protected-access
+          raise ActDecisionError(
+              'dz_rainbow_act: the one-launch decision did not complete (slot word %d, sticky '
+              'failure word %d); the acting workspace was re-armed' % (int(a), owner.last_act_fail))
+        return int(a), float(vals[0])
+
+      g = self._act_graphs.get((states.data_ptr(), slot.data_ptr(), self.online.data_ptr(),
+                                states.shape, states.dtype))
+      if g is not None and g[0] is None and states.dtype == torch.uint8:
+        self._act_fast[fk] = (g[4], read_polled)
       return read_polled
-    self.apply(states, packed_out=slot, next_sample=next_sample)
+    self.apply(states, packed_out=slot)
     ev = self._act_events[k]
     ev.record(_lib.current_stream(self.device))
+    owner = self
 
     def read():
       ev.synchronize()
-      return int(slot[0, 0]), float(slot[1].view(torch.float32)[0])
+      a = int(slot[0, 0])
+      if a == _lib.ACT_FAILED:   # (batch 1 is the one-launch decision whatever reads the slot)
+        owner._reset_act_seams()   # pylint: disable=protected-access
+        raise ActDecisionError('dz_rainbow_act: a seam of the one-launch decision timed out (sticky '
+                               'failure word %d); the acting workspace was re-armed' % owner.last_act_fail)
+      return a, float(slot[1].view(torch.float32)[0])
 
     return read
 
@@ -664,6 +738,18 @@ class DenseLearner:
     self._act_batch = b
 
   act_one_launch = True   # the decision for one state is ONE launch, its slot is polled
+  last_act_fail = 0
+
+  def _reset_act_seams(self) -> None:
+    """As RainbowLearner._reset_act_seams."""
+    torch.cuda.synchronize(self.device)
+    if self._act_ws is None:
+      return
+    lay = self.network.layout(self._act_batch, 1).c
+    off = int(lay.ws_act_seams)
+    self.last_act_fail = int(self._act_ws[off + 5 * 64:off + 5 * 64 + 1].view(torch.int32).item())
+    self._act_ws[off:int(lay.ws_count)].zero_()
+    torch.cuda.synchronize(self.device)
 
   def _q_async(self, states: torch.Tensor):
     """`head_async` as ONE launch (dz_dense_act): every head output (A q-values, or the
@@ -694,13 +780,25 @@ class DenseLearner:
               self._act_ws.data_ptr(), self._q_host[k].data_ptr())
       call = self._q_calls[key] = lambda st: chk(fn(*args, st), 'dz_dense_act')
     call(_lib.stream_ptr(self.device))
-    device, marks, vals = self.device, words[:, 1], words[:, 0]
+    marks, vals = words[:, 1], words[:, 0]
+    enq_stream = _lib.current_stream(self.device)   # the stream THIS decision was enqueued on
+    owner = self
 
     def read():
-      for _ in range(RainbowLearner.ACT_POLL_SPINS):
-        if marks.all():
-          return vals.copy()
-      torch.cuda.current_stream(device).synchronize()
+      deadline = None
+      while not marks.all():
+        now = time.monotonic()
+        if deadline is None:
+          deadline = now + RainbowLearner.ACT_POLL_SECONDS
+        elif now > deadline:
+          enq_stream.synchronize()   # stuck or very slow: the stream the kernel is on decides
+          break
+      if not marks.all() or (marks == _lib.ACT_FAILED_MARKER).any():
+        # a seam of the decision kernel timed out (DZ_ACT_FAILED_MARKER) or outputs never arrived
+        owner._reset_act_seams()   # pylint: disable=protected-access
+        raise ActDecisionError(
+            'dz_dense_act: the one-launch decision did not complete (sticky failure word %d); '
+            'the acting workspace was re-armed' % owner.last_act_fail)
       return vals.copy()
 
     return read

@@ -69,16 +69,6 @@ class Rainbow(parts.Agent):
     self._statistics = {'state_value': np.nan}
     self._obs = device_obs.ObservationCache(
         self._device, depth=device_obs.depth_for(transition_accumulator))
-    # True: in a learn frame the replay sample + gather ride in the decision's launch as its LAST
-    # blocks (after the frame's inserts were enqueued) and `_learn` enqueues the 14 launches of
-    # the update alone -- bit-identical to the separate sample launch (tests/test_agent_gpu.py),
-    # one launch fewer per learn period, and MEASURED SLOWER in this loop
-    # (tools/agent_loop_bench.py, same box: 10.76-10.82 k vs 11.09-11.16 k agent steps/s; as blocks
-    # of the five-launch apply's conv2 launch in round 4's first form 7.93-8.01 k vs 8.17-8.23 k):
-    # the GPU saves the 9 us sample launch, but the host's part of the sample (RNG draws, the
-    # descriptor) moves IN FRONT of the decision's enqueue, which is what the loop waits for.
-    # Off by default; EXPERIMENTS.md.
-    self.fuse_sample_into_acting = False
 
   # -- acting / stepping -------------------------------------------------------
   def step(self, timestep) -> parts.Action:
@@ -86,38 +76,28 @@ class Rainbow(parts.Agent):
     (ref: rainbow/agent.py:135-160)."""
     self._frame_t += 1
     timestep = self._preprocessor(timestep)
-    prepared = False
 
     if timestep is None:  # repeat action
       if self._action is None:
         raise RuntimeError('Cannot repeat if action has never been selected.')
       action = self._action
     else:
-      # Order of the ENQUEUED work: inserts, acting apply, learner step.  The reference
-      # runs act -> add -> learn (rainbow/agent.py:141-155); the insert needs nothing the
-      # apply computes (the accumulator only STORES a_t, parts.PendingAction, for
-      # transitions it emits on later steps) and the apply does not read the replay, so
-      # the inserts go first and the learner step's sample -- which must see them --
-      # can ride in the apply's launches instead of being a launch of its own.
+      # The reference's order, act -> add -> learn (rainbow/agent.py:141-155), as ENQUEUED work:
+      # the decision kernel first (greedy action w.r.t. a freshly-noised online network,
+      # rainbow/agent.py:171-179: enqueued, not awaited; the (action, value) pair lands in pinned
+      # host memory), then the inserts -- whose host time runs under the decision kernel --
+      # then the learner step.  The accumulator only STORES a_t (parts.PendingAction) for
+      # transitions it emits on later steps.
       obs_d = self._obs.upload(timestep.observation)
-      read = []
-      action = parts.PendingAction(lambda: read[0]())
+      action = parts.PendingAction(self._learner.apply_async(obs_d))
       for transition in self._transition_accumulator.step(timestep, action):
         # priority = running max priority, kept on the device (agent.py:149)
         # both states are already in HBM (uploaded for acting): no re-upload
         self._replay.add_with_device_priority(self._obs.on_device(transition))
-      desc = None
-      if (self.fuse_sample_into_acting and self._learn_now() and
-          self._batch_size <= self._replay.MAX_PREPARED_BATCH):
-        desc, _ = self._replay.prepare_next_sample(self._batch_size)
-        prepared = True
-      # greedy action w.r.t. a freshly-noised online network (rainbow/agent.py:171-179):
-      # enqueued, not awaited; the (action, value) pair lands in pinned host memory
-      read.append(self._learner.apply_async(obs_d, next_sample=desc))
 
     if self._replay.size >= self._min_replay_capacity:
       if self._frame_t % self._learn_period == 0:
-        self._learn(prepared)
+        self._learn()
         # a NaN/inf/negative priority or weight flagged by an earlier step's kernels
         # (sticky word in pinned host memory: a plain load, nothing is awaited)
         self._replay.poll_status()
@@ -143,18 +123,10 @@ class Rainbow(parts.Agent):
     processors.reset(self._preprocessor)
     self._action = None
 
-  def _learn_now(self) -> bool:
-    """The learning gate of this frame (ref: rainbow/agent.py:151-153), evaluated
-    after the frame's inserts."""
-    return (self._replay.size >= self._min_replay_capacity and
-            self._frame_t % self._learn_period == 0)
-
-  def _learn(self, prepared: bool = False) -> None:
+  def _learn(self) -> None:
     """Samples a batch and learns from it, entirely on the device
-    (ref: rainbow/agent.py:181-198).  `prepared`: the sample + gather were carried
-    by this frame's acting apply (`step`); 14 launches instead of 15."""
-    s = (self._replay.take_prepared() if prepared
-         else self._replay.sample_device(self._batch_size))
+    (ref: rainbow/agent.py:181-198)."""
+    s = self._replay.sample_device(self._batch_size)
     t = s.transitions
     # priorities = clip(|losses|, 0, 100) are written by the loss kernel and go
     # straight into the sum tree (and the running max priority) inside the

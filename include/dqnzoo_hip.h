@@ -392,30 +392,36 @@ int dz_rainbow_apply(int num_actions, int num_atoms, int batch, const float* par
  * the call can be captured once (dz_graph_capture_begin/end) and replayed per
  * decision.  greedy_out / vmax_out may point into pinned, device-mapped host
  * memory (the action is then on the host when the stream reaches that point).
- * next_sample (nullable): the replay sample + gather of the learner step that FOLLOWS
- * this decision (rainbow/agent.py:141-155: act, add, then -- every learn_period
- * frames -- sample and learn) rides in the apply's second launch as extra blocks:
- * exactly dz_prioritized_sample_gather / dz_replay_sample_uniform with these
- * arguments.  The caller enqueues the frame's replay inserts BEFORE this call (the
- * sample must see them; the apply does not read the replay) and then learns from the
- * descriptor's buffers instead of sampling: one launch fewer per learn period, same
- * ids, weights and rows.  The draws are by-value kernel arguments: such a call is
- * not graph-capturable.
  * batch == 1 with a step_counter (the agent's decision): the whole apply is ONE launch
  * (csrc/dz_act_one.h); `ws` must have been all-zero when it was created and its
  * ws_act_seams region must be touched by nothing else (the kernel keeps a generation
  * word and two alternating sets of intermediates there).  With greedy_out and vmax_out
  * adjacent and 8-byte aligned the pair is written with ONE 8-byte store: a host that set
- * the action word to -1 before the call may poll it with plain loads.  next_sample then
- * rides as the last blocks of that launch.  Every in-kernel wait is bounded: a failure
- * returns NaN q-values and sets the sticky word at ws_act_seams + 5 * 64.
+ * the action word to -1 before the call may poll it with plain loads.
+ * Liveness of the one-launch form: its workgroup roles (torso -> fc1 -> tail) wait for each
+ * other inside the launch, with dependencies pointing from lower to higher block ids only.
+ * That is deadlock-free under the dispatch order CDNA hardware implements (linear ids dealt
+ * round-robin to the XCDs, each XCD starting its share in ascending order) WITHOUT any
+ * co-residency requirement -- other streams may fill the chip -- but HIP does not promise
+ * that order, so every in-kernel wait is bounded: a seam that stays empty for
+ * dz_act_debug_spin_limit() polling rounds sets the sticky word at ws_act_seams + 5 * 64 and
+ * the decision comes back as greedy = DZ_ACT_FAILED with NaN value and NaN q-values --
+ * never as an action -- for this and every later call until the caller zeroes the
+ * ws_act_seams region (ws_count - ws_act_seams floats) again.
  * ref: rainbow/agent.py:125-131, 171-179 (select_action with a fresh key).    */
+#define DZ_ACT_FAILED (-2)
 int dz_rainbow_act(int num_actions, int num_atoms, int batch, const float* params,
                    const uint8_t* states, float* noise, uint64_t noise_seed,
                    uint64_t noise_counter, int32_t* step_counter,
                    const float* support, float* ws,
                    float* q_values_out, int32_t* greedy_out, float* vmax_out,
-                   const dz_next_sample_t* next_sample, dz_stream_t stream);
+                   dz_stream_t stream);
+
+/* Test hook of the one-launch decision kernels (dz_rainbow_act batch 1, dz_dense_act):
+ * sets the number of polling rounds a workgroup spends on an empty seam before it gives up
+ * (default 200000, >= 5 ms) and returns the previous value; limit < 0 only queries.  0 makes
+ * every consumer give up at its first look, i.e. forces the failure path described above. */
+int dz_act_debug_spin_limit(int limit);
 
 /* hipGraph form of dz_rainbow_learn: captures the launches of one call (same
  * args, same phases; every pointer in `args` is baked in) on `stream` and
@@ -541,7 +547,10 @@ int dz_dense_apply(int num_actions, int num_outputs, int shared_bias, int batch,
  * num_outputs 8-byte words {float value, float 1.0f}, each written with ONE store -- a
  * host that zeroed the words before the call may poll them with plain loads instead of
  * waiting for the stream, and then forms q-values from the head outputs as the
- * reference's network does (softmax expectation / quantile mean / identity).       */
+ * reference's network does (softmax expectation / quantile mean / identity).
+ * Liveness and failure: as dz_rainbow_act's one-launch form; a decision whose seams timed
+ * out (or that found the sticky word set) delivers {NaN, DZ_ACT_FAILED_MARKER} words.  */
+#define DZ_ACT_FAILED_MARKER 2.0f
 int dz_dense_act(int num_outputs, int shared_bias, const float* params,
                  const uint8_t* state, float* ws, void* pairs_out, dz_stream_t stream);
 

@@ -339,16 +339,14 @@ def test_set_state_restores_the_noise_streams_of_a_stepped_agent():
   assert a1.learner.act_step() == a2.learner.act_step()
 
 
-def test_sample_carried_by_the_acting_apply_is_bit_identical():
-  """in a learn frame the learner step's sample + gather ride in the
-  acting apply's second launch (dz_rainbow_act next_sample), after the frame's inserts --
-  the agent loop must produce the SAME actions, sampled ids, losses, parameters, tree
-  and running max priority as the loop with the separate sample launch, frame by frame
-  (n-step flushes at episode ends, learn_period 2, target syncs included)."""
-  def run(fuse):
+def test_agent_loop_is_reproducible_frame_by_frame():
+  """Two runs of the drop-in loop (act -> add -> learn, n-step flushes at episode ends,
+  learn_period 2, target syncs) from the same seeds produce the SAME actions, losses,
+  parameters, tree and running max priority, frame by frame: nothing in the enqueue order
+  (decision kernel, inserts, learner step) depends on timing."""
+  def run():
     ag, rep = _make_agent(seed=3, capacity=200, batch=10, learn_period=2, target_period=15,
                           min_frac=0.05)
-    ag.fuse_sample_into_acting = fuse
     env = SyntheticEnv(7, episode_length=13)
     ts = env.reset()
     ag.reset()
@@ -367,7 +365,7 @@ def test_sample_carried_by_the_acting_apply_is_bit_identical():
     return (log, ag.learner.online.cpu().numpy(), ag.learner.target.cpu().numpy(),
             rep.tree_storage.cpu().numpy(), ag.max_seen_priority, rep.size)
 
-  a, b = run(False), run(True)
+  a, b = run(), run()
   assert a[0][-1][1] >= 30            # it learned (both loops the same number of steps)
   for (aa, ca, la), (ab, cb, lb) in zip(a[0], b[0]):
     assert aa == ab and ca == cb
