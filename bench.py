@@ -83,6 +83,9 @@ def parse_args():
   ap.add_argument('--agent-form-steps', type=int, default=1000,
                   help='steps of the sequential form (what Rainbow._learn enqueues) timed '
                        'after the headline window for `agent_form` (0 disables)')
+  ap.add_argument('--separate-launches', action='store_true',
+                  help='one launch per stage of the head chain (learner.separate_launches) instead '
+                       'of the default multi-role launch: same-box A/B')
   ap.add_argument('--agent-loop-frames', type=int, default=6000,
                   help='frames of the whole drop-in loop (parts.run_loop: act -> insert -> learn '
                        'every 4th frame; Rainbow and DQN agents on a synthetic environment) timed '
@@ -139,6 +142,7 @@ def build_workload(args, device, seed):
   learner = learner_lib.RainbowLearner(net, learner_lib.AdamConfig(), b,
                                        seed=seed, device=device)
   learner.keep_all_grads = bool(getattr(args, 'stored_gradients', False))
+  learner.separate_launches = bool(getattr(args, 'separate_launches', False))
   torch.cuda.synchronize(device)
   return replay, learner, None
 

@@ -24,6 +24,7 @@ ST_BAD_TARGET = 2
 ST_BAD_INDEX = 4
 ST_ZERO_ROOT = 8
 ST_NONFINITE_WEIGHT = 16
+ST_CHAIN_TIMEOUT = 32
 
 MAX_FIELDS = 8
 
@@ -87,7 +88,7 @@ class RainbowArgs(ctypes.Structure):
       ('noise_seed', ctypes.c_uint64),
       ('prio_node', c_vp), ('prio_cap_pow2', c_i64), ('prio_capacity', c_i64),
       ('prio_ids', c_vp), ('prio_exponent', c_f64), ('prio_max_seen', c_vp),
-      ('prio_status', c_vp), ('keep_all_grads', c_i32), ('pad_', c_i32),
+      ('prio_status', c_vp), ('keep_all_grads', c_i32), ('separate_launches', c_i32),
       ('next_sample', c_vp),
   ]
 
@@ -172,6 +173,7 @@ class IqnArgs(ctypes.Structure):
 LOSS_Q, LOSS_DOUBLE_Q, LOSS_CATEGORICAL, LOSS_QUANTILE = 0, 1, 2, 3
 OPT_RMSPROP, OPT_ADAM = 0, 1
 SC_GNORM, SC_LOSS, SC_BC1, SC_BC2, SC_CLIP = 0, 1, 2, 3, 4
+SC_CHAIN_FAIL = 6
 PHASE_FORWARD, PHASE_BACKWARD, PHASE_OPTIMIZER, PHASE_ALL = 1, 2, 4, 7
 PHASE_FWD_NETS, PHASE_FWD_LOSS = 8, 16   # the two halves of PHASE_FORWARD
 

@@ -50,6 +50,7 @@
 #pragma once
 
 #include "dz_qnet_kernels.h"
+#include "dz_seam.h"
 #include "dz_sumtree_dev.h"
 
 namespace {
@@ -71,7 +72,6 @@ constexpr int kActSeamWords = act_seam_words(1024), kDenseActSeamWords = act_sea
 constexpr int kActLdsFloats = 8 * 20 * 36 + 4 * 256;   // largest patch (conv2) + partial tiles
 static_assert(kActFc1Splits * kActFc1Rows == kFlat, "fc1 K-splits");
 
-#define DZ_ACT_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 // (tools builds, -DDZ_ACT_STAMPS) per-workgroup wall-clock stamps in the idle dfeat slab buffer
 #ifdef DZ_ACT_STAMPS
 #define ACT_STAMP(i) do { if (threadIdx.x == 0) p.dbg[blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)
@@ -118,42 +118,11 @@ struct DenseActParams : ActTorso {    // dense heads: linear(512) + ReLU + linea
   unsigned long long* pairs_out;      // [N] {float output, float 1.0f}: one 8-byte store each
 };
 
-// ---- seams -----------------------------------------------------------------------------------
-__device__ __forceinline__ void act_store(float* p, float v) { __hip_atomic_store(p, v, DZ_ACT_RLX); }
-__device__ __forceinline__ float act_load(const float* p) {
-  return __hip_atomic_load(p, DZ_ACT_RLX);
-}
-__device__ __forceinline__ float2 act_load2(const float* p) {   // 8-byte aligned
-  const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, DZ_ACT_RLX);
-  return make_float2(__builtin_bit_cast(float, (unsigned)(v & 0xffffffffull)),
-                     __builtin_bit_cast(float, (unsigned)(v >> 32)));
-}
-// a zero is stored as -0.0f: all-zero bits mean "not written yet"
-__device__ __forceinline__ float act_mark(float v) { return v == 0.f ? -0.f : v; }
-__device__ __forceinline__ bool act_missing(float v) { return __builtin_bit_cast(unsigned, v) == 0u; }
+// ---- seams (primitives: dz_seam.h) ------------------------------------------------------------
 __device__ __forceinline__ unsigned* act_line(unsigned* sync, int i) { return sync + 64 * i; }
 __device__ __forceinline__ float* act_set(const ActTorso& p, unsigned gen) {
   return (float*)(p.sync + 64 * 8) + (gen & 1u) * p.set_floats;
 }
-// Before the polling rounds: ONE thread watches ONE of the words the workgroup needs (224 x 256
-// threads re-reading 14 words each starved every other access of the chip: 38 us per decision).
-// The rounds that follow see the rest, written within a microsecond of it.
-__device__ __forceinline__ void act_watch(const float* word, int limit) {
-  if (threadIdx.x == 0)
-    for (int i = 0; i < limit && act_missing(act_load(word)); ++i) __builtin_amdgcn_s_sleep(2);
-  __syncthreads();
-}
-// One polling round ends here: true = some thread still saw a missing value (go round again);
-// after `limit` rounds the sticky failure word is set and *give_up becomes true.
-__device__ __forceinline__ bool act_again(bool miss, int round, unsigned* fail, bool* give_up,
-                                          int limit) {
-  const bool again = __syncthreads_or(miss ? 1 : 0) != 0;
-  *give_up = again && round >= limit;
-  if (*give_up && threadIdx.x == 0) __hip_atomic_store(fail, 1u, DZ_ACT_RLX);
-  if (again) __builtin_amdgcn_s_sleep(1);
-  return again && !*give_up;
-}
-
 // ---- torso -----------------------------------------------------------------------------------
 // 16x16x4 operand maps: A lane l = A[l & 15][l >> 4], B lane l = B[l >> 4][l & 15],
 // D lane l reg r = D[4 (l >> 4) + r][l & 15].  The k's of one MFMA step are ANY four k's as long

@@ -6,6 +6,7 @@
 
 #include "dz_fc_stream.h"
 #include "dz_gram.h"
+#include "dz_seam.h"
 #include "dz_sumtree_dev.h"
 
 namespace {
@@ -440,27 +441,38 @@ struct HeadPre {
 };
 // Launch with 256 threads: the 4 waves share the selector's per-action softmaxes
 // (A of them, 3 wave reductions each); wave 0 alone runs the rest.
-template <int PRE>
-__global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
-    float* __restrict__ fc2_out, int ld, int val_off, int B, int A, int K,
-    int dueling, int sel_group, int tgt_group, const int64_t* __restrict__ a_tm1, const double* __restrict__ r_t,
-    const double* __restrict__ d_t, const float* __restrict__ weights,
-    const float* __restrict__ support, float* __restrict__ dout2,
-    float* __restrict__ losses, float* __restrict__ priorities,
-    float* __restrict__ q_sel_out, float* __restrict__ target_out, HeadPre pre,
-    GramX gram = GramX{}) {
-  extern __shared__ float s_rows[];  // PRE: [3][ld]
-  // workgroups beyond the batch: the wide layer's input Grams (dz_gram.h), which need
-  // nothing this kernel computes and run on CUs it leaves idle
-  if ((int)blockIdx.x >= B) {
-    __shared__ dz_d4 s_gram[3 * 64];
-    dz_gram_x_block(gram, blockIdx.x - (unsigned)B, s_gram);
-    return;
-  }
+struct HeadLossArgs {
+  float* fc2_out; int ld, val_off, B, A, K, dueling, sel_group, tgt_group;
+  const int64_t* a_tm1; const double* r_t; const double* d_t; const float* weights;
+  const float* support; float* dout2; float* losses; float* priorities;
+  float* q_sel_out; float* target_out; HeadPre pre;
+};
+// SEAM = 1 (the multi-role head launch, dz_head_chain.h): the fc2 slabs are produced by other
+// workgroups of the SAME launch -- they are read with coherent loads until none of the real
+// columns is missing (dz_seam.h) -- and dlogits are stored as a seam for the backward role.
+#ifndef DZ_HC_NAP_C
+#define DZ_HC_NAP_C 8
+#endif
+struct HeadSeam {
+  unsigned* fail = nullptr; int limit = 0;
+  int stages = 0, tiles0 = 0, tiles = 0, groups = 0;   // the producers: (stage, 64-column tile, apply)
+  long long* dbg = nullptr;                            // (DZ_HC_STAMPS builds)
+};
+template <int PRE, int SEAM>
+__device__ __forceinline__ void rainbow_head_loss_block(const HeadLossArgs& q, const int b,
+                                                        float* s_rows, const HeadSeam seam) {
+  float* const fc2_out = q.fc2_out;
+  const int ld = q.ld, val_off = q.val_off, B = q.B, A = q.A, K = q.K, dueling = q.dueling;
+  const int sel_group = q.sel_group, tgt_group = q.tgt_group;
+  const int64_t* const a_tm1 = q.a_tm1; const double* const r_t = q.r_t; const double* const d_t = q.d_t;
+  const float* const weights = q.weights; const float* const support = q.support;
+  float* const dout2 = q.dout2; float* const losses = q.losses; float* const priorities = q.priorities;
+  float* const q_sel_out = q.q_sel_out; float* const target_out = q.target_out;
+  const HeadPre& pre = q.pre;
   __shared__ float s_p[64];
   __shared__ float s_z[64];
   __shared__ float s_q[256];         // selector q-values (A <= 256)
-  const int b = blockIdx.x, k = threadIdx.x & 63;
+  const int k = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   // every per-sample scalar and the support are requested NOW, so that their
   // trips to memory overlap the slab loads below instead of following them
@@ -477,25 +489,131 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
     // number of round trips, not the 34 KB, is what this phase costs).
     constexpr int E = 5, SMAX = 8;
     const int n = (pre.groups ? pre.groups : 3) * ld;
+    if constexpr (SEAM) {
+      // one word per producer first: this sample's row of every (stage, column tile, apply)
+      // workgroup of the fc2 role (the first column of its tile)
+      const int np = seam.stages * seam.tiles * seam.groups;
+      for (int t0 = 0; t0 < np; t0 += 256) {   // (np <= 192 for every Atari action set: one trip)
+        const int t = t0 + (int)threadIdx.x;
+        const int st = t % seam.stages, gt = t / seam.stages, ct = gt % seam.tiles, g = gt / seam.tiles;
+        const int col = ct < seam.tiles0 ? 64 * ct : val_off + 64 * (ct - seam.tiles0);
+        const float* word = t < np ? pre.part + ((long)st * pre.rows + (long)g * B + b) * ld + col : nullptr;
+        if (act_watch_each<DZ_HC_NAP_C>(word, seam.fail, seam.limit)) {
+          if (threadIdx.x == 0) { losses[b] = __builtin_nanf(""); priorities[b] = __builtin_nanf(""); }
+          return;
+        }
+      }
+#ifdef DZ_HC_STAMPS
+      if (seam.dbg && threadIdx.x == 0) seam.dbg[1] = (long long)wall_clock64();
+#endif
+    }
+    if constexpr (SEAM) {
+      // 16-byte coherent loads: a thread owns four columns of one apply's row and reads their
+      // four stage slabs; fold order as below (slab order from 0.f, then the sigma bias)
+      const int ld4 = ld >> 2, n4 = (pre.groups ? pre.groups : 3) * ld4;
+      const __amdgpu_buffer_rsrc_t pr = act_rsrc(pre.part);
+      for (int base = 0; base < n4; base += 512) {
+        float4 v[2][4], bs4[2];
+        unsigned okc[2][4];
+        int round = 0;
+        bool miss = false, give_up = false;
+        do {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int i = min(base + (int)threadIdx.x + 256 * e, n4 - 1);
+            const int g = i / ld4, c = 4 * (i - g * ld4);
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+              v[e][st] = act_load4(pr, (unsigned)((st * pre.rows + g * B + b) * ld + c) * 4u);
+            const float* prm = g == 0 ? pre.prm[0] : (g == 1 ? pre.prm[1] : pre.prm[2]);
+            const float* nz = g == 0 ? pre.nz[0] : (g == 1 ? pre.nz[1] : pre.nz[2]);
+            const float4 ez = dz_ld4(nz + pre.eps_out + c), sb = dz_ld4(prm + pre.b_sig + c);
+            bs4[e] = dz_f4(sb.x * (pre.plain_bias ? 1.0f : ez.x), sb.y * (pre.plain_bias ? 1.0f : ez.y),
+                           sb.z * (pre.plain_bias ? 1.0f : ez.z), sb.w * (pre.plain_bias ? 1.0f : ez.w));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)   // (pad columns: nothing to wait for)
+              okc[e][j] = (c + j < A * K || (dueling && c + j >= val_off && c + j < val_off + K)) ? 0u : 1u;
+          }
+          unsigned all = 1u;
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+              all &= okc[e][0] | (__builtin_bit_cast(unsigned, v[e][st].x) != 0u ? 1u : 0u);
+              all &= okc[e][1] | (__builtin_bit_cast(unsigned, v[e][st].y) != 0u ? 1u : 0u);
+              all &= okc[e][2] | (__builtin_bit_cast(unsigned, v[e][st].z) != 0u ? 1u : 0u);
+              all &= okc[e][3] | (__builtin_bit_cast(unsigned, v[e][st].w) != 0u ? 1u : 0u);
+            }
+          miss = all == 0u;
+        } while (act_again(miss, round++, seam.fail, &give_up, seam.limit));
+        if (give_up) {   // (workgroup-uniform) the slabs never came: this sample's results are not numbers
+          if (threadIdx.x == 0) { losses[b] = __builtin_nanf(""); priorities[b] = __builtin_nanf(""); }
+          return;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int i = base + (int)threadIdx.x + 256 * e;
+          if (i < n4) {
+            const int g = i / ld4, c = 4 * (i - g * ld4);
+            float4 acc = dz_f4zero();
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+              acc.x += v[e][st].x; acc.y += v[e][st].y; acc.z += v[e][st].z; acc.w += v[e][st].w;
+            }
+            // (the one-launch-per-stage form adds four empty slabs here: x + 0.f)
+            acc.x += 0.f; acc.y += 0.f; acc.z += 0.f; acc.w += 0.f;
+            acc.x += bs4[e].x; acc.y += bs4[e].y; acc.z += bs4[e].z; acc.w += bs4[e].w;
+            *(float4*)(s_rows + g * ld + c) = acc;
+            *(float4*)(fc2_out + ((long)g * B + b) * ld + c) = acc;
+          }
+        }
+      }
+    } else
     for (int base = 0; base < n; base += 256 * E) {
       float v[E][SMAX];
       float bs[E];
+      unsigned okc[E];
+      int round = 0;
+      bool miss = false, give_up = false;
+      do {
+        miss = false;
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const int i = min(base + (int)threadIdx.x + 256 * e, n - 1);
-        const int g = i / ld, c = i - g * ld;
-        const float* src = pre.part;
-        const long row = (long)g * B + b;
-        const long rows = (long)pre.rows;
+        for (int e = 0; e < E; ++e) {
+          const int i = min(base + (int)threadIdx.x + 256 * e, n - 1);
+          const int g = i / ld, c = i - g * ld;
+          const float* src = pre.part;
+          const long row = (long)g * B + b;
+          const long rows = (long)pre.rows;
+          // (pad columns are never written by the producers: not waited for, and zero)
+          const bool real = c < A * K || (dueling && c >= val_off && c < val_off + K);
 #pragma unroll
-        for (int sidx = 0; sidx < SMAX; ++sidx) {
-          const float t = src[((long)min(sidx, pre.S - 1) * rows + row) * ld + c];
-          v[e][sidx] = sidx < pre.S ? t : 0.f;
+          for (int sidx = 0; sidx < SMAX; ++sidx) {
+            const float* sp = src + ((long)min(sidx, pre.S - 1) * rows + row) * ld + c;
+            float t;
+            if constexpr (SEAM) t = act_load(sp);
+            else t = *sp;
+            v[e][sidx] = sidx < pre.S ? t : 0.f;
+          }
+          okc[e] = real ? 0u : 1u;   // (pad columns: nothing to wait for)
+          const float* prm = g == 0 ? pre.prm[0] : (g == 1 ? pre.prm[1] : pre.prm[2]);
+          const float* nz = g == 0 ? pre.nz[0] : (g == 1 ? pre.nz[1] : pre.nz[2]);
+          const float ez = nz[pre.eps_out + c];
+          bs[e] = prm[pre.b_sig + c] * (pre.plain_bias ? 1.0f : ez);
         }
-        const float* prm = g == 0 ? pre.prm[0] : (g == 1 ? pre.prm[1] : pre.prm[2]);
-        const float* nz = g == 0 ? pre.nz[0] : (g == 1 ? pre.nz[1] : pre.nz[2]);
-        const float ez = nz[pre.eps_out + c];
-        bs[e] = prm[pre.b_sig + c] * (pre.plain_bias ? 1.0f : ez);
+        if constexpr (SEAM) {   // the checks behind ALL the loads, branch-free
+          unsigned all = 1u;
+#pragma unroll
+          for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int sidx = 0; sidx < SMAX; ++sidx)
+              all &= (okc[e] | (sidx >= pre.S ? 1u : 0u) |
+                      (__builtin_bit_cast(unsigned, v[e][sidx]) != 0u ? 1u : 0u));
+          miss = all == 0u;
+        }
+      } while (SEAM && act_again(miss, round++, seam.fail, &give_up, seam.limit));
+      if (SEAM && give_up) {   // (workgroup-uniform) the slabs never came: this sample's results are not numbers
+        if (threadIdx.x == 0) { losses[b] = __builtin_nanf(""); priorities[b] = __builtin_nanf(""); }
+        return;
       }
 #pragma unroll
       for (int e = 0; e < E; ++e) {
@@ -512,6 +630,9 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
       }
     }
     __syncthreads();
+#ifdef DZ_HC_STAMPS
+    if (SEAM && seam.dbg && threadIdx.x == 0) seam.dbg[2] = (long long)wall_clock64();
+#endif
   }
   const bool on = k < K;
   const int NA = val_off;  // value-head columns start at the padded offset
@@ -656,14 +777,43 @@ __global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
   const float gk = on ? (sm0 * msum - m) * (w_b / (float)B) : 0.f;
   if (on) {
     float* d = dout2 + (long)b * ld;
-    for (int a = 0; a < A; ++a)  // dueling: dadv[a][k] = G[a][k] - mean_a G[.][k]
-      d[a * K + k] = (a == a0 ? gk : 0.f) - (dueling ? gk * invA : 0.f);
-    if (dueling) d[NA + k] = gk;  // dval[k] = sum_a G[a][k]
+    for (int a = 0; a < A; ++a) {  // dueling: dadv[a][k] = G[a][k] - mean_a G[.][k]
+      const float dv = (a == a0 ? gk : 0.f) - (dueling ? gk * invA : 0.f);
+      if constexpr (SEAM) act_store(d + a * K + k, act_mark(dv));
+      else d[a * K + k] = dv;
+    }
+    if (dueling) {  // dval[k] = sum_a G[a][k]
+      if constexpr (SEAM) act_store(d + NA + k, act_mark(gk));
+      else d[NA + k] = gk;
+    }
   }
   if (k == 0) {
     losses[b] = loss;
     priorities[b] = fminf(fmaxf(fabsf(loss), 0.f), 100.f);
   }
+}
+
+
+template <int PRE>
+__global__ __launch_bounds__(256) void rainbow_head_loss_kernel(
+    float* __restrict__ fc2_out, int ld, int val_off, int B, int A, int K,
+    int dueling, int sel_group, int tgt_group, const int64_t* __restrict__ a_tm1, const double* __restrict__ r_t,
+    const double* __restrict__ d_t, const float* __restrict__ weights,
+    const float* __restrict__ support, float* __restrict__ dout2,
+    float* __restrict__ losses, float* __restrict__ priorities,
+    float* __restrict__ q_sel_out, float* __restrict__ target_out, HeadPre pre,
+    GramX gram = GramX{}) {
+  extern __shared__ float s_rows[];  // PRE: [3][ld]
+  // workgroups beyond the batch: the wide layer's input Grams (dz_gram.h), which need
+  // nothing this kernel computes and run on CUs it leaves idle
+  if ((int)blockIdx.x >= B) {
+    __shared__ dz_d4 s_gram[3 * 64];
+    dz_gram_x_block(gram, blockIdx.x - (unsigned)B, s_gram);
+    return;
+  }
+  const HeadLossArgs q = {fc2_out, ld, val_off, B, A, K, dueling, sel_group, tgt_group, a_tm1, r_t, d_t,
+                          weights, support, dout2, losses, priorities, q_sel_out, target_out, pre};
+  rainbow_head_loss_block<PRE, 0>(q, (int)blockIdx.x, s_rows, HeadSeam{});
 }
 
 // Partial sums of squares of the gradient (global norm) -- and the optimiser step
@@ -921,6 +1071,34 @@ struct NoiseSide {
     noise_fill_at(q, (long)block * 256 + threadIdx.x);
   }
 };
+
+// ---- the seam buffers go back to all-zero bits: side job of the step's first launch ---------------
+struct SeamClear {
+  float* ptr[3] = {nullptr, nullptr, nullptr};
+  int n4[3] = {0, 0, 0};                 // float4 counts
+  unsigned blocks = 0;                   // ceil(sum n4 / 256)
+};
+__device__ __forceinline__ void seam_clear_block(const SeamClear& q, unsigned blk) {
+  int i = (int)blk * 256 + (int)threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (i >= 0 && i < q.n4[j]) {
+      float* d = q.ptr[j] + 4 * (long)i;
+      act_store2(d, 0.f, 0.f); act_store2(d + 2, 0.f, 0.f);
+    }
+    i -= q.n4[j];
+  }
+}
+// Noise draw + seam clear as ONE side job of the conv1 forward launch.
+struct StepPre { NoiseParams noise; unsigned noise_blocks; SeamClear clr; };
+struct StepPreSide {
+  typedef StepPre Params;
+  __device__ static void run(const Params& q, unsigned block) {
+    if (block < q.noise_blocks) noise_fill_at(q.noise, (long)block * 256 + threadIdx.x);
+    else seam_clear_block(q.clr, block - q.noise_blocks);
+  }
+};
+
 
 // q_values[b][a] = sum_k softmax(v + adv_a - mean_a adv)[k] * support[k]
 // (ref: networks.py:254-258); also the greedy action and its value

@@ -24,6 +24,7 @@
 #include "dz_row_dgrad.h"
 #include "dz_fc1_dgrad.h"
 #include "dz_act_one.h"
+#include "dz_head_chain.h"
 
 namespace {
 
@@ -79,7 +80,8 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
                            const float* const* prm, const float* const* nz,
                            const uint8_t* const* in, float* ws, hipStream_t s,
                            const NoiseParams* resample = nullptr,
-                           bool skip_fc2_epilogue = false, bool stop_after_fc1 = false) {
+                           bool skip_fc2_epilogue = false, bool stop_after_fc1 = false,
+                           const SeamClear* clr = nullptr) {
   int rc = DZ_OK;
   const int NA = L.num_actions * L.num_atoms;
   const int ld2 = L.adv2_ld + L.val2_ld;
@@ -91,7 +93,7 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
 #ifdef DZ_GEMM_STAMPS
     if (G == 3) dbg = (long long*)(ws + L.ws_dfeat_part);
 #endif
-    rc = torso_forward(T, G, B, prm, in, s, resample, dbg);
+    rc = torso_forward(T, G, B, prm, in, s, resample, dbg, clr);
     if (rc) return rc;
   }
   {  // fc1: noisy adv1 | val1, split-K partials
@@ -288,13 +290,83 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   // (Gram partials of the layer input: the head of the conv weight-gradient slab buffer,
   // idle between the previous step's finalize and this step's conv backward launches)
   double* gram_part = (double*)(ws + ((L.ws_wgrad_part + 7) & ~(int64_t)7));
+  // The head chain -- fc1 epilogue, noisy fc2, loss, fc2 backward -- as ONE multi-role launch
+  // (dz_head_chain.h) whenever this one call runs the whole step on the on-the-fly path; its seam
+  // buffers (h1, four fc2 slabs, dlogits) are cleared by side blocks of the conv1 forward launch.
+  const int nj0_rd = (NA + 255) / 256;
+  const bool chain = onfly && do_nets && !a->separate_launches && Gf == 3 &&
+                     3 * ld2 <= kHcLdsFloats && nj0_rd >= 1 && nj0_rd <= 4 && K <= 256 &&
+                     ((kHid + kDg2Blocks - 1) / kDg2Blocks) * (nj0_rd + 1) <= 32 &&
+                     ((kHid + kDg2Blocks - 1) / kDg2Blocks) * 32 * 2 <= 512;
   if (do_nets) {
     const uint8_t* in[kG] = {a->s_tm1, a->s_t, a->s_t};
+    SeamClear clr;
+    if (chain) {
+      clr.ptr[0] = ws + L.ws_h1; clr.n4[0] = (int)(((int64_t)Gf * B * 1024) >> 2);
+      clr.ptr[1] = ws + L.ws_fc2_part; clr.n4[1] = (int)(((int64_t)kHcStages * Gf * B * ld2) >> 2);
+      clr.ptr[2] = ws + L.ws_dout2; clr.n4[2] = (int)(((int64_t)B * ld2) >> 2);
+      clr.blocks = (unsigned)((clr.n4[0] + clr.n4[1] + clr.n4[2] + 255) / 256);
+    }
     rc = rainbow_forward(L, H, Gf, B, prm, nz, in, ws, s,
-                         a->resample_noise ? &nq : nullptr, fuse);
+                         a->resample_noise ? &nq : nullptr, fuse, chain, chain ? &clr : nullptr);
     if (rc) return rc;
   }
-  if (do_loss) {
+  // the fc2 layer's gradient slots of the fused global norm (both forms of the head chain)
+  const int fc2_slots_hc = ((NA + FcWg::BN - 1) / FcWg::BN) * (kHid / FcWg::BM) * 2 * 4;
+  if (chain) {
+    HeadChain q = {};
+    q.fc1_part = ws + L.ws_fc1_part; q.rows = Gf * B; q.B = B; q.G = Gf;
+    for (int g = 0; g < kG; ++g) { q.prm[g] = prm[g]; q.nz[g] = nz[g]; }
+    q.fc1_mu_b = L.fc1_mu_b; q.fc1_sig_b = L.fc1_sig_b; q.n_fc1_out = (int)L.n_fc1_out;
+    q.h1 = ws + L.ws_h1;
+    q.fc2h[0] = fc2h[0]; q.fc2h[1] = fc2h[1];
+    q.tiles0 = (NA + 63) / 64; q.tiles1 = (K + 63) / 64;
+    q.fc2_part = ws + L.ws_fc2_part; q.ld2 = ld2;
+    HeadPre pre = {};
+    pre.part = ws + L.ws_fc2_part; pre.S = kHcStages; pre.rows = Gf * B;
+    for (int g = 0; g < kG; ++g) { pre.prm[g] = prm[g]; pre.nz[g] = nz[g]; }
+    pre.b_sig = L.fc2_sig_b; pre.eps_out = (int)L.n_fc2_out;
+    q.loss = {ws + L.ws_fc2_out, ld2, NAp, B, A, K, 1, 1, 2, a->a_tm1, a->r_t, a->discount_t,
+              a->weights, a->support, ws + L.ws_dout2, a->losses, a->priorities,
+              ws + L.ws_q_sel, ws + L.ws_target_probs, pre};
+    q.fail = reinterpret_cast<unsigned*>(ws + L.ws_scalars + DZ_SC_CHAIN_FAIL);
+    q.status = a->prio_node ? a->prio_status : nullptr;
+    q.limit = g_dz_act_spin_limit;
+    // role D: the arguments of fc2_bwd_rows_kernel
+    RowDgrad& r = q.rd;
+    r.params = a->online; r.noise = nz[0]; r.head[0] = fc2h[0]; r.head[1] = fc2h[1];
+    r.dy = ws + L.ws_dout2; r.ldy = ld2; r.mask = ws + L.ws_h1; r.out = ws + L.ws_dh1;
+    r.ldo = 1024; r.out_col[0] = 0; r.out_col[1] = 512; r.same_out = 0;
+    r.M = B; r.K = kHid; r.nblocks = kDg2Blocks;
+    r.fail = q.fail; r.limit = q.limit; r.poison = a->losses; r.watch_col = NAp + K - 1;
+    FcWgradParams& w = q.wg;
+    w.x = ws + L.ws_h1; w.ldx = 1024; w.dy = ws + L.ws_dout2; w.ldy = ld2; w.M = B;
+    w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc2h[0]; w.head[1] = fc2h[1];
+    w.grad = a->grad;
+    w.sumsq = ws + L.ws_norm_part + kNormFinal;
+    w.sq_nx = (NA + FcWg::BN - 1) / FcWg::BN; w.sq_ny = kHid / FcWg::BM;
+    DZ_REQUIRE(fc2_slots_hc <= kNormSlots);
+    q.gw = dim3((NA + FcWg::BN - 1) / FcWg::BN, kHid / FcWg::BM, 2);
+    q.gram.x = ws + L.ws_feat; q.gram.M = B; q.gram.K = kFlat;
+    q.gram.eps_in[0] = nz[0] + L.n_adv1_in; q.gram.eps_in[1] = nz[0] + L.n_val1_in;
+    q.gram.part = gram_part;
+    q.nA = (unsigned)(Gf * B * (1024 / kHcFoldCols));
+    q.nB = (unsigned)(kHcStages * Gf * (q.tiles0 + q.tiles1));
+    q.nC = (unsigned)B; q.nD1 = (unsigned)kDg2Blocks; q.nD2 = dz_count(q.gw);
+#ifdef DZ_HC_STAMPS
+    q.dbg = reinterpret_cast<long long*>(ws + L.ws_dfeat_part); q.rd.dbg = q.dbg;
+#endif
+    const dim3 grid(q.nA + q.nB + q.nC + q.nD1 + q.nD2 + (unsigned)kGramXBlocks);
+    switch (nj0_rd) {
+      case 1: hipLaunchKernelGGL(rainbow_head_chain_kernel<1>, grid, dim3(256), 0, s, q); break;
+      case 2: hipLaunchKernelGGL(rainbow_head_chain_kernel<2>, grid, dim3(256), 0, s, q); break;
+      case 3: hipLaunchKernelGGL(rainbow_head_chain_kernel<3>, grid, dim3(256), 0, s, q); break;
+      default: hipLaunchKernelGGL(rainbow_head_chain_kernel<4>, grid, dim3(256), 0, s, q); break;
+    }
+    DZ_LAUNCH_CHECK();
+    DZ_PROF(s, "head_chain");
+  }
+  if (do_loss && !chain) {
     {
       GramX gx;
       if (onfly) {
@@ -368,7 +440,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     float* part1 = ws + L.ws_wgrad_part;
     float* part2 = part1 + (long)kS_cw1 * Conv1Wg::KROWS * 32;
     float* part3 = part2 + (long)kS_cw2 * Conv2Wg::KROWS * 64;
-    {  // fc2: weight gradients (both heads) + input gradient of each head
+    if (!chain) {  // fc2: weight gradients (both heads) + input gradient of each head
       FcWgradParams w;
       w.x = ws + L.ws_h1; w.ldx = 1024; w.dy = ws + L.ws_dout2; w.ldy = ld2; w.M = B;
       w.NH = 2; w.noisy = 1; w.noise = nz[0]; w.head[0] = fc2h[0]; w.head[1] = fc2h[1];

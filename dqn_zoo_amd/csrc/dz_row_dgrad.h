@@ -21,7 +21,11 @@
 // ref: rainbow/agent.py:112-118 (jax.grad through the network), networks.py:150-180.
 #pragma once
 #include "dz_qnet_ops.h"
+#include "dz_seam.h"
 
+#ifndef DZ_HC_NAP_D
+#define DZ_HC_NAP_D 24
+#endif
 namespace {
 struct RowDgrad {
   const float* params;
@@ -36,6 +40,12 @@ struct RowDgrad {
   int same_out;           // 1: both heads add into out_col[0] + k; 0: head h owns out_col[h] + k
   int M, K;               // batch rows (<= 32), weight rows
   int nblocks;            // row-owning workgroups (rows are split as evenly as K allows)
+  // SEAM builds (row_dgrad_block<..., SEAM = true>; dz_head_chain.h): `dy` and `mask` are produced
+  // by other workgroups of the SAME launch and read as seams (dz_seam.h); on a timeout the sticky
+  // word is set and `poison[0..M)` (the step's losses) becomes NaN
+  unsigned* fail = nullptr; int limit = 0; float* poison = nullptr;
+  int watch_col = 0;      // column of dy every producer stores last
+  long long* dbg = nullptr;
 };
 // LDS: [row][job][lane group 0..7][32 batch rows + 4]: the +4 skews the eight groups over
 // the banks (a lane writes one float4 at group * 36 + 4 * (lane >> 3); without it the
@@ -80,7 +90,7 @@ static inline int row_dgrad_max_rows(const RowDgrad& q) { return (q.K + q.nblock
 // NOISY = false: plain linear layer (W_eff = W: no sigma matrix, no noise).
 // With one or two jobs per row the four waves form 4 / jobs ROW GROUPS (group g takes rows
 // g, g + groups, ...), so that no wave idles.
-template <int NJ0, int NJ1, bool SAME, int P = 2, bool NOISY = true>
+template <int NJ0, int NJ1, bool SAME, int P = 2, bool NOISY = true, bool SEAM = false>
 __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk, float* lds) {
   // NJ0 == 0: the job count is a run-time value (head 0 only; more registers, for the
   // rare very wide heads)
@@ -99,8 +109,11 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
   for (int j = 0; j < NO; ++j) {
     const int o = min(tid + 256 * j, nrows * 32 * nout - 1);
     const int sel = o >= nrows * 32 ? 1 : 0, r = (o - sel * nrows * 32) >> 5, b = min(o & 31, q.M - 1);
-    mk[j] = q.mask[(long)b * q.ldo + (sel ? q.out_col[1] : q.out_col[0]) + k0 + r];
+    const float* mp = q.mask + (long)b * q.ldo + (sel ? q.out_col[1] : q.out_col[0]) + k0 + r;
+    // (SEAM: possibly not written yet -- looked at again in the epilogue, when it must be)
+    mk[j] = SEAM ? act_load(mp) : *mp;
   }
+  bool wave_fail = false;
   const int grp = GROUPS > 1 ? wave / nj : 0;
   const int myrows = (nrows - grp + GROUPS - 1) / GROUPS;   // rows k0 + grp + GROUPS * i
   for (int job = GROUPS > 1 ? wave % nj : wave; job < nj; job += ONE ? 1 << 20 : 4) {   // (wave-uniform)
@@ -131,13 +144,66 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
     const float v0 = c0 < N ? 1.f : 0.f, v1 = c0 + 1 < N ? 1.f : 0.f;
     const float v2 = c0 + 2 < N ? 1.f : 0.f, v3 = c0 + 3 < N ? 1.f : 0.f;
     dz_f2 D[16][4];
+    if constexpr (SEAM) {
+      // dY comes from the loss role of this launch.  The wave first watches ONE word per sample (the
+      // word each sample's loss workgroup stores last: q.watch_col), one load per lane and round;
+      // then whole-wave rounds re-read the wave's columns of all batch rows until none of the
+      // real ones is missing (normally one round: each costs 64 loads per lane).
+      {
+        const float* word = q.dy + (unsigned)(min(lane, q.M - 1) * q.ldy) + q.watch_col;
+        for (int i = 0; i < q.limit; ++i) {
+          const bool m = lane < 32 && act_missing(act_load(word));
+          if (__builtin_amdgcn_ballot_w64(m) == 0ull) break;
+          __builtin_amdgcn_s_sleep(DZ_HC_NAP_D);
+        }
+      }
+#ifdef DZ_HC_STAMPS
+      if (q.dbg && tid == 0) q.dbg[blockIdx.x * 8 + 1] = (long long)wall_clock64();
+#endif
+      int round = 0;
+      bool again;
+      do {
+        // (all loads first, then the checks, branch-free)
+        float4 ra[16][2];
+        const __amdgpu_buffer_rsrc_t dr = act_rsrc(q.dy);
+        const unsigned ho = (unsigned)(dz_val(h1, q.head[1].out_off, q.head[0].out_off) + cc) * 4u;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float4 d0 = *(const float4*)(dyp + (unsigned)(min(2 * i, q.M - 1) * q.ldy + cc) * 4u);
-      const float4 d1 = *(const float4*)(dyp + (unsigned)(min(2 * i + 1, q.M - 1) * q.ldy + cc) * 4u);
-      const float m0 = 2 * i < q.M ? 1.f : 0.f, m1 = 2 * i + 1 < q.M ? 1.f : 0.f;
-      D[i][0] = dz_f2{d0.x * (m0 * v0), d1.x * (m1 * v0)}; D[i][1] = dz_f2{d0.y * (m0 * v1), d1.y * (m1 * v1)};
-      D[i][2] = dz_f2{d0.z * (m0 * v2), d1.z * (m1 * v2)}; D[i][3] = dz_f2{d0.w * (m0 * v3), d1.w * (m1 * v3)};
+        for (int i = 0; i < 16; ++i) {
+          ra[i][0] = act_load4(dr, (unsigned)(min(2 * i, q.M - 1) * q.ldy) * 4u + ho);
+          ra[i][1] = act_load4(dr, (unsigned)(min(2 * i + 1, q.M - 1) * q.ldy) * 4u + ho);
+        }
+        unsigned all = 1u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float2 a0 = make_float2(ra[i][0].x, ra[i][0].y), a1 = make_float2(ra[i][0].z, ra[i][0].w);
+          const float2 b0 = make_float2(ra[i][1].x, ra[i][1].y), b1 = make_float2(ra[i][1].z, ra[i][1].w);
+          const float m0 = 2 * i < q.M ? 1.f : 0.f, m1 = 2 * i + 1 < q.M ? 1.f : 0.f;
+          all &= (v0 == 0.f || (!act_missing(a0.x) && !act_missing(b0.x))) ? 1u : 0u;
+          all &= (v1 == 0.f || (!act_missing(a0.y) && !act_missing(b0.y))) ? 1u : 0u;
+          all &= (v2 == 0.f || (!act_missing(a1.x) && !act_missing(b1.x))) ? 1u : 0u;
+          all &= (v3 == 0.f || (!act_missing(a1.y) && !act_missing(b1.y))) ? 1u : 0u;
+          D[i][0] = dz_f2{a0.x * (m0 * v0), b0.x * (m1 * v0)}; D[i][1] = dz_f2{a0.y * (m0 * v1), b0.y * (m1 * v1)};
+          D[i][2] = dz_f2{a1.x * (m0 * v2), b1.x * (m1 * v2)}; D[i][3] = dz_f2{a1.y * (m0 * v3), b1.y * (m1 * v3)};
+        }
+        const bool miss = all == 0u;
+        again = __builtin_amdgcn_ballot_w64(miss) != 0ull;
+        if (again) {
+          if (round++ >= q.limit) { wave_fail = true; again = false; }
+          else __builtin_amdgcn_s_sleep(1);
+        }
+      } while (again);
+#ifdef DZ_HC_STAMPS
+      if (q.dbg && tid == 0) q.dbg[blockIdx.x * 8 + 2] = (long long)wall_clock64();
+#endif
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float4 d0 = *(const float4*)(dyp + (unsigned)(min(2 * i, q.M - 1) * q.ldy + cc) * 4u);
+        const float4 d1 = *(const float4*)(dyp + (unsigned)(min(2 * i + 1, q.M - 1) * q.ldy + cc) * 4u);
+        const float m0 = 2 * i < q.M ? 1.f : 0.f, m1 = 2 * i + 1 < q.M ? 1.f : 0.f;
+        D[i][0] = dz_f2{d0.x * (m0 * v0), d1.x * (m1 * v0)}; D[i][1] = dz_f2{d0.y * (m0 * v1), d1.y * (m1 * v1)};
+        D[i][2] = dz_f2{d0.z * (m0 * v2), d1.z * (m1 * v2)}; D[i][3] = dz_f2{d0.w * (m0 * v3), d1.w * (m1 * v3)};
+      }
     }
     float4 eo = dz_f4zero();
     if (NOISY) eo = *(const float4*)(q.noise + dz_val(h1, q.head[1].eps_out, q.head[0].eps_out) + cc);
@@ -200,12 +266,25 @@ __device__ __forceinline__ void row_dgrad_block(const RowDgrad& q, unsigned blk,
       }
     }
   }
-  __syncthreads();
+  if constexpr (SEAM) {
+    if (__syncthreads_or(wave_fail ? 1 : 0)) {   // dY never came: sticky word, the step's losses are not numbers
+      if (tid == 0) __hip_atomic_store(q.fail, 1u, DZ_ACT_RLX);
+      if (q.poison && tid < q.M) q.poison[tid] = __builtin_nanf("");
+      return;
+    }
+  } else {
+    __syncthreads();
+  }
 #pragma unroll
   for (int j = 0; j < NO; ++j) {
     const int o = tid + 256 * j;
     if (o < nrows * 32 * nout) {
       const int sel = o >= nrows * 32 ? 1 : 0, r = (o - sel * nrows * 32) >> 5, b = o & 31;
+      if constexpr (SEAM) {
+        // dY was seen, so the activation it was computed from is at the coherence point
+        if (act_missing(mk[j]))
+          mk[j] = act_load(q.mask + (long)min(b, q.M - 1) * q.ldo + (sel ? q.out_col[1] : q.out_col[0]) + k0 + r);
+      }
       // this output's jobs (ascending), eight lane groups each
       const int j0 = SAME ? 0 : (sel ? nj0 : 0), j1 = SAME ? nj : (sel ? nj : nj0);
       float s = 0.f;

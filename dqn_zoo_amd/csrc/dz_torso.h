@@ -26,8 +26,15 @@ inline int launch_conv_fwd(const ConvFwdParams& p, int CO, int G, int B, hipStre
 }
 template <class Op>
 inline int launch_conv1_fwd(const ConvFwdParams& p, int G, int B, const NoiseParams* side,
-                            hipStream_t s) {
+                            hipStream_t s, const SeamClear* clr = nullptr) {
   const dim3 g(32 / Op::BN, G * Op::tiles_per_group(B), 1);
+  if (clr) {  // + the step's seam buffers back to all-zero bits (dz_head_chain.h)
+    StepPre q;
+    q.noise = side ? *side : NoiseParams{};
+    q.noise_blocks = side ? (unsigned)((side->n + 255) / 256) : 0u;
+    q.clr = *clr;
+    return dz_launch_gemm_side<Op, StepPreSide>(p, g, q, q.noise_blocks + clr->blocks, s);
+  }
   if (side)  // the step's noise draw rides along as extra blocks: conv1 does not read it
     return dz_launch_gemm_side<Op, NoiseSide>(p, g, *side, (unsigned)((side->n + 255) / 256), s);
   return dz_launch_gemm<Op>(p, g, s);
@@ -38,7 +45,8 @@ inline int launch_conv1_fwd(const ConvFwdParams& p, int G, int B, const NoisePar
 // the conv1 launch.
 inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* prm,
                          const uint8_t* const* in, hipStream_t s,
-                         const NoiseParams* side = nullptr, long long* dbg = nullptr) {
+                         const NoiseParams* side = nullptr, long long* dbg = nullptr,
+                         const SeamClear* clr = nullptr) {
   int rc;
   {
     ConvFwdParams p;
@@ -47,8 +55,8 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
       p.w[g] = prm[g] + T.conv_w[0]; p.bias[g] = prm[g] + T.conv_b[0];
     }
     p.out = T.act1; p.B = B; p.G = G; p.dbg = dbg;
-    rc = B <= 8 ? launch_conv1_fwd<Conv1FwdAct>(p, G, B, side, s)
-                : launch_conv1_fwd<Conv1Fwd>(p, G, B, side, s);
+    rc = B <= 8 ? launch_conv1_fwd<Conv1FwdAct>(p, G, B, side, s, clr)
+                : launch_conv1_fwd<Conv1Fwd>(p, G, B, side, s, clr);
     if (rc) return rc;
     DZ_PROF(s, side ? "conv1_fwd+noise" : "conv1_fwd");
   }

@@ -111,6 +111,10 @@ class RainbowLearner:
     # input and output gradient (csrc/dz_fc1_onfly.h) -- and a split step stores only the
     # mu block; True: `grad` holds every block (inspection, tests, A/B)
     self.keep_all_grads = False
+    # True: one launch per stage of the head chain (fc1 epilogue, fc2, loss, fc2 backward) instead
+    # of the default multi-role launch of the one-call step (csrc/dz_head_chain.h): A/B and the
+    # bit-identity tests
+    self.separate_launches = False
     # inference (acting) side: own workspace + one noise block, so that an
     # apply never aliases the buffers of an enqueued learner step.
     self._act_batch = 0
@@ -418,7 +422,17 @@ class RainbowLearner:
     sc = self.ws[off:off + 8].cpu().numpy()
     return dict(gnorm=float(sc[_lib.SC_GNORM]), loss=float(sc[_lib.SC_LOSS]),
                 bc1=float(sc[_lib.SC_BC1]), bc2=float(sc[_lib.SC_BC2]),
-                unclipped=bool(sc[_lib.SC_CLIP] != 0))
+                unclipped=bool(sc[_lib.SC_CLIP] != 0),
+                chain_failed=bool(sc[_lib.SC_CHAIN_FAIL:_lib.SC_CHAIN_FAIL + 1].view(np.uint32)[0]))
+
+  def check_status(self) -> None:
+    """Synchronises; raises if a multi-role launch of an earlier step gave up on one of its
+    in-launch seams (ws_scalars[DZ_SC_CHAIN_FAIL], sticky: cleared here)."""
+    off = int(self.layout.c.ws_scalars) + _lib.SC_CHAIN_FAIL
+    if int(self.ws[off:off + 1].view(torch.int32).item()) != 0:
+      self.ws[off:off + 1].zero_()
+      raise RuntimeError('a multi-role learner launch timed out on an in-launch seam '
+                         '(DZ_SC_CHAIN_FAIL): the losses of that step are NaN')
 
   def ws_view(self, name: str, count: int) -> torch.Tensor:
     off = int(getattr(self.layout.c, 'ws_' + name))
@@ -458,7 +472,7 @@ class RainbowLearner:
       key = (s_tm1.data_ptr(), s_t.data_ptr(), a_tm1.data_ptr(), r_t.data_ptr(),
              discount_t.data_ptr(), weights.data_ptr(), phases,
              int(bool(resample_noise) and nets),
-             sink[0], sink[3], int(self.keep_all_grads))
+             sink[0], sink[3], int(self.keep_all_grads), int(self.separate_launches))
       g = self._graphs.get(key)
       if g is not None:
         _lib.check(self._lib.dz_graph_launch(g, stream), 'dz_graph_launch')
@@ -499,6 +513,7 @@ class RainbowLearner:
     # (seed, Adam step count): no per-step host argument, graph-replayable.
     a.resample_noise = int(bool(resample_noise) and nets)
     a.keep_all_grads = int(self.keep_all_grads)
+    a.separate_launches = int(self.separate_launches)
     a.next_sample = None if next_sample is None else ctypes.addressof(next_sample)
     if priority_sink is not None:
       if not phases & _lib.PHASE_BACKWARD:
@@ -515,7 +530,7 @@ class RainbowLearner:
             'hipGraph capture needs a non-default stream: run the learner under '
             '`torch.cuda.stream(torch.cuda.Stream())` (bench.py does)')
       key = (a.s_tm1, a.s_t, a.a_tm1, a.r_t, a.discount_t, a.weights, phases,
-             a.resample_noise, a.prio_node, a.prio_ids, a.keep_all_grads)
+             a.resample_noise, a.prio_node, a.prio_ids, a.keep_all_grads, a.separate_launches)
       g = self._graphs.get(key)
       if g is None:
         if self.use_graphs is None and len(self._graphs) >= self.MAX_AUTO_GRAPHS:

@@ -70,6 +70,9 @@ def _next_pow2(n):
 
 def _raise_status(bits):
   """Maps sticky device status bits to the reference's exceptions."""
+  if bits & _lib.ST_CHAIN_TIMEOUT:
+    raise RuntimeError('a multi-role learner launch timed out on an in-launch seam '
+                       '(DZ_ST_CHAIN_TIMEOUT): the step that raised it is not valid')
   if bits & _lib.ST_BAD_VALUE:
     raise ValueError('value must be finite and positive.')
   if bits & _lib.ST_BAD_TARGET:

@@ -40,6 +40,8 @@ extern "C" {
 #define DZ_ST_BAD_INDEX 4u      /* ref: replay.py:274-275 IndexError('index out of range ...') */
 #define DZ_ST_ZERO_ROOT 8u      /* pipelined sampling met root()==0 (ref takes a different RNG path, replay.py:556-557) */
 #define DZ_ST_NONFINITE_WEIGHT 16u /* ref: replay.py:241-242 ValueError('Weights are not finite') */
+#define DZ_ST_CHAIN_TIMEOUT 32u /* a multi-role learner launch gave up on one of its in-launch seams (no reference
+                                 * counterpart; dz_rainbow_args_t::separate_launches); the step's losses are NaN */
 
 typedef void* dz_stream_t;
 
@@ -277,6 +279,7 @@ int dz_rainbow_layout(int num_actions, int num_atoms, int batch,
 #define DZ_SC_BC1 2       /* 1 - b1^count                                     */
 #define DZ_SC_BC2 3       /* 1 - b2^count                                     */
 #define DZ_SC_CLIP 4      /* 1 if gnorm < max_norm else 0                     */
+#define DZ_SC_CHAIN_FAIL 6 /* (uint32 bits) sticky, non-zero once a multi-role launch of a step timed out */
 
 /* The NEXT step's replay sample, carried by a learner step (dz_rainbow_args_t::
  * next_sample): exactly the arguments of dz_prioritized_sample_gather.  The draws
@@ -350,7 +353,15 @@ typedef struct {
    *     block in the optimiser (bit-identical to storing it).
    * 1: every gradient block is materialised in `grad` (inspection, tests, A/B).       */
   int32_t keep_all_grads;
-  int32_t pad_;
+  /* 0 (default): in a call that runs the whole step (as above, batch <= 32) the four launches
+   * between fc1's forward stream and fc1's input gradient -- fc1 epilogue, noisy fc2, loss, fc2
+   * backward -- are workgroup ROLES of ONE launch that hand h1, the fc2 slabs and dlogits to each
+   * other through in-launch seams (csrc/dz_head_chain.h; bit-identical results).  Liveness as for
+   * dz_rainbow_act's one-launch form: progress needs only the in-order workgroup dispatch of CDNA
+   * hardware; every in-launch wait is bounded, and a timeout makes the step's losses NaN, sets
+   * ws_scalars[DZ_SC_CHAIN_FAIL] and raises DZ_ST_CHAIN_TIMEOUT in prio_status (if given).
+   * 1: one launch per stage, as in every other shape of the call (A/B, tests).               */
+  int32_t separate_launches;
   /* Optional (needs DZ_PHASE_BACKWARD | DZ_PHASE_OPTIMIZER in the call): the sample +
    * gather of the NEXT step rides in this step's optimiser launch as extra blocks, and
    * the priority write-back (prio_*) moves into an EARLIER backward launch, so that

@@ -1,0 +1,18 @@
+#!/bin/bash
+# One same-box look at the Rainbow step: bench line (3000 steps, eager) twice + a kernel trace summary.
+#   bash tools/quick_perf.sh [pattern]      (BENCH_ARGS, NB as in lib_ab.sh)
+ulimit -c 0
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/q
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+pat=${1:-.}
+BARGS="--cpu-seconds 0 --prof-steps 0 --other-configs 0 --sustain-steps 0 --agent-form-steps 0 --agent-loop-frames 0 ${BENCH_ARGS:-}"
+for i in $(seq 1 ${NB:-2}); do
+  timeout 300 python $R/bench.py --steps 3000 --warmup 300 $BARGS 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'])"
+done
+rm -rf $OUT/kt
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python $R/bench.py --steps 400 --warmup 50 $BARGS > $OUT/kt.log 2>&1 < /dev/null
+t=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
+python $R/tools/step_trace_summary.py "$t" 200 | grep -E "last 200|busy|$pat" | cut -c1-150
+rm -rf $OUT/kt
