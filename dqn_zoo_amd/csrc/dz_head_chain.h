@@ -63,7 +63,10 @@ namespace {
 #define DZ_HC_NAP_C 8     // the loss role waits ~9 us for the fc2 role
 #endif
 constexpr int kHcStages = 4;            // fc2's K = 512 as four 128-deep stages (FcFwdOp<1,2,2,4,2>)
-constexpr int kHcFoldCols = 256;        // role A: columns per workgroup
+#ifndef DZ_HC_FOLD_COLS
+#define DZ_HC_FOLD_COLS 1024
+#endif
+constexpr int kHcFoldCols = DZ_HC_FOLD_COLS;   // role A: columns per workgroup
 
 struct HeadChain {
   // ---- role A: fc1 epilogue --------------------------------------------------------------------
@@ -104,38 +107,54 @@ __device__ __forceinline__ void hc_fail(const HeadChain& p) {
 // fc_epilogue_kernel's arithmetic: wave w sums slabs w, w+4, .. in that order from 0.f, the four
 // wave sums combine as (r0 + r1) + (r2 + r3), then + b_mu, then + b_sig * eps_out, ReLU.
 __device__ __forceinline__ void hc_fold_block(const HeadChain& p, unsigned u, float* lds) {
-  constexpr int NC = 1024 / kHcFoldCols;
+  constexpr int NC = 1024 / kHcFoldCols, NP = kHcFoldCols / 256;   // passes of 256 columns
+  static_assert(kHcFoldCols % 256 == 0 && 1024 % kHcFoldCols == 0, "fold tile");
   const int r = (int)u / NC, cq = (int)u % NC;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int g = r / p.B;
   HC_STAMP(p, 0);
   const float* prm = dz_pick3(p.prm, g);
   const float* nz = dz_pick3(p.nz, g);
-  const int col = cq * kHcFoldCols + 4 * l;            // wave 0's lanes finish four columns each
-  const float4 bm = dz_ld4(prm + p.fc1_mu_b + col), bs = dz_ld4(prm + p.fc1_sig_b + col);
-  const float4 be = dz_ld4(nz + p.n_fc1_out + col);
-  const float* src = p.fc1_part + (long)r * 1024 + col;
+  const int col0 = cq * kHcFoldCols + 4 * l;           // + 256 pass: wave 0's lanes finish four columns each
+  const float* src = p.fc1_part + (long)r * 1024 + col0;
   const long stride = (long)p.rows * 1024;
-  float4 x[8];
+  float4 x[NP][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = dz_ld4(src + (long)(w + 4 * j) * stride);
-  float4 v = dz_f4zero();
+  for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { v.x += x[j].x; v.y += x[j].y; v.z += x[j].z; v.w += x[j].w; }
-  *(float4*)(lds + w * kHcFoldCols + 4 * l) = v;
+    for (int j = 0; j < 8; ++j) x[ps][j] = dz_ld4(src + 256 * ps + (long)(w + 4 * j) * stride);
+  float4 bm[NP], bs[NP], be[NP];
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    bm[ps] = dz_ld4(prm + p.fc1_mu_b + col0 + 256 * ps); bs[ps] = dz_ld4(prm + p.fc1_sig_b + col0 + 256 * ps);
+    be[ps] = dz_ld4(nz + p.n_fc1_out + col0 + 256 * ps);
+  }
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    float4 v = dz_f4zero();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v.x += x[ps][j].x; v.y += x[ps][j].y; v.z += x[ps][j].z; v.w += x[ps][j].w; }
+    *(float4*)(lds + w * kHcFoldCols + 256 * ps + 4 * l) = v;
+  }
   __syncthreads();
   HC_STAMP(p, 1);
-  if (w != 0) return;
-  const float4 r0 = *(const float4*)(lds + 4 * l), r1 = *(const float4*)(lds + kHcFoldCols + 4 * l);
-  const float4 r2 = *(const float4*)(lds + 2 * kHcFoldCols + 4 * l), r3 = *(const float4*)(lds + 3 * kHcFoldCols + 4 * l);
-  float4 o;
-  o.x = (r0.x + r1.x) + (r2.x + r3.x); o.y = (r0.y + r1.y) + (r2.y + r3.y);
-  o.z = (r0.z + r1.z) + (r2.z + r3.z); o.w = (r0.w + r1.w) + (r2.w + r3.w);
-  o.x += bm.x; o.y += bm.y; o.z += bm.z; o.w += bm.w;
-  o.x += bs.x * be.x; o.y += bs.y * be.y; o.z += bs.z * be.z; o.w += bs.w * be.w;
-  o.x = o.x > 0.f ? o.x : -0.f; o.y = o.y > 0.f ? o.y : -0.f;
-  o.z = o.z > 0.f ? o.z : -0.f; o.w = o.w > 0.f ? o.w : -0.f;
-  act_store4(act_rsrc(p.h1), (unsigned)(r * 1024 + col) * 4u, o);
+  // the four waves finish the passes round-robin (NP = 1: wave 0 alone)
+  const __amdgpu_buffer_rsrc_t hr = act_rsrc(p.h1);
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    if ((ps & 3) != w) continue;   // (wave-uniform)
+    const float* q0 = lds + 256 * ps + 4 * l;
+    const float4 r0 = *(const float4*)q0, r1 = *(const float4*)(q0 + kHcFoldCols);
+    const float4 r2 = *(const float4*)(q0 + 2 * kHcFoldCols), r3 = *(const float4*)(q0 + 3 * kHcFoldCols);
+    float4 o;
+    o.x = (r0.x + r1.x) + (r2.x + r3.x); o.y = (r0.y + r1.y) + (r2.y + r3.y);
+    o.z = (r0.z + r1.z) + (r2.z + r3.z); o.w = (r0.w + r1.w) + (r2.w + r3.w);
+    o.x += bm[ps].x; o.y += bm[ps].y; o.z += bm[ps].z; o.w += bm[ps].w;
+    o.x += bs[ps].x * be[ps].x; o.y += bs[ps].y * be[ps].y; o.z += bs[ps].z * be[ps].z; o.w += bs[ps].w * be[ps].w;
+    o.x = o.x > 0.f ? o.x : -0.f; o.y = o.y > 0.f ? o.y : -0.f;
+    o.z = o.z > 0.f ? o.z : -0.f; o.w = o.w > 0.f ? o.w : -0.f;
+    act_store4(hr, (unsigned)(r * 1024 + col0 + 256 * ps) * 4u, o);
+  }
   HC_STAMP(p, 2);
 }
 

@@ -43,6 +43,13 @@ constexpr int kFc2Splits = 8;        // fc2 forward k-splits
 //        weight-gradient contraction; dh1 leaves that launch finished (summed over n,
 //        ReLU-masked) -- no slabs to fold.
 constexpr int kDg2Blocks = 128;
+// ... and as a role of the multi-role head launch (dz_head_chain.h), where the role's arithmetic sits
+// on the launch's critical path behind the dlogit seam: 256 workgroups x 2 rows (same box, launch
+// 27.5 -> 26.4 us; 64 x 8: 29.3)
+#ifndef DZ_HC_D1_BLOCKS
+#define DZ_HC_D1_BLOCKS 256
+#endif
+constexpr int kHcD1Blocks = DZ_HC_D1_BLOCKS;
 // fc1's input gradient (dz_fc1_dgrad.h): one workgroup per 16 weight rows behind the side
 // blocks (Gram norms of dh1; optionally the sum-tree priority write-back).
 __global__ __launch_bounds__(256)
@@ -296,8 +303,8 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   const int nj0_rd = (NA + 255) / 256;
   const bool chain = onfly && do_nets && !a->separate_launches && Gf == 3 &&
                      3 * ld2 <= kHcLdsFloats && nj0_rd >= 1 && nj0_rd <= 4 && K <= 256 &&
-                     ((kHid + kDg2Blocks - 1) / kDg2Blocks) * (nj0_rd + 1) <= 32 &&
-                     ((kHid + kDg2Blocks - 1) / kDg2Blocks) * 32 * 2 <= 512;
+                     ((kHid + kHcD1Blocks - 1) / kHcD1Blocks) * (nj0_rd + 1) <= 32 &&
+                     ((kHid + kHcD1Blocks - 1) / kHcD1Blocks) * 32 * 2 <= 512;
   if (do_nets) {
     const uint8_t* in[kG] = {a->s_tm1, a->s_t, a->s_t};
     SeamClear clr;
@@ -337,7 +344,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     r.params = a->online; r.noise = nz[0]; r.head[0] = fc2h[0]; r.head[1] = fc2h[1];
     r.dy = ws + L.ws_dout2; r.ldy = ld2; r.mask = ws + L.ws_h1; r.out = ws + L.ws_dh1;
     r.ldo = 1024; r.out_col[0] = 0; r.out_col[1] = 512; r.same_out = 0;
-    r.M = B; r.K = kHid; r.nblocks = kDg2Blocks;
+    r.M = B; r.K = kHid; r.nblocks = kHcD1Blocks;
     r.fail = q.fail; r.limit = q.limit; r.poison = a->losses; r.watch_col = NAp + K - 1;
     FcWgradParams& w = q.wg;
     w.x = ws + L.ws_h1; w.ldx = 1024; w.dy = ws + L.ws_dout2; w.ldy = ld2; w.M = B;
@@ -352,7 +359,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     q.gram.part = gram_part;
     q.nA = (unsigned)(Gf * B * (1024 / kHcFoldCols));
     q.nB = (unsigned)(kHcStages * Gf * (q.tiles0 + q.tiles1));
-    q.nC = (unsigned)B; q.nD1 = (unsigned)kDg2Blocks; q.nD2 = dz_count(q.gw);
+    q.nC = (unsigned)B; q.nD1 = (unsigned)kHcD1Blocks; q.nD2 = dz_count(q.gw);
 #ifdef DZ_HC_STAMPS
     q.dbg = reinterpret_cast<long long*>(ws + L.ws_dfeat_part); q.rd.dbg = q.dbg;
 #endif

@@ -17,7 +17,7 @@ for _ in range(200):
 torch.cuda.synchronize()
 lay = learner.layout.c
 NA, K = 6 * 51, 51
-nA, nB, nC, nD1 = 3 * 32 * 4, 4 * 3 * ((NA + 63) // 64 + 1), 32, 128
+nA, nB, nC, nD1 = 3 * 32 * 1, 4 * 3 * ((NA + 63) // 64 + 1), 32, 256
 nD2 = ((NA + 63) // 64) * 8 * 2
 nG = 84
 n = nA + nB + nC + nD1 + nD2 + nG

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/q
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 pat=$1; shift
-BARGS="--cpu-seconds 0 --prof-steps 0 --other-configs 0 --sustain-steps 0 --agent-form-steps 0 ${BENCH_ARGS:-}"
+BARGS="--cpu-seconds 0 --prof-steps 0 --other-configs 0 --sustain-steps 0 --agent-form-steps 0 --agent-loop-frames 0 ${BENCH_ARGS:-}"
 for lib in "$@"; do
   cp $R/$lib $R/dqn_zoo_amd/libdqnzoo_hip.so
   echo "== $lib"
