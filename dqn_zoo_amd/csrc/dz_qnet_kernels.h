@@ -35,7 +35,7 @@ constexpr int kMaxSplitFc1 = 32;
 //                                                       WM WN WK KT
 
 // (conv1: 1 200 workgroups of 32 rows, K over the four waves -- 12.6 vs 13.1 us for <2,1,2,2>
-// once its loader stopped waiting; round 4 re-sweep of six shapes per layer, tools/lib_ab.sh)
+// once its loader stopped waiting; round 4 re-sweep of six shapes per layer, tools/ab.sh libs)
 using Conv1Fwd = ConvFwdOp<1, 84, 84, 4, 8, 4, 20, 20, 32, 1, 1, 4, 1>;
 using Conv2Fwd = ConvFwdOp<0, 20, 20, 32, 4, 2, 9, 9, 64, 1, 1, 4, 2>;
 using Conv3Fwd = ConvFwdOp<0, 9, 9, 64, 3, 1, 7, 7, 64, 1, 1, 4, 3, 0>;

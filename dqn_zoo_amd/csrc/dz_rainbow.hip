@@ -1,18 +1,21 @@
 // Rainbow learner step on one MI355X (ref: rainbow/agent.py:85-121).
 //
-// Launch sequence of the one-call step at batch <= 32 (14 launches, all on the caller's
+// Launch sequence of the one-call step at batch <= 32 (11 launches, all on the caller's
 // stream, no host sync; DESIGN.md 4 has the table):
-//   forward : conv1 (+ the step's noise draw as side blocks) -> conv2 -> conv3 (the 3
-//             applies batched as groups) -> fc1 (noisy adv1|val1: one weight stream per
-//             parameter set, W_eff in registers, split-K slabs) -> epilogue (fold + bias +
-//             ReLU) -> fc2 (noisy adv2, val2, split-K) -> head/loss (folds the fc2 slabs;
-//             dueling + softmax + double-Q selector + Cramer projection + cross-entropy +
-//             dlogits + priorities; side blocks: Gram matrices of fc1's input)
-//   backward: [fc2 input gradient as a row-owning stream | fc2 weight gradient] ->
-//             [Gram side blocks of dh1 | sum-tree priority write-back | fc1 input gradient
-//             as a row-owning stream] -> [conv3 wgrad | conv3 dgrad] -> [conv2 wgrad |
-//             conv2 dgrad] -> conv1 wgrad -> finalize (conv slabs, bias column sums,
-//             global-norm partials, step count)
+//   forward : conv1 (+ side blocks: the step's noise draw, the head launch's seam buffers back
+//             to all-zero bits) -> conv2 -> conv3 (the 3 applies batched as groups) -> fc1
+//             (noisy adv1|val1: one weight stream per parameter set, W_eff in registers,
+//             split-K slabs)
+//   head    : ONE multi-role launch (dz_head_chain.h): fold of fc1's slabs + bias + ReLU ->
+//             noisy fc2 (adv2, val2) -> loss (dueling + softmax + double-Q selector + Cramer
+//             projection + cross-entropy + dlogits + priorities) -> [fc2 input gradient as a
+//             row-owning stream | fc2 weight gradient]; side blocks: Gram matrices of fc1's
+//             input.  (dz_rainbow_args_t::separate_launches = 1, other shapes of the call:
+//             epilogue -> fc2 -> head/loss -> fc2 backward as four launches)
+//   backward: [Gram side blocks of dh1 | sum-tree priority write-back | fc1 input gradient on
+//             the matrix pipe] -> [conv3 wgrad | conv3 dgrad] -> [conv2 wgrad | conv2 dgrad]
+//             -> conv1 wgrad -> finalize (conv slabs, bias column sums, global-norm partials,
+//             step count)
 //   update  : Adam; forms fc1's mu and sigma weight gradients on the fly (dz_fc1_onfly.h)
 //             and, in the loop over a static replay, carries the next step's sample+gather
 // Other shapes of the call (split phases, batch > 32, keep_all_grads) store fc1's weight
@@ -31,7 +34,7 @@ namespace {
 // Launch constants: the measured best on MI355X at B = 32 (the sweeps and the
 // alternatives that lost are in EXPERIMENTS.md; the code that implemented them is gone).
 constexpr int kFc1Splits = 32;       // fc1 forward k-splits (98 rows each)
-constexpr int kFc1DgradSplits = 12;  // fc1 input-gradient k-splits: 11 slabs of 6 single-chunk stages (17.9 us; 16 x 4: 19.2; 10 x 7: 19.6)
+constexpr int kFc1DgradSplits = 12;  // fc1 input-gradient k-splits of the STORED-gradient forms (split steps, batch > 32, keep_all_grads): 11 slabs of 6 single-chunk stages
 constexpr int kFc2Splits = 8;        // fc2 forward k-splits
 // The two noisy linear layers' input gradients in the one-call step (dz_fc1_onfly.h):
 //   fc1: on the matrix pipe, weights transposed through LDS by LDS-DMA (dz_fc1_dgrad.h): 196

@@ -98,7 +98,7 @@ def rank_cpus(local_rank: int, local_world: int,
   cores this process may use (sorted ids: on a two-socket MI355X node the lower half
   of the ids -- and GPUs 0-3 -- sit on socket 0, so contiguous slices keep a replica's
   host thread on the socket its GPU hangs off).  Every replica's host thread draws
-  RNG numbers and enqueues ~17 launches every ~165 us; unpinned, the 8 threads migrate
+  RNG numbers and enqueues the step's 11 launches every ~150 us; unpinned, the 8 threads migrate
   and share cores with each other's runtime helper threads."""
   cpus = sorted(os.sched_getaffinity(0)) if available is None else sorted(available)
   if local_world <= 1 or len(cpus) < local_world:

@@ -1,4 +1,4 @@
-"""(-DDZ_HC_STAMPS build only: tools/build_variant_rb.sh) per-workgroup wall-clock stamps of the
+"""(-DDZ_HC_STAMPS build only: tools/build_variant.sh dz_rainbow) per-workgroup wall-clock stamps of the
 multi-role head launch (csrc/dz_head_chain.h), us after the launch's first stamp."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
