@@ -592,6 +592,20 @@ def make_loop_agent(which, learn_period=4, capacity=100000):
         learn_period=learn_period, target_network_update_period=2000, rng_key=1,
         grad_error_bound=1.0 / 32)
     return ag, rep
+  if which == 'iqn':   # iqn/run_atari.py:170-240 (64 / 32 / 64 tau samples, Adam)
+    from dqn_zoo_amd.iqn import agent as iqn_lib
+    rep = replay_lib.TransitionReplay(capacity, structure, np.random.RandomState(1))
+    ag = iqn_lib.Iqn(
+        preprocessor=processors.Identity(),
+        sample_network_input=iqn_lib.IqnInputs(state=np.zeros((84, 84, 4), np.uint8),
+                                               taus=np.zeros(1, np.float32)),
+        network=networks.IqnNetwork(NUM_ACTIONS, 64),
+        optimizer=learner_lib.AdamConfig(learning_rate=5e-5, eps=0.01 / 32, max_global_grad_norm=0.0),
+        transition_accumulator=replay_lib.TransitionAccumulator(), replay=rep, batch_size=32,
+        exploration_epsilon=lambda t: 0.1, min_replay_capacity_fraction=0.005,
+        learn_period=learn_period, target_network_update_period=2000, huber_param=1.0,
+        tau_samples_policy=32, tau_samples_s_tm1=64, tau_samples_s_t=64, rng_key=1)
+    return ag, rep
   from dqn_zoo_amd.rainbow import agent as rainbow_lib
   support = np.linspace(-VMAX, VMAX, NUM_ATOMS).astype(np.float32)
   rep = replay_lib.PrioritizedTransitionReplay(
@@ -919,7 +933,7 @@ def main():
         del step, seq_step, replay, learner
         torch.cuda.empty_cache()
       out['agent_loop'] = {w: measure_agent_loop(w, args.agent_loop_frames)
-                           for w in ('rainbow', 'dqn')}
+                           for w in ('rainbow', 'dqn', 'iqn')}
     if world == 1 and args.cpu_seconds > 0:
       out['cpu_baseline'] = cpu_baseline(args, args.seed, args.cpu_seconds)
       out['speedup_vs_cpu_baseline'] = round(

@@ -152,7 +152,7 @@ class IqnLayout(ctypes.Structure):
       ('ws_dact2', c_i64), ('ws_dact1', c_i64), ('ws_wgrad_part', c_i64),
       ('ws_fc2w_part', c_i64), ('ws_embw_part', c_i64),
       ('ws_bias_part', c_i64), ('ws_norm_part', c_i64), ('ws_scalars', c_i64),
-      ('ws_zeros', c_i64),
+      ('ws_zeros', c_i64), ('ws_act_seams', c_i64),
   ]
 
 
@@ -216,6 +216,8 @@ SIGNATURES = {
     'dz_iqn_learn': (c_int, [ctypes.POINTER(IqnArgs), c_int, c_vp]),
     'dz_iqn_apply': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                              c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'dz_iqn_act': (c_int, [c_int, c_int, c_int, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint64, c_vp,
+                           c_vp, c_vp, c_vp]),
     'dz_uniform_fill': (c_int, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64,
                                 c_vp, c_vp]),
     'dz_noise_fill': (c_int, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint64,

@@ -7,6 +7,7 @@
 // g0 = online(s_tm1), g1 = target(s_t) -- shared by the two target applies.
 #include "dz_iqn_ops.h"
 #include "dz_torso.h"
+#include "dz_iqn_act.h"
 
 namespace {
 constexpr int kS_iqn_fc2w = 32;   // row splits of the fc2 weight gradient
@@ -60,6 +61,7 @@ extern "C" int dz_iqn_layout(int A, int latent, int B, int n0, int n1, int n2,
   L->ws_norm_part = take(kNormBlocks);
   L->ws_scalars = take(16);
   L->ws_zeros = take(kFlat + 1024);
+  L->ws_act_seams = take(kIqnActSeamWords);   // (the last region: callers clear [ws_act_seams, ws_count))
   L->ws_count = w;
   return DZ_OK;
 }
@@ -307,6 +309,36 @@ extern "C" int dz_iqn_apply(int A, int latent, int B, int samples, const float* 
                        A, samples, q_values_out, greedy_out, vmax_out);
     DZ_LAUNCH_CHECK();
   }
+  return DZ_OK;
+}
+
+extern "C" int dz_iqn_act(int A, int latent, int samples, const float* params, const uint8_t* state,
+                          uint64_t tau_seed, uint64_t tau_counter, float* taus_out, float* ws,
+                          void* pairs_out, dz_stream_t stream) {
+  DZ_REQUIRE(params && state && ws && pairs_out && ((uintptr_t)pairs_out & 7) == 0);
+  DZ_REQUIRE(A > 0 && A <= 32 && samples > 0 && samples <= kIqnActMaxTaus && latent >= 16 &&
+             latent <= kIqnActMaxLatent && latent % 8 == 0);
+  dz_iqn_layout_t L;
+  int rc = dz_iqn_layout(A, latent, 1, samples, 1, 1, &L);
+  if (rc) return rc;
+  IqnActParams q;
+  q.obs = state; q.prm = params;
+  for (int i = 0; i < 3; ++i) { q.conv_w[i] = L.conv_w[i]; q.conv_b[i] = L.conv_b[i]; }
+  q.sync = reinterpret_cast<unsigned*>(ws + L.ws_act_seams);   // zero in a fresh workspace
+  q.set_floats = act_set_floats(kIqnActPartLd); q.ncg = 4; q.part_ld = kIqnActPartLd;
+  q.spin_limit = g_dz_act_spin_limit;
+  q.fc1_mu_w = L.fc1_w; q.fc1_ld = L.fc1_ld;
+#ifdef DZ_ACT_STAMPS
+  q.dbg = reinterpret_cast<long long*>(ws + L.ws_hin);
+#endif
+  q.latent = latent; q.N = samples; q.A = A; q.ld2 = L.fc2_ld;
+  q.emb_w = L.emb_w; q.emb_b = L.emb_b; q.fc1_b = L.fc1_b; q.fc2_w = L.fc2_w; q.fc2_b = L.fc2_b;
+  q.tau_seed = tau_seed; q.tau_counter = tau_counter; q.taus_out = taus_out;
+  q.out = ws + L.ws_out; q.pairs_out = (unsigned long long*)pairs_out;
+  hipLaunchKernelGGL(iqn_act_one_kernel,
+                     dim3((unsigned)(kActTorsoBlocks + kIqnActFc1Blocks + samples)), dim3(256), 0,
+                     dz_s(stream), q);
+  DZ_LAUNCH_CHECK();
   return DZ_OK;
 }
 

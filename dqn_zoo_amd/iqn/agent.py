@@ -116,12 +116,20 @@ class Iqn(dense_agent.DenseAgent):
     self._act_counter = 0
     self._act_seed = (int(rng_key) * 0x9E3779B97F4A7C15 + 1) & 0xFFFFFFFFFFFFFFFF
 
+  act_one_launch = True   # the decision for one state is ONE launch (tau_samples_policy <= 32)
+
   def _act(self, timestep) -> parts.PendingAction:
     """ref: iqn/agent.py:234-247 select_action: tau_samples_policy fresh draws,
     epsilon-greedy on the sample mean."""
     ln = self._learner
     obs_d = self._obs.upload(timestep.observation)
     n = self._tau_samples_policy
+    if self.act_one_launch and ln.can_decide_in_one_launch(n):
+      # ONE launch per decision (csrc/dz_iqn_act.h): the taus are drawn inside the kernel at the
+      # same stream position dz_uniform_fill would use, the q-values polled in a pinned slot
+      read = ln.q_async(obs_d, n, self._act_seed, self._act_counter)
+      self._act_counter += n
+      return parts.PendingAction(self._deferred_policy(read, self.exploration_epsilon))
     learner_lib._lib.check(ln._lib.dz_uniform_fill(  # pylint: disable=protected-access
         self._act_taus.data_ptr(), n, self._act_seed, self._act_counter, None,
         learner_lib._lib.stream_ptr(self._device)), 'dz_uniform_fill')

@@ -943,6 +943,75 @@ class IqnLearner:
   set_opt_state = DenseLearner.set_opt_state
   ws_view = DenseLearner.ws_view
 
+  ACT_RING = 8
+  ONE_LAUNCH_MAX_TAUS = 32      # dz_iqn_act: samples <= 32, num_actions <= 32, latent_dim <= 64
+  last_act_fail = 0
+
+  def can_decide_in_one_launch(self, samples: int) -> bool:
+    return (samples <= self.ONE_LAUNCH_MAX_TAUS and self.network.num_actions <= 32 and
+            self.network.latent_dim <= 64 and self.network.latent_dim % 8 == 0)
+
+  def q_async(self, states: torch.Tensor, samples: int, tau_seed: int, tau_counter: int,
+              taus_out=None):
+    """The actor's decision for ONE state as ONE launch (dz_iqn_act, csrc/dz_iqn_act.h):
+    `samples` tau draws at stream position `tau_counter` of seed `tau_seed` (the draws
+    `dz_uniform_fill` would make there; written to `taus_out` [samples] if given), q = mean over
+    the taus.  Every q-value lands in a pinned slot as an 8-byte {value, marker} word; returns
+    `read() -> float32 [num_actions]`, which polls the markers with plain loads.
+    ref: iqn/agent.py:234-247."""
+    a = self.network.num_actions
+    if getattr(self, '_q_host', None) is None:
+      self._q_host = torch.zeros((self.ACT_RING, a, 2), dtype=torch.float32).pin_memory()
+      self._q_host_np = self._q_host.numpy()
+      self._q_pos = 0
+    key = (1, int(samples))
+    if key not in self._act_ws:
+      self._act_ws[key] = torch.zeros(self.network.layout(1, (int(samples), 1, 1)).ws_count,
+                                      dtype=torch.float32, device=self.device)
+    ws = self._act_ws[key]
+    k = self._q_pos % self.ACT_RING
+    self._q_pos += 1
+    words = self._q_host_np[k]
+    words[:] = 0.0
+    _lib.check(self._lib.dz_iqn_act(
+        a, self.network.latent_dim, int(samples), self.online.data_ptr(), states.data_ptr(),
+        int(tau_seed) & 0xFFFFFFFFFFFFFFFF, int(tau_counter), 
+        None if taus_out is None else taus_out.data_ptr(), ws.data_ptr(),
+        self._q_host[k].data_ptr(), _lib.stream_ptr(self.device)), 'dz_iqn_act')
+    marks, vals = words[:, 1], words[:, 0]
+    enq_stream = _lib.current_stream(self.device)
+    owner, samples = self, int(samples)
+
+    def read():
+      deadline = None
+      while not marks.all():
+        now = time.monotonic()
+        if deadline is None:
+          deadline = now + RainbowLearner.ACT_POLL_SECONDS
+        elif now > deadline:
+          enq_stream.synchronize()
+          break
+      if not marks.all() or (marks == _lib.ACT_FAILED_MARKER).any():
+        owner._reset_act_seams(samples)   # pylint: disable=protected-access
+        raise ActDecisionError(
+            'dz_iqn_act: the one-launch decision did not complete (sticky failure word %d); '
+            'the acting workspace was re-armed' % owner.last_act_fail)
+      return vals.copy()
+
+    return read
+
+  def _reset_act_seams(self, samples: int) -> None:
+    """As RainbowLearner._reset_act_seams."""
+    torch.cuda.synchronize(self.device)
+    ws = self._act_ws.get((1, int(samples)))
+    if ws is None:
+      return
+    lay = self.network.layout(1, (int(samples), 1, 1)).c
+    off = int(lay.ws_act_seams)
+    self.last_act_fail = int(ws[off + 5 * 64:off + 5 * 64 + 1].view(torch.int32).item())
+    ws[off:int(lay.ws_count)].zero_()
+    torch.cuda.synchronize(self.device)
+
   def sample_taus(self) -> None:
     """Fresh U[0,1) draws for the three tau sets; the stream position is the
     optimiser step count, read on the device (no host sync)."""

@@ -588,6 +588,7 @@ typedef struct {
   int64_t ws_dout, ws_dh1, ws_dhin, ws_dfeat, ws_dact2, ws_dact1;
   int64_t ws_wgrad_part, ws_fc2w_part, ws_embw_part, ws_bias_part;
   int64_t ws_norm_part, ws_scalars, ws_zeros;
+  int64_t ws_act_seams;      /* one-launch decision (dz_iqn_act): zero at creation, owned by it; the last region */
 } dz_iqn_layout_t;
 
 int dz_iqn_layout(int num_actions, int latent_dim, int batch, int samples_tm1,
@@ -626,6 +627,20 @@ int dz_iqn_apply(int num_actions, int latent_dim, int batch, int samples,
                  const float* params, const uint8_t* states, const float* taus,
                  float* ws, float* q_dist_out, float* q_values_out,
                  int32_t* greedy_out, float* vmax_out, dz_stream_t stream);
+
+/* The IQN actor's decision for ONE observation as ONE launch (csrc/dz_iqn_act.h; ref:
+ * iqn/agent.py:234-247 select_action): samples (<= 32) fresh tau draws -- tau_j is the value
+ * dz_uniform_fill(seed = tau_seed, counter = tau_counter + j) produces, drawn inside the kernel and
+ * written to taus_out [samples] if given --, the network on those taus, q = mean over the taus.
+ * num_actions <= 32, latent_dim <= 64.  `ws`: a dz_iqn_layout(num_actions, latent_dim, 1, samples,
+ * 1, 1) workspace, zero when created and used by nothing else in between (its ws_act_seams region
+ * belongs to this call).  `pairs_out` (8-byte aligned; pinned device-mapped host memory or device
+ * memory): num_actions words {float q, float 1.0f}, each written with ONE store: a host that
+ * zeroed them before the call may poll them.  Liveness and failure as dz_dense_act
+ * ({NaN, DZ_ACT_FAILED_MARKER} words; zero the ws_act_seams region before the next decision).   */
+int dz_iqn_act(int num_actions, int latent_dim, int samples, const float* params,
+               const uint8_t* state, uint64_t tau_seed, uint64_t tau_counter, float* taus_out,
+               float* ws, void* pairs_out, dz_stream_t stream);
 
 /* out[i] = U[0,1) from the counter-based generator keyed by (seed, counter +
  * *step * n + i); `step` may be NULL.  The tau draws of iqn/agent.py:47-51.     */

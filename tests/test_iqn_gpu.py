@@ -210,3 +210,68 @@ def test_iqn_and_dense_learners_replay_from_graphs_bit_identically():
     p_g, m_g = run(make, True)
     p_e, m_e = run(make, False)
     assert torch.equal(p_g, p_e) and torch.equal(m_g, m_e)
+
+
+def _make_actor(actions, samples, seed):
+  from dqn_zoo_amd import learner as ll, networks
+  rs = np.random.RandomState(seed)
+  online = qo.init_params('iqn', actions, rs)
+  online['fc2/w'] = (online['fc2/w'] * 20).astype(np.float32)
+  ln = ll.IqnLearner(networks.IqnNetwork(actions, 64), ll.AdamConfig(), 8,
+                     tau_samples=(8, samples, 8), seed=seed, params=online)
+  return rs, online, ln
+
+
+@pytest.mark.parametrize('actions,samples', [(6, 32), (18, 32), (4, 8), (3, 1)])
+def test_one_launch_iqn_decision(actions, samples):
+  """`IqnLearner.q_async` is ONE launch (dz_iqn_act, csrc/dz_iqn_act.h): the taus drawn inside the
+  kernel are the draws dz_uniform_fill makes at the same stream position, the q-values (mean over
+  the taus) land in a pinned slot as 8-byte {value, marker} words.  Nine decisions (more than
+  the ring of slots, both sets of intermediates many times) against the oracle on those taus
+  and against the multi-launch apply; an all-zero observation; the seam words left re-armed."""
+  from dqn_zoo_amd import _lib
+  rs, online, ln = _make_actor(actions, samples, 90 + actions)
+  lib = _lib.load()
+  seed, counter = 0x1234567, 40
+  for i in range(9):
+    x = rs.randint(0, 256, (1, 84, 84, 4)).astype(np.uint8)
+    if i == 4:
+      x[:] = 0
+    xd = torch.from_numpy(x).cuda()
+    taus = torch.zeros(samples, dtype=torch.float32, device='cuda')
+    q = ln.q_async(xd, samples, seed, counter, taus_out=taus)()
+    # the draws of dz_uniform_fill at the same position
+    ref_t = torch.empty(samples, dtype=torch.float32, device='cuda')
+    _lib.check(lib.dz_uniform_fill(ref_t.data_ptr(), samples, seed, counter, None,
+                                   _lib.stream_ptr(ln.device)), 'dz_uniform_fill')
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(taus.cpu().numpy(), ref_t.cpu().numpy())
+    counter += samples
+    t = taus.cpu().numpy()[None]
+    _, ref_q, _ = qo.iqn_fwd(online, x, t)
+    np.testing.assert_allclose(q, ref_q[0], rtol=5e-5, atol=5e-6)
+    _, q5, _, _ = ln.apply(xd, taus[None])            # the multi-launch kernels on the same taus
+    np.testing.assert_allclose(q, q5.cpu().numpy()[0], rtol=2e-5, atol=5e-6)
+  lay = ln.network.layout(1, (samples, 1, 1)).c
+  seams = int(lay.ws_act_seams)
+  words = ln._act_ws[(1, samples)][seams:seams + 64 * 8:64].view(torch.int32).tolist()  # pylint: disable=protected-access
+  assert words[3] == 9 and words[4] == 0 and words[5] == 0, words
+
+
+def test_forced_seam_timeout_in_the_iqn_decision():
+  from dqn_zoo_amd import _lib, learner
+  lib = _lib.load()
+  rs, online, ln = _make_actor(6, 32, 91)
+  x = rs.randint(0, 256, (1, 84, 84, 4)).astype(np.uint8)
+  xd = torch.from_numpy(x).cuda()
+  taus = torch.zeros(32, dtype=torch.float32, device='cuda')
+  q0 = ln.q_async(xd, 32, 5, 0, taus_out=taus)()
+  old = lib.dz_act_debug_spin_limit(0)
+  try:
+    with pytest.raises(learner.ActDecisionError, match='re-armed'):
+      ln.q_async(xd, 32, 5, 0)()
+    assert ln.last_act_fail == 1
+  finally:
+    lib.dz_act_debug_spin_limit(old)
+  for _ in range(3):
+    np.testing.assert_array_equal(ln.q_async(xd, 32, 5, 0)(), q0)   # same taus, same state: same bits

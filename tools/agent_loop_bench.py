@@ -27,7 +27,7 @@ def main():
 
 
 def instrument(ag, rep, which, acc):
-  add_name = 'add' if which == 'dqn' else 'add_with_device_priority'
+  add_name = 'add_with_device_priority' if which == 'rainbow' else 'add'
   if 'eager-learn' in sys.argv[3:]:
     ag._learner.use_graphs = False   # learner launches eager, acting applies still from graphs  # pylint: disable=protected-access
   def wrap(obj, name, key):
@@ -43,7 +43,9 @@ def instrument(ag, rep, which, acc):
   else:   # Rainbow: the acting apply is enqueued inside step() 
     wrap(ag._learner, 'apply_async', 'act')   # pylint: disable=protected-access
   wrap(ag, '_learn', 'learn'); wrap(rep, add_name, 'add')
-  if which != 'dqn':   # A/B switches of the acting path (defaults: both on)
+  if which == 'iqn':
+    ag.act_one_launch = 'multi-launch-act' not in sys.argv[3:]
+  if which == 'rainbow':   # A/B switches of the acting path (defaults: both on)
     ag._learner.poll_action_slot = 'event-wait' not in sys.argv[3:]   # pylint: disable=protected-access
     ag._learner.act_direct = 'act-graph' not in sys.argv[3:]          # pylint: disable=protected-access
 
