@@ -118,6 +118,47 @@ def find_moments(state):
 
 
 # --------------------------------------------------------------------------- #
+#  the random draws of one update, replaced by the case's values IN THE ORDER the reference
+#  makes them (both feeders refuse a request whose shape does not fit the next value: a wrong
+#  order cannot go unnoticed)
+# --------------------------------------------------------------------------- #
+def noise_feeder(noises, used, asarray, default_dtype):
+  """Stand-in for `jax.random.truncated_normal` during ONE Rainbow update: per apply
+  (online(s_tm1), online(s_t), target(s_t): rainbow/agent.py:87-96) the network draws adv1 in /
+  out, adv2 in / out, val1 in / out, val2 in / out (networks.py:239-252, each noisy_linear:
+  input noise then output noise, networks.py:169-170).  Returns x with sign(x) sqrt|x| == the
+  case's value; what the network then forms from it is appended to `used`."""
+  queue = [np.asarray(noises[g][k], np.float32) for g in range(3) for k in NOISE_ORDER]
+
+  def fake_tn(key, lower, upper, shape=None, dtype=None):
+    del key
+    assert float(lower) == -2.0 and float(upper) == 2.0, (lower, upper)   # networks.py:143
+    v = queue.pop(0)
+    assert shape is not None and int(np.prod(shape)) == v.size and tuple(shape)[0] == 1, (
+        'draw %d of the update asks for shape %r, the case has %d values next: the order of the '
+        'noise draws differs from NOISE_ORDER' % (len(used), shape, v.size))
+    x = (np.sign(v) * v.astype(np.float64) ** 2).astype(np.float32)
+    used.append(np.sign(x) * np.sqrt(np.abs(x)))          # what make_noise_sqrt forms
+    return asarray(x, dtype or default_dtype).reshape(shape)
+
+  return fake_tn, queue
+
+
+def tau_feeder(taus, asarray):
+  """Stand-in for `iqn.agent._sample_tau` (iqn/agent.py:45-50) during ONE update: tau_tm1,
+  tau_t_selector, tau_t in that order (iqn/agent.py:181-187)."""
+  tq = [np.asarray(t, np.float32) for t in taus]
+
+  def fake_sample_tau(key, shape):
+    del key
+    t = tq.pop(0)
+    assert tuple(shape) == tuple(t.shape), (shape, t.shape)
+    return asarray(t).reshape(shape)
+
+  return fake_sample_tau, tq
+
+
+# --------------------------------------------------------------------------- #
 #  one agent, one update
 # --------------------------------------------------------------------------- #
 def run_reference(name, zoo_root):
@@ -203,22 +244,15 @@ def run_reference(name, zoo_root):
   used_noise = []
   undo = []
   if name == 'rainbow':
-    queue = [np.asarray(inp['noises'][g][k], np.float32) for g in range(3) for k in NOISE_ORDER]
+    fake_tn, queue = noise_feeder(inp['noises'], used_noise, lambda x, dt: jnp.asarray(x, dt),
+                                  jnp.float32)
     orig_tn = jax.random.truncated_normal
-
-    def fake_tn(key, lower, upper, shape=None, dtype=jnp.float32):
-      del key, lower, upper
-      v = queue.pop(0)
-      x = (np.sign(v) * v.astype(np.float64) ** 2).astype(np.float32)
-      used_noise.append(np.sign(x) * np.sqrt(np.abs(x)))          # what make_noise_sqrt forms
-      return jnp.asarray(x, dtype).reshape(shape)
-
     jax.random.truncated_normal = fake_tn
     undo.append(lambda: setattr(jax.random, 'truncated_normal', orig_tn))
   if name == 'iqn':
-    tq = [np.asarray(t, np.float32) for t in inp['taus']]
+    fake_st, tq = tau_feeder(inp['taus'], jnp.asarray)
     orig_st = agent_lib._sample_tau                                # pylint: disable=protected-access
-    agent_lib._sample_tau = lambda key, shape: jnp.asarray(tq.pop(0)).reshape(shape)  # pylint: disable=protected-access
+    agent_lib._sample_tau = fake_st                                # pylint: disable=protected-access
     undo.append(lambda: setattr(agent_lib, '_sample_tau', orig_st))
   try:
     with jax.disable_jit():
@@ -298,10 +332,39 @@ def selfcheck():
       x = (np.sign(v) * v.astype(np.float64) ** 2).astype(np.float32)
       used = np.sign(x) * np.sqrt(np.abs(x))
       assert np.abs(used - v).max() <= np.spacing(np.abs(v).max()), 'noise inversion'
+    if name == 'rainbow':
+      # the noise feeder, driven in the reference's draw order with the shapes its network asks
+      # for (networks.py:169-170, 239-252): 3 applies x 8 draws, every value used exactly once
+      used = []
+      fake_tn, queue = noise_feeder(inp['noises'], used, lambda x, dt: np.asarray(x, dt), np.float32)
+      nak = qc.A * len(qc.SUPPORT)
+      for g in range(3):
+        for n_in, n_out in ((3136, 512), (512, nak), (3136, 512), (512, len(qc.SUPPORT))):
+          for n in (n_in, n_out):
+            got = fake_tn(None, -2.0, 2.0, shape=[1, n])
+            assert got.shape == (1, n) and got.dtype == np.float32
+      assert not queue and len(used) == 24
+      for i, u in enumerate(used):
+        ref = np.asarray(inp['noises'][i // 8][NOISE_ORDER[i % 8]], np.float32)
+        assert np.allclose(u, ref, rtol=2e-7, atol=0), (i, NOISE_ORDER[i % 8])
+      # a network that drew in another order (value head first) is refused at its second draw
+      bad, _q = noise_feeder(inp['noises'], [], lambda x, dt: np.asarray(x, dt), np.float32)
+      bad(None, -2.0, 2.0, shape=[1, 3136])
+      try:
+        bad(None, -2.0, 2.0, shape=[1, len(qc.SUPPORT)])
+        raise SystemExit('selfcheck: a wrong draw order was accepted')
+      except AssertionError:
+        pass
+    if name == 'iqn':
+      fake_st, tq = tau_feeder(inp['taus'], np.asarray)
+      for t in inp['taus']:
+        assert np.array_equal(fake_st(None, np.shape(t)), np.asarray(t, np.float32))
+      assert not tq
     res = qc.oracle_step(name, qc.make_inputs(name))
     packed = qc.pack(res)
     assert 'g/conv1/w' in packed and packed['losses'].shape == (qc.B,)
-  print('selfcheck OK (mapping for 7 agents, tree round trip, noise inversion, pack)')
+  print('selfcheck OK (mapping for 7 agents, tree round trip, noise inversion, noise / tau draw '
+        'order and shapes, pack)')
 
 
 def main():
