@@ -24,7 +24,7 @@ dev = (torch.randint(0, 256, (B, 84, 84, 4), dtype=torch.uint8, device='cuda', g
        torch.full((B,), 0.97, dtype=torch.float64, device='cuda'),
        torch.randint(0, 256, (B, 84, 84, 4), dtype=torch.uint8, device='cuda', generator=g))
 w = None if which == 'dqn' else torch.rand(B, dtype=torch.float32, device='cuda', generator=g)
-for _ in range(12):
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
   ln.step(*dev, w)
 torch.cuda.synchronize()
 print('done')
