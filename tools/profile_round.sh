@@ -7,23 +7,29 @@
 # Outputs under gpurun_out/<tag>/ (python tools/collect_profiles.py <tag> copies the
 # summaries into profiles/).
 ulimit -c 0
-TAG=${1:-r4}
+TAG=${1:-r5}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python $R/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err < /dev/null
 echo "bench rc=$?"
-timeout 600 python $R/bench.py --steps 40000 --warmup 500 --cpu-seconds 0 --other-configs 0 --prof-steps 0 --sustain-steps 0 --agent-form-steps 0 > $OUT/bench_40k.json 2> $OUT/bench_40k.err < /dev/null
+timeout 600 python $R/bench.py --steps 40000 --warmup 500 --cpu-seconds 0 --other-configs 0 --prof-steps 0 --sustain-steps 0 --agent-form-steps 0 --agent-loop-frames 0 > $OUT/bench_40k.json 2> $OUT/bench_40k.err < /dev/null
 echo "bench 40k rc=$?"
 for mode in fused sequential; do
   rm -rf $OUT/kt
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py --mode $mode --steps 300 --warmup 50 --cpu-seconds 0 --prof-steps 0 --other-configs 0 --sustain-steps 0 --agent-form-steps 0 > $OUT/kt_$mode.log 2>&1 < /dev/null
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py --mode $mode --steps 300 --warmup 50 --cpu-seconds 0 --prof-steps 0 --other-configs 0 --sustain-steps 0 --agent-form-steps 0 --agent-loop-frames 0 > $OUT/kt_$mode.log 2>&1 < /dev/null
   f=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats_$mode.csv
   t=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
   [ -n "$t" ] && python $R/tools/step_trace_summary.py "$t" 100 > $OUT/kernel_step_summary_$mode.txt 2>&1
   rm -rf $OUT/kt
 done
+# the one-launch-per-stage form of the head chain (dz_rainbow_args_t::separate_launches), same session
+rm -rf $OUT/kt
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python $R/bench.py --separate-launches --steps 300 --warmup 50 --cpu-seconds 0 --prof-steps 0 --other-configs 0 --sustain-steps 0 --agent-form-steps 0 --agent-loop-frames 0 > $OUT/kt_sep.log 2>&1 < /dev/null
+t=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
+[ -n "$t" ] && python $R/tools/step_trace_summary.py "$t" 100 > $OUT/kernel_step_summary_separate_launches.txt 2>&1
+rm -rf $OUT/kt
 pmc_table() {  # $1 = counter_collection.csv, $2 = counter name
 python - "$1" "$2" <<'PY'
 import csv, sys
@@ -64,6 +70,15 @@ done
 # the agent loop (act -> insert -> learn every 4th frame) and the dense learners' kernel trace
 python $R/tools/agent_loop_bench.py 20000 rainbow json 2>/dev/null | tail -1 > $OUT/agent_loop_rainbow.json
 python $R/tools/agent_loop_bench.py 20000 dqn json 2>/dev/null | tail -1 > $OUT/agent_loop_dqn.json
+python $R/tools/agent_loop_bench.py 8000 iqn json 2>/dev/null | tail -1 > $OUT/agent_loop_iqn.json
+# per-kernel durations of the DQN learner's loop (BASELINE config 2)
+DZ_STEP_MARKER=finalize_grads bash $R/tools/trace_summary.sh 200 python $R/tools/run_dense.py dqn 400 > $OUT/kernel_step_summary_dqn.txt 2>&1
+# in-kernel timeline of the multi-role head launch (a -DDZ_HC_STAMPS build of dz_rainbow.hip, if present)
+if [ -f $R/tools/ab/hc_stamps.so ]; then
+  cp $R/dqn_zoo_amd/libdqnzoo_hip.so /tmp/lib_keep.so; cp $R/tools/ab/hc_stamps.so $R/dqn_zoo_amd/libdqnzoo_hip.so
+  timeout 200 python $R/tools/hc_stamps.py > $OUT/head_chain_stamps.txt 2>&1
+  cp /tmp/lib_keep.so $R/dqn_zoo_amd/libdqnzoo_hip.so
+fi
 # the one-launch decision: parity print-out, back-to-back and per-decision latency, kernel durations
 bash $R/tools/act_prof.sh > $OUT/act_decision.txt 2>&1
 bash $R/tools/dense_trace.sh 200 > $OUT/kernel_step_summary_double_q.txt 2>&1
