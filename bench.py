@@ -250,13 +250,6 @@ def dense_kernel_work(b, g, a=NUM_ACTIONS):
   w['head+loss'] = (f(g * b, a, 512), sets * 512 * a * 4 + 32 * g * b * 512 * 4)  # slab sums + second layer + TD loss
   w['fc1_wgrad+dgrad'] = (f(3136, 512, b) + f(b, 3136, 512), 2 * 3136 * 512 * 4)
   w['fc2_wgrad+dgrad'] = (f(512, a, b) + f(b, 512, a), 2 * 512 * a * 4)
-  # the multi-role head launch (csrc/dz_head_chain.h): fold of fc1's 32 slabs, noisy fc2 (W_eff
-  # form: depth K), loss, fc2 backward.  Bytes: the slabs read once, h1 / fc2 slabs / dlogits
-  # written and read back through the seams, fc2's parameters (mu, sigma; online + target) and
-  # its gradient -- a latency chain, neither figure is its bound
-  w['head_chain'] = (f(g * b, na + k, 512) + f(512, na + k, b) + f(b, 1024, (na + k) / 2.0),
-                     32 * g * b * 1024 * 4 + 2 * g * b * 1024 * 4 + 2 * 4 * g * b * (na + k) * 4 +
-                     2 * 2 * 512 * (na + k) * 4 + 2 * 512 * (na + k) * 4)
   w['conv3_wgrad+dgrad'] = (f(576, 64, b * 49) + f(b * 81, 64, 576),
                             2 * b * (5184 + 3136) * 4)
   w['conv2_wgrad+dgrad'] = (f(512, 64, b * 81) + f(b * 400, 32, 256),
