@@ -461,14 +461,18 @@ struct HeadSeam {
 template <int PRE, int SEAM>
 __device__ __forceinline__ void rainbow_head_loss_block(const HeadLossArgs& q, const int b,
                                                         float* s_rows, const HeadSeam seam) {
-  float* const fc2_out = q.fc2_out;
+  // (block-scope restrict: the kernel's pointer arguments were __restrict__ before they moved into
+  // HeadLossArgs; without it every store to fc2_out / q_sel_out orders the loads behind it)
+  float* __restrict__ const fc2_out = q.fc2_out;
   const int ld = q.ld, val_off = q.val_off, B = q.B, A = q.A, K = q.K, dueling = q.dueling;
   const int sel_group = q.sel_group, tgt_group = q.tgt_group;
-  const int64_t* const a_tm1 = q.a_tm1; const double* const r_t = q.r_t; const double* const d_t = q.d_t;
-  const float* const weights = q.weights; const float* const support = q.support;
-  float* const dout2 = q.dout2; float* const losses = q.losses; float* const priorities = q.priorities;
-  float* const q_sel_out = q.q_sel_out; float* const target_out = q.target_out;
-  const HeadPre& pre = q.pre;
+  const int64_t* __restrict__ const a_tm1 = q.a_tm1; const double* __restrict__ const r_t = q.r_t;
+  const double* __restrict__ const d_t = q.d_t;
+  const float* __restrict__ const weights = q.weights; const float* __restrict__ const support = q.support;
+  float* __restrict__ const dout2 = q.dout2; float* __restrict__ const losses = q.losses;
+  float* __restrict__ const priorities = q.priorities;
+  float* __restrict__ const q_sel_out = q.q_sel_out; float* __restrict__ const target_out = q.target_out;
+  const HeadPre pre = q.pre;
   __shared__ float s_p[64];
   __shared__ float s_z[64];
   __shared__ float s_q[256];         // selector q-values (A <= 256)
@@ -912,6 +916,41 @@ __device__ __forceinline__ AdamScalars adam_scalars(const float* __restrict__ pa
   AdamScalars o;
   o.gn = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
   const int c = *count;  // already incremented (finalize / sumsq_kernel)
+  o.bc1 = 1.0f - powf(b1, (float)c); o.bc2 = 1.0f - powf(b2, (float)c);
+  o.pass = !(max_norm > 0.f && !(o.gn < max_norm));
+  return o;
+}
+// The same in two halves, for callers that want the partials' trip to memory in flight before
+// their own streams (adam_fc1_block): `adam_partials_request` issues the loads (at most 16 x 256
+// partials), `adam_scalars_from` is the rest -- identical arithmetic and order.
+constexpr int kAdamPartRounds = 2;   // x 8 loads per thread
+struct AdamPartials { float x[kAdamPartRounds][8]; };
+__device__ __forceinline__ AdamPartials adam_partials_request(const float* __restrict__ part, int nparts) {
+  AdamPartials r;
+#pragma unroll
+  for (int q = 0; q < kAdamPartRounds; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      r.x[q][j] = part[min(q * 8 * 256 + j * 256 + (int)threadIdx.x, nparts - 1)];
+  return r;
+}
+__device__ __forceinline__ AdamScalars adam_scalars_from(const AdamPartials& r, int nparts,
+                                                         const int32_t* __restrict__ count, float b1,
+                                                         float b2, float max_norm, float* red) {
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < kAdamPartRounds; ++q) {
+    if (q * 8 * 256 < nparts) {   // (uniform) adam_scalars' rounds: `base < nparts`
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (q * 8 * 256 + j * 256 + (int)threadIdx.x) < nparts ? r.x[q][j] : 0.f;
+    }
+  }
+  s = dz_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  AdamScalars o;
+  o.gn = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+  const int c = *count;
   o.bc1 = 1.0f - powf(b1, (float)c); o.bc2 = 1.0f - powf(b2, (float)c);
   o.pass = !(max_norm > 0.f && !(o.gn < max_norm));
   return o;
