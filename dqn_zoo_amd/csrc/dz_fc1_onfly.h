@@ -59,8 +59,7 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
                                                float* __restrict__ p, float* __restrict__ m,
                                                float* __restrict__ v, const float* part, int nparts,
                                                const int32_t* count, float lr, float b1, float b2,
-                                               float eps, float max_norm, float* red, float* lds,
-                                               const AdamScalars* given = nullptr) {
+                                               float eps, float max_norm, float* red, float* lds) {
   using T = OfTile<C, IT>;
   float* s_dh1 = lds; float* s_ft = lds + 32 * C; float* s_eo = s_ft + T::R * T::FS;
   const int strip = blk % T::kStrips, rg = blk / T::kStrips;
@@ -68,12 +67,10 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
   const int tid = threadIdx.x, rl = tid / T::TPR, c4 = tid % T::TPR;
   const int col = c0 + 4 * c4;
   const float* ein = c0 < 512 ? q.eps_in0 : q.eps_in1;
-#ifndef DZ_OF_PARTIALS_LATE
   // the norm partials are requested FIRST: their (cold) trip to memory then ends before the six
-  // streams' first tiles arrive, instead of behind them (vector loads return in order)
-  AdamPartials parts;
-  if (!given) parts = adam_partials_request(part, nparts);
-#endif
+  // streams' first tiles arrive, instead of behind them (vector loads return in order; same
+  // box 6 603-6 625 -> 6 645-6 665 steps/s)
+  const AdamPartials parts = adam_partials_request(part, nparts);
   {  // LDS fill first (its staging registers die before the streams are requested):
      // dh1 strip [32][C], X tile [R][32 (+4)], the strip's eps_out and the rows' eps_in
 #pragma unroll
@@ -97,13 +94,7 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
   unsigned os = q.sig_b + ((unsigned)(k0 + rl) * (unsigned)q.ld + (unsigned)col) * 4u;
   float4 pm = ld_off(p, om), mm = ld_off(m, om), vm = ld_off(v, om);
   float4 ps = ld_off(p, os), ms = ld_off(m, os), vs = ld_off(v, os);
-  AdamScalars sc0;
-  if (given) { sc0 = *given; __syncthreads(); }   // (probe builds: the barrier behind the LDS fill)
-#ifndef DZ_OF_PARTIALS_LATE
-  else sc0 = adam_scalars_from(parts, nparts, count, b1, b2, max_norm, red);  // (syncs)
-#else
-  else sc0 = adam_scalars(part, nparts, count, b1, b2, max_norm, red);  // (syncs)
-#endif
+  const AdamScalars sc0 = adam_scalars_from(parts, nparts, count, b1, b2, max_norm, red);  // (syncs)
   const float gn = dz_sgpr(sc0.gn), bc1 = dz_sgpr(sc0.bc1), bc2 = dz_sgpr(sc0.bc2);
   const bool pass = __builtin_amdgcn_readfirstlane((int)sc0.pass) != 0;
   const unsigned rstep = (unsigned)(T::RP * q.ld) * 4u;
@@ -253,13 +244,7 @@ __device__ __forceinline__ void adam_flat_ranges(unsigned bid, unsigned nblk, co
 // 36.6 us, 16 x 128 34.3, 32 x 128 34.6, 56 x 128 33.2, 112 x 64 33.0; the next rows'
 // streams requested before the current arithmetic 33.8 (no gain: the arithmetic is the
 // exposed part, see adam_fc1_block).
-#ifndef DZ_OF_IT
-#define DZ_OF_IT 7
-#endif
-#ifndef DZ_OF_FLAT
-#define DZ_OF_FLAT 64
-#endif
-constexpr int kOfC = 64, kOfIT = DZ_OF_IT, kOfFlatBlocks = DZ_OF_FLAT;
+constexpr int kOfC = 64, kOfIT = 7, kOfFlatBlocks = 64;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void adam_onfly_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -275,15 +260,8 @@ void adam_onfly_kernel(
   if (bid < sg_blocks) { SampleGatherSide::run(sg, bid); return; }
   bid -= sg_blocks;
   if (bid < fc1_blocks) {
-#ifdef DZ_OF_STALE_SCALARS   // (timing probe only: the PREVIOUS step's published scalars, no fold of the partials)
-    AdamScalars st; st.gn = scal[DZ_SC_GNORM]; st.bc1 = scal[DZ_SC_BC1]; st.bc2 = scal[DZ_SC_BC2];
-    st.pass = scal[DZ_SC_CLIP] != 0.f;
-    adam_fc1_block<kOfC, kOfIT>(bid, q, p, m, v, part, nparts, count, lr, b1, b2, eps, max_norm,
-                                red, lds, &st);
-#else
     adam_fc1_block<kOfC, kOfIT>(bid, q, p, m, v, part, nparts, count, lr, b1, b2, eps, max_norm,
                                 red, lds);
-#endif
     return;
   }
   const AdamScalars sc = adam_scalars(part, nparts, count, b1, b2, max_norm, red);
