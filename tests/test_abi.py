@@ -157,3 +157,37 @@ def test_div_by_uniform_divisor_is_the_ieee_quotient():
       assert want == np.float32(a / b)          # (numpy's division is the IEEE one)
       bad += got != want
   assert bad == 0
+
+
+def test_kernels_with_hand_counted_waits_do_not_spill():
+  """`fc1_dgrad_mfma_kernel` issues LDS-DMA loads from inline assembly and counts its own
+  `s_waitcnt vmcnt(N)`; a register spill (scratch loads and stores count in vmcnt) between the
+  first DMA and the last wait would make the MFMAs read LDS too early.  The build must report
+  ScratchSize 0 for it -- and for the seam kernels, whose polling loops were the round-4 spill
+  source (rainbow_act_one_kernel) -- and 135 KB of LDS needs gfx950's 160 KB."""
+  import subprocess
+  src = os.path.join(ROOT, 'dqn_zoo_amd', 'csrc', 'dz_rainbow.hip')
+  cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
+         '-ffp-contract=off', '-fno-fast-math', '-I', os.path.join(ROOT, 'include'),
+         '-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', os.devnull]
+  out = subprocess.run(cmd, capture_output=True, text=True, timeout=600).stderr
+  usage, name = {}, None
+  for line in out.splitlines():
+    m = re.search(r'Function Name: (\S+)', line)
+    if m:
+      name = m.group(1)
+    m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', line)
+    if m and name:
+      usage.setdefault(name, {})['scratch'] = int(m.group(1))
+    m = re.search(r'LDS Size \[bytes/block\]: (\d+)', line)
+    if m and name:
+      usage.setdefault(name, {})['lds'] = int(m.group(1))
+  checked = 0
+  for k, u in usage.items():
+    # (the head launch counts no waits by hand: its widest variant, 13+ actions, may spill; the
+    # BASELINE shape -- two 256-column chunks of the advantage head -- must not)
+    if any(t in k for t in ('fc1_dgrad_mfma_kernel', 'rainbow_head_chain_kernelILi2E', 'rainbow_act_one_kernel')):
+      assert u['scratch'] == 0, (k, u)
+      assert u['lds'] <= 160 * 1024, (k, u)
+      checked += 1
+  assert checked >= 3, sorted(usage)
