@@ -32,7 +32,12 @@ def epsilon_greedy_sample(q_values: np.ndarray, epsilon: float,
   a = q.shape[0]
   greedy = (q == q.max())
   probs = epsilon / a + (1.0 - epsilon) * greedy / greedy.sum()
-  return int(random_state.choice(a, p=probs / probs.sum()))
+  # RandomState.choice(a, p=p) for one draw, without its argument checks (8 of the 15 us this
+  # function cost per frame): one uniform, normalised cumulative sum, searchsorted -- the same
+  # arithmetic and the same use of the stream, so the same actions for the same seed
+  cdf = (probs / probs.sum()).cumsum()
+  cdf /= cdf[-1]
+  return int(cdf.searchsorted(random_state.random_sample(), side='right'))
 
 
 class DenseAgent(parts.Agent):

@@ -799,16 +799,19 @@ class DenseLearner:
     enq_stream = _lib.current_stream(self.device)   # the stream THIS decision was enqueued on
     owner = self
 
+    n_out = float(len(marks))
+
     def read():
+      # (one reduction per look: every marker 1.0 <=> sum == n; a FAILED marker is 2.0)
       deadline = None
-      while not marks.all():
+      while marks.min() == 0.0:
         now = time.monotonic()
         if deadline is None:
           deadline = now + RainbowLearner.ACT_POLL_SECONDS
         elif now > deadline:
           enq_stream.synchronize()   # stuck or very slow: the stream the kernel is on decides
           break
-      if not marks.all() or (marks == _lib.ACT_FAILED_MARKER).any():
+      if marks.sum() != n_out:
         # a seam of the decision kernel timed out (DZ_ACT_FAILED_MARKER) or outputs never arrived
         owner._reset_act_seams()   # pylint: disable=protected-access
         raise ActDecisionError(
