@@ -11,7 +11,7 @@
 
 namespace {
 constexpr int kS_iqn_fc2w = 32;   // row splits of the fc2 weight gradient
-constexpr int kS_iqn_embw = 8;    // row splits of the embedding weight gradient
+constexpr int kS_iqn_embw = 8;    // row splits of the embedding weight gradient (4: +6 us; 16, 32: +-0)
 constexpr int kS_iqn_bias = 32;   // row splits of the bias column sums
 }
 extern "C" int dz_iqn_layout(int A, int latent, int B, int n0, int n1, int n2,
@@ -99,12 +99,13 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
     p.row0[g] = ap.row0[gg]; p.rows[g] = ap.rows[gg]; p.params[g] = ap.params[gg];
     p.feat_row0[g] = ap.feat_row0[gg]; p.samples[g] = ap.samples[gg];
   }
-  const unsigned my = (unsigned)((max_rows + IqnLin::BM - 1) / IqnLin::BM);
   {  // relu(cos @ Wemb + b) * feat -> head_in
     p.x = ws + L.ws_cos; p.ldx = latent; p.w_off = L.emb_w; p.b_off = L.emb_b;
     p.ldw = L.emb_ld; p.K = latent; p.N = kFlat; p.epi = IQN_EPI_MIX;
     p.out = ws + L.ws_hin; p.ldo = kFlat; p.feat = ws + L.ws_feat; p.temb = temb;
-    rc = dz_launch_gemm<IqnLin>(p, dim3(kFlat / IqnLin::BN, my, ap.G), s);
+    // (64x64 tiles, two 32-deep stages; one stage, 32-row / 32-column tiles and 2-4 accumulators
+    // per wave all measured slower: the launch writes 90 MB for 2 GFLOP)
+    rc = dz_launch_gemm<IqnLin>(p, dim3(kFlat / IqnLin::BN, (unsigned)((max_rows + IqnLin::BM - 1) / IqnLin::BM), ap.G), s);
     if (rc) return rc;
     DZ_PROF(s, "emb_fwd");
   }
@@ -112,11 +113,17 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
     p.x = ws + L.ws_hin; p.ldx = kFlat; p.w_off = L.fc1_w; p.b_off = L.fc1_b;
     p.ldw = L.fc1_ld; p.K = kFlat; p.N = kHid; p.epi = IQN_EPI_BIAS_RELU;
     p.out = ws + L.ws_h1; p.ldo = kHid; p.feat = nullptr; p.temb = nullptr;
-    // 64x64 tiles, KT4, tiles in XCD-aware order (all column tiles of one A-row slab on
-    // one XCD: the 77 MB activation crosses the fabric once instead of 8 times, +4 %).
-    // Measured alternatives (removed): KT2 207 us vs 192; 2-4 accumulators per wave
-    // 258-325 us (141-256 VGPRs, occupancy 1-2): EXPERIMENTS.md.
-    rc = dz_launch_gemm_xcd<IqnLinOp<2, 2, 1, 4>>(p, dim3(kHid / 64, my, ap.G), s);
+    // 64-row x 32-column tiles, two waves share the depth of a tile (48-deep stages), tiles in
+    // XCD-aware order (all column tiles of one A-row slab on one XCD: the 77 MB activation
+    // crosses the fabric once instead of 8 times, +4 %).  The learner's 5 120 rows x 512 columns
+    // are then 1 280 tiles = FIVE per CU, all resident at once; the 64x64 tiles of rounds 2-4
+    // were 640 = 2.5 per CU, i.e. half the CUs ran three tiles while the others ran two (whole
+    // step 544 -> 530 us on the same box).  Measured alternatives: <2,2,1,4> (64x64) 185 us for
+    // this launch, KT2 207; <2,1,2,2> / <2,1,2,4> / <2,1,2,5> +19 / +44 / +24 us on the step,
+    // 32x64 tiles <1,2,2,3> +20, 32x32 <1,1,4,2> +27; 2-4 accumulators per wave 258-325 us
+    // (141-256 VGPRs, occupancy 1-2): EXPERIMENTS.md.
+    using Fc1Fwd = IqnLinOp<2, 1, 2, 3>;
+    rc = dz_launch_gemm_xcd<Fc1Fwd>(p, dim3(kHid / Fc1Fwd::BN, (unsigned)((max_rows + Fc1Fwd::BM - 1) / Fc1Fwd::BM), ap.G), s);
     if (rc) return rc;
     DZ_PROF(s, "fc1_fwd");
   }
@@ -124,8 +131,11 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
     p.x = ws + L.ws_h1; p.ldx = kHid; p.w_off = L.fc2_w; p.b_off = L.fc2_b;
     p.ldw = ld2; p.K = kHid; p.N = L.num_actions; p.epi = IQN_EPI_BIAS;
     p.out = ws + L.ws_out; p.ldo = ld2;
-    rc = dz_launch_gemm<IqnLin>(
-        p, dim3((L.num_actions + IqnLin::BN - 1) / IqnLin::BN, my, ap.G), s);
+    // N = num_actions <= 32 columns: 32x32 tiles with the FOUR waves sharing the depth (128-deep
+    // stages) -- 160 workgroups of 4 stages instead of 80 of 16 (the 64x64 form: 24 -> 13 us)
+    using Fc2Fwd = IqnLinOp<1, 1, 4, 4>;
+    rc = dz_launch_gemm<Fc2Fwd>(
+        p, dim3((L.num_actions + Fc2Fwd::BN - 1) / Fc2Fwd::BN, (unsigned)((max_rows + Fc2Fwd::BM - 1) / Fc2Fwd::BM), ap.G), s);
     if (rc) return rc;
     DZ_PROF(s, "fc2_fwd");
   }
@@ -203,6 +213,9 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       d.dy = ws + L.ws_dh1; d.ldy = kHid; d.M = M0; d.NH = 1; d.S = 1; d.noisy = 0;
       d.params = a->online; d.noise = zeros; d.head[0] = h1; d.head[1] = h1;
       d.part = ws + L.ws_dhin; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
+      // (64x64 tiles, 32-deep stages for both halves.  Measured against it, whole step, same box:
+      // weight gradient <2,1,2,3> +2, <2,2,1,4> +-0, <1,2,2,4> +12 us; input gradient <2,1,2,2> +5,
+      // <2,2,1,4> +9, <2,1,2,3> +41, <1,2,2,4> +79 us: EXPERIMENTS.md)
       const dim3 gw(kHid / 64, kFlat / 64, 1), gd(kFlat / 64, (M0 + 63) / 64, 1);
       rc = dz_launch_gemm2<IqnWg, IqnDg>(w, gw, d, gd, s);
       if (rc) return rc;

@@ -9,9 +9,19 @@ ag, rep = bench.make_loop_agent('iqn', 4)
 loop = parts.run_loop(ag, bench.SyntheticFrames(3), max_steps_per_episode=0)
 for _ in range(1500): next(loop)
 torch.cuda.synchronize()
-if len(sys.argv) > 1:   # learner steps only (for rocprofv3 --kernel-trace --stats)
-  for _ in range(300): ag._learn()
-  torch.cuda.synchronize(); sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == 'prof':   # HIP-event duration of every launch of the step
+  ag._learner.use_graphs = False
+  avg = bench.profile_kernels(ag._learn, 30)
+  for k, v in avg.items(): print('%-24s %7.2f us' % (k, v * 1e6))
+  print('sum %.1f us' % (1e6 * sum(avg.values())))
+  sys.exit(0)
+if len(sys.argv) > 1:   # learner steps only (`learn`: for rocprofv3 --kernel-trace --stats; `time`: us per step)
+  for rep_ in range(3 if sys.argv[1] == 'time' else 1):
+    t0 = time.perf_counter()
+    for _ in range(300): ag._learn()
+    torch.cuda.synchronize()
+    print('learn us/step %.1f' % (1e6 * (time.perf_counter() - t0) / 300))
+  sys.exit(0)
 # (a) the loop
 t0 = time.perf_counter()
 for _ in range(4000): next(loop)
