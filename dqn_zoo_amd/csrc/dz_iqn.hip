@@ -57,7 +57,7 @@ extern "C" int dz_iqn_layout(int A, int latent, int B, int n0, int n1, int n2,
   L->ws_wgrad_part = take(torso_wgrad_part_elems());
   L->ws_fc2w_part = take((int64_t)kS_iqn_fc2w * kHid * ld2);
   L->ws_embw_part = take((int64_t)kS_iqn_embw * latent * kFlat);
-  L->ws_bias_part = take((int64_t)kS_iqn_bias * (kFlat + kHid + ld2));
+  L->ws_bias_part = take((int64_t)B * kFlat + (int64_t)kS_iqn_bias * (kHid + ld2));
   L->ws_norm_part = take(kNormBlocks);
   L->ws_scalars = take(16);
   L->ws_zeros = take(kFlat + 1024);
@@ -76,22 +76,24 @@ struct IqnApplies {
   const float* tau[3];
 };
 
-// tau embedding -> mix with the state embedding -> value head, for every apply.
+// The cosine table of every apply's taus (networks.py:277-278): a side job of the step's conv1
+// launch (torso_forward_side<IqnCosSide>).
+IqnCosParams iqn_cos_params(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws) {
+  IqnCosParams q;
+  q.t0 = ap.tau[0]; q.t1 = ap.tau[ap.G > 1 ? 1 : 0]; q.t2 = ap.tau[ap.G > 2 ? 2 : 0];
+  q.n0 = ap.rows[0]; q.n1 = ap.G > 1 ? ap.rows[1] : 0; q.n2 = ap.G > 2 ? ap.rows[2] : 0;
+  q.latent = L.latent_dim; q.out = ws + L.ws_cos;
+  return q;
+}
+
+// tau embedding -> mix with the state embedding -> value head, for every apply (the cosine
+// table is already in ws_cos).
 int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
                      float* temb, hipStream_t s) {
   int rc;
   const int latent = L.latent_dim, ld2 = L.fc2_ld;
-  int Mt = 0, max_rows = 0;
-  for (int g = 0; g < ap.G; ++g) { Mt += ap.rows[g]; if (ap.rows[g] > max_rows) max_rows = ap.rows[g]; }
-  {
-    const long total = (long)Mt * latent;
-    hipLaunchKernelGGL(iqn_cos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       ap.tau[0], ap.tau[ap.G > 1 ? 1 : 0], ap.tau[ap.G > 2 ? 2 : 0],
-                       ap.rows[0], ap.G > 1 ? ap.rows[1] : 0, ap.G > 2 ? ap.rows[2] : 0,
-                       latent, ws + L.ws_cos);
-    DZ_LAUNCH_CHECK();
-    DZ_PROF(s, "tau_cos");
-  }
+  int max_rows = 0;
+  for (int g = 0; g < ap.G; ++g) if (ap.rows[g] > max_rows) max_rows = ap.rows[g];
   IqnLinParams p;
   p.G = ap.G;
   for (int g = 0; g < 3; ++g) {
@@ -163,8 +165,6 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
   if (phases & DZ_PHASE_FORWARD) {
     const float* prm[2] = {a->online, a->target};
     const uint8_t* in[2] = {a->s_tm1, a->s_t};
-    rc = torso_forward(T, 2, B, prm, in, s);
-    if (rc) return rc;
     IqnApplies ap;
     ap.G = 3;
     ap.rows[0] = B * n0; ap.rows[1] = B * n1; ap.rows[2] = B * n2;
@@ -173,6 +173,9 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
     ap.feat_row0[0] = 0; ap.feat_row0[1] = B; ap.feat_row0[2] = B;
     ap.params[0] = a->online; ap.params[1] = a->target; ap.params[2] = a->target;
     ap.tau[0] = a->tau_tm1; ap.tau[1] = a->tau_sel; ap.tau[2] = a->tau_t;
+    const IqnCosParams cq = iqn_cos_params(L, ap, ws);
+    rc = torso_forward_side<IqnCosSide>(T, 2, B, prm, in, s, cq, IqnCosSide::blocks(cq));
+    if (rc) return rc;
     rc = iqn_head_forward(L, ap, ws, ws + L.ws_temb, s);
     if (rc) return rc;
     hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(256), 0, s, ws + L.ws_out, ld2, B, A,
@@ -221,34 +224,31 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       if (rc) return rc;
       DZ_PROF(s, "fc1_wgrad+dgrad");
     }
+    // bias-gradient partials: the embedding's come out of the mix backward pass (one slab per
+    // batch element), fc1's and fc2's column sums ride in the embedding weight-gradient launch
+    float* bp_emb = ws + L.ws_bias_part;
+    float* bp_fc1 = bp_emb + (long)B * kFlat;
+    float* bp_fc2 = bp_fc1 + (long)kS_iqn_bias * kHid;
     hipLaunchKernelGGL(iqn_mix_bwd_kernel, dim3((kFlat + 255) / 256, B), dim3(256), 0, s,
                        ws + L.ws_dhin, ws + L.ws_temb, ws + L.ws_feat, B, n0, kFlat,
-                       ws + L.ws_dfeat);
+                       ws + L.ws_dfeat, bp_emb);
     DZ_LAUNCH_CHECK();
     DZ_PROF(s, "mix_bwd");
-    {  // tau-embedding weight-gradient partials
+    {  // tau-embedding weight-gradient partials (+ the two column sums as side workgroups)
       IqnWgradParams w;
       w.x = ws + L.ws_cos; w.ldx = latent; w.dy = ws + L.ws_dhin; w.ldy = kFlat; w.M = M0;
       w.K = latent; w.N = kFlat; w.ldw = L.emb_ld; w.S = kS_iqn_embw;
       w.part = ws + L.ws_embw_part;
-      rc = dz_launch_gemm<IqnWg>(
-          w, dim3(kFlat / IqnWg::BN, (latent + IqnWg::BM - 1) / IqnWg::BM, kS_iqn_embw), s);
-      if (rc) return rc;
-      DZ_PROF(s, "emb_wgrad");
-    }
-    float* bpart = ws + L.ws_bias_part;
-    float* bp_emb = bpart;
-    float* bp_fc1 = bp_emb + (long)kS_iqn_bias * kFlat;
-    float* bp_fc2 = bp_fc1 + (long)kS_iqn_bias * kHid;
-    {
       ColPartJobs J;
-      J.j[0] = {ws + L.ws_dhin, M0, kFlat, kFlat, bp_emb};
-      J.j[1] = {ws + L.ws_dh1, M0, kHid, kHid, bp_fc1};
-      J.j[2] = {ws + L.ws_dout, M0, A, ld2, bp_fc2};
-      hipLaunchKernelGGL(colsum_part_kernel, dim3(kFlat / 64, kS_iqn_bias, 3), dim3(256), 0,
-                         s, J, kS_iqn_bias);
-      DZ_LAUNCH_CHECK();
-      DZ_PROF(s, "bias_colsum");
+      J.j[0] = {ws + L.ws_dh1, M0, kHid, kHid, bp_fc1};
+      J.j[1] = {ws + L.ws_dout, M0, A, ld2, bp_fc2};
+      J.S = kS_iqn_bias;
+      J.end0 = ColsumSide::blocks_of(J.j[0], J.S);
+      rc = dz_launch_gemm_side<IqnWg, ColsumSide>(
+          w, dim3(kFlat / IqnWg::BN, (latent + IqnWg::BM - 1) / IqnWg::BM, kS_iqn_embw), J,
+          J.end0 + ColsumSide::blocks_of(J.j[1], J.S), s);
+      if (rc) return rc;
+      DZ_PROF(s, "emb_wgrad+colsum");
     }
     ReduceJob conv_jobs[3];
     rc = torso_backward(T, B, a->online, a->s_tm1, ws + L.ws_dfeat, ws + L.ws_dact2,
@@ -260,7 +260,7 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       for (int j = 0; j < 3; ++j) J.r[j] = conv_jobs[j];
       J.r[3] = {ws + L.ws_fc2w_part, kS_iqn_fc2w, (long)kHid * ld2, grad + L.fc2_w};
       J.r[4] = {ws + L.ws_embw_part, kS_iqn_embw, (long)latent * kFlat, grad + L.emb_w};
-      J.r[5] = {bp_emb, kS_iqn_bias, (long)kFlat, grad + L.emb_b};
+      J.r[5] = {bp_emb, B, (long)kFlat, grad + L.emb_b};
       J.r[6] = {bp_fc1, kS_iqn_bias, (long)kHid, grad + L.fc1_b};
       J.r[7] = {bp_fc2, kS_iqn_bias, (long)A, grad + L.fc2_b};
       unsigned acc = 0;
@@ -303,14 +303,13 @@ extern "C" int dz_iqn_apply(int A, int latent, int B, int samples, const float* 
   const uint8_t* in[1] = {states};
   const bool prof = g_dz_prof_on;
   g_dz_prof_on = false;
-  rc = torso_forward(T, 1, B, prm, in, s);
-  if (!rc) {
-    IqnApplies ap;
-    ap.G = 1;
-    ap.rows[0] = B * samples; ap.row0[0] = 0; ap.samples[0] = samples; ap.feat_row0[0] = 0;
-    ap.params[0] = params; ap.tau[0] = taus;
-    rc = iqn_head_forward(L, ap, ws, nullptr, s);
-  }
+  IqnApplies ap;
+  ap.G = 1;
+  ap.rows[0] = B * samples; ap.row0[0] = 0; ap.samples[0] = samples; ap.feat_row0[0] = 0;
+  ap.params[0] = params; ap.tau[0] = taus;
+  const IqnCosParams cq = iqn_cos_params(L, ap, ws);
+  rc = torso_forward_side<IqnCosSide>(T, 1, B, prm, in, s, cq, IqnCosSide::blocks(cq));
+  if (!rc) rc = iqn_head_forward(L, ap, ws, nullptr, s);
   g_dz_prof_on = prof;
   if (rc) return rc;
   if (q_dist_out)

@@ -165,16 +165,31 @@ using IqnDg = FcDgradOp<2, 2, 1, 2>;
 
 // cosemb[row][i] = cos(pi_i * tau[row]),  pi_i = float32(i+1) * float32(pi)
 // (networks.py:277-278; both products in float32 as in the reference).
-__global__ void iqn_cos_kernel(const float* t0, const float* t1, const float* t2, int n0,
-                               int n1, int n2, int latent, float* __restrict__ out) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)(n0 + n1 + n2) * latent;
+struct IqnCosParams {
+  const float* t0; const float* t1; const float* t2;
+  int n0, n1, n2, latent;
+  float* out;
+};
+__device__ __forceinline__ void iqn_cos_at(const IqnCosParams& q, long i) {
+  const long total = (long)(q.n0 + q.n1 + q.n2) * q.latent;
   if (i >= total) return;
-  const int row = (int)(i / latent), l = (int)(i % latent);
-  const float tau = row < n0 ? t0[row] : (row < n0 + n1 ? t1[row - n0] : t2[row - n0 - n1]);
+  const int row = (int)(i / q.latent), l = (int)(i % q.latent);
+  const float tau = row < q.n0 ? q.t0[row]
+                               : (row < q.n0 + q.n1 ? q.t1[row - q.n0] : q.t2[row - q.n0 - q.n1]);
   const float pm = (float)(l + 1) * 3.14159274101257324f;
-  out[i] = cosf(pm * tau);
+  q.out[i] = cosf(pm * tau);
 }
+// ... as extra workgroups of the step's conv1 launch (torso_forward_side): the taus exist
+// before the step starts and conv1 does not read the table
+struct IqnCosSide {
+  typedef IqnCosParams Params;
+  __device__ static void run(const Params& q, unsigned block) {
+    iqn_cos_at(q, (long)block * 256 + threadIdx.x);
+  }
+  static unsigned blocks(const Params& q) {
+    return (unsigned)(((long)(q.n0 + q.n1 + q.n2) * q.latent + 255) / 256);
+  }
+};
 
 // U[0,1) samples for the tau draws (iqn/agent.py:47-51 jax.random.uniform: 23
 // random mantissa bits), counter-based so a step's draws depend only on (seed,
@@ -273,16 +288,20 @@ __global__ __launch_bounds__(256) void iqn_loss_kernel(
 // Backward of head_in = temb * feat[b] (networks.py:285) for the online apply:
 //   dzt[row][c]  = dhin[row][c] * feat[b][c] * (temb[row][c] > 0)     (in place)
 //   dfeat[b][c]  = (feat[b][c] > 0) * sum_n dhin[b*N+n][c] * temb[b*N+n][c]
+//   bias_part[b][c] = sum_n dzt[b*N+n][c]   (the embedding bias gradient's partial of batch
+//                     element b: B slabs folded by reduce_jobs_kernel -- the 26 MB this pass
+//                     has in registers anyway, instead of a second pass over it)
 __global__ __launch_bounds__(256) void iqn_mix_bwd_kernel(float* __restrict__ dhin,
                                                           const float* __restrict__ temb,
                                                           const float* __restrict__ feat,
                                                           int B, int samples, int F,
-                                                          float* __restrict__ dfeat) {
+                                                          float* __restrict__ dfeat,
+                                                          float* __restrict__ bias_part) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (c >= F) return;
   const float f = feat[(long)b * F + c];
-  float acc = 0.f;
+  float acc = 0.f, bsum = 0.f;
   const long o0 = (long)b * samples * F + c;
   // 8 rows per round, all 16 loads first: dhin is updated in place, so the compiler
   // cannot move a later row's load above an earlier row's store by itself
@@ -297,33 +316,46 @@ __global__ __launch_bounds__(256) void iqn_mix_bwd_kernel(float* __restrict__ dh
     for (int j = 0; j < 8; ++j) {
       if (n0 + j < samples) {
         acc += d[j] * e[j];
-        dhin[o0 + (long)(n0 + j) * F] = e[j] > 0.f ? d[j] * f : 0.f;
+        const float dz = e[j] > 0.f ? d[j] * f : 0.f;
+        dhin[o0 + (long)(n0 + j) * F] = dz;
+        bsum += dz;
       }
     }
   }
   dfeat[(long)b * F + c] = f > 0.f ? acc : 0.f;
+  bias_part[(long)b * F + c] = bsum;
 }
 
 // part[split][c] = sum of rows [split*rps, (split+1)*rps) of m[.][c]; a set of
 // matrices per launch (blockIdx.z).  The S partial rows are folded by
 // reduce_jobs_kernel.
 struct ColPartJob { const float* m; int rows; int cols; int ld; float* part; };
-struct ColPartJobs { ColPartJob j[3]; };
-__global__ __launch_bounds__(256) void colsum_part_kernel(ColPartJobs jobs, int S) {
+struct ColPartJobs { ColPartJob j[2]; unsigned end0; int S; };  // blocks [0, end0) = job 0
+__device__ __forceinline__ void colsum_part_block(const ColPartJob& jb, int S, unsigned bx,
+                                                  unsigned by) {
   __shared__ float red[4][64];
-  const ColPartJob jb = jobs.j[blockIdx.z];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + l;
-  if (blockIdx.x * 64 >= jb.cols) return;
+  const int c = bx * 64 + l;
   const int rps = (jb.rows + S - 1) / S;
-  const int r0 = blockIdx.y * rps, r1 = min(jb.rows, r0 + rps);
+  const int r0 = by * rps, r1 = min(jb.rows, r0 + rps);
   const float v = r1 > r0 ? dz_slab_sum(jb.m + (long)r0 * jb.ld, r1 - r0, jb.ld,
                                         min(c, jb.cols - 1), w) : 0.f;
   red[w][l] = v;
   __syncthreads();
   if (w == 0 && c < jb.cols)
-    jb.part[(long)blockIdx.y * jb.cols + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    jb.part[(long)by * jb.cols + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
 }
+// ... as extra workgroups of the embedding weight-gradient launch (it reads neither result)
+struct ColsumSide {
+  typedef ColPartJobs Params;
+  __device__ static void run(const Params& q, unsigned block) {
+    const bool first = block < q.end0;
+    const ColPartJob jb = first ? q.j[0] : q.j[1];
+    const unsigned i = first ? block : block - q.end0;
+    colsum_part_block(jb, q.S, i / (unsigned)q.S, i % (unsigned)q.S);
+  }
+  static unsigned blocks_of(const ColPartJob& jb, int S) { return (unsigned)((jb.cols + 63) / 64) * S; }
+};
 
 // out[i] = sum_s part[s][i] for up to 8 jobs in one launch.
 struct ReduceJobs8 { ReduceJob r[8]; unsigned r_end[8]; int n; };

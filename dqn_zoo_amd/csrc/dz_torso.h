@@ -43,23 +43,19 @@ inline int launch_conv1_fwd(const ConvFwdParams& p, int G, int B, const NoisePar
 // relu(conv3(relu(conv2(relu(conv1(u8/255)))))) for G groups; group g reads
 // images in[g] with parameters prm[g].  `side`: optional noise draw fused into
 // the conv1 launch.
-inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* prm,
-                         const uint8_t* const* in, hipStream_t s,
-                         const NoiseParams* side = nullptr, long long* dbg = nullptr,
-                         const SeamClear* clr = nullptr) {
-  int rc;
-  {
-    ConvFwdParams p;
-    for (int g = 0; g < G; ++g) {
-      p.in[g] = in[g]; p.in_img_base[g] = 0;
-      p.w[g] = prm[g] + T.conv_w[0]; p.bias[g] = prm[g] + T.conv_b[0];
-    }
-    p.out = T.act1; p.B = B; p.G = G; p.dbg = dbg;
-    rc = B <= 8 ? launch_conv1_fwd<Conv1FwdAct>(p, G, B, side, s, clr)
-                : launch_conv1_fwd<Conv1Fwd>(p, G, B, side, s, clr);
-    if (rc) return rc;
-    DZ_PROF(s, side ? "conv1_fwd+noise" : "conv1_fwd");
+inline ConvFwdParams torso_conv1_params(const TorsoBufs& T, int G, int B, const float* const* prm,
+                                        const uint8_t* const* in, long long* dbg) {
+  ConvFwdParams p;
+  for (int g = 0; g < G; ++g) {
+    p.in[g] = in[g]; p.in_img_base[g] = 0;
+    p.w[g] = prm[g] + T.conv_w[0]; p.bias[g] = prm[g] + T.conv_b[0];
   }
+  p.out = T.act1; p.B = B; p.G = G; p.dbg = dbg;
+  return p;
+}
+inline int torso_forward_rest(const TorsoBufs& T, int G, int B, const float* const* prm,
+                              hipStream_t s, long long* dbg) {
+  int rc;
   {
     ConvFwdParams p;
     for (int g = 0; g < G; ++g) {
@@ -83,6 +79,35 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
     DZ_PROF(s, "conv3_fwd");
   }
   return DZ_OK;
+}
+inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* prm,
+                         const uint8_t* const* in, hipStream_t s,
+                         const NoiseParams* side = nullptr, long long* dbg = nullptr,
+                         const SeamClear* clr = nullptr) {
+  const ConvFwdParams p = torso_conv1_params(T, G, B, prm, in, dbg);
+  const int rc = B <= 8 ? launch_conv1_fwd<Conv1FwdAct>(p, G, B, side, s, clr)
+                        : launch_conv1_fwd<Conv1Fwd>(p, G, B, side, s, clr);
+  if (rc) return rc;
+  DZ_PROF(s, side ? "conv1_fwd+noise" : "conv1_fwd");
+  return torso_forward_rest(T, G, B, prm, s, dbg);
+}
+// The same with any side job that conv1 does not depend on as `side_blocks` extra workgroups
+// of the conv1 launch (the IQN steps' cosine table: dz_iqn.hip).
+template <class Side>
+inline int torso_forward_side(const TorsoBufs& T, int G, int B, const float* const* prm,
+                              const uint8_t* const* in, hipStream_t s,
+                              const typename Side::Params& sp, unsigned side_blocks) {
+  const ConvFwdParams p = torso_conv1_params(T, G, B, prm, in, nullptr);
+  int rc;
+  if (B <= 8)
+    rc = dz_launch_gemm_side<Conv1FwdAct, Side>(
+        p, dim3(32 / Conv1FwdAct::BN, G * Conv1FwdAct::tiles_per_group(B), 1), sp, side_blocks, s);
+  else
+    rc = dz_launch_gemm_side<Conv1Fwd, Side>(
+        p, dim3(32 / Conv1Fwd::BN, G * Conv1Fwd::tiles_per_group(B), 1), sp, side_blocks, s);
+  if (rc) return rc;
+  DZ_PROF(s, "conv1_fwd+side");
+  return torso_forward_rest(T, G, B, prm, s, nullptr);
 }
 
 inline int64_t torso_wgrad_part_elems() {
