@@ -78,7 +78,8 @@ for name in ('kernel_stats_fused.csv', 'kernel_stats_sequential.csv',
              'pmc_dqn_FETCH_SIZE.csv', 'pmc_dqn_WRITE_SIZE.csv', 'pmc_double_q_FETCH_SIZE.csv',
              'pmc_double_q_WRITE_SIZE.csv', 'agent_loop_rainbow.json', 'agent_loop_dqn.json',
              'kernel_step_summary_double_q.txt', 'kernel_step_summary_dqn.txt', 'act_decision.txt',
-             'head_chain_stamps.txt', 'agent_loop_iqn.json', 'kernel_step_summary_separate_launches.txt'):
+             'head_chain_stamps.txt', 'agent_loop_iqn.json', 'kernel_step_summary_separate_launches.txt',
+             'iqn_step_launches.txt', 'pmc_sq_iqn.txt', 'dense_c51_qr_steps.txt'):
   p = os.path.join(src, name)
   if os.path.exists(p):
     shutil.copy(p, os.path.join(dst, '%s_%s' % (tag, name)))

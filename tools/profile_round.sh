@@ -83,5 +83,10 @@ fi
 bash $R/tools/act_prof.sh > $OUT/act_decision.txt 2>&1
 bash $R/tools/dense_trace.sh 200 > $OUT/kernel_step_summary_double_q.txt 2>&1
 bash $R/tools/pmc_rainbow.sh > $OUT/pmc_sq_rainbow.txt 2>&1
+# the IQN learner step: HIP-event duration of every launch, un-profiled step time, SQ counters
+(timeout 150 python $R/tools/iqn_probe.py prof; timeout 150 python $R/tools/iqn_probe.py time) 2>&1 | grep -v amdgpu.ids > $OUT/iqn_step_launches.txt
+bash $R/tools/pmc_iqn.sh > $OUT/pmc_sq_iqn.txt 2>&1
+# the C51 / QR-DQN learner steps (HIP-event durations, steps per second)
+for w in c51 qr; do timeout 150 python $R/tools/run_dense.py $w 12 prof 2>&1 | grep -v amdgpu.ids; done > $OUT/dense_c51_qr_steps.txt
 ls -la $OUT | tail -20
 head -3 $OUT/kernel_step_summary_fused.txt
