@@ -336,7 +336,7 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
       learner.use_graphs = False
       e['roofline'] = roofline_of(profile_kernels(step, prof_steps), work)
       # HBM bytes of the dominant launch from the committed PMC passes of this learner
-      # (tools/run_dense.py under --pmc FETCH_SIZE / WRITE_SIZE; profiles/r4_hbm_traffic.json)
+      # (tools/run_dense.py under --pmc FETCH_SIZE / WRITE_SIZE; profiles/r5_hbm_traffic.json)
       doc, _ = _profile_json('hbm_traffic')
       t = (doc or {}).get('dense', {}).get(desc.get('pmc_key'))
       if t and e['roofline'].get('kernel', '').startswith('finalize'):
@@ -411,8 +411,8 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
 
 
 def _profile_json(name):
-  """A committed profile table (profiles/r3_<name>.json, else the round-2 file)."""
-  for tag in ('r4', 'r3', 'r2'):
+  """A committed profile table (profiles/r5_<name>.json, else the latest earlier round's)."""
+  for tag in ('r5', 'r4', 'r3', 'r2'):
     try:
       with open(os.path.join(ROOT, 'profiles', '%s_%s.json' % (tag, name))) as f:
         return json.load(f), tag
@@ -423,7 +423,7 @@ def _profile_json(name):
 
 def pmc_traffic(kernel):
   """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-  (profiles/r3_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate passes and
+  (profiles/r5_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate passes and
   corrected as MI355X_MICROARCH.md prescribes, the dword-operand kernels with a factor
   calibrated on a known byte count in the same access pattern); None if not collected."""
   doc, _ = _profile_json('hbm_traffic')
@@ -435,7 +435,7 @@ def pmc_traffic(kernel):
 
 def pmc_mfma_util():
   """mark name -> MFMA-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x
-  kernel cycles)) from the committed SQ counter pass (profiles/r3_mfma_util.json)."""
+  kernel cycles)) from the committed SQ counter pass (profiles/r5_mfma_util.json)."""
   doc, tag = _profile_json('mfma_util')
   return ({}, None) if not doc else (doc.get('kernels', {}), tag)
 
