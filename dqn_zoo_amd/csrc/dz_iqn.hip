@@ -118,9 +118,9 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
     // 64-row x 32-column tiles, two waves share the depth of a tile (48-deep stages), tiles in
     // XCD-aware order (all column tiles of one A-row slab on one XCD: the 77 MB activation
     // crosses the fabric once instead of 8 times, +4 %).  The learner's 5 120 rows x 512 columns
-    // are then 1 280 tiles = FIVE per CU, all resident at once; the 64x64 tiles of rounds 2-4
-    // were 640 = 2.5 per CU, i.e. half the CUs ran three tiles while the others ran two (whole
-    // step 544 -> 530 us on the same box).  Measured alternatives: <2,2,1,4> (64x64) 185 us for
+    // are then 1 280 tiles = FIVE per CU (43 KB of LDS each: three resident, the next one starts
+    // when one retires); the 64x64 tiles of rounds 2-4 were 640 = 2.5 per CU, all resident: half
+    // the CUs ran three tiles while the others ran two (whole step 544 -> 530 us on the same box).  Measured alternatives: <2,2,1,4> (64x64) 185 us for
     // this launch, KT2 207; <2,1,2,2> / <2,1,2,4> / <2,1,2,5> +19 / +44 / +24 us on the step,
     // 32x64 tiles <1,2,2,3> +20, 32x32 <1,1,4,2> +27; 2-4 accumulators per wave 258-325 us
     // (141-256 VGPRs, occupancy 1-2): EXPERIMENTS.md.
