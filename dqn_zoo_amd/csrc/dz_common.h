@@ -6,6 +6,13 @@
 
 #include "../../include/dqnzoo_hip.h"
 
+// The kernels are written for ONE target: 160 KB of LDS per workgroup (fc1's input gradient
+// holds 135 KB), `global_load_lds_dwordx4`, the gfx950 lane-swap instructions, hand-counted
+// `s_waitcnt` around LDS-DMA.  A device pass for anything else must not compile.
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__ && !defined(__gfx950__)
+#error "libdqnzoo_hip is gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 extern int g_dz_last_hip_error;
 
 #define DZ_HIP_CHECK(expr)                         \
