@@ -212,15 +212,22 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       IqnWgradParams w;
       w.x = ws + L.ws_hin; w.ldx = kFlat; w.dy = ws + L.ws_dh1; w.ldy = kHid; w.M = M0;
       w.K = kFlat; w.N = kHid; w.ldw = L.fc1_ld; w.S = 1; w.part = grad + L.fc1_w;
-      FcDgradParams d;
-      d.dy = ws + L.ws_dh1; d.ldy = kHid; d.M = M0; d.NH = 1; d.S = 1; d.noisy = 0;
-      d.params = a->online; d.noise = zeros; d.head[0] = h1; d.head[1] = h1;
-      d.part = ws + L.ws_dhin; d.ldo = kFlat; d.K = kFlat; d.x_off = 0;
-      // (64x64 tiles, 32-deep stages for both halves.  Measured against it, whole step, same box:
-      // weight gradient <2,1,2,3> +2, <2,2,1,4> +-0, <1,2,2,4> +12 us; input gradient <2,1,2,2> +5,
-      // <2,2,1,4> +9, <2,1,2,3> +41, <1,2,2,4> +79 us: EXPERIMENTS.md)
-      const dim3 gw(kHid / 64, kFlat / 64, 1), gd(kFlat / 64, (M0 + 63) / 64, 1);
-      rc = dz_launch_gemm2<IqnWg, IqnDg>(w, gw, d, gd, s);
+      IqnDgradParams d;   // (no ReLU between the mix and fc1: no mask)
+      d.dy = ws + L.ws_dh1; d.ldy = kHid; d.w = a->online + L.fc1_w; d.ldw = L.fc1_ld;
+      d.M = M0; d.N = kHid; d.K = kFlat; d.dx = ws + L.ws_dhin; d.ldo = kFlat;
+      d.relu_mask = nullptr;
+      // 64x64 tiles; 64-deep stages for the weight gradient, 32-deep for the input gradient (one
+      // launch: the LDS block is the larger of the two).  With the loaders selecting on addresses
+      // (third loader rule) the pair went 158 -> 140 us, the deeper weight-gradient stages took
+      // another 10.  Measured against it, whole step, same box: weight gradient <2,2,1,2> +10.5,
+      // <2,1,2,3> +3, <2,2,1,3> +10, <2,2,1,5> +1.5, <2,2,1,6> +3 (with the input gradient at
+      // 64-deep stages); input gradient <2,2,1,4> +3 (alone -9.5, together with the deeper weight
+      // gradient it loses), <2,2,1,3> +1, <2,1,2,2> -4 alone / not combined, <2,1,2,4> +3,
+      // <2,2,1,6> +18, both <2,2,1,8> +32: EXPERIMENTS.md.
+      using Dg1 = IqnDgradOp<2, 2, 1, 2>;
+      using Wg1 = IqnWgradOp<2, 2, 1, 4>;
+      const dim3 gw(kHid / Wg1::BN, kFlat / Wg1::BM, 1), gd(kFlat / Dg1::BN, (M0 + Dg1::BM - 1) / Dg1::BM, 1);
+      rc = dz_launch_gemm2<Wg1, Dg1>(w, gw, d, gd, s);
       if (rc) return rc;
       DZ_PROF(s, "fc1_wgrad+dgrad");
     }

@@ -60,18 +60,23 @@ struct IqnLinOp {
   }
   __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int row, int q) {
+    // (third loader rule, dz_qnet_ops.h: a masked slot selects on the ADDRESS; a select on the
+    // loaded value puts the stage's vmcnt waits in front of its MFMA block -- rounds 2-4 of this
+    // Op did exactly that and ran the weight stream un-overlapped)
     const int gc = st * CPS + c, total = p.K / 16;
     const int m = t.m0 + row;
     const bool ok = (m < t.rows) & (gc < total);
     const int k = min(gc, total - 1) * 16 + 4 * q;
-    return dz_sel4(ok, dz_ld4(p.x + (long)(t.row0 + min(m, t.rows - 1)) * p.ldx + k));
+    const float* src = p.x + (long)(t.row0 + min(m, t.rows - 1)) * p.ldx + k;
+    return dz_ld4(ok ? src : dz_page_zero);
   }
   __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
     const int gc = st * CPS + c, total = p.K / 16;
     const int k = min(gc, total - 1) * 16 + kk;
     const int n = min(t.n0 + 4 * rq, p.ldw - 4);
-    return dz_sel4(gc < total, dz_ld4(t.prm + p.w_off + (long)k * p.ldw + n));
+    const float* src = t.prm + p.w_off + (long)k * p.ldw + n;
+    return dz_ld4(gc < total ? src : dz_page_zero);
   }
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
@@ -138,13 +143,15 @@ struct IqnWgradOp {
                                   int kk, int rq) {
     const int m = st * BK + c * 16 + kk;
     const int k = min(t.m0 + 4 * rq, p.K - 4);
-    return dz_sel4(m < p.M, dz_ld4(p.x + (long)min(m, p.M - 1) * p.ldx + k));
+    const float* src = p.x + (long)min(m, p.M - 1) * p.ldx + k;
+    return dz_ld4(m < p.M ? src : dz_page_zero);
   }
   __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
     const int m = st * BK + c * 16 + kk;
     const int n = min(t.n0 + 4 * rq, p.ldw - 4);
-    return dz_sel4(m < p.M, dz_ld4(p.dy + (long)min(m, p.M - 1) * p.ldy + n));
+    const float* src = p.dy + (long)min(m, p.M - 1) * p.ldy + n;
+    return dz_ld4(m < p.M ? src : dz_page_zero);
   }
   __device__ static void store(const Params& p, const Tile& t, int wm, int wn,
                                int lane, const f32x16& acc) {
@@ -155,6 +162,59 @@ struct IqnWgradOp {
     for (int r = 0; r < 16; ++r) {
       const int k = t.m0 + wm * 32 + dz_acc_row(r, lane);
       if (k < p.K) base[(long)k * p.ldw] = col < p.N ? acc[r] : 0.f;
+    }
+  }
+};
+
+// Input gradient of a plain linear layer:  dx[m][k] = relu'(.) sum_n dy[m][n] W[k][n]  (n < N,
+// N a multiple of 4: no float4 straddles the edge).  The general FcDgradOp (noisy layers,
+// two heads) scales its operands in the loaders, which waits for every load in front of the
+// MFMA block (third loader rule); here both operands are plain float4 loads.
+struct IqnDgradParams {
+  const float* dy; int ldy;     // [M][ldy]
+  const float* w; int ldw;      // [K][ldw]
+  int M, N, K;
+  float* dx; int ldo;           // [M][ldo]
+  const float* relu_mask;       // [M][ldo] or null: dx *= (mask > 0)
+};
+template <int WM_, int WN_, int WK_, int KT_>
+struct IqnDgradOp {
+  static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
+  static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_KC, A_MAP = DZ_MAP_QUAD;
+  static constexpr int BM = 32 * WM, BN = 32 * WN, BK = 16 * CPS;
+  typedef IqnDgradParams Params;
+  typedef DzTile Tile;
+  __device__ static bool tile(const Params& p, const dim3& bid, Tile& t) {
+    t.z = 0; t.m0 = bid.y * BM; t.n0 = bid.x * BN;
+    t.st_begin = 0; t.st_end = (p.N + BK - 1) / BK;
+    return t.m0 < p.M && t.n0 < p.K;
+  }
+  // A tile row = batch row m, 4 consecutive reduction indices n
+  __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c, int row, int q) {
+    const int m = t.m0 + row, n = (st * CPS + c) * 16 + 4 * q;
+    const float* src = p.dy + (long)min(m, p.M - 1) * p.ldy + min(n, p.N - 4);
+    return dz_ld4((m < p.M) & (n < p.N) ? src : dz_page_zero);
+  }
+  // B tile row = output column k, 4 consecutive reduction indices n
+  __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c, int row, int q) {
+    const int k = min(t.n0 + row, p.K - 1), n = (st * CPS + c) * 16 + 4 * q;
+    const float* src = p.w + (long)k * p.ldw + min(n, p.N - 4);
+    return dz_ld4(n < p.N ? src : dz_page_zero);
+  }
+  __device__ static void store(const Params& p, const Tile& t, int wm, int wn, int lane,
+                               const f32x16& acc) {
+    const int col = t.n0 + wn * 32 + (lane & 31);
+    if (col >= p.K) return;
+    float mv[16];
+    if (p.relu_mask) {  // (uniform) all 16 mask values first, then the stores
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        mv[r] = p.relu_mask[(long)min(t.m0 + wm * 32 + dz_acc_row(r, lane), p.M - 1) * p.ldo + col];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = t.m0 + wm * 32 + dz_acc_row(r, lane);
+      if (m < p.M) p.dx[(long)m * p.ldo + col] = (!p.relu_mask || mv[r] > 0.f) ? acc[r] : 0.f;
     }
   }
 };
