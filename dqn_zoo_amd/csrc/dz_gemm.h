@@ -588,6 +588,25 @@ static inline int dz_launch_gemm_xcd(const typename Op::Params& p, dim3 g, hipSt
   DZ_LAUNCH_CHECK();
   return DZ_OK;
 }
+// ... compiled for OCC waves per SIMD (register budget 512 / OCC).  At the default the
+// compiler aims for 8 waves and squeezes a 64-VGPR allocation out of the stage loop by parking
+// freshly LOADED registers in others around the MFMA block -- a copy that waits for the
+// prefetch in front of the MFMAs (IQN fc1 forward ISA, round 5); the LDS block admits 3-5
+// workgroups per CU anyway.
+template <class Op, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
+void dz_mfma_gemm_xcd_occ(typename Op::Params p, dim3 g) {
+  __shared__ __attribute__((aligned(16))) float smem[DzGemmSmem<Op>::ELEMS];
+  dim3 bid;
+  if (!dz_xcd_tile(blockIdx.x, g, bid)) return;
+  dz_gemm_body<Op>(p, bid, smem);
+}
+template <class Op, int OCC>
+static inline int dz_launch_gemm_xcd_occ(const typename Op::Params& p, dim3 g, hipStream_t s) {
+  hipLaunchKernelGGL((dz_mfma_gemm_xcd_occ<Op, OCC>), dim3(dz_xcd_blocks(g)), dim3(256), 0, s, p, g);
+  DZ_LAUNCH_CHECK();
+  return DZ_OK;
+}
 template <class OpA, class OpB>
 __global__ __launch_bounds__(256) void dz_mfma_gemm2_xcd(typename OpA::Params pa, dim3 ga,
                                                          typename OpB::Params pb, dim3 gb) {

@@ -115,17 +115,29 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
     p.x = ws + L.ws_hin; p.ldx = kFlat; p.w_off = L.fc1_w; p.b_off = L.fc1_b;
     p.ldw = L.fc1_ld; p.K = kFlat; p.N = kHid; p.epi = IQN_EPI_BIAS_RELU;
     p.out = ws + L.ws_h1; p.ldo = kHid; p.feat = nullptr; p.temb = nullptr;
-    // 64-row x 32-column tiles, two waves share the depth of a tile (48-deep stages), tiles in
-    // XCD-aware order (all column tiles of one A-row slab on one XCD: the 77 MB activation
-    // crosses the fabric once instead of 8 times, +4 %).  The learner's 5 120 rows x 512 columns
-    // are then 1 280 tiles = FIVE per CU (43 KB of LDS each: three resident, the next one starts
-    // when one retires); the 64x64 tiles of rounds 2-4 were 640 = 2.5 per CU, all resident: half
-    // the CUs ran three tiles while the others ran two (whole step 544 -> 530 us on the same box).  Measured alternatives: <2,2,1,4> (64x64) 185 us for
-    // this launch, KT2 207; <2,1,2,2> / <2,1,2,4> / <2,1,2,5> +19 / +44 / +24 us on the step,
-    // 32x64 tiles <1,2,2,3> +20, 32x32 <1,1,4,2> +27; 2-4 accumulators per wave 258-325 us
-    // (141-256 VGPRs, occupancy 1-2): EXPERIMENTS.md.
+    // 64-row x 32-column tiles, two waves share the depth of a tile, tiles in XCD-aware order
+    // (all column tiles of one A-row slab on one XCD: the 77 MB activation crosses the fabric
+    // once instead of 8 times, +4 %).  The learner's 5 120 rows x 512 columns are 1 280 tiles =
+    // FIVE per CU; the 64x64 tiles of rounds 2-4 were 640 = 2.5 per CU (half the CUs ran three
+    // while the others ran two).
+    //  * whole tiles (every group's rows a multiple of 64, as in every learner step): loaders
+    //    WITHOUT masks, 32-deep stages (14.5 KB of LDS: five workgroups per CU resident), compiled
+    //    for five waves per SIMD -- at the default target of eight the allocator parks freshly
+    //    loaded registers around the MFMA block, a copy that waits for the prefetch in front of
+    //    the MFMAs.  Whole step, same box: 475 (masked <2,1,2,3>) -> 459 us; <2,1,2,2> 464,
+    //    64x64 <2,2,1,1> 480 / <2,2,1,4> 475-478 / <2,2,1,7> 491, 32x64 <1,2,2,1> 473, 32x32
+    //    <1,1,4,1> 486; occupancy target 4 / 6 / 8 instead of 5: +4 / +5 / +6.
+    //  * any other shape (acting applies, odd batch sizes): masked loaders, 48-deep stages
+    //    (<2,2,1,4> 64x64 +16 us on the step, <2,1,2,2> +-0, <2,1,2,4> +44; 2-4 accumulators
+    //    per wave 258-325 us for this launch: EXPERIMENTS.md).
     using Fc1Fwd = IqnLinOp<2, 1, 2, 3>;
-    rc = dz_launch_gemm_xcd<Fc1Fwd>(p, dim3(kHid / Fc1Fwd::BN, (unsigned)((max_rows + Fc1Fwd::BM - 1) / Fc1Fwd::BM), ap.G), s);
+    using Fc1Full = IqnLinOp<2, 1, 2, 1, 1, 1, 1>;
+    bool whole = kFlat % Fc1Full::BK == 0 && kHid % Fc1Full::BN == 0;
+    for (int g = 0; g < ap.G; ++g) whole = whole && ap.rows[g] % Fc1Full::BM == 0;
+    if (whole)
+      rc = dz_launch_gemm_xcd_occ<Fc1Full, 5>(p, dim3(kHid / Fc1Full::BN, (unsigned)(max_rows / Fc1Full::BM), ap.G), s);
+    else
+      rc = dz_launch_gemm_xcd<Fc1Fwd>(p, dim3(kHid / Fc1Fwd::BN, (unsigned)((max_rows + Fc1Fwd::BM - 1) / Fc1Fwd::BM), ap.G), s);
     if (rc) return rc;
     DZ_PROF(s, "fc1_fwd");
   }
@@ -226,8 +238,19 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       // <2,2,1,6> +18, both <2,2,1,8> +32: EXPERIMENTS.md.
       using Dg1 = IqnDgradOp<2, 2, 1, 2>;
       using Wg1 = IqnWgradOp<2, 2, 1, 4>;
+      // whole tiles (every learner step): loaders without masks, compiled for three waves per SIMD
+      // (-4.5 us on the step; targets 4 / 5 / 6: -3 / +-0 / -4; 64-deep input-gradient stages -4 at
+      // target 5, not additive)
+      using Dg1F = IqnDgradOp<2, 2, 1, 2, 1>;
+      using Wg1F = IqnWgradOp<2, 2, 1, 4, 1, 1, 1>;
       const dim3 gw(kHid / Wg1::BN, kFlat / Wg1::BM, 1), gd(kFlat / Dg1::BN, (M0 + Dg1::BM - 1) / Dg1::BM, 1);
-      rc = dz_launch_gemm2<Wg1, Dg1>(w, gw, d, gd, s);
+      bool whole = M0 % Wg1F::BK == 0 && M0 % Dg1F::BM == 0 && kHid % Dg1F::BK == 0 && kHid % Wg1F::BN == 0 &&
+                   kFlat % Wg1F::BM == 0 && kFlat % Dg1F::BN == 0 && L.fc1_ld == kHid;
+      if (whole)
+        rc = dz_launch_gemm2_occ<Wg1F, Dg1F, 3>(
+            w, dim3(kHid / Wg1F::BN, kFlat / Wg1F::BM, 1), d, dim3(kFlat / Dg1F::BN, M0 / Dg1F::BM, 1), s);
+      else
+        rc = dz_launch_gemm2<Wg1, Dg1>(w, gw, d, gd, s);
       if (rc) return rc;
       DZ_PROF(s, "fc1_wgrad+dgrad");
     }

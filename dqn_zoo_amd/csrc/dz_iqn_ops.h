@@ -38,7 +38,9 @@ struct IqnLinParams {
   float* temb;        // [rows[0]][N] or null (MIX)
 };
 
-template <int WM_, int WN_, int WK_, int KT_, int MI_ = 1, int NI_ = 1>
+// FULL_ = 1: every tile is whole (the rows of every group a multiple of BM, N of BN, K of BK --
+// the launcher checks): the loaders carry no masks at all.
+template <int WM_, int WN_, int WK_, int KT_, int MI_ = 1, int NI_ = 1, int FULL_ = 0>
 struct IqnLinOp {
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int MI = MI_, NI = NI_;
@@ -63,6 +65,8 @@ struct IqnLinOp {
     // (third loader rule, dz_qnet_ops.h: a masked slot selects on the ADDRESS; a select on the
     // loaded value puts the stage's vmcnt waits in front of its MFMA block -- rounds 2-4 of this
     // Op did exactly that and ran the weight stream un-overlapped)
+    if constexpr (FULL_ != 0)
+      return dz_ld4(p.x + (long)(t.row0 + t.m0 + row) * p.ldx + (st * CPS + c) * 16 + 4 * q);
     const int gc = st * CPS + c, total = p.K / 16;
     const int m = t.m0 + row;
     const bool ok = (m < t.rows) & (gc < total);
@@ -72,6 +76,8 @@ struct IqnLinOp {
   }
   __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
+    if constexpr (FULL_ != 0)
+      return dz_ld4(t.prm + p.w_off + (long)((st * CPS + c) * 16 + kk) * p.ldw + t.n0 + 4 * rq);
     const int gc = st * CPS + c, total = p.K / 16;
     const int k = min(gc, total - 1) * 16 + kk;
     const int n = min(t.n0 + 4 * rq, p.ldw - 4);
@@ -120,7 +126,7 @@ struct IqnWgradParams {
   float* part; // [S][K][ldw]
 };
 
-template <int WM_, int WN_, int WK_, int KT_, int MI_ = 1, int NI_ = 1>
+template <int WM_, int WN_, int WK_, int KT_, int MI_ = 1, int NI_ = 1, int FULL_ = 0>
 struct IqnWgradOp {
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int MI = MI_, NI = NI_;
@@ -141,6 +147,8 @@ struct IqnWgradOp {
   }
   __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
+    if constexpr (FULL_ != 0)   // (whole tiles, M a multiple of BK: no masks)
+      return dz_ld4(p.x + (long)(st * BK + c * 16 + kk) * p.ldx + t.m0 + 4 * rq);
     const int m = st * BK + c * 16 + kk;
     const int k = min(t.m0 + 4 * rq, p.K - 4);
     const float* src = p.x + (long)min(m, p.M - 1) * p.ldx + k;
@@ -148,6 +156,8 @@ struct IqnWgradOp {
   }
   __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c,
                                   int kk, int rq) {
+    if constexpr (FULL_ != 0)
+      return dz_ld4(p.dy + (long)(st * BK + c * 16 + kk) * p.ldy + t.n0 + 4 * rq);
     const int m = st * BK + c * 16 + kk;
     const int n = min(t.n0 + 4 * rq, p.ldw - 4);
     const float* src = p.dy + (long)min(m, p.M - 1) * p.ldy + n;
@@ -177,7 +187,7 @@ struct IqnDgradParams {
   float* dx; int ldo;           // [M][ldo]
   const float* relu_mask;       // [M][ldo] or null: dx *= (mask > 0)
 };
-template <int WM_, int WN_, int WK_, int KT_>
+template <int WM_, int WN_, int WK_, int KT_, int FULL_ = 0>
 struct IqnDgradOp {
   static constexpr int WM = WM_, WN = WN_, WK = WK_, KT = KT_, CPS = WK_ * KT_;
   static constexpr int A_LAYOUT = DZ_KC, B_LAYOUT = DZ_KC, A_MAP = DZ_MAP_QUAD;
@@ -191,12 +201,16 @@ struct IqnDgradOp {
   }
   // A tile row = batch row m, 4 consecutive reduction indices n
   __device__ static float4 load_a(const Params& p, const Tile& t, int st, int c, int row, int q) {
+    if constexpr (FULL_ != 0)
+      return dz_ld4(p.dy + (long)(t.m0 + row) * p.ldy + (st * CPS + c) * 16 + 4 * q);
     const int m = t.m0 + row, n = (st * CPS + c) * 16 + 4 * q;
     const float* src = p.dy + (long)min(m, p.M - 1) * p.ldy + min(n, p.N - 4);
     return dz_ld4((m < p.M) & (n < p.N) ? src : dz_page_zero);
   }
   // B tile row = output column k, 4 consecutive reduction indices n
   __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c, int row, int q) {
+    if constexpr (FULL_ != 0)
+      return dz_ld4(p.w + (long)(t.n0 + row) * p.ldw + (st * CPS + c) * 16 + 4 * q);
     const int k = min(t.n0 + row, p.K - 1), n = (st * CPS + c) * 16 + 4 * q;
     const float* src = p.w + (long)k * p.ldw + min(n, p.N - 4);
     return dz_ld4(n < p.N ? src : dz_page_zero);

@@ -52,7 +52,8 @@ def _make(b, samples, seed, lr=0.00005):
   return rs, online, target, ln, taus
 
 
-@pytest.mark.parametrize('b,samples', [(8, (16, 8, 24)), (32, (64, 64, 64)), (3, (5, 7, 6))])
+@pytest.mark.parametrize('b,samples', [(8, (16, 8, 24)), (32, (64, 64, 64)), (3, (5, 7, 6)),
+                                       (32, (64, 32, 64)), (5, (24, 16, 40))])
 def test_iqn_step(b, samples):
   from dqn_zoo_amd import _lib
   rs, online, target, ln, taus = _make(b, samples, 40 + b)
