@@ -245,7 +245,10 @@ __device__ __forceinline__ void adam_flat_ranges(unsigned bid, unsigned nblk, co
 // streams requested before the current arithmetic 33.8 (no gain: the arithmetic is the
 // exposed part, see adam_fc1_block).
 constexpr int kOfC = 64, kOfIT = 7, kOfFlatBlocks = 64;
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+// (compiled for SIX waves per SIMD -- the occupancy the allocation reaches anyway: the target of
+// eight of rounds 3-4 was never met (77 VGPRs) and cost 0.3-0.5 us of squeezing; targets 5 / 4:
+// the same; 3: 38 us -- the launch's ~1 060 workgroups no longer fit)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void adam_onfly_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
     float* __restrict__ v, const float* __restrict__ part, int nparts,
