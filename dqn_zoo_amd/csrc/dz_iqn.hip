@@ -45,7 +45,7 @@ extern "C" int dz_iqn_layout(int A, int latent, int B, int n0, int n1, int n2,
   L->ws_feat = take(2LL * B * kFlat);
   L->ws_cos = take(Mt * latent);
   L->ws_hin = take(Mt * kFlat);
-  L->ws_temb = take(M0 * kFlat);
+  L->ws_temb = take(0);   // (not stored since round 5: the mix backward pass works from head_in)
   L->ws_h1 = take(Mt * kHid);
   L->ws_out = take(Mt * ld2);
   L->ws_dout = take(M0 * ld2);
@@ -188,7 +188,7 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
     const IqnCosParams cq = iqn_cos_params(L, ap, ws);
     rc = torso_forward_side<IqnCosSide>(T, 2, B, prm, in, s, cq, IqnCosSide::blocks(cq));
     if (rc) return rc;
-    rc = iqn_head_forward(L, ap, ws, ws + L.ws_temb, s);
+    rc = iqn_head_forward(L, ap, ws, nullptr, s);   // (temb is not stored: iqn_mix_bwd_kernel)
     if (rc) return rc;
     hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(256), 0, s, ws + L.ws_out, ld2, B, A,
                        n0, n1, n2, a->tau_tm1, a->a_tm1, a->r_t, a->discount_t, a->huber,
@@ -260,7 +260,7 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
     float* bp_fc1 = bp_emb + (long)B * kFlat;
     float* bp_fc2 = bp_fc1 + (long)kS_iqn_bias * kHid;
     hipLaunchKernelGGL(iqn_mix_bwd_kernel, dim3((kFlat + 255) / 256, B), dim3(256), 0, s,
-                       ws + L.ws_dhin, ws + L.ws_temb, ws + L.ws_feat, B, n0, kFlat,
+                       ws + L.ws_dhin, ws + L.ws_hin, ws + L.ws_feat, B, n0, kFlat,
                        ws + L.ws_dfeat, bp_emb);
     DZ_LAUNCH_CHECK();
     DZ_PROF(s, "mix_bwd");

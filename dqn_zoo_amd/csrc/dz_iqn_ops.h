@@ -359,14 +359,17 @@ __global__ __launch_bounds__(256) void iqn_loss_kernel(
   }
 }
 
-// Backward of head_in = temb * feat[b] (networks.py:285) for the online apply:
+// Backward of head_in = temb * feat[b] (networks.py:285) for the online apply, from head_in
+// itself (the forward pass does not store temb: 26 MB less written and kept):
 //   dzt[row][c]  = dhin[row][c] * feat[b][c] * (temb[row][c] > 0)     (in place)
 //   dfeat[b][c]  = (feat[b][c] > 0) * sum_n dhin[b*N+n][c] * temb[b*N+n][c]
+// With f = feat[b][c] > 0: temb > 0 <=> head_in = temb f > 0, and sum_n dhin temb =
+// (sum_n dhin head_in) / f; with f == 0 both results are 0 whatever temb was.
 //   bias_part[b][c] = sum_n dzt[b*N+n][c]   (the embedding bias gradient's partial of batch
 //                     element b: B slabs folded by reduce_jobs_kernel -- the 26 MB this pass
 //                     has in registers anyway, instead of a second pass over it)
 __global__ __launch_bounds__(256) void iqn_mix_bwd_kernel(float* __restrict__ dhin,
-                                                          const float* __restrict__ temb,
+                                                          const float* __restrict__ hin,
                                                           const float* __restrict__ feat,
                                                           int B, int samples, int F,
                                                           float* __restrict__ dfeat,
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256) void iqn_mix_bwd_kernel(float* __restrict__ dh
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const long o = o0 + (long)min(n0 + j, samples - 1) * F;
-      d[j] = dhin[o]; e[j] = temb[o];
+      d[j] = dhin[o]; e[j] = hin[o];
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(256) void iqn_mix_bwd_kernel(float* __restrict__ dh
       }
     }
   }
-  dfeat[(long)b * F + c] = f > 0.f ? acc : 0.f;
+  dfeat[(long)b * F + c] = f > 0.f ? acc / f : 0.f;
   bias_part[(long)b * F + c] = bsum;
 }
 
