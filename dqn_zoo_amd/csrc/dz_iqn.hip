@@ -8,6 +8,7 @@
 #include "dz_iqn_ops.h"
 #include "dz_torso.h"
 #include "dz_iqn_act.h"
+#include "dz_iqn_emb.h"
 
 namespace {
 constexpr int kS_iqn_fc2w = 32;   // row splits of the fc2 weight gradient
@@ -105,10 +106,29 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
     p.x = ws + L.ws_cos; p.ldx = latent; p.w_off = L.emb_w; p.b_off = L.emb_b;
     p.ldw = L.emb_ld; p.K = latent; p.N = kFlat; p.epi = IQN_EPI_MIX;
     p.out = ws + L.ws_hin; p.ldo = kFlat; p.feat = ws + L.ws_feat; p.temb = temb;
-    // (64x64 tiles, two 32-deep stages; one stage, 32-row / 32-column tiles and 2-4 accumulators
-    // per wave all measured slower: the launch writes 90 MB for 2 GFLOP)
-    rc = dz_launch_gemm<IqnLin>(p, dim3(kFlat / IqnLin::BN, (unsigned)((max_rows + IqnLin::BM - 1) / IqnLin::BM), ap.G), s);
-    if (rc) return rc;
+    // (GEMM form, any shape: 64x64 tiles, two 32-deep stages; one stage, 32-row / 32-column tiles
+    // and 2-4 accumulators per wave all measured slower)
+    bool whole_e = latent == 64 && kFlat % 64 == 0 && L.emb_ld == kFlat && temb == nullptr;
+    for (int g = 0; g < ap.G; ++g) whole_e = whole_e && ap.rows[g] % 64 == 0;
+    if (whole_e) {   // the embedding's own kernel (dz_iqn_emb.h): 43 -> 38 us
+      IqnEmbParams q;
+      q.cos = ws + L.ws_cos; q.G = ap.G;
+      int tiles = 0;
+      for (int g = 0; g < 3; ++g) {
+        const int gg = g < ap.G ? g : 0;
+        q.row0[g] = ap.row0[gg]; q.tiles[g] = g < ap.G ? ap.rows[gg] / 64 : 0;
+        q.params[g] = ap.params[gg]; q.feat_row0[g] = ap.feat_row0[gg]; q.samples[g] = ap.samples[gg];
+        tiles += q.tiles[g];
+      }
+      q.w_off = L.emb_w; q.b_off = L.emb_b; q.ldw = L.emb_ld; q.N = kFlat;
+      q.feat = ws + L.ws_feat; q.out = ws + L.ws_hin;
+      q.segs = (kFlat / 64 + 1) / 2;   // two column tiles per workgroup
+      hipLaunchKernelGGL(iqn_emb_fwd_kernel, dim3((unsigned)(tiles * q.segs)), dim3(256), 0, s, q);
+      DZ_LAUNCH_CHECK();
+    } else {
+      rc = dz_launch_gemm<IqnLin>(p, dim3(kFlat / IqnLin::BN, (unsigned)((max_rows + IqnLin::BM - 1) / IqnLin::BM), ap.G), s);
+      if (rc) return rc;
+    }
     DZ_PROF(s, "emb_fwd");
   }
   {  // relu(head_in @ W1 + b1)
