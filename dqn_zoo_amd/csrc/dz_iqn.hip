@@ -58,7 +58,12 @@ extern "C" int dz_iqn_layout(int A, int latent, int B, int n0, int n1, int n2,
   L->ws_wgrad_part = take(torso_wgrad_part_elems());
   L->ws_fc2w_part = take((int64_t)kS_iqn_fc2w * kHid * ld2);
   L->ws_embw_part = take((int64_t)kS_iqn_embw * latent * kFlat);
-  L->ws_bias_part = take((int64_t)B * kFlat + (int64_t)kS_iqn_bias * (kHid + ld2));
+  {  // embedding bias partials ([max(B, M0/32)][kFlat]) + the fused mix backward's dfeat partials
+     // ([M0/32][kFlat]) + fc1 / fc2 bias partials
+    const int64_t mixb = (M0 + 31) / 32;
+    L->ws_bias_part = take((mixb > B ? mixb : (int64_t)B) * kFlat + mixb * kFlat +
+                           (int64_t)kS_iqn_bias * (kHid + ld2));
+  }
   L->ws_norm_part = take(kNormBlocks);
   L->ws_scalars = take(16);
   L->ws_zeros = take(kFlat + 1024);
@@ -240,6 +245,16 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       if (rc) return rc;
       DZ_PROF(s, "fc2_wgrad+dgrad");
     }
+    // bias-gradient partials.  Embedding: one slab per 32-row block out of the fused mix backward
+    // (or one per batch element out of iqn_mix_bwd_kernel); fc1's and fc2's column sums ride in
+    // the embedding weight-gradient launch.  mix_s1: the fused form's dfeat partials.
+    const int mix_blocks = (M0 + 31) / 32;
+    float* bp_emb = ws + L.ws_bias_part;
+    float* mix_s2 = bp_emb;
+    float* mix_s1 = bp_emb + (long)(mix_blocks > B ? mix_blocks : B) * kFlat;
+    float* bp_fc1 = mix_s1 + (long)mix_blocks * kFlat;
+    float* bp_fc2 = bp_fc1 + (long)kS_iqn_bias * kHid;
+    bool fuse_mix = false;
     {  // fc1: weight gradient (straight into grad) + input gradient
       IqnWgradParams w;
       w.x = ws + L.ws_hin; w.ldx = kFlat; w.dy = ws + L.ws_dh1; w.ldy = kHid; w.M = M0;
@@ -266,25 +281,36 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       const dim3 gw(kHid / Wg1::BN, kFlat / Wg1::BM, 1), gd(kFlat / Dg1::BN, (M0 + Dg1::BM - 1) / Dg1::BM, 1);
       bool whole = M0 % Wg1F::BK == 0 && M0 % Dg1F::BM == 0 && kHid % Dg1F::BK == 0 && kHid % Wg1F::BN == 0 &&
                    kFlat % Wg1F::BM == 0 && kFlat % Dg1F::BN == 0 && L.fc1_ld == kHid;
-      if (whole)
+      // ... and, when the 32 rows of a wave's block belong to one batch element (samples % 32
+      // == 0), with the backward of the mix in the input gradient's store (IqnDgradMixOp): the
+      // separate pass over the 26 MB gradient and its launch are gone
+      fuse_mix = whole && n0 % 32 == 0;
+      if (fuse_mix) {
+        using Dg1M = IqnDgradMixOp<2, 2, 1, 2>;
+        IqnDgradMixParams dm;
+        static_cast<IqnDgradParams&>(dm) = d;
+        dm.hin = ws + L.ws_hin; dm.feat = ws + L.ws_feat; dm.samples = n0;
+        dm.s1 = mix_s1; dm.s2 = mix_s2;
+        rc = dz_launch_gemm2_occ<Wg1F, Dg1M, 3>(
+            w, dim3(kHid / Wg1F::BN, kFlat / Wg1F::BM, 1), dm, dim3(kFlat / Dg1M::BN, M0 / Dg1M::BM, 1), s);
+      } else if (whole) {
         rc = dz_launch_gemm2_occ<Wg1F, Dg1F, 3>(
             w, dim3(kHid / Wg1F::BN, kFlat / Wg1F::BM, 1), d, dim3(kFlat / Dg1F::BN, M0 / Dg1F::BM, 1), s);
-      else
+      } else {
         rc = dz_launch_gemm2<Wg1, Dg1>(w, gw, d, gd, s);
+      }
       if (rc) return rc;
-      DZ_PROF(s, "fc1_wgrad+dgrad");
+      DZ_PROF(s, fuse_mix ? "fc1_wgrad+dgrad+mix" : "fc1_wgrad+dgrad");
     }
-    // bias-gradient partials: the embedding's come out of the mix backward pass (one slab per
-    // batch element), fc1's and fc2's column sums ride in the embedding weight-gradient launch
-    float* bp_emb = ws + L.ws_bias_part;
-    float* bp_fc1 = bp_emb + (long)B * kFlat;
-    float* bp_fc2 = bp_fc1 + (long)kS_iqn_bias * kHid;
-    hipLaunchKernelGGL(iqn_mix_bwd_kernel, dim3((kFlat + 255) / 256, B), dim3(256), 0, s,
-                       ws + L.ws_dhin, ws + L.ws_hin, ws + L.ws_feat, B, n0, kFlat,
-                       ws + L.ws_dfeat, bp_emb);
-    DZ_LAUNCH_CHECK();
-    DZ_PROF(s, "mix_bwd");
-    {  // tau-embedding weight-gradient partials (+ the two column sums as side workgroups)
+    if (!fuse_mix) {
+      hipLaunchKernelGGL(iqn_mix_bwd_kernel, dim3((kFlat + 255) / 256, B), dim3(256), 0, s,
+                         ws + L.ws_dhin, ws + L.ws_hin, ws + L.ws_feat, B, n0, kFlat,
+                         ws + L.ws_dfeat, bp_emb);
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "mix_bwd");
+    }
+    {  // tau-embedding weight-gradient partials (+ the two column sums -- and the fused form's
+       // dfeat fold -- as side workgroups)
       IqnWgradParams w;
       w.x = ws + L.ws_cos; w.ldx = latent; w.dy = ws + L.ws_dhin; w.ldy = kFlat; w.M = M0;
       w.K = latent; w.N = kFlat; w.ldw = L.emb_ld; w.S = kS_iqn_embw;
@@ -294,9 +320,14 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       J.j[1] = {ws + L.ws_dout, M0, A, ld2, bp_fc2};
       J.S = kS_iqn_bias;
       J.end0 = ColsumSide::blocks_of(J.j[0], J.S);
-      rc = dz_launch_gemm_side<IqnWg, ColsumSide>(
-          w, dim3(kFlat / IqnWg::BN, (latent + IqnWg::BM - 1) / IqnWg::BM, kS_iqn_embw), J,
-          J.end0 + ColsumSide::blocks_of(J.j[1], J.S), s);
+      IqnBwdSideParams sp;
+      sp.col = J;
+      sp.col_blocks = J.end0 + ColsumSide::blocks_of(J.j[1], J.S);
+      sp.df = {mix_s1, ws + L.ws_feat, ws + L.ws_dfeat, B, kFlat, n0 / 32};
+      const unsigned df_blocks = fuse_mix ? (unsigned)(((long)B * kFlat + 255) / 256) : 0u;
+      rc = dz_launch_gemm_side<IqnWg, IqnBwdSide>(
+          w, dim3(kFlat / IqnWg::BN, (latent + IqnWg::BM - 1) / IqnWg::BM, kS_iqn_embw), sp,
+          sp.col_blocks + df_blocks, s);
       if (rc) return rc;
       DZ_PROF(s, "emb_wgrad+colsum");
     }
@@ -310,7 +341,7 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       for (int j = 0; j < 3; ++j) J.r[j] = conv_jobs[j];
       J.r[3] = {ws + L.ws_fc2w_part, kS_iqn_fc2w, (long)kHid * ld2, grad + L.fc2_w};
       J.r[4] = {ws + L.ws_embw_part, kS_iqn_embw, (long)latent * kFlat, grad + L.emb_w};
-      J.r[5] = {bp_emb, B, (long)kFlat, grad + L.emb_b};
+      J.r[5] = {bp_emb, fuse_mix ? mix_blocks : B, (long)kFlat, grad + L.emb_b};
       J.r[6] = {bp_fc1, kS_iqn_bias, (long)kHid, grad + L.fc1_b};
       J.r[7] = {bp_fc2, kS_iqn_bias, (long)A, grad + L.fc2_b};
       unsigned acc = 0;
