@@ -222,6 +222,7 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
     DZ_PROF(s, "loss");
   }
 
+  bool norm_skipped = false;   // (DZ_SC_GNORM then reads 0)
   if (phases & DZ_PHASE_BACKWARD) {
     DZ_REQUIRE(a->grad);
     float* grad = a->grad;
@@ -346,6 +347,10 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       J.r[7] = {bp_fc2, kS_iqn_bias, (long)A, grad + L.fc2_b};
       unsigned acc = 0;
       for (int j = 0; j < 8; ++j) { acc += (unsigned)((J.r[j].n + 63) / 64); J.r_end[j] = acc; }
+      // without clipping (iqn/run_atari.py:213-215: plain optax.adam) nothing reads the global
+      // norm: no norm launch, the step count is incremented here
+      norm_skipped = (phases & DZ_PHASE_OPTIMIZER) && !(a->max_norm > 0.f);
+      if (norm_skipped) J.bump_count = a->opt_count;
       hipLaunchKernelGGL(reduce_jobs_kernel, dim3(acc), dim3(256), 0, s, J);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "finalize_grads");
@@ -355,12 +360,15 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
   if (phases & DZ_PHASE_OPTIMIZER) {
     DZ_REQUIRE(a->grad && a->opt_m && a->opt_v && a->opt_count);
     float* sc = ws + L.ws_scalars;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
-                       (long)L.param_count, ws + L.ws_norm_part, a->opt_count);
-    DZ_LAUNCH_CHECK();
-    DZ_PROF(s, "grad_sumsq");
+    if (!norm_skipped) {
+      hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, a->grad,
+                         (long)L.param_count, ws + L.ws_norm_part, a->opt_count);
+      DZ_LAUNCH_CHECK();
+      DZ_PROF(s, "grad_sumsq");
+    }
     hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, a->online, a->grad, a->opt_m,
-                       a->opt_v, (long)(L.param_count >> 2), ws + L.ws_norm_part, kNormBlocks,
+                       a->opt_v, (long)(L.param_count >> 2), ws + L.ws_norm_part,
+                       norm_skipped ? 0 : kNormBlocks,
                        a->opt_count, a->losses, zeros, B, sc, a->lr, a->b1, a->b2, a->eps,
                        a->max_norm);
     DZ_LAUNCH_CHECK();

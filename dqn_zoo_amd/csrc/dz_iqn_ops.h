@@ -512,11 +512,14 @@ struct IqnBwdSide {
 };
 
 // out[i] = sum_s part[s][i] for up to 8 jobs in one launch.
-struct ReduceJobs8 { ReduceJob r[8]; unsigned r_end[8]; int n; };
+// `bump_count` (optional): optax's `count_inc = count + 1` for the Adam launch that follows,
+// when no norm launch (sumsq_kernel) is there to do it.
+struct ReduceJobs8 { ReduceJob r[8]; unsigned r_end[8]; int n; int32_t* bump_count = nullptr; };
 __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceJobs8 J) {
   __shared__ float red[4][64];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const unsigned b = blockIdx.x;
+  if (J.bump_count && b == 0 && threadIdx.x == 0) *J.bump_count = *J.bump_count + 1;
   int j = 0;
   while (j < J.n - 1 && b >= J.r_end[j]) ++j;
   const ReduceJob jb = J.r[j];

@@ -614,7 +614,9 @@ typedef struct {
   float* ws;
   float* losses;             /* [batch] per-sample quantile-regression loss     */
   float lr, b1, b2, eps;
-  float max_norm;            /* <= 0: no clipping (iqn/run_atari.py:213-215)    */
+  float max_norm;            /* <= 0: no clipping (iqn/run_atari.py:213-215);
+                                a one-call step then computes no global norm:
+                                ws_scalars[DZ_SC_GNORM] reads 0                  */
   float huber;               /* kappa                                           */
 } dz_iqn_args_t;
 
