@@ -21,7 +21,7 @@ elif which == 'c51':   # c51/run_atari.py:200-216
 elif which == 'qr':    # qrdqn/run_atari.py:196-214
   ln = ll.DenseLearner(networks.DenseNetwork('qr', A, quantiles=(np.arange(201) + 0.5) / 201),
                        'quantile', ll.AdamConfig(learning_rate=0.00005, eps=0.01 / 32,
-                                                 max_global_grad_norm=0.0), B)
+                                                 max_global_grad_norm=10.0), B)
 else:
   ln = ll.DenseLearner(networks.DenseNetwork('double_dqn', A), 'double_q',
                        ll.RmsPropConfig(learning_rate=0.00025 / 4, decay=0.95,
