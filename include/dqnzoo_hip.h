@@ -584,7 +584,9 @@ typedef struct {
   int64_t emb_w, emb_b, fc1_w, fc1_b, fc2_w, fc2_b;
   int64_t param_count, param_count_ref;
   int64_t ws_count;
-  int64_t ws_act1, ws_act2, ws_feat, ws_cos, ws_hin, ws_temb, ws_h1, ws_out;
+  int64_t ws_act1, ws_act2, ws_feat, ws_cos, ws_hin;
+  int64_t ws_temb;           /* empty since round 5 (the embedding activation is not stored) */
+  int64_t ws_h1, ws_out;
   int64_t ws_dout, ws_dh1, ws_dhin, ws_dfeat, ws_dact2, ws_dact1;
   int64_t ws_wgrad_part, ws_fc2w_part, ws_embw_part, ws_bias_part;
   int64_t ws_norm_part, ws_scalars, ws_zeros;
