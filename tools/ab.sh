@@ -8,6 +8,10 @@
 #   bash tools/ab.sh env   <pattern> "VAR=0" "VAR=1" ...                    environment variants
 #   bash tools/ab.sh dense tools/ab/base.so tools/ab/new.so ...             BASELINE configs 2 / 3
 #   bash tools/ab.sh now   [pattern]                                        the current build alone
+#   bash tools/ab.sh iqn   tools/ab/base.so tools/ab/new.so ...             the IQN learner step (tools/iqn_probe.py;
+#                          MODE=time|prof, PAT=<grep pattern of the printed lines>)
+#   bash tools/ab.sh steps tools/ab/base.so tools/ab/new.so ...             the C51 / QR-DQN learner steps
+#                          (tools/run_dense.py <kind> 12 prof; KINDS="c51 qr")
 # BENCH_ARGS adds bench.py arguments to every run; NB = bench lines per variant; TRACE=0 skips
 # the kernel trace.  (A variant library is built with tools/build_variant.sh.)
 ulimit -c 0
@@ -43,5 +47,17 @@ case $mode in
            done
          done ;;
   now)   one "" "" "${1:-.}" ;;
+  iqn)   cp $R/dqn_zoo_amd/libdqnzoo_hip.so /tmp/lib_keep.so
+         for lib in "$@"; do
+           cp $R/$lib $R/dqn_zoo_amd/libdqnzoo_hip.so; echo "== $lib"
+           timeout 100 python $R/tools/iqn_probe.py ${MODE:-time} 2>&1 | grep -E "${PAT:-learn us}"
+         done
+         cp /tmp/lib_keep.so $R/dqn_zoo_amd/libdqnzoo_hip.so ;;
+  steps) cp $R/dqn_zoo_amd/libdqnzoo_hip.so /tmp/lib_keep.so
+         for lib in "$@"; do
+           cp $R/$lib $R/dqn_zoo_amd/libdqnzoo_hip.so; echo "== $lib"
+           for w in ${KINDS:-c51 qr}; do timeout 100 python $R/tools/run_dense.py $w 12 prof 2>&1 | grep "us/step" | tail -2; done
+         done
+         cp /tmp/lib_keep.so $R/dqn_zoo_amd/libdqnzoo_hip.so ;;
   *)     echo "usage: see the header of tools/ab.sh"; exit 2 ;;
 esac
