@@ -159,7 +159,28 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
     using Fc1Full = IqnLinOp<2, 1, 2, 1, 1, 1, 1>;
     bool whole = kFlat % Fc1Full::BK == 0 && kHid % Fc1Full::BN == 0;
     for (int g = 0; g < ap.G; ++g) whole = whole && ap.rows[g] % Fc1Full::BM == 0;
-    if (whole)
+    //  * the learner's three applies at the reference sizes, as TWO tile sets of 256 workgroups in
+    //    one launch: the online rows (2 048) as 64x64 tiles with two column blocks per wave, the
+    //    target rows of the two s_t applies (3 072, contiguous, the same parameters) as 96x64 tiles
+    //    with three row blocks per wave; 64-deep stages, three waves per SIMD: two workgroups per CU,
+    //    2-3 MFMA chains per wave, 1.6 x less L2 -> LDS traffic than the 64x32 tiles.  The chunk loop
+    //    alone runs at 0.93 of the pipe's rate at 2-3 waves per SIMD and 0.78 at five
+    //    (tools/micro/lds_mfma_micro.hip).  Whole step: 437.7 -> 432.7 us (32-deep stages 445-448;
+    //    occupancy target 2: 433.9).
+    using F2A = IqnLinOp<2, 1, 2, 2, 1, 2, 1>;
+    using F2B = IqnLinOp<1, 2, 2, 2, 3, 1, 1>;
+    const bool two_sets = whole && ap.G == 3 && ap.params[1] == ap.params[2] &&
+                          ap.row0[2] == ap.row0[1] + ap.rows[1] && ap.rows[0] % F2A::BM == 0 &&
+                          (ap.rows[1] + ap.rows[2]) % F2B::BM == 0 && kHid % 64 == 0 &&
+                          kFlat % F2A::BK == 0;
+    if (two_sets) {
+      IqnLinParams pa = p, pb = p;
+      pa.G = 1;
+      pb.G = 1; pb.row0[0] = ap.row0[1]; pb.rows[0] = ap.rows[1] + ap.rows[2]; pb.params[0] = ap.params[1];
+      rc = dz_launch_gemm2_xcd_occ<F2A, F2B, 3>(
+          pa, dim3(kHid / F2A::BN, (unsigned)(pa.rows[0] / F2A::BM), 1),
+          pb, dim3(kHid / F2B::BN, (unsigned)(pb.rows[0] / F2B::BM), 1), s);
+    } else if (whole)
       rc = dz_launch_gemm_xcd_occ<Fc1Full, 5>(p, dim3(kHid / Fc1Full::BN, (unsigned)(max_rows / Fc1Full::BM), ap.G), s);
     else
       rc = dz_launch_gemm_xcd<Fc1Fwd>(p, dim3(kHid / Fc1Fwd::BN, (unsigned)((max_rows + Fc1Fwd::BM - 1) / Fc1Fwd::BM), ap.G), s);
