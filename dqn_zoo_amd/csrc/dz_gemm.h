@@ -631,30 +631,6 @@ static inline int dz_launch_gemm2_xcd(const typename OpA::Params& pa, dim3 ga,
   return DZ_OK;
 }
 
-// ... compiled for OCC waves per SIMD (see dz_mfma_gemm_xcd_occ).
-template <class OpA, class OpB, int OCC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
-void dz_mfma_gemm2_xcd_occ(typename OpA::Params pa, dim3 ga, typename OpB::Params pb, dim3 gb) {
-  constexpr int SM = DzGemmSmem<OpA>::ELEMS > DzGemmSmem<OpB>::ELEMS
-                         ? DzGemmSmem<OpA>::ELEMS : DzGemmSmem<OpB>::ELEMS;
-  __shared__ __attribute__((aligned(16))) float smem[SM];
-  const unsigned na = 8 * ga.x * ((ga.y * ga.z + 7) / 8);
-  dim3 bid;
-  if (blockIdx.x < na) {
-    if (dz_xcd_tile(blockIdx.x, ga, bid)) dz_gemm_body<OpA>(pa, bid, smem);
-  } else {
-    if (dz_xcd_tile(blockIdx.x - na, gb, bid)) dz_gemm_body<OpB>(pb, bid, smem);
-  }
-}
-template <class OpA, class OpB, int OCC>
-static inline int dz_launch_gemm2_xcd_occ(const typename OpA::Params& pa, dim3 ga,
-                                          const typename OpB::Params& pb, dim3 gb, hipStream_t s) {
-  hipLaunchKernelGGL((dz_mfma_gemm2_xcd_occ<OpA, OpB, OCC>), dim3(dz_xcd_blocks(ga) + dz_xcd_blocks(gb)),
-                     dim3(256), 0, s, pa, ga, pb, gb);
-  DZ_LAUNCH_CHECK();
-  return DZ_OK;
-}
-
 // A contraction plus an unrelated small elementwise job in the same launch
 // (blocks beyond the GEMM grid run Side::run): saves the ~5 us launch floor of a
 // tiny kernel that nothing in the GEMM depends on.

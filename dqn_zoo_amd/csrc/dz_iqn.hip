@@ -9,6 +9,7 @@
 #include "dz_torso.h"
 #include "dz_iqn_act.h"
 #include "dz_iqn_emb.h"
+#include "dz_iqn_fc1_dma.h"
 
 namespace {
 constexpr int kS_iqn_fc2w = 32;   // row splits of the fc2 weight gradient
@@ -140,46 +141,54 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
     p.x = ws + L.ws_hin; p.ldx = kFlat; p.w_off = L.fc1_w; p.b_off = L.fc1_b;
     p.ldw = L.fc1_ld; p.K = kFlat; p.N = kHid; p.epi = IQN_EPI_BIAS_RELU;
     p.out = ws + L.ws_h1; p.ldo = kHid; p.feat = nullptr; p.temb = nullptr;
-    // 64-row x 32-column tiles, two waves share the depth of a tile, tiles in XCD-aware order
-    // (all column tiles of one A-row slab on one XCD: the 77 MB activation crosses the fabric
-    // once instead of 8 times, +4 %).  The learner's 5 120 rows x 512 columns are 1 280 tiles =
-    // FIVE per CU; the 64x64 tiles of rounds 2-4 were 640 = 2.5 per CU (half the CUs ran three
-    // while the others ran two).
-    //  * whole tiles (every group's rows a multiple of 64, as in every learner step): loaders
-    //    WITHOUT masks, 32-deep stages (14.5 KB of LDS: five workgroups per CU resident), compiled
-    //    for five waves per SIMD -- at the default target of eight the allocator parks freshly
-    //    loaded registers around the MFMA block, a copy that waits for the prefetch in front of
-    //    the MFMAs.  Whole step, same box: 475 (masked <2,1,2,3>) -> 459 us; <2,1,2,2> 464,
-    //    64x64 <2,2,1,1> 480 / <2,2,1,4> 475-478 / <2,2,1,7> 491, 32x64 <1,2,2,1> 473, 32x32
-    //    <1,1,4,1> 486; occupancy target 4 / 6 / 8 instead of 5: +4 / +5 / +6.
-    //  * any other shape (acting applies, odd batch sizes): masked loaders, 48-deep stages
-    //    (<2,2,1,4> 64x64 +16 us on the step, <2,1,2,2> +-0, <2,1,2,4> +44; 2-4 accumulators
-    //    per wave 258-325 us for this launch: EXPERIMENTS.md).
+    // Three forms, by shape (all with tiles in XCD-aware order: the column tiles of one row slab
+    // run on ONE XCD, so the 77 MB activation crosses the fabric once instead of 8 times, +4 %):
+    //  (1) the learner's three applies at the reference sizes (online rows % 64 == 0, the two
+    //      s_t applies' target rows contiguous, the same parameters, % 96 == 0): TWO tile sets of
+    //      256 workgroups each in one launch -- 64x64 tiles with two column blocks per wave for
+    //      the online rows, 96x64 tiles with three row blocks per wave for the target rows --
+    //      i.e. two workgroups per CU and 2-3 independent MFMA chains per wave, 1.6 x less
+    //      L2 -> LDS traffic than (2); operands by LDS-DMA (dz_iqn_fc1_dma.h).  The chunk loop
+    //      alone runs at 0.93 of the matrix pipe's rate at 2-3 waves per SIMD and at 0.78 at
+    //      five (tools/micro/lds_mfma_micro.hip).
+    //  (2) other whole-tile shapes (every group's rows % 64 == 0): 64x32 tiles, two waves share a
+    //      tile's depth -- 5 120 x 512 outputs are 1 280 tiles = FIVE per CU (the 64x64 tiles of
+    //      rounds 2-4 were 640 = 2.5 per CU: half the CUs ran three while the others ran two) --
+    //      loaders WITHOUT masks, 32-deep stages (14.5 KB of LDS: five workgroups per CU resident),
+    //      compiled for five waves per SIMD: at the default target of eight the allocator parks
+    //      freshly loaded registers around the MFMA block, a copy that waits for the prefetch in
+    //      front of the MFMAs.  Whole step, same box: 475 (form 3) -> 459 us; <2,1,2,2> 464, 64x64
+    //      <2,2,1,1> 480 / <2,2,1,4> 475-478 / <2,2,1,7> 491, 32x64 <1,2,2,1> 473, 32x32 <1,1,4,1>
+    //      486; occupancy target 4 / 6 / 8 instead of 5: +4 / +5 / +6.
+    //  (3) any other shape (acting applies, odd batch sizes): masked loaders, 48-deep stages
+    //      (<2,2,1,4> 64x64 +16 us on the step, <2,1,2,2> +-0, <2,1,2,4> +44; 2-4 accumulators
+    //      per wave 258-325 us for this launch: EXPERIMENTS.md).
     using Fc1Fwd = IqnLinOp<2, 1, 2, 3>;
     using Fc1Full = IqnLinOp<2, 1, 2, 1, 1, 1, 1>;
     bool whole = kFlat % Fc1Full::BK == 0 && kHid % Fc1Full::BN == 0;
     for (int g = 0; g < ap.G; ++g) whole = whole && ap.rows[g] % Fc1Full::BM == 0;
-    //  * the learner's three applies at the reference sizes, as TWO tile sets of 256 workgroups in
-    //    one launch: the online rows (2 048) as 64x64 tiles with two column blocks per wave, the
-    //    target rows of the two s_t applies (3 072, contiguous, the same parameters) as 96x64 tiles
-    //    with three row blocks per wave; 64-deep stages, three waves per SIMD: two workgroups per CU,
-    //    2-3 MFMA chains per wave, 1.6 x less L2 -> LDS traffic than the 64x32 tiles.  The chunk loop
-    //    alone runs at 0.93 of the pipe's rate at 2-3 waves per SIMD and 0.78 at five
-    //    (tools/micro/lds_mfma_micro.hip).  Whole step: 437.7 -> 432.7 us (32-deep stages 445-448;
-    //    occupancy target 2: 433.9).
-    using F2A = IqnLinOp<2, 1, 2, 2, 1, 2, 1>;
-    using F2B = IqnLinOp<1, 2, 2, 2, 3, 1, 1>;
     const bool two_sets = whole && ap.G == 3 && ap.params[1] == ap.params[2] &&
-                          ap.row0[2] == ap.row0[1] + ap.rows[1] && ap.rows[0] % F2A::BM == 0 &&
-                          (ap.rows[1] + ap.rows[2]) % F2B::BM == 0 && kHid % 64 == 0 &&
-                          kFlat % F2A::BK == 0;
+                          ap.row0[2] == ap.row0[1] + ap.rows[1] && ap.rows[0] % 64 == 0 &&
+                          (ap.rows[1] + ap.rows[2]) % 96 == 0 && kHid % 64 == 0 && kFlat % 32 == 0;
     if (two_sets) {
-      IqnLinParams pa = p, pb = p;
-      pa.G = 1;
-      pb.G = 1; pb.row0[0] = ap.row0[1]; pb.rows[0] = ap.rows[1] + ap.rows[2]; pb.params[0] = ap.params[1];
-      rc = dz_launch_gemm2_xcd_occ<F2A, F2B, 3>(
-          pa, dim3(kHid / F2A::BN, (unsigned)(pa.rows[0] / F2A::BM), 1),
-          pb, dim3(kHid / F2B::BN, (unsigned)(pb.rows[0] / F2B::BM), 1), s);
+      // 32-deep stages, two stage buffers (40 KB per workgroup).  Whole step, same box: form (2)
+      // 437.7; the same two tile sets on the register-staged skeleton (64-deep stages) 432.7-434.2;
+      // this 419.6; three stage buffers 424.8; 64-deep stages x two buffers 422.9.
+      using CA = IqnFc1DmaCfg<1, 2, 2, 1, 1, 2>;
+      using CB = IqnFc1DmaCfg<3, 1, 1, 2, 1, 2>;
+      IqnFc1DmaSet qa, qb;
+      qa.x = p.x + (long)ap.row0[0] * kFlat; qa.ldx = kFlat; qa.tiles = ap.rows[0] / CA::BM;
+      qa.w = ap.params[0] + L.fc1_w; qa.bias = ap.params[0] + L.fc1_b; qa.ldw = L.fc1_ld;
+      qa.K = kFlat; qa.N = kHid; qa.out = ws + L.ws_h1 + (long)ap.row0[0] * kHid; qa.ldo = kHid;
+      qb = qa;
+      qb.x = p.x + (long)ap.row0[1] * kFlat; qb.tiles = (ap.rows[1] + ap.rows[2]) / CB::BM;
+      qb.w = ap.params[1] + L.fc1_w; qb.bias = ap.params[1] + L.fc1_b;
+      qb.out = ws + L.ws_h1 + (long)ap.row0[1] * kHid;
+      const dim3 ga(kHid / 64, (unsigned)qa.tiles, 1), gb(kHid / 64, (unsigned)qb.tiles, 1);
+      hipLaunchKernelGGL((iqn_fc1_fwd_dma2_kernel<CA, CB, 2>),
+                         dim3(dz_xcd_blocks(ga) + dz_xcd_blocks(gb)), dim3(256), 0, s, qa, ga, qb, gb);
+      DZ_LAUNCH_CHECK();
+      rc = DZ_OK;
     } else if (whole)
       rc = dz_launch_gemm_xcd_occ<Fc1Full, 5>(p, dim3(kHid / Fc1Full::BN, (unsigned)(max_rows / Fc1Full::BM), ap.G), s);
     else

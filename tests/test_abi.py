@@ -166,11 +166,13 @@ def test_kernels_with_hand_counted_waits_do_not_spill():
   ScratchSize 0 for it -- and for the seam kernels, whose polling loops were the round-4 spill
   source (rainbow_act_one_kernel) -- and 135 KB of LDS needs gfx950's 160 KB."""
   import subprocess
-  src = os.path.join(ROOT, 'dqn_zoo_amd', 'csrc', 'dz_rainbow.hip')
-  cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
-         '-ffp-contract=off', '-fno-fast-math', '-I', os.path.join(ROOT, 'include'),
-         '-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', os.devnull]
-  out = subprocess.run(cmd, capture_output=True, text=True, timeout=600).stderr
+  out = ''
+  for unit in ('dz_rainbow.hip', 'dz_iqn.hip'):   # (dz_iqn: the LDS-DMA fc1 forward, dz_iqn_fc1_dma.h)
+    src = os.path.join(ROOT, 'dqn_zoo_amd', 'csrc', unit)
+    cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
+           '-ffp-contract=off', '-fno-fast-math', '-I', os.path.join(ROOT, 'include'),
+           '-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', os.devnull]
+    out += subprocess.run(cmd, capture_output=True, text=True, timeout=600).stderr
   usage, name = {}, None
   for line in out.splitlines():
     m = re.search(r'Function Name: (\S+)', line)
@@ -186,8 +188,9 @@ def test_kernels_with_hand_counted_waits_do_not_spill():
   for k, u in usage.items():
     # (the head launch counts no waits by hand: its widest variant, 13+ actions, may spill; the
     # BASELINE shape -- two 256-column chunks of the advantage head -- must not)
-    if any(t in k for t in ('fc1_dgrad_mfma_kernel', 'rainbow_head_chain_kernelILi2E', 'rainbow_act_one_kernel')):
+    if any(t in k for t in ('fc1_dgrad_mfma_kernel', 'rainbow_head_chain_kernelILi2E', 'rainbow_act_one_kernel',
+                            'iqn_fc1_fwd_dma2_kernel')):
       assert u['scratch'] == 0, (k, u)
       assert u['lds'] <= 160 * 1024, (k, u)
       checked += 1
-  assert checked >= 3, sorted(usage)
+  assert checked >= 4, sorted(usage)
