@@ -174,21 +174,18 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
       // 32-deep stages, two stage buffers (40 KB per workgroup).  Whole step, same box: form (2)
       // 437.7; the same two tile sets on the register-staged skeleton (64-deep stages) 432.7-434.2;
       // this 419.6; three stage buffers 424.8; 64-deep stages x two buffers 422.9.
-      using CA = IqnFc1DmaCfg<1, 2, 2, 1, 1, 2>;
-      using CB = IqnFc1DmaCfg<3, 1, 1, 2, 1, 2>;
-      IqnFc1DmaSet qa, qb;
-      qa.x = p.x + (long)ap.row0[0] * kFlat; qa.ldx = kFlat; qa.tiles = ap.rows[0] / CA::BM;
-      qa.w = ap.params[0] + L.fc1_w; qa.bias = ap.params[0] + L.fc1_b; qa.ldw = L.fc1_ld;
-      qa.K = kFlat; qa.N = kHid; qa.out = ws + L.ws_h1 + (long)ap.row0[0] * kHid; qa.ldo = kHid;
+      using CA = DzDmaCfg<1, 2, 2, 1, 1, 2, true, false>;
+      using CB = DzDmaCfg<3, 1, 1, 2, 1, 2, true, false>;
+      DzDmaOperands qa, qb;
+      qa.a = p.x + (long)ap.row0[0] * kFlat; qa.lda = kFlat;
+      qa.b = ap.params[0] + L.fc1_w; qa.ldb = L.fc1_ld; qa.K = kFlat;
       qb = qa;
-      qb.x = p.x + (long)ap.row0[1] * kFlat; qb.tiles = (ap.rows[1] + ap.rows[2]) / CB::BM;
-      qb.w = ap.params[1] + L.fc1_w; qb.bias = ap.params[1] + L.fc1_b;
-      qb.out = ws + L.ws_h1 + (long)ap.row0[1] * kHid;
-      const dim3 ga(kHid / 64, (unsigned)qa.tiles, 1), gb(kHid / 64, (unsigned)qb.tiles, 1);
-      hipLaunchKernelGGL((iqn_fc1_fwd_dma2_kernel<CA, CB, 2>),
-                         dim3(dz_xcd_blocks(ga) + dz_xcd_blocks(gb)), dim3(256), 0, s, qa, ga, qb, gb);
-      DZ_LAUNCH_CHECK();
-      rc = DZ_OK;
+      qb.a = p.x + (long)ap.row0[1] * kFlat; qb.b = ap.params[1] + L.fc1_w;
+      const IqnFwdEpi::Params ea = {ap.params[0] + L.fc1_b, ws + L.ws_h1 + (long)ap.row0[0] * kHid, kHid};
+      const IqnFwdEpi::Params eb = {ap.params[1] + L.fc1_b, ws + L.ws_h1 + (long)ap.row0[1] * kHid, kHid};
+      rc = dz_launch_dma_gemm2<CA, IqnFwdEpi, CB, IqnFwdEpi, 2>(
+          qa, ea, dim3(kHid / CA::BN, (unsigned)(ap.rows[0] / CA::BM), 1),
+          qb, eb, dim3(kHid / CB::BN, (unsigned)((ap.rows[1] + ap.rows[2]) / CB::BM), 1), s);
     } else if (whole)
       rc = dz_launch_gemm_xcd_occ<Fc1Full, 5>(p, dim3(kHid / Fc1Full::BN, (unsigned)(max_rows / Fc1Full::BM), ap.G), s);
     else
@@ -313,17 +310,27 @@ extern "C" int dz_iqn_learn(const dz_iqn_args_t* a, int phases, dz_stream_t stre
       bool whole = M0 % Wg1F::BK == 0 && M0 % Dg1F::BM == 0 && kHid % Dg1F::BK == 0 && kHid % Wg1F::BN == 0 &&
                    kFlat % Wg1F::BM == 0 && kFlat % Dg1F::BN == 0 && L.fc1_ld == kHid;
       // ... and, when the 32 rows of a wave's block belong to one batch element (samples % 32
-      // == 0), with the backward of the mix in the input gradient's store (IqnDgradMixOp): the
+      // == 0), with the backward of the mix in the input gradient's store (IqnDgradMixEpi): the
       // separate pass over the 26 MB gradient and its launch are gone
-      fuse_mix = whole && n0 % 32 == 0;
+      // ... on the LDS-DMA mainloop (dz_dma_gemm.h), as for the forward: the weight gradient as
+      // 64x128 tiles (four column blocks per wave), the input gradient as 64x64 tiles (two), 32-deep
+      // stages, two stage buffers, two workgroups per CU.  Whole step, same box: register-staged
+      // skeleton pair (the same store on IqnDgradOp) 420.2; this 411.4-412.5; weight gradient 64x64 416.7;
+      // input gradient 128x64 (four chains) 412.4 / 64x128 419.8; three stage buffers 416.1; 64-deep
+      // stages 432.6; occupancy target 3: 414.4 / 425.6.
+      using CW = DzDmaCfg<1, 4, 2, 1, 1, 2, false, false>;
+      using CD = DzDmaCfg<1, 2, 2, 1, 1, 2, true, true>;
+      static_assert(kFlat % CW::BM == 0 && kHid % CW::BN == 0 && kFlat % CD::BN == 0 && kHid % CD::BK == 0,
+                    "the backward tile sets divide the layer");
+      fuse_mix = whole && n0 % 32 == 0 && M0 % CW::BK == 0 && M0 % CD::BM == 0;
       if (fuse_mix) {
-        using Dg1M = IqnDgradMixOp<2, 2, 1, 2>;
-        IqnDgradMixParams dm;
-        static_cast<IqnDgradParams&>(dm) = d;
-        dm.hin = ws + L.ws_hin; dm.feat = ws + L.ws_feat; dm.samples = n0;
-        dm.s1 = mix_s1; dm.s2 = mix_s2;
-        rc = dz_launch_gemm2_occ<Wg1F, Dg1M, 3>(
-            w, dim3(kHid / Wg1F::BN, kFlat / Wg1F::BM, 1), dm, dim3(kFlat / Dg1M::BN, M0 / Dg1M::BM, 1), s);
+        DzDmaOperands qw, qd;
+        qw.a = ws + L.ws_hin; qw.lda = kFlat; qw.b = ws + L.ws_dh1; qw.ldb = kHid; qw.K = M0;
+        qd.a = ws + L.ws_dh1; qd.lda = kHid; qd.b = a->online + L.fc1_w; qd.ldb = L.fc1_ld; qd.K = kHid;
+        const IqnPlainEpi::Params ew = {grad + L.fc1_w, L.fc1_ld};
+        const IqnDgradMixEpi::Params ed = {ws + L.ws_dhin, kFlat, ws + L.ws_hin, ws + L.ws_feat, n0, mix_s1, mix_s2};
+        rc = dz_launch_dma_gemm2<CW, IqnPlainEpi, CD, IqnDgradMixEpi, 2>(
+            qw, ew, dim3(kHid / CW::BN, kFlat / CW::BM, 1), qd, ed, dim3(kFlat / CD::BN, M0 / CD::BM, 1), s);
       } else if (whole) {
         rc = dz_launch_gemm2_occ<Wg1F, Dg1F, 3>(
             w, dim3(kHid / Wg1F::BN, kFlat / Wg1F::BM, 1), d, dim3(kFlat / Dg1F::BN, M0 / Dg1F::BM, 1), s);

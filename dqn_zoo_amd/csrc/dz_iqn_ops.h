@@ -233,62 +233,6 @@ struct IqnDgradOp {
   }
 };
 
-// fc1's input gradient with the backward of the mix (head_in = temb * feat[b], networks.py:285)
-// in its store -- whole tiles, samples a multiple of 32, so that the 32 rows of a wave's block
-// belong to ONE batch element b:
-//   dzt[row][c]      = (head_in[row][c] > 0) ? dhin[row][c] * feat[b][c] : 0      -> dx
-//   s1[blk][c]       = sum over the block's 32 rows of dhin * head_in             (blk = row / 32)
-//   s2[blk][c]       = sum over the block's 32 rows of dzt
-// (dfeat[b][c] = (feat > 0) * sum_blk s1 / feat, folded by IqnBwdSide; the embedding bias
-// gradient = sum_blk s2, folded by reduce_jobs_kernel.)  The separate pass over the 26 MB input
-// gradient (iqn_mix_bwd_kernel: read, rewrite in place) and its launch disappear; head_in and
-// the feature factor are requested in the PROLOGUE (Op::Pre), under the whole contraction.
-struct IqnDgradMixParams : IqnDgradParams {
-  const float* hin;     // [M][ldo]
-  const float* feat;    // [B][ldo]
-  int samples;
-  float* s1;            // [M/32][ldo]
-  float* s2;            // [M/32][ldo]
-};
-template <int WM_, int WN_, int WK_, int KT_>
-struct IqnDgradMixOp : IqnDgradOp<WM_, WN_, WK_, KT_, 1> {
-  typedef IqnDgradMixParams Params;
-  typedef DzTile Tile;
-  struct Pre { float e[16]; float f; };
-  __device__ static Pre prefetch(const Params& p, const Tile& t, int wm, int wn, int lane,
-                                 unsigned /*rmask*/) {
-    Pre q;
-    const int col = t.n0 + wn * 32 + (lane & 31);
-    const int m0 = t.m0 + wm * 32;
-    q.f = p.feat[(long)(m0 / p.samples) * p.ldo + col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) q.e[r] = p.hin[(long)(m0 + dz_acc_row(r, lane)) * p.ldo + col];
-    return q;
-  }
-  __device__ static void store(const Params& p, const Tile& t, int wm, int wn, int lane,
-                               const f32x16& acc, unsigned /*rmask*/, const Pre& q) {
-    const int col = t.n0 + wn * 32 + (lane & 31);
-    const int m0 = t.m0 + wm * 32;
-    float s1 = 0.f, s2 = 0.f;
-    float* o = p.dx + (long)m0 * p.ldo + col;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float d = acc[r], e = q.e[r];
-      s1 += d * e;
-      const float dz = e > 0.f ? d * q.f : 0.f;
-      s2 += dz;
-      o[(long)dz_acc_row(r, lane) * p.ldo] = dz;
-    }
-    // the other 16 rows of the block live in lane ^ 32
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 32);
-    if (lane < 32) {
-      p.s1[(long)(m0 >> 5) * p.ldo + col] = s1;
-      p.s2[(long)(m0 >> 5) * p.ldo + col] = s2;
-    }
-  }
-};
-
 using IqnLin = IqnLinOp<2, 2, 1, 2>;
 using IqnWg = IqnWgradOp<2, 2, 1, 2>;
 using IqnDg = FcDgradOp<2, 2, 1, 2>;
@@ -491,7 +435,7 @@ struct ColsumSide {
 };
 
 // dfeat[b][c] = (feat[b][c] > 0) * (sum of the samples/32 row-block partials s1) / feat[b][c]
-// (IqnDgradMixOp), one thread per (b, c).
+// (IqnDgradMixEpi, dz_iqn_fc1_dma.h), one thread per (b, c).
 struct DfeatJob { const float* s1; const float* feat; float* dfeat; int B, F, blocks_per_b; };
 // The two column sums (ColsumSide) and that fold as ONE side job of the embedding
 // weight-gradient launch.

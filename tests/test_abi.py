@@ -167,7 +167,7 @@ def test_kernels_with_hand_counted_waits_do_not_spill():
   source (rainbow_act_one_kernel) -- and 135 KB of LDS needs gfx950's 160 KB."""
   import subprocess
   out = ''
-  for unit in ('dz_rainbow.hip', 'dz_iqn.hip'):   # (dz_iqn: the LDS-DMA fc1 forward, dz_iqn_fc1_dma.h)
+  for unit in ('dz_rainbow.hip', 'dz_iqn.hip'):   # (dz_iqn: the LDS-DMA contractions, dz_dma_gemm.h)
     src = os.path.join(ROOT, 'dqn_zoo_amd', 'csrc', unit)
     cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
            '-ffp-contract=off', '-fno-fast-math', '-I', os.path.join(ROOT, 'include'),
@@ -189,7 +189,7 @@ def test_kernels_with_hand_counted_waits_do_not_spill():
     # (the head launch counts no waits by hand: its widest variant, 13+ actions, may spill; the
     # BASELINE shape -- two 256-column chunks of the advantage head -- must not)
     if any(t in k for t in ('fc1_dgrad_mfma_kernel', 'rainbow_head_chain_kernelILi2E', 'rainbow_act_one_kernel',
-                            'iqn_fc1_fwd_dma2_kernel')):
+                            'dz_dma_gemm2_kernel')):
       assert u['scratch'] == 0, (k, u)
       assert u['lds'] <= 160 * 1024, (k, u)
       checked += 1
