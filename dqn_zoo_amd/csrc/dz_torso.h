@@ -5,6 +5,23 @@
 
 #include "dz_qnet_kernels.h"
 #include "dz_sumtree_dev.h"
+#include "dz_conv_dma.h"
+#include "dz_conv1_dma.h"
+
+// A/B switches (tools/build_variant.sh): SUBN * 100 + KT * 10 + NBUF of the LDS-DMA forward
+// convolutions, 0 = the register-staged ConvFwdOp
+#ifndef DZ_CONV2_DMA
+#define DZ_CONV2_DMA 223
+#endif
+#ifndef DZ_CONV3_DMA
+#define DZ_CONV3_DMA 223
+#endif
+#ifndef DZ_CONV1_DMA   // row blocks of 16 per wave (workgroup = 32 x this rows), 0 = ConvFwdOp
+#define DZ_CONV1_DMA 21
+#endif
+#ifndef DZ_CONV_DMA_OCC
+#define DZ_CONV_DMA_OCC 2
+#endif
 
 namespace {
 
@@ -63,6 +80,18 @@ inline int torso_forward_rest(const TorsoBufs& T, int G, int B, const float* con
       p.w[g] = prm[g] + T.conv_w[1]; p.bias[g] = prm[g] + T.conv_b[1];
     }
     p.out = T.act2; p.B = B; p.G = G; p.dbg = dbg ? dbg + 65536 * 8 : nullptr;
+#if DZ_CONV2_DMA
+    using C2 = ConvDmaCfg<20, 20, 32, 4, 2, 9, 9, 64, DZ_CONV2_DMA / 100, (DZ_CONV2_DMA / 10) % 10, DZ_CONV2_DMA % 10>;
+    if (C2::fits(B)) {
+      ConvDmaParams q;
+      for (int g = 0; g < DZ_MAX_GROUPS; ++g) {
+        q.in[g] = (const float*)p.in[g < G ? g : 0]; q.in_img_base[g] = p.in_img_base[g < G ? g : 0];
+        q.w[g] = p.w[g < G ? g : 0]; q.bias[g] = p.bias[g < G ? g : 0];
+      }
+      q.out = T.act2; q.B = B; q.G = G; q.dbg = p.dbg;
+      rc = dz_launch_conv_dma_fwd<C2, DZ_CONV_DMA_OCC>(q, s);
+    } else
+#endif
     rc = launch_conv_fwd<Conv2Fwd>(p, 64, G, B, s);
     if (rc) return rc;
     DZ_PROF(s, "conv2_fwd");
@@ -74,16 +103,61 @@ inline int torso_forward_rest(const TorsoBufs& T, int G, int B, const float* con
       p.w[g] = prm[g] + T.conv_w[2]; p.bias[g] = prm[g] + T.conv_b[2];
     }
     p.out = T.feat; p.B = B; p.G = G; p.dbg = dbg ? dbg + 2 * 65536 * 8 : nullptr;
+#if DZ_CONV3_DMA
+    using C3 = ConvDmaCfg<9, 9, 64, 3, 1, 7, 7, 64, DZ_CONV3_DMA / 100, (DZ_CONV3_DMA / 10) % 10, DZ_CONV3_DMA % 10>;
+    if (C3::fits(B)) {
+      ConvDmaParams q;
+      for (int g = 0; g < DZ_MAX_GROUPS; ++g) {
+        q.in[g] = (const float*)p.in[g < G ? g : 0]; q.in_img_base[g] = p.in_img_base[g < G ? g : 0];
+        q.w[g] = p.w[g < G ? g : 0]; q.bias[g] = p.bias[g < G ? g : 0];
+      }
+      q.out = T.feat; q.B = B; q.G = G; q.dbg = p.dbg;
+      rc = dz_launch_conv_dma_fwd<C3, DZ_CONV_DMA_OCC>(q, s);
+    } else
+#endif
     rc = launch_conv_fwd<Conv3Fwd>(p, 64, G, B, s);
     if (rc) return rc;
     DZ_PROF(s, "conv3_fwd");
   }
   return DZ_OK;
 }
+#if DZ_CONV1_DMA
+using Conv1Dma = Conv1DmaCfg<DZ_CONV1_DMA % 10, DZ_CONV1_DMA / 10 ? DZ_CONV1_DMA / 10 : 2>;   // NRG * 10 + NRB
+inline Conv1DmaParams torso_conv1_dma_params(const TorsoBufs& T, int G, int B, const float* const* prm,
+                                             const uint8_t* const* in) {
+  Conv1DmaParams q;
+  for (int g = 0; g < DZ_MAX_GROUPS; ++g) {
+    const int gg = g < G ? g : 0;
+    q.in[g] = in[gg]; q.w[g] = prm[gg] + T.conv_w[0]; q.bias[g] = prm[gg] + T.conv_b[0];
+  }
+  q.out = T.act1; q.B = B; q.G = G;
+  return q;
+}
+#endif
 inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* prm,
                          const uint8_t* const* in, hipStream_t s,
                          const NoiseParams* side = nullptr, long long* dbg = nullptr,
                          const SeamClear* clr = nullptr) {
+#if DZ_CONV1_DMA
+  if (B > 8 && Conv1Dma::fits(B)) {
+    const Conv1DmaParams q = torso_conv1_dma_params(T, G, B, prm, in);
+    int rc;
+    if (clr) {
+      StepPre sp;
+      sp.noise = side ? *side : NoiseParams{};
+      sp.noise_blocks = side ? (unsigned)((side->n + 255) / 256) : 0u;
+      sp.clr = *clr;
+      rc = dz_launch_conv1_dma<Conv1Dma, StepPreSide>(q, sp, sp.noise_blocks + clr->blocks, s);
+    } else if (side) {
+      rc = dz_launch_conv1_dma<Conv1Dma, NoiseSide>(q, *side, (unsigned)((side->n + 255) / 256), s);
+    } else {
+      rc = dz_launch_conv1_dma<Conv1Dma, DzNoSide>(q, DzNoSide::Params{0}, 0u, s);
+    }
+    if (rc) return rc;
+    DZ_PROF(s, side ? "conv1_fwd+noise" : "conv1_fwd");
+    return torso_forward_rest(T, G, B, prm, s, dbg);
+  }
+#endif
   const ConvFwdParams p = torso_conv1_params(T, G, B, prm, in, dbg);
   const int rc = B <= 8 ? launch_conv1_fwd<Conv1FwdAct>(p, G, B, side, s, clr)
                         : launch_conv1_fwd<Conv1Fwd>(p, G, B, side, s, clr);
@@ -97,6 +171,15 @@ template <class Side>
 inline int torso_forward_side(const TorsoBufs& T, int G, int B, const float* const* prm,
                               const uint8_t* const* in, hipStream_t s,
                               const typename Side::Params& sp, unsigned side_blocks) {
+#if DZ_CONV1_DMA
+  if (B > 8 && Conv1Dma::fits(B)) {
+    const Conv1DmaParams q = torso_conv1_dma_params(T, G, B, prm, in);
+    const int rc1 = dz_launch_conv1_dma<Conv1Dma, Side>(q, sp, side_blocks, s);
+    if (rc1) return rc1;
+    DZ_PROF(s, "conv1_fwd+side");
+    return torso_forward_rest(T, G, B, prm, s, nullptr);
+  }
+#endif
   const ConvFwdParams p = torso_conv1_params(T, G, B, prm, in, nullptr);
   int rc;
   if (B <= 8)
