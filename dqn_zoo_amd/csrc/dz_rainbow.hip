@@ -558,7 +558,6 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       ConvDgradParams d;
       d.dy = ws + L.ws_dfeat; d.w = a->online + L.conv_w[2]; d.act = ws + L.ws_act2;
       d.dx = ws + L.ws_dact2; d.B = B;
-      const dim3 gw(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), gd(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1);
       // (with the next step's sample riding in the optimiser launch the write-back must
       // be complete BEFORE that launch: it stays here)
       const bool prio_in_adam = (phases & DZ_PHASE_OPTIMIZER) != 0 && !a->next_sample && !onfly;
@@ -568,10 +567,10 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         // (Measured hosts: this launch hides it completely; inside the HBM-heavy fc1
         // launch its dependent loads stretch to 18 us, inside conv1's 8.5 us launch
         // it sticks out by 4 us.)
-        rc = dz_launch_gemm2_side<Conv3Wg, Conv3Dg, PrioUpdateSideFast>(w, gw, d, gd, prio_q, 1, s);
+        rc = launch_conv3_bwd(w, d, B, s, &prio_q);
         prio_pending = false;
       } else {
-        rc = dz_launch_gemm2<Conv3Wg, Conv3Dg>(w, gw, d, gd, s);
+        rc = launch_conv3_bwd(w, d, B, s);
       }
       if (rc) return rc;
       DZ_PROF(s, "conv3_wgrad+dgrad");
@@ -582,16 +581,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       ConvDgradParams d;
       d.dy = ws + L.ws_dact2; d.w = a->online + L.conv_w[1]; d.act = ws + L.ws_act1;
       d.dx = ws + L.ws_dact1; d.B = B;
-      rc = dz_launch_gemm2<Conv2Wg, Conv2Dg>(
-          w, dim3(64 / Conv2Wg::BN, Conv2Wg::MT, kS_cw2), d,
-          dim3(32 / Conv2Dg::BN, Conv2Dg::tiles(B), 4), s);
+      rc = launch_conv2_bwd(w, d, B, s);
       if (rc) return rc;
       DZ_PROF(s, "conv2_wgrad+dgrad");
     }
     {  // conv1 weight+bias gradient partials straight from the uint8 states
       ConvWgradParams p;
       p.in = a->s_tm1; p.dy = ws + L.ws_dact1; p.part = part1; p.B = B; p.S = kS_cw1;
-      rc = dz_launch_gemm<Conv1Wg>(p, dim3(32 / Conv1Wg::BN, Conv1Wg::MT, kS_cw1), s);
+      rc = launch_conv1_wgrad(p, s);
       if (rc) return rc;
       DZ_PROF(s, "conv1_wgrad");
     }

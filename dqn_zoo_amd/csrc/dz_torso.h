@@ -7,6 +7,7 @@
 #include "dz_sumtree_dev.h"
 #include "dz_conv_dma.h"
 #include "dz_conv1_dma.h"
+#include "dz_conv_bwd_dma.h"
 
 // A/B switches (tools/build_variant.sh): SUBN * 100 + KT * 10 + NBUF of the LDS-DMA forward
 // convolutions, 0 = the register-staged ConvFwdOp
@@ -19,8 +20,21 @@
 #ifndef DZ_CONV1_DMA   // row blocks of 16 per wave (workgroup = 32 x this rows), 0 = ConvFwdOp
 #define DZ_CONV1_DMA 21
 #endif
-#ifndef DZ_CONV_DMA_OCC
+// backward pairs on the LDS-DMA skeleton: (dgrad SUBN) * 1000 + (dgrad KT) * 100 + (wgrad KT) * 10 + NBUF, 0 = off
+#ifndef DZ_CONV3_BWD_DMA
+#define DZ_CONV3_BWD_DMA 1123
+#endif
+#ifndef DZ_CONV2_BWD_DMA
+#define DZ_CONV2_BWD_DMA 123
+#endif
+#ifndef DZ_CONV1_WG_DMA   // conv1's weight gradient: KT * 10 + NBUF, 0 = ConvWgradOp
+#define DZ_CONV1_WG_DMA 0
+#endif
+#ifndef DZ_CONV_DMA_OCC   // waves per SIMD the forward kernels are compiled for (one workgroup per CU)
 #define DZ_CONV_DMA_OCC 2
+#endif
+#ifndef DZ_CONV_BWD_OCC   // ... and the backward pairs (conv2's is 643 workgroups: three per CU must fit; 2: 10.6 us, 3: 9.3)
+#define DZ_CONV_BWD_OCC 3
 #endif
 
 namespace {
@@ -193,6 +207,54 @@ inline int torso_forward_side(const TorsoBufs& T, int G, int B, const float* con
   return torso_forward_rest(T, G, B, prm, s, nullptr);
 }
 
+// conv3 / conv2 backward: weight (+ bias) gradient slabs fused with the layer's input gradient.
+// `prio`: optional sum-tree priority write-back carried as one extra block.
+inline int launch_conv3_bwd(const ConvWgradParams& w, const ConvDgradParams& d, int B, hipStream_t s,
+                            const PrioUpdateParams* prio = nullptr) {
+#if DZ_CONV3_BWD_DMA
+  using Wg = ConvWgDmaOp<9, 9, 64, 3, 1, 7, 7, 64, (DZ_CONV3_BWD_DMA / 10) % 10, DZ_CONV3_BWD_DMA % 10>;
+  using Dg = ConvDgDmaOp<9, 9, 64, 3, 1, 7, 7, 64, DZ_CONV3_BWD_DMA / 1000, (DZ_CONV3_BWD_DMA / 100) % 10, DZ_CONV3_BWD_DMA % 10>;
+  static_assert(Wg::KROWS == Conv3Wg::KROWS, "slab layout");
+  if (Dg::fits(B)) {
+    const dim3 gw(1, Wg::MT, w.S), gd(64 / Dg::BN, Dg::tiles(B), 1);
+    if (prio) return dz_launch_dmaop2_side<Wg, Dg, PrioUpdateSideFast, DZ_CONV_BWD_OCC>(w, gw, d, gd, *prio, 1, s);
+    return dz_launch_dmaop2<Wg, Dg, DZ_CONV_BWD_OCC>(w, gw, d, gd, s);
+  }
+#endif
+  const dim3 gw(64 / Conv3Wg::BN, Conv3Wg::MT, w.S), gd(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1);
+  if (prio) return dz_launch_gemm2_side<Conv3Wg, Conv3Dg, PrioUpdateSideFast>(w, gw, d, gd, *prio, 1, s);
+  return dz_launch_gemm2<Conv3Wg, Conv3Dg>(w, gw, d, gd, s);
+}
+inline int launch_conv2_bwd(const ConvWgradParams& w, const ConvDgradParams& d, int B, hipStream_t s) {
+#if DZ_CONV2_BWD_DMA
+  using Wg = ConvWgDmaOp<20, 20, 32, 4, 2, 9, 9, 64, (DZ_CONV2_BWD_DMA / 10) % 10, DZ_CONV2_BWD_DMA % 10>;
+  using Dg = ConvDgDmaOp<20, 20, 32, 4, 2, 9, 9, 64, 1, (DZ_CONV2_BWD_DMA / 100) % 10, DZ_CONV2_BWD_DMA % 10>;
+  static_assert(Wg::KROWS == Conv2Wg::KROWS, "slab layout");
+#ifdef DZ_BWD_ABL   // timing ablations (results are wrong): 1 = weight gradient only, 2 = input gradient only
+  if (DZ_BWD_ABL == 1) return dz_launch_dmaop<Wg, DZ_CONV_BWD_OCC>(w, dim3(1, Wg::MT, w.S), s);
+  if (DZ_BWD_ABL == 2) return dz_launch_dmaop<Dg, DZ_CONV_BWD_OCC>(d, dim3(1, Dg::tiles(B), 4), s);
+#endif
+  if (Dg::fits(B))
+    return dz_launch_dmaop2<Wg, Dg, DZ_CONV_BWD_OCC>(w, dim3(1, Wg::MT, w.S), d, dim3(1, Dg::tiles(B), 4), s);
+#endif
+#ifdef DZ_BWD_ABL
+  if (DZ_BWD_ABL == 3) return dz_launch_gemm<Conv2Wg>(w, dim3(64 / Conv2Wg::BN, Conv2Wg::MT, w.S), s);
+  if (DZ_BWD_ABL == 4) return dz_launch_gemm<Conv2Dg>(d, dim3(32 / Conv2Dg::BN, Conv2Dg::tiles(B), 4), s);
+#endif
+  return dz_launch_gemm2<Conv2Wg, Conv2Dg>(w, dim3(64 / Conv2Wg::BN, Conv2Wg::MT, w.S), d,
+                                          dim3(32 / Conv2Dg::BN, Conv2Dg::tiles(B), 4), s);
+}
+
+inline int launch_conv1_wgrad(const ConvWgradParams& p, hipStream_t s) {
+#if DZ_CONV1_WG_DMA
+  using Wg = Conv1WgDmaOp<DZ_CONV1_WG_DMA / 10, DZ_CONV1_WG_DMA % 10>;
+  static_assert(Wg::KROWS == Conv1Wg::KROWS, "slab layout");
+  return dz_launch_dmaop<Wg, DZ_CONV_BWD_OCC>(p, dim3(1, Wg::MT, p.S), s);
+#else
+  return dz_launch_gemm<Conv1Wg>(p, dim3(32 / Conv1Wg::BN, Conv1Wg::MT, p.S), s);
+#endif
+}
+
 inline int64_t torso_wgrad_part_elems() {
   return (int64_t)kS_cw1 * Conv1Wg::KROWS * 32 + (int64_t)kS_cw2 * Conv2Wg::KROWS * 64 +
          (int64_t)kS_cw3 * Conv3Wg::KROWS * 64;
@@ -216,11 +278,7 @@ inline int torso_backward(const TorsoBufs& T, int B, const float* online,
     w.in = T.act2; w.dy = dfeat; w.part = part3; w.B = B; w.S = kS_cw3;
     ConvDgradParams d;
     d.dy = dfeat; d.w = online + T.conv_w[2]; d.act = T.act2; d.dx = dact2; d.B = B;
-    const dim3 gw(64 / Conv3Wg::BN, Conv3Wg::MT, kS_cw3), gd(64 / Conv3Dg::BN, Conv3Dg::tiles(B), 1);
-    if (prio)
-      rc = dz_launch_gemm2_side<Conv3Wg, Conv3Dg, PrioUpdateSideFast>(w, gw, d, gd, *prio, 1, s);
-    else
-      rc = dz_launch_gemm2<Conv3Wg, Conv3Dg>(w, gw, d, gd, s);
+    rc = launch_conv3_bwd(w, d, B, s, prio);
     if (rc) return rc;
     DZ_PROF(s, "conv3_wgrad+dgrad");
   }
@@ -229,15 +287,14 @@ inline int torso_backward(const TorsoBufs& T, int B, const float* online,
     w.in = T.act1; w.dy = dact2; w.part = part2; w.B = B; w.S = kS_cw2;
     ConvDgradParams d;
     d.dy = dact2; d.w = online + T.conv_w[1]; d.act = T.act1; d.dx = dact1; d.B = B;
-    rc = dz_launch_gemm2<Conv2Wg, Conv2Dg>(w, dim3(64 / Conv2Wg::BN, Conv2Wg::MT, kS_cw2), d,
-                                          dim3(32 / Conv2Dg::BN, Conv2Dg::tiles(B), 4), s);
+    rc = launch_conv2_bwd(w, d, B, s);
     if (rc) return rc;
     DZ_PROF(s, "conv2_wgrad+dgrad");
   }
   {
     ConvWgradParams p;
     p.in = s_tm1; p.dy = dact1; p.part = part1; p.B = B; p.S = kS_cw1;
-    rc = dz_launch_gemm<Conv1Wg>(p, dim3(32 / Conv1Wg::BN, Conv1Wg::MT, kS_cw1), s);
+    rc = launch_conv1_wgrad(p, s);
     if (rc) return rc;
     DZ_PROF(s, "conv1_wgrad");
   }

@@ -33,6 +33,7 @@ def dump(path):
       out['%s_%d' % (name, it)] = ln.ws_view(name, n).cpu().numpy()
     out['losses_%d' % it] = ln.losses.cpu().numpy()
     out['params_%d' % it] = ln.online.cpu().numpy()
+    out['grad_%d' % it] = ln.grad.cpu().numpy()[:77984]   # the conv gradients (fc1's is never stored)
   np.savez(path, **out)
   print('dumped', path)
 
