@@ -118,11 +118,12 @@ __device__ __forceinline__ void hc_fold_block(const HeadChain& p, unsigned u, fl
   const int col0 = cq * kHcFoldCols + 4 * l;           // + 256 pass: wave 0's lanes finish four columns each
   const float* src = p.fc1_part + (long)r * 1024 + col0;
   const long stride = (long)p.rows * 1024;
-  float4 x[NP][8];
+  constexpr int SPW = kFc1Splits / 4;   // slabs per wave
+  float4 x[NP][SPW];
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[ps][j] = dz_ld4(src + 256 * ps + (long)(w + 4 * j) * stride);
+    for (int j = 0; j < SPW; ++j) x[ps][j] = dz_ld4(src + 256 * ps + (long)(w + 4 * j) * stride);
   float4 bm[NP], bs[NP], be[NP];
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
@@ -133,7 +134,7 @@ __device__ __forceinline__ void hc_fold_block(const HeadChain& p, unsigned u, fl
   for (int ps = 0; ps < NP; ++ps) {
     float4 v = dz_f4zero();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { v.x += x[ps][j].x; v.y += x[ps][j].y; v.z += x[ps][j].z; v.w += x[ps][j].w; }
+    for (int j = 0; j < SPW; ++j) { v.x += x[ps][j].x; v.y += x[ps][j].y; v.z += x[ps][j].z; v.w += x[ps][j].w; }
     *(float4*)(lds + w * kHcFoldCols + 256 * ps + 4 * l) = v;
   }
   __syncthreads();

@@ -29,6 +29,12 @@ constexpr int kNormSlots = 12288;   // per-wave slots of the weight-gradient ker
 
 inline int64_t align4(int64_t v) { return (v + 3) & ~(int64_t)3; }
 constexpr int kMaxSplitFc1 = 32;
+// Rainbow's fc1 forward k-splits (dz_fc_stream.h): 32 x 100 rows, or 16 x 196 (A/B switch)
+#ifndef DZ_FC1_SPLITS
+#define DZ_FC1_SPLITS 32
+#endif
+constexpr int kFc1Splits = DZ_FC1_SPLITS;
+static_assert(kFc1Splits % 4 == 0 && kFc1Splits <= kMaxSplitFc1, "four waves fold the slabs");
 
 // conv geometries (networks.py:194-198)
 //                      U8  H   W   C  KS S  OH  OW  CO

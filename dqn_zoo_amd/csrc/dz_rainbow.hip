@@ -33,7 +33,6 @@ namespace {
 
 // Launch constants: the measured best on MI355X at B = 32 (the sweeps and the
 // alternatives that lost are in EXPERIMENTS.md; the code that implemented them is gone).
-constexpr int kFc1Splits = 32;       // fc1 forward k-splits (98 rows each)
 constexpr int kFc1DgradSplits = 12;  // fc1 input-gradient k-splits of the STORED-gradient forms (split steps, batch > 32, keep_all_grads): 11 slabs of 6 single-chunk stages
 constexpr int kFc2Splits = 8;        // fc2 forward k-splits
 // The two noisy linear layers' input gradients in the one-call step (dz_fc1_onfly.h):
@@ -127,10 +126,32 @@ static int rainbow_forward(const dz_rainbow_layout_t& L, const FwdHeads& H, int 
       q.head[0] = fc1h[0]; q.head[1] = fc1h[1];
       q.part = p.part; q.ldo = p.ldo;
       q.rows_per_split = ((kFlat + kFc1Splits - 1) / kFc1Splits + 3) & ~3;
-      static_assert((((kFlat + kFc1Splits - 1) / kFc1Splits + 3) & ~3) <= 100, "NL = 50 k-pairs per lane");
+      constexpr int kRps = ((kFlat + kFc1Splits - 1) / kFc1Splits + 3) & ~3;   // rows per split: 100 / 196
+#ifndef DZ_FC1_CH
+#define DZ_FC1_CH (kFc1Splits == 32 ? 5 : 7)
+#endif
+#ifndef DZ_FC1_DEPTH
+#define DZ_FC1_DEPTH 3
+#endif
+      constexpr int kNl = (kRps / 2 + DZ_FC1_CH - 1) / DZ_FC1_CH * DZ_FC1_CH;   // k-pairs per lane
       q.xcd_order = (kFc1Splits * ns) % 8 == 0;
+#ifndef DZ_FC1_DMA   // ring slots per wave of the LDS-DMA weight stream, 0 = the register pipeline
+#define DZ_FC1_DMA 0
+#endif
+#if DZ_FC1_DMA
+      constexpr int kNch = (kRps + 7) / 8;   // 8-row slots per split
+      const size_t lds = ((size_t)4 * DZ_FC1_DMA * 512 + (size_t)q.rows_per_split * (2 * 32 + 2)) * sizeof(float);
+      static bool once = [] {
+        (void)hipFuncSetAttribute((const void*)dz_fc_stream_dma<1, kNch, DZ_FC1_DMA>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+      }();
+      (void)once;
+      hipLaunchKernelGGL((dz_fc_stream_dma<1, kNch, DZ_FC1_DMA>), dim3(8, kFc1Splits, ns), dim3(256), lds, s, q);
+#else
       const size_t lds = (size_t)q.rows_per_split * (2 * 32 + 2) * sizeof(float);
-      hipLaunchKernelGGL((dz_fc_stream_fwd3<1, 50>), dim3(8, kFc1Splits, ns), dim3(256), lds, s, q);
+      hipLaunchKernelGGL((dz_fc_stream_fwd3<1, kNl, DZ_FC1_CH, DZ_FC1_DEPTH>), dim3(8, kFc1Splits, ns), dim3(256), lds, s, q);
+#endif
       DZ_LAUNCH_CHECK();
       rc = DZ_OK;
     }
