@@ -30,8 +30,12 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int NRB_, int NRG_ = 2>
+// AHEAD_: K-stages requested up front; stage s + AHEAD_ is requested behind stage s's barrier.
+// (All four at once queue every co-resident workgroup's 40 KB in front of anyone's SECOND stage:
+// in-kernel stamps showed the launch's first MFMA 1.8 us after the workgroups start.)
+template <int NRB_, int NRG_ = 2, int AHEAD_ = 4>
 struct Conv1DmaCfg {
+  static constexpr int AHEAD = AHEAD_;
   static constexpr int NRB = NRB_, NRG = NRG_, NW = 2 * NRG_, THREADS = 64 * NW, BMW = 16 * NRB_ * NRG_;
   static constexpr int H = 84, W = 84, OH = 20, OW = 20, CO = 32, K = 256, NSTG = 4;
   static constexpr int ROWB = W * 4;                       // bytes per input row
@@ -53,7 +57,13 @@ struct Conv1DmaParams {
   const float* bias[DZ_MAX_GROUPS];
   float* out;                         // [G*B][20][20][32]
   int B, G;
+  long long* dbg = nullptr;           // (DZ_GEMM_STAMPS builds) per-workgroup wall-clock stamps
 };
+#ifdef DZ_GEMM_STAMPS
+#define DZ_C1_STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(long)(4 * mt) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define DZ_C1_STAMP(i) do {} while (0)
+#endif
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant)
 __device__ __forceinline__ void dz_wait_vmcnt(int n) {
@@ -77,6 +87,7 @@ __device__ __forceinline__ void dz_conv1_dma_body(const Conv1DmaParams& p, int m
   unsigned char* As = lds;
   const float* Bs = (const float*)(lds + C::A_BYTES);
 
+  DZ_C1_STAMP(0);
   const int tpg = p.B * C::OH * C::OW / C::BMW;
   const int g = mt / tpg;
   const int m0 = (mt - g * tpg) * C::BMW;
@@ -109,8 +120,7 @@ __device__ __forceinline__ void dz_conv1_dma_body(const Conv1DmaParams& p, int m
     const int k = min(8 * (C::NW * j + wave), 56) + (lane >> 3);
     bsrc[j] = wgt + (long)k * C::CO + 4 * ((lane & 7) ^ (4 * ((k >> 3) & 1)));
   }
-#pragma unroll
-  for (int s = 0; s < C::NSTG; ++s) {
+  auto issue = [&](int s) {
 #pragma unroll
     for (int j = 0; j < NAJ; ++j)
       if (j < na)
@@ -121,8 +131,11 @@ __device__ __forceinline__ void dz_conv1_dma_body(const Conv1DmaParams& p, int m
       if (j < nb)
         dz_glds16<0>(bsrc[j] + s * 64 * C::CO,
                      lds0 + (unsigned)(C::A_BYTES + s * 64 * 128) + (unsigned)((C::NW * j + wave) * 1024));
-  }
+  };
+#pragma unroll
+  for (int s = 0; s < C::AHEAD && s < C::NSTG; ++s) issue(s);
 
+  DZ_C1_STAMP(1);
   f32x4v acc[C::NRB];
 #pragma unroll
   for (int rb = 0; rb < C::NRB; ++rb) acc[rb] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -130,8 +143,13 @@ __device__ __forceinline__ void dz_conv1_dma_body(const Conv1DmaParams& p, int m
   const int slot_x = (li >> 2) & 3;
 #pragma unroll
   for (int s = 0; s < C::NSTG; ++s) {
-    dz_wait_vmcnt(nper * (C::NSTG - 1 - s));
+    {  // stages s + 1 .. min(s + AHEAD, NSTG) - 1 may still be in flight
+      const int hi = s + C::AHEAD < C::NSTG ? s + C::AHEAD : C::NSTG;
+      dz_wait_vmcnt(nper * (hi - 1 - s));
+    }
     __syncthreads();
+    if (s == 0) DZ_C1_STAMP(2);
+    if (s + C::AHEAD < C::NSTG) issue(s + C::AHEAD);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {   // 32 depth indices: lane (i, q) holds k = 64 s + 32 c + 8 q + t, t < 8
       float bf[8];
@@ -156,6 +174,7 @@ __device__ __forceinline__ void dz_conv1_dma_body(const Conv1DmaParams& p, int m
         }
     }
   }
+  DZ_C1_STAMP(3);
   // ---- bias + ReLU, transposed through LDS, 16-byte coalesced stores ---------------------
   __syncthreads();   // every wave has finished reading A
   float* Os = (float*)lds;
@@ -169,6 +188,7 @@ __device__ __forceinline__ void dz_conv1_dma_body(const Conv1DmaParams& p, int m
       Os[((rg * C::NRB + rb) * 16 + 4 * kq + r) * C::OUT_PITCH + cb * 16 + li] = v > 0.f ? v : 0.f;
     }
   __syncthreads();
+  DZ_C1_STAMP(4);
   float* out = p.out + ((long)g * tpg * C::BMW + m0) * C::CO;
   static_assert((C::BMW * 8) % C::THREADS == 0, "whole float4 rounds");
 #pragma unroll
@@ -177,6 +197,7 @@ __device__ __forceinline__ void dz_conv1_dma_body(const Conv1DmaParams& p, int m
     const float4 v = *(const float4*)(Os + (idx >> 3) * C::OUT_PITCH + 4 * (idx & 7));
     *(float4*)(out + 4 * (long)idx) = v;
   }
+  DZ_C1_STAMP(5);
 }
 
 // the conv tiles first, then `Side` blocks (noise draw / seam clear / cosine table: jobs conv1

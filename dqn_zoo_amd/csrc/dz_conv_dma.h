@@ -23,14 +23,14 @@
 
 namespace {
 
-template <int H_, int W_, int C_, int KS_, int S_, int OH_, int OW_, int CO_, int SUBN_, int KT_, int NBUF_>
+template <int H_, int W_, int C_, int KS_, int S_, int OH_, int OW_, int CO_, int SUBN_, int KT_, int NBUF_, int NI_ = 1>
 struct ConvDmaCfg {
   static constexpr int H = H_, W = W_, C = C_, KS = KS_, S = S_, OH = OH_, OW = OW_, CO = CO_;
-  static constexpr int SUBN = SUBN_, WKD = 4 / SUBN_, KT = KT_, NBUF = NBUF_;
-  static constexpr int BM = 32, BN = 32 * SUBN, BK = 16 * WKD * KT;
+  static constexpr int SUBN = SUBN_, WKD = 4 / SUBN_, KT = KT_, NBUF = NBUF_, NI = NI_;   // NI accumulator chains per wave
+  static constexpr int BM = 32, BN = 32 * SUBN * NI, BK = 16 * WKD * KT;
   static constexpr int K = KS * KS * C, ROWLEN = KS * C, SPR = ROWLEN / BK, NST = K / BK;
   static constexpr int A_FLOATS = BM * BK, B_FLOATS = BK * BN, STAGE = A_FLOATS + B_FLOATS;
-  static constexpr int EXCH = 4 * 16 * 64;   // the depth groups' exchange (floats)
+  static constexpr int EXCH = 4 * NI * 16 * 64;   // the depth groups' exchange (floats)
   static constexpr int LDS_FLOATS = NBUF * STAGE > EXCH ? NBUF * STAGE : EXCH;
   static constexpr int A_PER_WAVE = A_FLOATS / 1024, B_PER_WAVE = B_FLOATS / 1024;
   static constexpr int PER_STAGE = A_PER_WAVE + B_PER_WAVE;
@@ -72,7 +72,7 @@ __device__ __forceinline__ void dz_conv_dma_body(const ConvDmaParams& p, int mt,
   const int half = lane >> 5, l31 = lane & 31;
   const unsigned lds0 = (unsigned)(uintptr_t)lds;
 #ifdef DZ_GEMM_STAMPS
-  long long* dbgp = p.dbg ? p.dbg + (long)(mt * (C::CO / C::BN) + nt) * 8 : nullptr;
+  long long* dbgp = p.dbg ? p.dbg + (long)(nt + 4 * mt) * 8 : nullptr;   // (tools/conv_stamps.py: x + 4 y)
 #endif
   DZ_CD_STAMP(0);
 
@@ -87,7 +87,9 @@ __device__ __forceinline__ void dz_conv_dma_body(const ConvDmaParams& p, int mt,
 
   // the bias of this lane's output column: the ONLY ordinary global load, issued before the
   // first DMA (vmcnt counts in order: the first stage wait covers it)
-  const float bcol = bias[n0 + sub * 32 + l31];
+  float bcol[C::NI];
+#pragma unroll
+  for (int ni = 0; ni < C::NI; ++ni) bcol[ni] = bias[n0 + (sub * C::NI + ni) * 32 + l31];
 
   // ---- DMA sources ------------------------------------------------------------------
   const float* asrc[C::A_PER_WAVE]; unsigned adst[C::A_PER_WAVE];
@@ -122,9 +124,11 @@ __device__ __forceinline__ void dz_conv_dma_body(const ConvDmaParams& p, int mt,
     for (int j = 0; j < C::B_PER_WAVE; ++j) { dz_glds16<0>(bsrc[j], base + bdst[j]); bsrc[j] += (long)C::BK * C::CO; }
   };
 
-  f32x16 acc;
+  f32x16 acc[C::NI];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[ni][i] = 0.f;
 
 #pragma unroll
   for (int s = 0; s < C::NBUF - 1; ++s)
@@ -142,50 +146,70 @@ __device__ __forceinline__ void dz_conv_dma_body(const ConvDmaParams& p, int mt,
     if (st + C::NBUF - 1 < C::NST) issue(st + C::NBUF - 1);
     const float* As = lds + (st % C::NBUF) * C::STAGE;
     const float* Bs = As + C::A_FLOATS;
-#pragma unroll
-    for (int kt = 0; kt < C::KT; ++kt) {
+#ifndef DZ_CONV_DMA_PF   // 1: chunk kt + 1's fragments are requested in front of chunk kt's MFMAs
+#define DZ_CONV_DMA_PF 1
+#endif
+    auto frag = [&](int kt, float (&fa)[8], float (&fb)[C::NI][8]) {
       const int ch = wk * C::KT + kt;
-      float fa[8], fb[8];
       {
         const int fr = C::swz(l31), u0 = ch * 4 + half * 2;
         const float4 v0 = *(const float4*)(As + l31 * C::BK + 4 * (u0 ^ fr));
         const float4 v1 = *(const float4*)(As + l31 * C::BK + 4 * ((u0 + 1) ^ fr));
         fa[0] = v0.x; fa[1] = v0.y; fa[2] = v0.z; fa[3] = v0.w; fa[4] = v1.x; fa[5] = v1.y; fa[6] = v1.z; fa[7] = v1.w;
       }
-      {
-        const int blk = C::UW >= 16 ? (sub ^ half) : 0;
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) {
+        const int b0 = sub * C::NI + ni;
+        const int blk = C::UW >= 16 ? (b0 ^ half) : b0;
         const float* bl = Bs + (ch * 16 + half * 8) * C::BN + blk * 32 + l31;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) fb[s] = bl[s * C::BN];
+        for (int s = 0; s < 8; ++s) fb[ni][s] = bl[s * C::BN];
+      }
+    };
+    float fa[2][8], fb[2][C::NI][8];
+    frag(0, fa[0], fb[0]);
+#pragma unroll
+    for (int kt = 0; kt < C::KT; ++kt) {
+      if (DZ_CONV_DMA_PF && kt + 1 < C::KT) {
+        frag(kt + 1, fa[(kt + 1) & 1], fb[(kt + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni)
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kt & 1][s], fb[kt & 1][ni][s], acc[ni], 0, 0, 0);
+      if (!DZ_CONV_DMA_PF && kt + 1 < C::KT) frag(kt + 1, fa[(kt + 1) & 1], fb[(kt + 1) & 1]);
     }
   }
   DZ_CD_STAMP(3);
   // ---- the depth groups meet in LDS; every wave finishes 16 / WKD registers -------------
   __syncthreads();
-  {
-    float* dst = lds + ((wk * C::SUBN + sub) * 16) * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dst[i * 64] = acc[i];
+  for (int ni = 0; ni < C::NI; ++ni) {
+    float* dst = lds + (((wk * C::SUBN + sub) * C::NI + ni) * 16) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[i * 64] = acc[ni][i];
   }
   __syncthreads();
   constexpr int RPW = 16 / C::WKD;
-  float b = bcol;
-  asm volatile("" : "+v"(b));
-  const int col = n0 + sub * 32 + l31;
   const long orow0 = (long)g * tpg * C::BM + m0;
   DZ_CD_STAMP(4);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    if (i / RPW == wk) {   // wave-uniform
-      const float* src = lds + (sub * 16 + i) * 64 + lane;
-      float v = src[0];
+  for (int ni = 0; ni < C::NI; ++ni) {
+    float b = bcol[ni];
+    asm volatile("" : "+v"(b));
+    const int col = n0 + (sub * C::NI + ni) * 32 + l31;
 #pragma unroll
-      for (int k2 = 1; k2 < C::WKD; ++k2) v += src[k2 * C::SUBN * 16 * 64];
-      v += b;
-      p.out[(orow0 + dz_acc_row(i, lane)) * C::CO + col] = v > 0.f ? v : 0.f;
+    for (int i = 0; i < 16; ++i) {
+      if (i / RPW == wk) {   // wave-uniform
+        const float* src = lds + ((sub * C::NI + ni) * 16 + i) * 64 + lane;
+        float v = src[0];
+#pragma unroll
+        for (int k2 = 1; k2 < C::WKD; ++k2) v += src[k2 * C::SUBN * C::NI * 16 * 64];
+        v += b;
+        p.out[(orow0 + dz_acc_row(i, lane)) * C::CO + col] = v > 0.f ? v : 0.f;
+      }
     }
   }
   DZ_CD_STAMP(5);

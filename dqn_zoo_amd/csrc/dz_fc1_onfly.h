@@ -51,7 +51,9 @@ template <int C, int IT>
 struct OfTile {
   static constexpr int TPR = C / 4, RP = 256 / TPR, R = RP * IT, FS = 36;
   static constexpr int kStrips = 1024 / C, kBlocks = (kFlat / R) * kStrips;
-  static constexpr int kLds = 32 * C + R * FS + C + R;   // floats
+  static constexpr int GP = C + 4;                        // row pitch of the gradient tile (MFMA form)
+  static constexpr int kFill = 32 * C + R * FS;           // dh1 strip + X tile (dead once the tile exists)
+  static constexpr int kLds = (kFill > R * GP ? kFill : R * GP) + C + R;   // floats
   static_assert(kFlat % R == 0, "rows");
 };
 template <int C, int IT>
@@ -61,7 +63,8 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
                                                const int32_t* count, float lr, float b1, float b2,
                                                float eps, float max_norm, float* red, float* lds) {
   using T = OfTile<C, IT>;
-  float* s_dh1 = lds; float* s_ft = lds + 32 * C; float* s_eo = s_ft + T::R * T::FS;
+  float* s_dh1 = lds; float* s_ft = lds + 32 * C;
+  float* s_eo = lds + (T::kFill > T::R * T::GP ? T::kFill : T::R * T::GP);
   const int strip = blk % T::kStrips, rg = blk / T::kStrips;
   const int k0 = rg * T::R, c0 = strip * C;
   const int tid = threadIdx.x, rl = tid / T::TPR, c4 = tid % T::TPR;
@@ -98,6 +101,40 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
   const float gn = dz_sgpr(sc0.gn), bc1 = dz_sgpr(sc0.bc1), bc2 = dz_sgpr(sc0.bc2);
   const bool pass = __builtin_amdgcn_readfirstlane((int)sc0.pass) != 0;
   const unsigned rstep = (unsigned)(T::RP * q.ld) * 4u;
+#ifndef DZ_ADAM_MFMA
+#define DZ_ADAM_MFMA 0
+#endif
+#if DZ_ADAM_MFMA
+  // The gradient tile G[k][n] = sum_b x[b][k] dh1[b][n] on the matrix pipe (round 6): wave w
+  // owns the 16-column block w of the strip (C = 64) and all R / 16 row blocks, depth 32 =
+  // eight `v_mfma_f32_16x16x4_f32` per block with k-slot b = 4 s + (lane >> 4): the same
+  // ascending-b fma chain per element as the VALU loop below.  The tile then replaces the
+  // factors in LDS (row pitch C + 4) and every thread reads its four gradients per row as
+  // ONE ds_read_b128 instead of 40 -- the VALU loop spent 128 FMAs and 640 bytes of LDS reads
+  // per thread and row on it.
+  static_assert(C == 64 && T::R % 16 == 0, "four column blocks of 16, whole row blocks");
+  {
+    typedef float f32x4m __attribute__((ext_vector_type(4)));
+    constexpr int NRB = T::R / 16;
+    const int lane = tid & 63, wv = tid >> 6, li = lane & 15, kq = lane >> 4;
+    f32x4m acc[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) acc[rb] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const float bv = s_dh1[(4 * st + kq) * C + 16 * wv + li];
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_ft[(16 * rb + li) * T::FS + 4 * st + kq], bv, acc[rb], 0, 0, 0);
+    }
+    __syncthreads();   // every wave has read the factors
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[(16 * rb + 4 * kq + r) * T::GP + 16 * wv + li] = acc[rb][r];
+    __syncthreads();
+  }
+#endif
   // Measured alternatives (optimiser role alone; this form 31.4-31.9 us, a bare float4
   // read-modify-write stream of the same 165 MB 24.65 us): one pass over the batch for all seven rows (28
   // accumulators, LDS reads -69 %) 35.1 us -- the rows' streams then start only after the
@@ -107,6 +144,10 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
   {
 #pragma unroll 1
     for (int it = 0; it < IT; ++it) {
+#if DZ_ADAM_MFMA
+      const float4 g4 = *(const float4*)(lds + (it * T::RP + rl) * T::GP + 4 * c4);
+      float a0 = g4.x, a1 = g4.y, a2 = g4.z, a3 = g4.w;
+#else
       const float* ft = s_ft + (it * T::RP + rl) * T::FS;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll 1
@@ -120,6 +161,7 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
           a2 = __builtin_fmaf(fx[j], d.z, a2); a3 = __builtin_fmaf(fx[j], d.w, a3);
         }
       }
+#endif
       const float G[4] = {a0, a1, a2, a3};
       const float4 eo = *(const float4*)(s_eo + 4 * c4);
       const float ei = s_eo[C + it * T::RP + rl];

@@ -95,7 +95,7 @@ inline int torso_forward_rest(const TorsoBufs& T, int G, int B, const float* con
     }
     p.out = T.act2; p.B = B; p.G = G; p.dbg = dbg ? dbg + 65536 * 8 : nullptr;
 #if DZ_CONV2_DMA
-    using C2 = ConvDmaCfg<20, 20, 32, 4, 2, 9, 9, 64, DZ_CONV2_DMA / 100, (DZ_CONV2_DMA / 10) % 10, DZ_CONV2_DMA % 10>;
+    using C2 = ConvDmaCfg<20, 20, 32, 4, 2, 9, 9, 64, (DZ_CONV2_DMA / 100) % 10, (DZ_CONV2_DMA / 10) % 10, DZ_CONV2_DMA % 10, DZ_CONV2_DMA / 1000 ? DZ_CONV2_DMA / 1000 : 1>;   // NI * 1000 + SUBN * 100 + KT * 10 + NBUF
     if (C2::fits(B)) {
       ConvDmaParams q;
       for (int g = 0; g < DZ_MAX_GROUPS; ++g) {
@@ -118,7 +118,7 @@ inline int torso_forward_rest(const TorsoBufs& T, int G, int B, const float* con
     }
     p.out = T.feat; p.B = B; p.G = G; p.dbg = dbg ? dbg + 2 * 65536 * 8 : nullptr;
 #if DZ_CONV3_DMA
-    using C3 = ConvDmaCfg<9, 9, 64, 3, 1, 7, 7, 64, DZ_CONV3_DMA / 100, (DZ_CONV3_DMA / 10) % 10, DZ_CONV3_DMA % 10>;
+    using C3 = ConvDmaCfg<9, 9, 64, 3, 1, 7, 7, 64, (DZ_CONV3_DMA / 100) % 10, (DZ_CONV3_DMA / 10) % 10, DZ_CONV3_DMA % 10, DZ_CONV3_DMA / 1000 ? DZ_CONV3_DMA / 1000 : 1>;
     if (C3::fits(B)) {
       ConvDmaParams q;
       for (int g = 0; g < DZ_MAX_GROUPS; ++g) {
@@ -136,7 +136,7 @@ inline int torso_forward_rest(const TorsoBufs& T, int G, int B, const float* con
   return DZ_OK;
 }
 #if DZ_CONV1_DMA
-using Conv1Dma = Conv1DmaCfg<DZ_CONV1_DMA % 10, DZ_CONV1_DMA / 10 ? DZ_CONV1_DMA / 10 : 2>;   // NRG * 10 + NRB
+using Conv1Dma = Conv1DmaCfg<DZ_CONV1_DMA % 10, (DZ_CONV1_DMA / 10) % 10, DZ_CONV1_DMA / 100 ? DZ_CONV1_DMA / 100 : 4>;   // AHEAD * 100 + NRG * 10 + NRB
 inline Conv1DmaParams torso_conv1_dma_params(const TorsoBufs& T, int G, int B, const float* const* prm,
                                              const uint8_t* const* in) {
   Conv1DmaParams q;
@@ -154,7 +154,8 @@ inline int torso_forward(const TorsoBufs& T, int G, int B, const float* const* p
                          const SeamClear* clr = nullptr) {
 #if DZ_CONV1_DMA
   if (B > 8 && Conv1Dma::fits(B)) {
-    const Conv1DmaParams q = torso_conv1_dma_params(T, G, B, prm, in);
+    Conv1DmaParams q = torso_conv1_dma_params(T, G, B, prm, in);
+    q.dbg = dbg;
     int rc;
     if (clr) {
       StepPre sp;

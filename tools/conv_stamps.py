@@ -13,7 +13,7 @@ for _ in range(50): step()
 torch.cuda.synchronize()
 off = int(learner.layout.c.ws_dfeat_part)
 names = ['start', 'loads issued', 'stage0 in LDS', 'mfma done', 'exchanged', 'stored']
-for li, (nm, nx, ny) in enumerate((('conv1', 1, 1200), ('conv2', 2, 243), ('conv3', 2, 147))):
+for li, (nm, nx, ny) in enumerate((('conv1', 1, 1200), ('conv2', 1, 243), ('conv3', 1, 147))):
   raw = learner.ws[off + li * 65536 * 16: off + (li + 1) * 65536 * 16].cpu().numpy().view(np.int64).reshape(-1, 8)
   idx = [x + 4 * y for y in range(ny) for x in range(nx)]
   r = raw[idx][:, :6]
