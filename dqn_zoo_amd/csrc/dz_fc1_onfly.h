@@ -297,12 +297,13 @@ void adam_onfly_kernel(
     const int32_t* __restrict__ count, const float* __restrict__ losses,
     const float* __restrict__ weights, int B, float* __restrict__ scal, float lr, float b1,
     float b2, float eps, float max_norm, Fc1OnFly q, AdamRanges rg, SampleGatherParams sg,
-    unsigned sg_blocks) {
+    unsigned sg_blocks, const unsigned* abort) {
   __shared__ __attribute__((aligned(16))) float lds[OfTile<kOfC, kOfIT>::kLds];
   __shared__ float red[4];
   constexpr unsigned fc1_blocks = OfTile<kOfC, kOfIT>::kBlocks;
   unsigned bid = blockIdx.x;
   if (bid < sg_blocks) { SampleGatherSide::run(sg, bid); return; }
+  if (abort && *abort) return;   // the step is void (adam_kernel); the next step's sample is still good
   bid -= sg_blocks;
   if (bid < fc1_blocks) {
     adam_fc1_block<kOfC, kOfIT>(bid, q, p, m, v, part, nparts, count, lr, b1, b2, eps, max_norm,

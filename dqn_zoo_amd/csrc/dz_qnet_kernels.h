@@ -308,6 +308,7 @@ struct FinalizeJobs {
   const float* presum_src = nullptr;
   int presum_n = 0;
   int32_t* bump_count = nullptr;    // optax count_inc, done here when the optimiser follows
+  const unsigned* abort = nullptr;  // non-zero word: the step is void (dz_head_chain.h gave up): no count_inc
   RmsApply rms;                     // p == nullptr: off
   RmsOnFly of;                      // feat == nullptr: off; `of.blocks` tile blocks in front of the flat ones
 };
@@ -327,7 +328,7 @@ __device__ __forceinline__ void finalize_grads_block(const FinalizeJobs& J, unsi
   __shared__ float red[4][64];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const unsigned b_in = b;   // this block's index in the partial list
-  if (b == 0 && threadIdx.x == 0 && J.bump_count) *J.bump_count = *J.bump_count + 1;
+  if (b == 0 && threadIdx.x == 0 && J.bump_count && !(J.abort && *J.abort)) *J.bump_count = *J.bump_count + 1;
   float v = 0.f;
   if (b < J.r_end[2]) {
     const int j = b < J.r_end[0] ? 0 : (b < J.r_end[1] ? 1 : 2);
@@ -1029,7 +1030,10 @@ __global__ __launch_bounds__(256) void adam_kernel(
     const int32_t* __restrict__ count, const float* __restrict__ losses,
     const float* __restrict__ weights, int B, float* __restrict__ sc, float lr, float b1,
     float b2, float eps, float max_norm, DerivedGrad dg = DerivedGrad{},
-    PrioUpdateParams prio = PrioUpdateParams{}) {
+    PrioUpdateParams prio = PrioUpdateParams{}, const unsigned* abort = nullptr) {
+  // `abort` (nullable, launch-uniform): a multi-role launch of THIS step gave up on a seam
+  // (ws_scalars[DZ_SC_CHAIN_FAIL]): the step is void -- no parameter, moment or tree changes
+  if (abort && *abort) return;
   // Optional side job (prio.node != null): block 0 is the sum-tree priority
   // write-back (a ~10 us chain of dependent loads on one workgroup that needs only
   // the loss kernel's priorities); this launch is the longest of the step and does
@@ -1055,8 +1059,9 @@ __global__ __launch_bounds__(256) void adam_sg_kernel(
     const int32_t* __restrict__ count, const float* __restrict__ losses,
     const float* __restrict__ weights, int B, float* __restrict__ sc, float lr, float b1,
     float b2, float eps, float max_norm, DerivedGrad dg, SampleGatherParams sg,
-    unsigned sg_blocks) {
+    unsigned sg_blocks, const unsigned* abort = nullptr) {
   if (blockIdx.x < sg_blocks) { SampleGatherSide::run(sg, blockIdx.x); return; }
+  if (abort && *abort) return;   // (see adam_kernel; the next step's sample is still good)
   adam_body(blockIdx.x - sg_blocks, gridDim.x - sg_blocks, p, g, m, v, n4, part, nparts, count,
             losses, weights, B, sc, lr, b1, b2, eps, max_norm, dg);
 }

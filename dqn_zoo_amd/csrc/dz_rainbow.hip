@@ -325,6 +325,9 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   // (dz_head_chain.h) whenever this one call runs the whole step on the on-the-fly path; its seam
   // buffers (h1, four fc2 slabs, dlogits) are cleared by side blocks of the conv1 forward launch.
   const int nj0_rd = (NA + 255) / 256;
+  // (a step whose head launch gave up on a seam is VOID: its finalize, optimiser and priority
+  // write-back launches read the sticky word and change nothing -- ADVICE r5)
+  const unsigned* chain_abort = reinterpret_cast<const unsigned*>(ws + L.ws_scalars + DZ_SC_CHAIN_FAIL);
   const bool chain = onfly && do_nets && !a->separate_launches && Gf == 3 &&
                      3 * ld2 <= kHcLdsFloats && nj0_rd >= 1 && nj0_rd <= 4 && K <= 256 &&
                      ((kHid + kHcD1Blocks - 1) / kHcD1Blocks) * (nj0_rd + 1) <= 32 &&
@@ -451,6 +454,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
                a->prio_exponent >= 0.0 && B <= 256);
     prio_q = {a->prio_node, a->prio_cap_pow2, a->prio_capacity, 0, 0, a->prio_ids,
               a->priorities, 1, a->prio_exponent, B, a->prio_max_seen, a->prio_status, 0};
+    prio_q.abort = chain_abort;
   }
   if (phases & DZ_PHASE_BACKWARD) {
     DZ_REQUIRE(a->grad);
@@ -632,6 +636,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       J.sumsq = sq_final; J.presum_src = sq_slots;
       J.presum_n = fc2_slots + (onfly ? GramDSide::kBlocks : fc1_slots);
       J.bump_count = (phases & DZ_PHASE_OPTIMIZER) ? a->adam_count : nullptr;
+      J.abort = chain_abort;
       hipLaunchKernelGGL(finalize_grads_kernel, dim3((unsigned)n_final), dim3(256), 0, s, J);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "finalize_grads");
@@ -685,14 +690,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       hipLaunchKernelGGL(adam_onfly_kernel, dim3(adam_onfly_blocks(sgb)), dim3(256), 0, s,
                          a->online, a->grad, a->adam_m, a->adam_v, ws + L.ws_norm_part, nparts,
                          a->adam_count, a->losses, a->weights, B, sc, a->lr, a->b1, a->b2, a->eps,
-                         a->max_norm, of, rg, q, sgb);
+                         a->max_norm, of, rg, q, sgb, chain_abort);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, a->next_sample ? "adam+next_sample" : "adam");
     } else if (a->next_sample) {
       hipLaunchKernelGGL(adam_sg_kernel, dim3(sgb + (unsigned)kAdamBlocksSG), dim3(256), 0, s,
                          a->online, a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
                          ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,
-                         a->lr, a->b1, a->b2, a->eps, a->max_norm, dg, q, sgb);
+                         a->lr, a->b1, a->b2, a->eps, a->max_norm, dg, q, sgb, chain_abort);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "adam+next_sample");
     } else {
@@ -702,7 +707,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
                          a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
                          ws + L.ws_norm_part, nparts, a->adam_count, a->losses, a->weights, B, sc,
                          a->lr, a->b1, a->b2, a->eps, a->max_norm, dg,
-                         prio_pending ? prio_q : PrioUpdateParams{});
+                         prio_pending ? prio_q : PrioUpdateParams{}, chain_abort);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, "adam");
     }

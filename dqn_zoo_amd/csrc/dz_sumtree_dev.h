@@ -174,9 +174,11 @@ struct PrioUpdateParams {
   const int64_t* ids; const void* prio; int is_f32; double exponent; int n;
   double* max_seen; uint32_t* status;
   int check_ids;   // 0: ids come straight from this replay's sampler (live by construction)
+  const unsigned* abort = nullptr;   // non-zero word: the step that produced `prio` is void, write nothing
 };
 __device__ __forceinline__ void prio_update_body(const PrioUpdateParams& q, int64_t* s_leaf,
                                                  double* s_red, WbScratch* wb = nullptr) {
+  if (q.abort && *q.abort) return;   // (launch-uniform)
   double* node = q.node;
   const int64_t cap = q.cap, N = q.N, size = q.size, t = q.t;
   const int64_t* __restrict__ ids = q.ids;

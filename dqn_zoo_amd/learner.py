@@ -425,14 +425,24 @@ class RainbowLearner:
                 unclipped=bool(sc[_lib.SC_CLIP] != 0),
                 chain_failed=bool(sc[_lib.SC_CHAIN_FAIL:_lib.SC_CHAIN_FAIL + 1].view(np.uint32)[0]))
 
-  def check_status(self) -> None:
-    """Synchronises; raises if a multi-role launch of an earlier step gave up on one of its
-    in-launch seams (ws_scalars[DZ_SC_CHAIN_FAIL], sticky: cleared here)."""
+  def check_status(self, fallback: bool = True) -> None:
+    """Synchronises; raises `replay.ChainTimeoutError` if a multi-role launch of an earlier step
+    gave up on one of its in-launch seams (ws_scalars[DZ_SC_CHAIN_FAIL], sticky: cleared here).
+    Such a step is VOID -- its losses are NaN and its finalize / optimiser / priority write-back
+    launches changed nothing (they read the word) -- and every step enqueued behind it was void
+    too until this call clears the word.  `fallback`: later steps use the four-launch form of the
+    head (`separate_launches`), whose liveness needs no dispatch-order assumption."""
     off = int(self.layout.c.ws_scalars) + _lib.SC_CHAIN_FAIL
     if int(self.ws[off:off + 1].view(torch.int32).item()) != 0:
       self.ws[off:off + 1].zero_()
-      raise RuntimeError('a multi-role learner launch timed out on an in-launch seam '
-                         '(DZ_SC_CHAIN_FAIL): the losses of that step are NaN')
+      if fallback and not self.separate_launches:
+        self.separate_launches = True
+        self.drop_graphs()   # (captured steps bake the launch form in)
+      from dqn_zoo_amd import replay as _replay
+      raise _replay.ChainTimeoutError(
+          'a multi-role learner launch timed out on an in-launch seam (DZ_SC_CHAIN_FAIL): the '
+          'step was skipped (NaN losses, no parameter / moment / priority change)'
+          + ('; falling back to separate launches' if fallback else ''))
 
   def ws_view(self, name: str, count: int) -> torch.Tensor:
     off = int(getattr(self.layout.c, 'ws_' + name))

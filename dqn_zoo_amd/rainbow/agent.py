@@ -100,7 +100,10 @@ class Rainbow(parts.Agent):
         self._learn()
         # a NaN/inf/negative priority or weight flagged by an earlier step's kernels
         # (sticky word in pinned host memory: a plain load, nothing is awaited)
-        self._replay.poll_status()
+        try:
+          self._replay.poll_status()
+        except replay_lib.ChainTimeoutError as e:
+          self._recover_from_chain_timeout(e)
 
       if self._frame_t % self._target_network_update_period == 0:
         self._learner.sync_target()
@@ -108,7 +111,11 @@ class Rainbow(parts.Agent):
         # goes NaN/inf/negative (replay.py:233-242,281-282); here those land in a
         # sticky word; polled without waiting at every learner step, and definitively
         # (one host sync) once per target period
-        self._replay.check_status()
+        try:
+          self._replay.check_status()
+          self._learner.check_status()
+        except replay_lib.ChainTimeoutError as e:
+          self._recover_from_chain_timeout(e)
 
     if isinstance(action, parts.PendingAction):
       # everything of this frame is queued; now wait for the acting launches only
@@ -122,6 +129,20 @@ class Rainbow(parts.Agent):
     self._transition_accumulator.reset()
     processors.reset(self._preprocessor)
     self._action = None
+
+  def _recover_from_chain_timeout(self, err) -> None:
+    """The head launch of a learner step gave up on an in-launch seam (HIP does not promise the
+    dispatch order its liveness argument uses).  The step was void on the device (no parameter,
+    moment, count or priority change), so nothing is lost but that step: clear both sticky words,
+    use the four-launch form of the head from now on, say so once, carry on."""
+    import warnings
+    try:
+      self._learner.check_status(fallback=True)   # clears ws_scalars[DZ_SC_CHAIN_FAIL]
+    except replay_lib.ChainTimeoutError:
+      pass
+    self.chain_timeouts = getattr(self, 'chain_timeouts', 0) + 1
+    warnings.warn('%s -- continuing with separate launches (%d so far)' % (err, self.chain_timeouts),
+                  RuntimeWarning)
 
   def _learn(self) -> None:
     """Samples a batch and learns from it, entirely on the device

@@ -68,11 +68,18 @@ def _next_pow2(n):
   return c
 
 
+class ChainTimeoutError(RuntimeError):
+  """A multi-role learner launch gave up on one of its in-launch seams (no reference
+  counterpart).  The step that raised it was VOID: its optimiser, optax count and priority
+  write-back launches read the sticky word and changed nothing, so a caller may clear the
+  flag (`RainbowLearner.check_status()`), fall back to separate launches and carry on."""
+
+
 def _raise_status(bits):
   """Maps sticky device status bits to the reference's exceptions."""
   if bits & _lib.ST_CHAIN_TIMEOUT:
-    raise RuntimeError('a multi-role learner launch timed out on an in-launch seam '
-                       '(DZ_ST_CHAIN_TIMEOUT): the step that raised it is not valid')
+    raise ChainTimeoutError('a multi-role learner launch timed out on an in-launch seam '
+                            '(DZ_ST_CHAIN_TIMEOUT): the step that raised it was skipped')
   if bits & _lib.ST_BAD_VALUE:
     raise ValueError('value must be finite and positive.')
   if bits & _lib.ST_BAD_TARGET:

@@ -130,7 +130,20 @@ def _busy_learner(seed):
   r = torch.from_numpy(rs.uniform(-1, 1, 32)).cuda()
   d = torch.full((32,), 0.97, dtype=torch.float64, device='cuda')
   w = torch.ones(32, dtype=torch.float32, device='cuda')
-  return lambda: ln.step(s[0], a, r, d, s[1], w)
+  step = lambda: ln.step(s[0], a, r, d, s[1], w)
+  step.learner = ln   # every one of its steps is a multi-role head launch under contention too
+  return step
+
+
+def _assert_busy_learner_is_healthy(step_other):
+  """The noise source's own in-launch seams (csrc/dz_head_chain.h) held up beside the decision
+  kernels: no step of it gave up (sticky word clear, losses finite, optimiser ran every step)."""
+  ln = step_other.learner
+  assert not ln.separate_launches
+  ln.check_status()                      # raises ChainTimeoutError if any head launch timed out
+  assert not ln.scalars()['chain_failed']
+  assert np.isfinite(ln.losses.cpu().numpy()).all()
+  return int(ln.adam_count.item())
 
 
 def test_ten_thousand_decisions_while_another_stream_fills_the_chip():
@@ -187,6 +200,7 @@ def test_ten_thousand_decisions_while_another_stream_fills_the_chip():
     gen, tickets, sticky = ln.act_seam_words()
     assert gen == n and tickets == 0 and sticky == 0
     assert ln.act_step() == n
+    assert _assert_busy_learner_is_healthy(step_other) == n + 4   # that many head-chain launches under contention
   finally:
     torch.cuda.synchronize()
     torch.cuda.set_stream(prev)
@@ -215,6 +229,7 @@ def test_dense_decisions_while_another_stream_fills_the_chip():
     seams = int(ln.network.layout(1, 1).c.ws_act_seams)
     words = ln._act_ws[seams:seams + 64 * 8:64].view(torch.int32).tolist()  # pylint: disable=protected-access
     assert words[3] == 3000 and words[4] == 0 and words[5] == 0, words
+    assert _assert_busy_learner_is_healthy(step_other) == 3000
   finally:
     torch.cuda.synchronize()
     torch.cuda.set_stream(prev)

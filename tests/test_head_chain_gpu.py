@@ -80,8 +80,10 @@ def test_step_with_stale_seam_buffers_is_still_correct():
 
 def test_forced_seam_timeout_in_the_head_chain_is_loud():
   """dz_act_debug_spin_limit(0): every consumer role gives up at its first look -- the step's
-  losses are NaN, the sticky word is set (RainbowLearner.check_status raises) and the next
-  step, with the normal limit, is bit-identical to the four-launch form again."""
+  losses are NaN, the sticky word is set (RainbowLearner.check_status raises) and the step is VOID:
+  its finalize / optimiser launches read the word and change neither parameters, moments nor the
+  optax count -- also for a second step enqueued behind it; after the flag is cleared
+  the next step is bit-identical to the four-launch form, which check_status() has switched to."""
   A, B = 6, 32
   lib = _lib.load()
   online, target, batch, w, noises = _problem(A, B, 6)
@@ -97,13 +99,72 @@ def test_forced_seam_timeout_in_the_head_chain_is_loud():
     lib.dz_act_debug_spin_limit(old)
   assert np.isnan(ln.losses.cpu().numpy()).any()
   assert ln.scalars()['chain_failed']
-  with pytest.raises(RuntimeError, match='DZ_SC_CHAIN_FAIL'):
+  ln.step(*dev, resample_noise=False)   # enqueued behind the failure, before anyone looked: void too
+  torch.cuda.synchronize()
+  assert torch.equal(ln.online, p0) and torch.equal(ln.adam_m, m0) and torch.equal(ln.adam_v, v0)
+  assert int(ln.adam_count.item()) == 0
+  from dqn_zoo_amd import replay as replay_lib
+  with pytest.raises(replay_lib.ChainTimeoutError, match='DZ_SC_CHAIN_FAIL'):
     ln.check_status()
+  assert ln.separate_launches          # the fallback
   ln.check_status()       # cleared
-  # restore the state the failed step may have touched, then a normal step
-  ln.online.copy_(p0); ln.adam_m.copy_(m0); ln.adam_v.copy_(v0); ln.adam_count.zero_()
   ln.step(*dev, resample_noise=False)
   torch.cuda.synchronize()
   ref = _run(A, B, 6, separate=True, steps=1)[0]
   np.testing.assert_array_equal(ln.losses.cpu().numpy(), ref['losses'])
   np.testing.assert_array_equal(ln.online.cpu().numpy(), ref['online'])
+
+
+def test_forced_seam_timeout_leaves_the_sum_tree_and_the_agent_running():
+  """The same forced give-up with a priority sink: the write-back block reads the sticky word and
+  writes NOTHING (tree and running max unchanged), the replay's pinned status word raises
+  `ChainTimeoutError` at the next poll, and `Rainbow._recover_from_chain_timeout` clears both words
+  and switches the learner to the four-launch form instead of aborting the run."""
+  from dqn_zoo_amd import learner as ll, networks, parts
+  from dqn_zoo_amd import replay as rl
+  A, B, cap = 6, 32, 400
+  sup = np.linspace(-10, 10, 51).astype(np.float32)
+  T = rl.Transition
+  rep = rl.PrioritizedTransitionReplay(
+      cap, T(None, None, None, None, None), 0.5,
+      parts.LinearSchedule(begin_t=0, end_t=1000, begin_value=0.4, end_value=1.0),
+      1e-3, True, np.random.RandomState(11))
+  rs = np.random.RandomState(5)
+  for i in range(cap):
+    rep.add(T(rs.randint(0, 256, (84, 84, 4)).astype(np.uint8), int(rs.randint(A)),
+              float(rs.randint(-1, 2)), 0.97, rs.randint(0, 256, (84, 84, 4)).astype(np.uint8)),
+            1.0 + (i % 7))
+  ln = ll.RainbowLearner(networks.RainbowNetwork(A, sup, 0.1), ll.AdamConfig(), B, seed=3)
+  ln.use_graphs = False
+  lib = _lib.load()
+  s = rep.sample_device(B)
+  t = s.transitions
+  torch.cuda.synchronize()
+  tree0 = rep.tree_storage.clone()
+  max0 = float(rep.max_seen_priority_device.item())
+  p0 = ln.online.clone()
+  old = lib.dz_act_debug_spin_limit(0)
+  try:
+    ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32, priority_sink=rep.priority_sink(s.ids))
+    torch.cuda.synchronize()
+  finally:
+    lib.dz_act_debug_spin_limit(old)
+  assert torch.equal(rep.tree_storage, tree0) and float(rep.max_seen_priority_device.item()) == max0
+  assert torch.equal(ln.online, p0) and int(ln.adam_count.item()) == 0
+  with pytest.raises(rl.ChainTimeoutError):
+    rep.poll_status()
+  # what the agent does with it
+  from dqn_zoo_amd.rainbow import agent as agent_lib
+  shell = agent_lib.Rainbow.__new__(agent_lib.Rainbow)
+  shell._learner = ln
+  with pytest.warns(RuntimeWarning, match='separate launches'):
+    shell._recover_from_chain_timeout(rl.ChainTimeoutError('forced'))
+  assert ln.separate_launches and shell.chain_timeouts == 1 and not ln.scalars()['chain_failed']
+  # the run goes on: a normal step writes priorities again
+  s = rep.sample_device(B)
+  t = s.transitions
+  ln.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32, priority_sink=rep.priority_sink(s.ids))
+  torch.cuda.synchronize()
+  rep.check_status(); ln.check_status()
+  assert np.isfinite(ln.losses.cpu().numpy()).all() and not torch.equal(rep.tree_storage, tree0)
+  assert int(ln.adam_count.item()) == 1
