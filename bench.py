@@ -296,6 +296,43 @@ def roofline_of(avg, work):
   return out
 
 
+def measure_rainbow_actions(args, device, replay, num_actions, steps, warmup, prof_steps):
+  """The headline's learner step with another action count (same replay, same loop)."""
+  from dqn_zoo_amd import learner as learner_lib
+  from dqn_zoo_amd import networks
+  support = np.linspace(-VMAX, VMAX, NUM_ATOMS).astype(np.float32)
+  ln = learner_lib.RainbowLearner(networks.RainbowNetwork(num_actions, support, 0.1),
+                                  learner_lib.AdamConfig(), args.batch, seed=args.seed, device=device)
+  ln.use_graphs = False
+  fused = args.mode == 'fused'
+  st = make_step(replay, ln, args.batch, fused_next_sample=fused)
+  for _ in range(max(warmup, replay.SAMPLE_RING_DEPTH)):
+    st()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    st()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  replay.check_status()
+  ln.check_status()
+  e = {'metric': 'gradient-steps/sec (Rainbow, %d actions, batch %d)' % (num_actions, args.batch),
+       'value': round(steps / dt, 2), 'unit': 'steps/s', 'steps': steps,
+       'ms_per_step': round(1e3 * dt / steps, 4), 'dtype': 'f32',
+       'config': {'workload': 'the headline\'s Rainbow learner step with the %d-action head '
+                              '(advantage layer 512 -> %d)' % (num_actions, num_actions * NUM_ATOMS),
+                  'num_actions': num_actions, 'num_atoms': NUM_ATOMS, 'mode': args.mode,
+                  'replay_capacity': args.capacity, 'global_batch': args.batch}}
+  if prof_steps > 0:
+    avg = profile_kernels(st, prof_steps)
+    e['roofline'] = roofline_of(avg, kernel_work(args.batch, a=num_actions))
+    e['per_kernel_us'] = {k: round(v * 1e6, 2) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])}
+  # the prepared-sample hand-off belongs to this loop's learner: the headline's loop is over
+  del st, ln
+  torch.cuda.empty_cache()
+  return e
+
+
 def measure_other_configs(args, device, steps, warmup, prof_steps):
   """BASELINE.json configs[1] and configs[2] at full size (1M-transition store in
   HBM, batch 32): the whole sample -> update (-> priority write-back) step, as
@@ -927,6 +964,13 @@ def main():
       # the write-back timed as its own kernel (in the measured step it rides
       # inside a backward launch)
       out['replay'] = measure_replay(replay, learner, args.batch)
+    a18 = None
+    if world == 1 and args.other_configs:
+      # the headline's step with the 18-action head of the full Atari action set (rainbow/
+      # run_atari.py:145 takes num_actions from the environment; a large part of the 57 games),
+      # on the SAME store, before it is released
+      a18 = measure_rainbow_actions(args, device, replay, 18, steps=max(args.steps, 1000),
+                                    warmup=max(args.warmup, 50), prof_steps=min(args.prof_steps, 20))
     if world == 1 and args.other_configs:
       # BASELINE configs 2 and 3 (the headline's store is released first)
       del step, seq_step, replay, learner
@@ -934,6 +978,7 @@ def main():
       out['other_configs'] = measure_other_configs(
           args, device, steps=max(args.steps, 1000), warmup=max(args.warmup, 50),
           prof_steps=min(args.prof_steps, 20))
+      out['other_configs']['rainbow_a18'] = a18
     if world == 1 and args.agent_loop_frames > 0:
       # the whole drop-in loop on this run's clock (the headline's store is gone by now)
       if 'step' in dir():

@@ -377,7 +377,7 @@ void rainbow_head_chain_kernel(HeadChain p) {
   b -= p.nC;
   if (b < p.nD1) {
     HC_STAMP(p, 0);
-    row_dgrad_block<NJ0, 1, false, 4, true, true>(p.rd, b, lds);
+    row_dgrad_block<NJ0, 1, false, (NJ0 >= 4 ? 1 : 4), true, true>(p.rd, b, lds);   // (five jobs: two rows in flight keep the launch at 256 VGPRs without scratch)
     HC_STAMP(p, 3);
     return;
   }

@@ -186,11 +186,12 @@ def test_kernels_with_hand_counted_waits_do_not_spill():
       usage.setdefault(name, {})['lds'] = int(m.group(1))
   checked = 0
   for k, u in usage.items():
-    # (the head launch counts no waits by hand: its widest variant, 13+ actions, may spill; the
-    # BASELINE shape -- two 256-column chunks of the advantage head -- must not)
-    if any(t in k for t in ('fc1_dgrad_mfma_kernel', 'rainbow_head_chain_kernelILi2E', 'rainbow_act_one_kernel',
-                            'dz_dma_gemm2_kernel')):
+    # (every instantiation of the head launch -- 1..4 column chunks of the advantage head, i.e. up
+    # to the 18-action games -- and the kernels with hand-counted waits: no scratch)
+    if any(t in k for t in ('fc1_dgrad_mfma_kernel', 'rainbow_head_chain_kernel', 'fc2_bwd_rows_kernel',
+                            'rainbow_act_one_kernel', 'dz_dma_gemm2_kernel', 'dz_conv_dma_fwd_kernel',
+                            'dz_conv1_dma_kernel', 'dz_dmaop2_kernel')):
       assert u['scratch'] == 0, (k, u)
       assert u['lds'] <= 160 * 1024, (k, u)
       checked += 1
-  assert checked >= 4, sorted(usage)
+  assert checked >= 14, sorted(usage)
