@@ -636,7 +636,7 @@ def make_loop_agent(which, learn_period=4, capacity=100000):
         learn_period=learn_period, target_network_update_period=2000, rng_key=1,
         grad_error_bound=1.0 / 32)
     return ag, rep
-  if which == 'iqn':   # iqn/run_atari.py:170-240 (64 / 32 / 64 tau samples, Adam)
+  if which == 'iqn':   # iqn/run_atari.py:97-100, 170-240: the reference's defaults, 64 / 64 / 64 tau samples, Adam
     from dqn_zoo_amd.iqn import agent as iqn_lib
     rep = replay_lib.TransitionReplay(capacity, structure, np.random.RandomState(1))
     ag = iqn_lib.Iqn(
@@ -648,7 +648,7 @@ def make_loop_agent(which, learn_period=4, capacity=100000):
         transition_accumulator=replay_lib.TransitionAccumulator(), replay=rep, batch_size=32,
         exploration_epsilon=lambda t: 0.1, min_replay_capacity_fraction=0.005,
         learn_period=learn_period, target_network_update_period=2000, huber_param=1.0,
-        tau_samples_policy=32, tau_samples_s_tm1=64, tau_samples_s_t=64, rng_key=1)
+        tau_samples_policy=64, tau_samples_s_tm1=64, tau_samples_s_t=64, rng_key=1)
     return ag, rep
   from dqn_zoo_amd.rainbow import agent as rainbow_lib
   support = np.linspace(-VMAX, VMAX, NUM_ATOMS).astype(np.float32)

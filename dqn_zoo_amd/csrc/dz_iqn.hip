@@ -143,10 +143,12 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
     p.out = ws + L.ws_h1; p.ldo = kHid; p.feat = nullptr; p.temb = nullptr;
     // Three forms, by shape (all with tiles in XCD-aware order: the column tiles of one row slab
     // run on ONE XCD, so the 77 MB activation crosses the fabric once instead of 8 times, +4 %):
-    //  (1) the learner's three applies at the reference sizes (online rows % 64 == 0, the two
-    //      s_t applies' target rows contiguous, the same parameters, % 96 == 0): TWO tile sets of
-    //      256 workgroups each in one launch -- 64x64 tiles with two column blocks per wave for
-    //      the online rows, 96x64 tiles with three row blocks per wave for the target rows --
+    //  (1) the learner's three applies (online rows % 64 == 0, the two s_t applies' target rows
+    //      contiguous, the same parameters): TWO tile sets of 256 workgroups each in one launch --
+    //      64x64 tiles with two column blocks per wave for the online rows and, for the target rows,
+    //      128x64 tiles with four row blocks per wave at the reference's defaults (64 / 64 / 64 taus,
+    //      batch 32: 2 048 + 4 096 rows; round 6) or 96x64 tiles with three (target rows % 96 == 0,
+    //      e.g. a 32-tau policy: 2 048 + 3 072 rows, the shape round 5 tuned) --
     //      i.e. two workgroups per CU and 2-3 independent MFMA chains per wave, 1.6 x less
     //      L2 -> LDS traffic than (2); operands by LDS-DMA (dz_iqn_fc1_dma.h).  The chunk loop
     //      alone runs at 0.93 of the matrix pipe's rate at 2-3 waves per SIMD and at 0.78 at
@@ -167,10 +169,29 @@ int iqn_head_forward(const dz_iqn_layout_t& L, const IqnApplies& ap, float* ws,
     using Fc1Full = IqnLinOp<2, 1, 2, 1, 1, 1, 1>;
     bool whole = kFlat % Fc1Full::BK == 0 && kHid % Fc1Full::BN == 0;
     for (int g = 0; g < ap.G; ++g) whole = whole && ap.rows[g] % Fc1Full::BM == 0;
-    const bool two_sets = whole && ap.G == 3 && ap.params[1] == ap.params[2] &&
-                          ap.row0[2] == ap.row0[1] + ap.rows[1] && ap.rows[0] % 64 == 0 &&
-                          (ap.rows[1] + ap.rows[2]) % 96 == 0 && kHid % 64 == 0 && kFlat % 32 == 0;
-    if (two_sets) {
+    const bool sets_ok = whole && ap.G == 3 && ap.params[1] == ap.params[2] &&
+                         ap.row0[2] == ap.row0[1] + ap.rows[1] && ap.rows[0] % 64 == 0 &&
+                         kHid % 64 == 0 && kFlat % 32 == 0;
+    const int trows = ap.rows[1] + ap.rows[2];
+    // the reference's defaults (iqn/run_atari.py:98-100: 64 / 64 / 64 tau samples, batch 32):
+    // 2 048 online + 4 096 target rows -- 64x64 tiles (two column blocks per wave) + 128x64 tiles
+    // (FOUR row blocks per wave): 256 + 256 workgroups, one of each per CU
+    const bool two_sets128 = sets_ok && trows % 128 == 0 && trows == 2 * ap.rows[0];
+    const bool two_sets = sets_ok && !two_sets128 && trows % 96 == 0;
+    if (two_sets128) {
+      using CA = DzDmaCfg<1, 2, 2, 1, 1, 2, true, false>;
+      using CB = DzDmaCfg<4, 1, 1, 2, 1, 2, true, false>;
+      DzDmaOperands qa, qb;
+      qa.a = p.x + (long)ap.row0[0] * kFlat; qa.lda = kFlat;
+      qa.b = ap.params[0] + L.fc1_w; qa.ldb = L.fc1_ld; qa.K = kFlat;
+      qb = qa;
+      qb.a = p.x + (long)ap.row0[1] * kFlat; qb.b = ap.params[1] + L.fc1_w;
+      const IqnFwdEpi::Params ea = {ap.params[0] + L.fc1_b, ws + L.ws_h1 + (long)ap.row0[0] * kHid, kHid};
+      const IqnFwdEpi::Params eb = {ap.params[1] + L.fc1_b, ws + L.ws_h1 + (long)ap.row0[1] * kHid, kHid};
+      rc = dz_launch_dma_gemm2<CA, IqnFwdEpi, CB, IqnFwdEpi, 2>(
+          qa, ea, dim3(kHid / CA::BN, (unsigned)(ap.rows[0] / CA::BM), 1),
+          qb, eb, dim3(kHid / CB::BN, (unsigned)(trows / CB::BM), 1), s);
+    } else if (two_sets) {
       // 32-deep stages, two stage buffers (40 KB per workgroup).  Whole step, same box: form (2)
       // 437.7; the same two tile sets on the register-staged skeleton (64-deep stages) 432.7-434.2;
       // this 419.6; three stage buffers 424.8; 64-deep stages x two buffers 422.9.

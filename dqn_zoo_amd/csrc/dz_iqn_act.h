@@ -5,7 +5,8 @@
 //  cos(pi i tau) -> linear(3136) -> ReLU, times the torso features, -> linear(512) -> ReLU ->
 //  linear(A).)
 //
-// At one observation the value head still sees N rows (N = 32 by default): the multi-launch apply
+// At one observation the value head still sees N rows (N = tau_samples_policy = 64 by default,
+// iqn/run_atari.py:98; up to 64 here, two 32-row MFMA blocks per fc1 workgroup): the multi-launch apply
 // is a tau draw, three convolutions, the cosine table, three GEMM launches, a copy and the
 // q-value kernel -- ten launches, ~70 us, almost all of it launch floors.  Here:
 //
@@ -30,13 +31,13 @@
 
 namespace {
 
-constexpr int kIqnActMaxTaus = 32, kIqnActMaxLatent = 64;
-constexpr int kIqnActPartLd = kIqnActMaxTaus * kHid;                     // one K-split's slab: [32][512]
+constexpr int kIqnActMaxTaus = 64, kIqnActMaxLatent = 64;
+constexpr int kIqnActPartLd = kIqnActMaxTaus * kHid;                     // one K-split's slab: [64][512]
 constexpr int kIqnActSeamWords = act_seam_words(kIqnActPartLd);
 constexpr int kIqnActFc1Blocks = kActFc1Splits * 4;
 
 struct IqnActParams : ActTorso {
-  int latent, N, A, ld2;                 // N <= 32 taus, A <= 32 actions
+  int latent, N, A, ld2;                 // N <= 64 taus, A <= 32 actions
   long emb_w, emb_b, fc1_b, fc2_w, fc2_b;   // (fc1_mu_w / fc1_ld of ActTorso: the [3136][512] matrix)
   uint64_t tau_seed, tau_counter;        // tau_j = the draw dz_uniform_fill makes at counter + j
   float* taus_out;                       // [N] (nullable): the draws, written out for tests
@@ -49,19 +50,26 @@ __device__ __forceinline__ float iqn_tau_at(uint64_t seed, uint64_t pos) {   // 
   return (float)(h >> 41) * (1.0f / 8388608.0f);
 }
 
-// LDS of the fc1 role: cos [32][65] | emb / hin [112][33] -> later the [32][132] output tile
-constexpr int kIqnCosLd = kIqnActMaxLatent + 1, kIqnHinLd = kIqnActMaxTaus + 1, kIqnTileLd = 132;
-constexpr int kIqnActLdsFloats =
-    (32 * kIqnCosLd + kActFc1Rows * kIqnHinLd) > 32 * kIqnTileLd ? (32 * kIqnCosLd + kActFc1Rows * kIqnHinLd)
-                                                                   : 32 * kIqnTileLd;
-static_assert(kIqnActLdsFloats <= kActLdsFloats, "the torso role's LDS block covers the fc1 role");
+// LDS of the fc1 role (NT = 32 NB taus): cos [NT][65] | emb / hin [112][NT + 1] -> later the
+// [NT][132] output tile
+constexpr int kIqnCosLd = kIqnActMaxLatent + 1, kIqnTileLd = 132;
+constexpr int iqn_act_lds_floats(int nt) {
+  return (nt * kIqnCosLd + kActFc1Rows * (nt + 1)) > nt * kIqnTileLd ? (nt * kIqnCosLd + kActFc1Rows * (nt + 1))
+                                                                     : nt * kIqnTileLd;
+}
+constexpr int kIqnActLdsFloats = iqn_act_lds_floats(kIqnActMaxTaus) > kActLdsFloats ? iqn_act_lds_floats(kIqnActMaxTaus)
+                                                                                     : kActLdsFloats;
+static_assert(iqn_act_lds_floats(32) <= kActLdsFloats, "up to 32 taus the torso role's LDS block covers the fc1 role");
 
+// NB = 32-row blocks of taus (1: N <= 32, 2: N <= 64)
+template <int NB>
 __device__ __forceinline__ void iqn_act_fc1_block(const IqnActParams& p, int fb, float* lds) {
+  constexpr int NT = 32 * NB, kIqnHinLd = NT + 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int split = fb >> 2, cg = fb & 3;
   const int k0 = kActFc1Rows * split, n0 = 128 * cg + 32 * wave;
-  float* s_cos = lds;                               // [32][65]
-  float* s_hin = lds + 32 * kIqnCosLd;              // [112][33]: emb, then emb * feat
+  float* s_cos = lds;                               // [NT][65]
+  float* s_hin = lds + NT * kIqnCosLd;              // [112][NT + 1]: emb, then emb * feat
   ACT_STAMP(0);
   const unsigned gen = *act_line(p.sync, 3);
   float* const set = act_set(p, gen);
@@ -81,15 +89,15 @@ __device__ __forceinline__ void iqn_act_fc1_block(const IqnActParams& p, int fb,
   }
   __builtin_amdgcn_sched_barrier(0);
   // (2) the taus and their cosine table cos(pi (i + 1) tau_j)   (iqn_cos_kernel's arithmetic)
-  if (tid < 32) {
+  if (tid < NT) {
     const float tau = iqn_tau_at(p.tau_seed, p.tau_counter + (uint64_t)min(tid, p.N - 1));
     if (fb == 0 && tid < p.N && p.taus_out) p.taus_out[tid] = tau;
-    lds[32 * kIqnCosLd + tid] = tau;   // (parked in the hin block until the table is built)
+    lds[NT * kIqnCosLd + tid] = tau;   // (parked in the hin block until the table is built)
   }
   __syncthreads();
-  for (int e = tid; e < 32 * p.latent; e += 256) {
+  for (int e = tid; e < NT * p.latent; e += 256) {
     const int j = e / p.latent, i = e - j * p.latent;
-    const float tau = lds[32 * kIqnCosLd + j];
+    const float tau = lds[NT * kIqnCosLd + j];
     s_cos[j * kIqnCosLd + i] = cosf((float)(i + 1) * 3.14159274101257324f * tau);
   }
   __syncthreads();
@@ -98,9 +106,10 @@ __device__ __forceinline__ void iqn_act_fc1_block(const IqnActParams& p, int fb,
   const int kk = tid & 127, jg = tid >> 7;
   const bool kon = kk < kActFc1Rows;
   const int kc = min(kk, kActFc1Rows - 1);
-  float acc[16];
+  constexpr int TPT = 16 * NB;   // taus per thread
+  float acc[TPT];
 #pragma unroll
-  for (int jj = 0; jj < 16; ++jj) acc[jj] = 0.f;
+  for (int jj = 0; jj < TPT; ++jj) acc[jj] = 0.f;
   {
     const float* we = p.prm + p.emb_w + k0 + kc;
     for (int i0 = 0; i0 < p.latent; i0 += 8) {
@@ -110,8 +119,8 @@ __device__ __forceinline__ void iqn_act_fc1_block(const IqnActParams& p, int fb,
 #pragma unroll
       for (int q = 0; q < 8; ++q)
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj)
-          acc[jj] = __builtin_fmaf(s_cos[(16 * jg + jj) * kIqnCosLd + i0 + q], wv[q], acc[jj]);
+        for (int jj = 0; jj < TPT; ++jj)
+          acc[jj] = __builtin_fmaf(s_cos[(TPT * jg + jj) * kIqnCosLd + i0 + q], wv[q], acc[jj]);
     }
   }
   const float be = p.prm[p.emb_b + k0 + kc];
@@ -131,29 +140,36 @@ __device__ __forceinline__ void iqn_act_fc1_block(const IqnActParams& p, int fb,
   ACT_STAMP(2);
   if (kon) {
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-      const int j = 16 * jg + jj;
+    for (int jj = 0; jj < TPT; ++jj) {
+      const int j = TPT * jg + jj;
       const float e = acc[jj] + be;
       s_hin[kk * kIqnHinLd + j] = j < p.N ? (e > 0.f ? e : 0.f) * f : 0.f;   // networks.py:281-285
     }
   }
   __syncthreads();
   // (5) partial[j][n] = sum_k hin[j][k] W1[k][n] over the K slice: rows = taus
-  f32x16 pacc;
+  f32x16 pacc[NB];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pacc[nb][i] = 0.f;
 #pragma unroll
   for (int u = 0; u < kActFc1Rows / 2; ++u)
-    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_hin[(2 * u + half) * kIqnHinLd + l31], wb[u], pacc, 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      pacc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_hin[(2 * u + half) * kIqnHinLd + 32 * nb + l31], wb[u],
+                                                      pacc[nb], 0, 0, 0);
   __syncthreads();   // (hin is dead: the output tile takes its place)
   ACT_STAMP(3);
-  float* T = lds;    // [32][132]
+  float* T = lds;    // [NT][132]
 #pragma unroll
-  for (int i = 0; i < 16; ++i) T[dz_acc_row(i, lane) * kIqnTileLd + 32 * wave + l31] = pacc[i];
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T[(32 * nb + dz_acc_row(i, lane)) * kIqnTileLd + 32 * wave + l31] = pacc[nb][i];
   __syncthreads();
   const __amdgpu_buffer_rsrc_t sr = act_rsrc(set + kActOffPart);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < 4 * NB; ++q) {
     const int idx = tid + 256 * q, j = idx >> 5, c4 = idx & 31;
     if (j < p.N)
       act_store4(sr, (unsigned)(split * p.part_ld + j * kHid + 128 * cg + 4 * c4) * 4u,
@@ -270,11 +286,13 @@ __device__ __forceinline__ void iqn_act_tail_block(const IqnActParams& p, int j,
 }
 
 __global__ __launch_bounds__(256, 2) void iqn_act_one_kernel(IqnActParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[kActLdsFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kIqnActLdsFloats];
   const int b = blockIdx.x;
   if (b < kActTorsoBlocks) act_torso_block(p, b, lds);
-  else if (b < kActTorsoBlocks + kIqnActFc1Blocks) iqn_act_fc1_block(p, b - kActTorsoBlocks, lds);
-  else iqn_act_tail_block(p, b - kActTorsoBlocks - kIqnActFc1Blocks, lds);
+  else if (b < kActTorsoBlocks + kIqnActFc1Blocks) {
+    if (p.N <= 32) iqn_act_fc1_block<1>(p, b - kActTorsoBlocks, lds);   // (launch-uniform)
+    else iqn_act_fc1_block<2>(p, b - kActTorsoBlocks, lds);
+  } else iqn_act_tail_block(p, b - kActTorsoBlocks - kIqnActFc1Blocks, lds);
 }
 
 }  // namespace

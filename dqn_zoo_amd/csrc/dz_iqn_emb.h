@@ -1,7 +1,7 @@
 // The IQN tau embedding's forward pass (round 5):
 //   head_in[row][c] = relu(sum_l cos[row][l] Wemb_g[l][c] + b_g[c]) * feat[feat_row(row)][c]
-// (networks.py:277-285) for 5 120 rows x 3 136 columns x 64 deep at the reference sizes: 2 GFLOP
-// for 64 MB written.  As a tile GEMM of the general skeleton (IqnLinOp, IQN_EPI_MIX) that is
+// (networks.py:277-285) for 6 144 rows x 3 136 columns x 64 deep at the reference sizes (64 / 64 / 64 taus): 2.5 GFLOP
+// for 77 MB written (64 MB at round 5's 5 120 rows, where the numbers below were taken).  As a tile GEMM of the general skeleton (IqnLinOp, IQN_EPI_MIX) that is
 // 3 920 workgroups of two stages behind masked loaders and two barriers each: 43 us.  Here a
 // workgroup owns a 64-row tile -- its cosine rows go to LDS once, in the skeleton's KC fragment
 // layout, and from there into each wave's registers for good -- and walks over a segment of

@@ -1,5 +1,6 @@
 // The IQN learner's three large contractions on the LDS-DMA GEMM mainloop (dz_dma_gemm.h), at
-// the reference sizes (5 120 = 2 048 online + 3 072 target rows, 3 136 -> 512):
+// the reference sizes (iqn/run_atari.py:98-100, batch 32 x 64 / 64 / 64 taus: 6 144 = 2 048 online + 4 096
+// target rows, 3 136 -> 512; round 5 tuned 5 120 = 2 048 + 3 072 rows, a 32-tau policy, which stays covered):
 //   forward   h1 = relu(head_in @ W1 + b1)        A = head_in (depth-contiguous), B = W1 (output-contiguous)
 //   weight gradient  dW1[k][n] = sum_m head_in[m][k] dh1[m][n]      both operands output-contiguous
 //   input gradient   dhin[m][k] = sum_n dh1[m][n] W1[k][n]          both operands depth-contiguous

@@ -957,7 +957,7 @@ class IqnLearner:
   ws_view = DenseLearner.ws_view
 
   ACT_RING = 8
-  ONE_LAUNCH_MAX_TAUS = 32      # dz_iqn_act: samples <= 32, num_actions <= 32, latent_dim <= 64
+  ONE_LAUNCH_MAX_TAUS = 64      # dz_iqn_act: samples <= 64 (the reference's default), num_actions <= 32, latent_dim <= 64
   last_act_fail = 0
 
   def can_decide_in_one_launch(self, samples: int) -> bool:

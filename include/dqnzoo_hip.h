@@ -633,7 +633,7 @@ int dz_iqn_apply(int num_actions, int latent_dim, int batch, int samples,
                  int32_t* greedy_out, float* vmax_out, dz_stream_t stream);
 
 /* The IQN actor's decision for ONE observation as ONE launch (csrc/dz_iqn_act.h; ref:
- * iqn/agent.py:234-247 select_action): samples (<= 32) fresh tau draws -- tau_j is the value
+ * iqn/agent.py:234-247 select_action): samples (<= 64: the reference default) fresh tau draws -- tau_j is the value
  * dz_uniform_fill(seed = tau_seed, counter = tau_counter + j) produces, drawn inside the kernel and
  * written to taus_out [samples] if given --, the network on those taus, q = mean over the taus.
  * num_actions <= 32, latent_dim <= 64.  `ws`: a dz_iqn_layout(num_actions, latent_dim, 1, samples,

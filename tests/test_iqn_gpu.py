@@ -223,7 +223,7 @@ def _make_actor(actions, samples, seed):
   return rs, online, ln
 
 
-@pytest.mark.parametrize('actions,samples', [(6, 32), (18, 32), (4, 8), (3, 1)])
+@pytest.mark.parametrize('actions,samples', [(6, 64), (18, 64), (6, 32), (18, 32), (5, 48), (4, 8), (3, 1)])
 def test_one_launch_iqn_decision(actions, samples):
   """`IqnLearner.q_async` is ONE launch (dz_iqn_act, csrc/dz_iqn_act.h): the taus drawn inside the
   kernel are the draws dz_uniform_fill makes at the same stream position, the q-values (mean over
