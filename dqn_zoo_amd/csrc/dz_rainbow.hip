@@ -447,6 +447,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
   // optional priority write-back (dz_rainbow_args_t::prio_*), carried by one of this
   // call's launches as an extra block
   bool prio_pending = a->prio_node != nullptr;
+  ConvWgDeferred wg_defer;   // conv3's / conv2's weight gradients travel with conv1's (dz_torso.h)
   PrioUpdateParams prio_q = {};
   if (prio_pending) {
     DZ_REQUIRE(a->prio_ids && a->prio_status && dz_is_pow2(a->prio_cap_pow2) &&
@@ -595,10 +596,10 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         rc = launch_conv3_bwd(w, d, B, s, &prio_q);
         prio_pending = false;
       } else {
-        rc = launch_conv3_bwd(w, d, B, s);
+        rc = launch_conv3_bwd(w, d, B, s, nullptr, &wg_defer);
       }
       if (rc) return rc;
-      DZ_PROF(s, "conv3_wgrad+dgrad");
+      DZ_PROF(s, wg_defer.on3 ? "conv3_dgrad" : "conv3_wgrad+dgrad");
     }
     {  // conv2
       ConvWgradParams w;
@@ -606,16 +607,16 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       ConvDgradParams d;
       d.dy = ws + L.ws_dact2; d.w = a->online + L.conv_w[1]; d.act = ws + L.ws_act1;
       d.dx = ws + L.ws_dact1; d.B = B;
-      rc = launch_conv2_bwd(w, d, B, s);
+      rc = launch_conv2_bwd(w, d, B, s, &wg_defer);
       if (rc) return rc;
-      DZ_PROF(s, "conv2_wgrad+dgrad");
+      DZ_PROF(s, wg_defer.on2 ? "conv2_dgrad" : "conv2_wgrad+dgrad");
     }
     {  // conv1 weight+bias gradient partials straight from the uint8 states
       ConvWgradParams p;
       p.in = a->s_tm1; p.dy = ws + L.ws_dact1; p.part = part1; p.B = B; p.S = kS_cw1;
-      rc = launch_conv1_wgrad(p, s);
+      rc = launch_conv1_wgrad(p, s, &wg_defer);
       if (rc) return rc;
-      DZ_PROF(s, "conv1_wgrad");
+      DZ_PROF(s, wg_defer.on2 ? "conv_wgrads" : "conv1_wgrad");
     }
     {  // reduce the three conv partial slabs; linear-layer bias gradients
       FinalizeJobs J;

@@ -208,16 +208,49 @@ inline int torso_forward_side(const TorsoBufs& T, int G, int B, const float* con
   return torso_forward_rest(T, G, B, prm, s, nullptr);
 }
 
+// The backward chain's CRITICAL PATH is dfeat -> dact2 -> dact1: the input gradients.  The weight
+// gradients are leaves (nothing of the backward pass reads them), so they need not share their own
+// layer's launch.  DZ_CONV_BWD_SPLIT, same box, us per launch:
+//   0  [w3 + d3] [w2 + d2] [w1]          8.1 + 9.5 + 7.9  = 25.4   (rounds 2-5: each layer's pair)
+//   1  [d3] [d2] [w1 + w2 + w3]          7.7 + 6.1 + 13.4 = 27.2
+//   2  [w3 + d3] [d2] [w1 + w2]          8.1 + 6.1 + 10.2 = 24.3   <- conv2's weight gradient rides
+//      with conv1's (the chain's last launch, 250 + 243 workgroups); conv3's stays (it costs its
+//      launch 0.4 us).
+#ifndef DZ_CONV_BWD_SPLIT
+#define DZ_CONV_BWD_SPLIT 2
+#endif
+struct ConvWgDeferred { bool on3 = false, on2 = false; ConvWgradParams w3, w2; };
+
+// conv1's weight gradient (register-staged skeleton), conv2's and conv3's (LDS-DMA Ops) in ONE launch
+template <class W1, class W2, class W3, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
+void dz_conv_wgrad3_kernel(ConvWgradParams p1, dim3 g1, ConvWgradParams p2, dim3 g2, ConvWgradParams p3, dim3 g3) {
+  constexpr int A1 = DzGemmSmem<W1>::ELEMS, A2 = DzDmaOpShape<W2>::LDS_FLOATS, A3 = DzDmaOpShape<W3>::LDS_FLOATS;
+  constexpr int LDS = A1 > A2 ? (A1 > A3 ? A1 : A3) : (A2 > A3 ? A2 : A3);
+  __shared__ __attribute__((aligned(1024))) float lds[LDS];
+  const unsigned n1 = g1.x * g1.y * g1.z, n2 = g2.x * g2.y * g2.z;
+  if (blockIdx.x < n1) dz_gemm_body<W1>(p1, dz_unflatten(blockIdx.x, g1), lds);
+  else if (blockIdx.x < n1 + n2) dz_dmaop_body<W2>(p2, dz_unflatten(blockIdx.x - n1, g2), lds);
+  else dz_dmaop_body<W3>(p3, dz_unflatten(blockIdx.x - n1 - n2, g3), lds);
+}
+
 // conv3 / conv2 backward: weight (+ bias) gradient slabs fused with the layer's input gradient.
-// `prio`: optional sum-tree priority write-back carried as one extra block.
+// `prio`: optional sum-tree priority write-back carried as one extra block.  `defer` (nullable):
+// the weight gradient is left for launch_conv1_wgrad (DZ_CONV_BWD_SPLIT).
 inline int launch_conv3_bwd(const ConvWgradParams& w, const ConvDgradParams& d, int B, hipStream_t s,
-                            const PrioUpdateParams* prio = nullptr) {
+                            const PrioUpdateParams* prio = nullptr, ConvWgDeferred* defer = nullptr) {
 #if DZ_CONV3_BWD_DMA
   using Wg = ConvWgDmaOp<9, 9, 64, 3, 1, 7, 7, 64, (DZ_CONV3_BWD_DMA / 10) % 10, DZ_CONV3_BWD_DMA % 10>;
   using Dg = ConvDgDmaOp<9, 9, 64, 3, 1, 7, 7, 64, DZ_CONV3_BWD_DMA / 1000, (DZ_CONV3_BWD_DMA / 100) % 10, DZ_CONV3_BWD_DMA % 10>;
   static_assert(Wg::KROWS == Conv3Wg::KROWS, "slab layout");
   if (Dg::fits(B)) {
     const dim3 gw(1, Wg::MT, w.S), gd(64 / Dg::BN, Dg::tiles(B), 1);
+#if DZ_CONV_BWD_SPLIT == 1 && DZ_CONV2_BWD_DMA
+    if (defer && !prio) {
+      defer->on3 = true; defer->w3 = w;
+      return dz_launch_dmaop<Dg, DZ_CONV_BWD_OCC>(d, gd, s);
+    }
+#endif
     if (prio) return dz_launch_dmaop2_side<Wg, Dg, PrioUpdateSideFast, DZ_CONV_BWD_OCC>(w, gw, d, gd, *prio, 1, s);
     return dz_launch_dmaop2<Wg, Dg, DZ_CONV_BWD_OCC>(w, gw, d, gd, s);
   }
@@ -226,7 +259,8 @@ inline int launch_conv3_bwd(const ConvWgradParams& w, const ConvDgradParams& d, 
   if (prio) return dz_launch_gemm2_side<Conv3Wg, Conv3Dg, PrioUpdateSideFast>(w, gw, d, gd, *prio, 1, s);
   return dz_launch_gemm2<Conv3Wg, Conv3Dg>(w, gw, d, gd, s);
 }
-inline int launch_conv2_bwd(const ConvWgradParams& w, const ConvDgradParams& d, int B, hipStream_t s) {
+inline int launch_conv2_bwd(const ConvWgradParams& w, const ConvDgradParams& d, int B, hipStream_t s,
+                            ConvWgDeferred* defer = nullptr) {
 #if DZ_CONV2_BWD_DMA
   using Wg = ConvWgDmaOp<20, 20, 32, 4, 2, 9, 9, 64, (DZ_CONV2_BWD_DMA / 10) % 10, DZ_CONV2_BWD_DMA % 10>;
   using Dg = ConvDgDmaOp<20, 20, 32, 4, 2, 9, 9, 64, 1, (DZ_CONV2_BWD_DMA / 100) % 10, DZ_CONV2_BWD_DMA % 10>;
@@ -234,6 +268,12 @@ inline int launch_conv2_bwd(const ConvWgradParams& w, const ConvDgradParams& d, 
 #ifdef DZ_BWD_ABL   // timing ablations (results are wrong): 1 = weight gradient only, 2 = input gradient only
   if (DZ_BWD_ABL == 1) return dz_launch_dmaop<Wg, DZ_CONV_BWD_OCC>(w, dim3(1, Wg::MT, w.S), s);
   if (DZ_BWD_ABL == 2) return dz_launch_dmaop<Dg, DZ_CONV_BWD_OCC>(d, dim3(1, Dg::tiles(B), 4), s);
+#endif
+#if DZ_CONV_BWD_SPLIT && DZ_CONV3_BWD_DMA
+  if (Dg::fits(B) && defer && (defer->on3 || DZ_CONV_BWD_SPLIT == 2)) {   // (1: conv3's is waiting already)
+    defer->on2 = true; defer->w2 = w;
+    return dz_launch_dmaop<Dg, DZ_CONV_BWD_OCC>(d, dim3(1, Dg::tiles(B), 4), s);
+  }
 #endif
   if (Dg::fits(B))
     return dz_launch_dmaop2<Wg, Dg, DZ_CONV_BWD_OCC>(w, dim3(1, Wg::MT, w.S), d, dim3(1, Dg::tiles(B), 4), s);
@@ -246,7 +286,20 @@ inline int launch_conv2_bwd(const ConvWgradParams& w, const ConvDgradParams& d, 
                                           dim3(32 / Conv2Dg::BN, Conv2Dg::tiles(B), 4), s);
 }
 
-inline int launch_conv1_wgrad(const ConvWgradParams& p, hipStream_t s) {
+inline int launch_conv1_wgrad(const ConvWgradParams& p, hipStream_t s, const ConvWgDeferred* defer = nullptr) {
+#if DZ_CONV_BWD_SPLIT && DZ_CONV3_BWD_DMA && DZ_CONV2_BWD_DMA
+  if (defer && defer->on2) {
+    using W3 = ConvWgDmaOp<9, 9, 64, 3, 1, 7, 7, 64, (DZ_CONV3_BWD_DMA / 10) % 10, DZ_CONV3_BWD_DMA % 10>;
+    using W2 = ConvWgDmaOp<20, 20, 32, 4, 2, 9, 9, 64, (DZ_CONV2_BWD_DMA / 10) % 10, DZ_CONV2_BWD_DMA % 10>;
+    const dim3 g1(32 / Conv1Wg::BN, Conv1Wg::MT, p.S), g2(1, W2::MT, defer->w2.S),
+        g3(1, W3::MT, defer->on3 ? defer->w3.S : 0);
+    hipLaunchKernelGGL((dz_conv_wgrad3_kernel<Conv1Wg, W2, W3, DZ_CONV_BWD_OCC>),
+                       dim3(dz_count(g1) + dz_count(g2) + dz_count(g3)), dim3(256), 0, s, p, g1, defer->w2, g2,
+                       defer->on3 ? defer->w3 : defer->w2, g3);
+    DZ_LAUNCH_CHECK();
+    return DZ_OK;
+  }
+#endif
 #if DZ_CONV1_WG_DMA
   using Wg = Conv1WgDmaOp<DZ_CONV1_WG_DMA / 10, DZ_CONV1_WG_DMA % 10>;
   static_assert(Wg::KROWS == Conv1Wg::KROWS, "slab layout");
@@ -271,6 +324,7 @@ inline int torso_backward(const TorsoBufs& T, int B, const float* online,
                           float* dact1, float* part, float* grad, ReduceJob* jobs,
                           hipStream_t s, const PrioUpdateParams* prio = nullptr) {
   int rc;
+  ConvWgDeferred defer;
   float* part1 = part;
   float* part2 = part1 + (long)kS_cw1 * Conv1Wg::KROWS * 32;
   float* part3 = part2 + (long)kS_cw2 * Conv2Wg::KROWS * 64;
@@ -279,7 +333,7 @@ inline int torso_backward(const TorsoBufs& T, int B, const float* online,
     w.in = T.act2; w.dy = dfeat; w.part = part3; w.B = B; w.S = kS_cw3;
     ConvDgradParams d;
     d.dy = dfeat; d.w = online + T.conv_w[2]; d.act = T.act2; d.dx = dact2; d.B = B;
-    rc = launch_conv3_bwd(w, d, B, s, prio);
+    rc = launch_conv3_bwd(w, d, B, s, prio, &defer);
     if (rc) return rc;
     DZ_PROF(s, "conv3_wgrad+dgrad");
   }
@@ -288,16 +342,16 @@ inline int torso_backward(const TorsoBufs& T, int B, const float* online,
     w.in = T.act1; w.dy = dact2; w.part = part2; w.B = B; w.S = kS_cw2;
     ConvDgradParams d;
     d.dy = dact2; d.w = online + T.conv_w[1]; d.act = T.act1; d.dx = dact1; d.B = B;
-    rc = launch_conv2_bwd(w, d, B, s);
+    rc = launch_conv2_bwd(w, d, B, s, &defer);
     if (rc) return rc;
     DZ_PROF(s, "conv2_wgrad+dgrad");
   }
   {
     ConvWgradParams p;
     p.in = s_tm1; p.dy = dact1; p.part = part1; p.B = B; p.S = kS_cw1;
-    rc = launch_conv1_wgrad(p, s);
+    rc = launch_conv1_wgrad(p, s, &defer);
     if (rc) return rc;
-    DZ_PROF(s, "conv1_wgrad");
+    DZ_PROF(s, defer.on2 ? "conv_wgrads" : "conv1_wgrad");
   }
   jobs[0] = {part1, kS_cw1, (long)Conv1Wg::KROWS * 32, grad + T.conv_w[0]};
   jobs[1] = {part2, kS_cw2, (long)Conv2Wg::KROWS * 64, grad + T.conv_w[1]};
