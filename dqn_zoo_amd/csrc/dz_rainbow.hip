@@ -549,7 +549,24 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         gdp.gx_part = gram_part; gdp.dot_out = sq_slots + fc2_slots;
         // the sum-tree priority write-back rides HERE in the one-call step (same-box A/B:
         // +0.8 us on this launch, +1.3 us on conv3's backward launch)
-        const bool carry_prio = prio_pending;
+        // Round 6: the block's chain of three dependent trips to memory (ids -> path siblings ->
+        // running maximum; then the walk) is ~9.5 us, longer than any launch of the backward chain: it
+        // set THIS launch's duration (12.0 us with it, 9.9 without; conv3's 8.1 -> 12.1, the weight
+        // gradients' 10.2 -> 14.4).  DZ_PRIO_HOST 3 cuts it in two (PrioUpdateParams::phase): checks,
+        // maximum and the siblings' trip here, the walk and the stores in conv3's backward launch, the
+        // hand-over in an idle workspace region.
+#ifndef DZ_PRIO_HOST   // 0: whole block here, 1: in conv3's backward, 2: with the weight gradients, 3: split here + conv3's
+#define DZ_PRIO_HOST 3
+#endif
+        const bool split_prio = DZ_PRIO_HOST == 3 && prio_pending && B <= 64 &&   // (one wave walks the batch)
+                                a->prio_cap_pow2 <= ((int64_t)1 << 31) &&
+                                (int64_t)kPrioScratchDoubles * 2 <= (int64_t)kMaxS_dfeat * B * kFlat;
+        const bool carry_prio = prio_pending && (DZ_PRIO_HOST == 0 || split_prio);
+        if (split_prio) {
+          prio_q.phase = 1;
+          // (the END of the idle split-K slab region of the stored-gradient forms)
+          prio_q.scratch = reinterpret_cast<double*>(ws + L.ws_dfeat_part + (int64_t)kMaxS_dfeat * B * kFlat) - kPrioScratchDoubles;
+        }
         Fc1DgradMfma m = {};
         m.params = a->online; m.noise = nz[0];
         m.w_mu = L.fc1_mu_w; m.w_sig = L.fc1_sig_w; m.ldw = L.fc1_ld;
@@ -560,7 +577,8 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         hipLaunchKernelGGL(fc1_dgrad_mfma_kernel,
                            dim3(GramDSide::kBlocks + kFlat / 16 + (carry_prio ? 1 : 0)), dim3(256),
                            0, s, m, gdp, carry_prio ? prio_q : PrioUpdateParams{});
-        if (carry_prio) prio_pending = false;
+        if (carry_prio && !split_prio) prio_pending = false;
+        if (split_prio) prio_q.phase = 2;   // (the second half stays pending: conv3's backward launch)
         DZ_LAUNCH_CHECK();
         rc = DZ_OK;
       } else {
@@ -587,7 +605,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       // (with the next step's sample riding in the optimiser launch the write-back must
       // be complete BEFORE that launch: it stays here)
       const bool prio_in_adam = (phases & DZ_PHASE_OPTIMIZER) != 0 && !a->next_sample && !onfly;
-      if (prio_pending && !prio_in_adam) {
+      if (prio_pending && !prio_in_adam && DZ_PRIO_HOST != 2) {
         // The sum-tree priority write-back rides in this launch as one extra block:
         // it needs only the loss kernel's priorities and nothing here reads the tree.
         // (Measured hosts: this launch hides it completely; inside the HBM-heavy fc1
@@ -614,7 +632,12 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
     {  // conv1 weight+bias gradient partials straight from the uint8 states
       ConvWgradParams p;
       p.in = a->s_tm1; p.dy = ws + L.ws_dact1; p.part = part1; p.B = B; p.S = kS_cw1;
-      rc = launch_conv1_wgrad(p, s, &wg_defer);
+      if (prio_pending && DZ_PRIO_HOST == 2) {
+        rc = launch_conv1_wgrad(p, s, &wg_defer, &prio_q);
+        prio_pending = false;
+      } else {
+        rc = launch_conv1_wgrad(p, s, &wg_defer);
+      }
       if (rc) return rc;
       DZ_PROF(s, wg_defer.on2 ? "conv_wgrads" : "conv1_wgrad");
     }

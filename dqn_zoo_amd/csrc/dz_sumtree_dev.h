@@ -76,26 +76,13 @@ struct WbScratch {                       // 14.3 KB; may alias a host kernel's i
   double v1[256];                        //   ... pong (one barrier per level)
   unsigned char partner[kWbMaxLevels + 1][256];   // [l][i]: thread i's partner at level l (0xFF: none)
 };
-__device__ __forceinline__ void set_leaves_and_ancestors_fast(
-    double* node, int64_t cap, int64_t my_leaf, double my_val, bool active, int n,
-    WbScratch& S) {
-  constexpr int kMaxLevels = kWbMaxLevels;
+// The scan of the batch (steps 2 above): this thread's value with duplicates resolved, and its
+// partners' batch indices in S.partner[.][i].  S.x / S.v0 are filled here.
+__device__ __forceinline__ double wb_scan(uint32_t x32, double my_val, bool active, int n, WbScratch& S) {
   const int i = threadIdx.x;
-  const int lg = 63 - __builtin_clzll((unsigned long long)cap);   // levels above the leaves
-  const int64_t x0 = active ? cap + my_leaf : 0;
-  const uint32_t x32 = (uint32_t)x0;
-  DZ_WB_STAMP(0);
-  // (unconditional loads from clamped indices: a conditional load is an exec-mask block
-  // with its own full wait, i.e. one round trip per level again)
-  double sib[kMaxLevels];
-#pragma unroll
-  for (int l = 0; l < kMaxLevels; ++l) {
-    const int64_t xl = x0 >> l;
-    sib[l] = node[(active && xl > 1) ? (xl ^ 1) : 1];
-  }
   S.x[i] = x32; S.v0[i] = my_val;
 #pragma unroll
-  for (int l = 0; l <= kMaxLevels; ++l) S.partner[l][i] = 0xFF;
+  for (int l = 0; l <= kWbMaxLevels; ++l) S.partner[l][i] = 0xFF;
   __syncthreads();
   DZ_WB_STAMP(1);
   // the one scan, in batches of 8 (all LDS reads of a batch issued before any use)
@@ -116,6 +103,14 @@ __device__ __forceinline__ void set_leaves_and_ancestors_fast(
       }
     }
   }
+  return val;
+}
+// The walk (steps 3 and 4): `val` = this thread's leaf value, `sib` its prefetched siblings,
+// S.partner its partners.
+__device__ __forceinline__ void wb_walk(double* node, int lg, int64_t x0, double val, bool active,
+                                        const double (&sib)[kWbMaxLevels], WbScratch& S) {
+  constexpr int kMaxLevels = kWbMaxLevels;
+  const int i = threadIdx.x;
   double pv[kMaxLevels + 1];
   int64_t x = x0;
   DZ_WB_STAMP(2);
@@ -125,10 +120,8 @@ __device__ __forceinline__ void set_leaves_and_ancestors_fast(
     DZ_WB_STAMP(3 + l);
     if (l < lg) {                         // uniform
       double* buf = (l & 1) ? S.v1 : S.v0;
-      if (l > 0 || true) {
-        if (l == 0) __syncthreads();      // every scan read of v0 is done before it is reused
-        buf[i] = val;
-      }
+      if (l == 0) __syncthreads();        // every scan read of v0 is done before it is reused
+      buf[i] = val;
       __syncthreads();
       const uint32_t pj = S.partner[l < kMaxLevels ? l : 0][i];   // (own writes: ordered by the barrier)
       const double fresh = buf[pj == 0xFFu ? (uint32_t)i : pj];
@@ -142,6 +135,47 @@ __device__ __forceinline__ void set_leaves_and_ancestors_fast(
   for (int l = 0; l <= kMaxLevels; ++l)
     if (active && l <= lg) node[x0 >> l] = pv[l];
   DZ_WB_STAMP(40);
+}
+// ... for a batch of at most 64 (one wave holds it: thread index = batch index): the partner's
+// value comes over the lane crossbar, no LDS buffer, no barrier.  `pb` = this thread's partner
+// bytes (level l in byte l).  Only wave 0 may call it.
+__device__ __forceinline__ void wb_walk_wave(double* node, int lg, int64_t x0, double val, bool active,
+                                             const double (&sib)[kWbMaxLevels], const unsigned char (&pb)[32]) {
+  constexpr int kMaxLevels = kWbMaxLevels;
+  double pv[kMaxLevels + 1];
+  int64_t x = x0;
+#pragma unroll
+  for (int l = 0; l <= kMaxLevels; ++l) {
+    pv[l] = val;
+    if (l < lg) {                         // uniform
+      const uint32_t pj = pb[l < kMaxLevels ? l : 0];
+      const double fresh = __shfl(val, (int)(pj & 63u), 64);
+      const double sv = pj == 0xFFu ? sib[l < kMaxLevels ? l : 0] : fresh;
+      val = (x & 1) ? sv + val : val + sv;   // fl(left + right)
+      x >>= 1;
+    }
+  }
+#pragma unroll
+  for (int l = 0; l <= kMaxLevels; ++l)
+    if (active && l <= lg) node[x0 >> l] = pv[l];
+}
+__device__ __forceinline__ void set_leaves_and_ancestors_fast(
+    double* node, int64_t cap, int64_t my_leaf, double my_val, bool active, int n,
+    WbScratch& S) {
+  constexpr int kMaxLevels = kWbMaxLevels;
+  const int lg = 63 - __builtin_clzll((unsigned long long)cap);   // levels above the leaves
+  const int64_t x0 = active ? cap + my_leaf : 0;
+  DZ_WB_STAMP(0);
+  // (unconditional loads from clamped indices: a conditional load is an exec-mask block
+  // with its own full wait, i.e. one round trip per level again)
+  double sib[kMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) {
+    const int64_t xl = x0 >> l;
+    sib[l] = node[(active && xl > 1) ? (xl ^ 1) : 1];
+  }
+  const double val = wb_scan((uint32_t)x0, my_val, active, n, S);
+  wb_walk(node, lg, x0, val, active, sib, S);
 }
 
 // id -> tree index and back for the fixed-capacity distribution
@@ -175,19 +209,54 @@ struct PrioUpdateParams {
   double* max_seen; uint32_t* status;
   int check_ids;   // 0: ids come straight from this replay's sampler (live by construction)
   const unsigned* abort = nullptr;   // non-zero word: the step that produced `prio` is void, write nothing
+  // The write-back as TWO blocks in two consecutive launches (one workgroup's chain of three
+  // dependent trips to memory is ~9.5 us -- longer than either host launch): phase 1 checks the
+  // batch, updates the running maximum, and leaves the leaf values, node indices and the 31
+  // siblings of every path in `scratch` (kPrioScratchDoubles doubles, nobody else's); phase 2 reads
+  // them back (one trip, L2) and does the walk and the stores.  The tree must not change in between.
+  int phase = 0;                     // 0: everything in one block
+  double* scratch = nullptr;
 };
+// flag | values (duplicates resolved) | node indices | siblings [31][256] | partners [256][32 bytes]
+constexpr int kPrioScratchDoubles = 1 + 2 * 256 + kWbMaxLevels * 256 + 4 * 256;
+constexpr int kPrioScrSib = 1 + 512, kPrioScrPartner = kPrioScrSib + kWbMaxLevels * 256;
 __device__ __forceinline__ void prio_update_body(const PrioUpdateParams& q, int64_t* s_leaf,
                                                  double* s_red, WbScratch* wb = nullptr) {
-  if (q.abort && *q.abort) return;   // (launch-uniform)
+  const int i = threadIdx.x;
   double* node = q.node;
   const int64_t cap = q.cap, N = q.N, size = q.size, t = q.t;
+  const int n = q.n;
+  if (q.phase == 2) {   // ---- second half: the walk, from what phase 1 left in the scratch ----
+    // (phase 1 found the step void or the batch bad: nothing to do; all threads look BEFORE the clear)
+    if (!__syncthreads_or(q.scratch[0] == 1.0 ? 1 : 0)) return;
+    if (i == 0) q.scratch[0] = 0.0;    // consumed (a phase 2 without its phase 1 does nothing)
+    if (i >= 64) return;               // (phase 1 took the split only for batches of <= 64: one wave)
+    const bool active = i < n;
+    const int lg = 63 - __builtin_clzll((unsigned long long)cap);
+    const double val = q.scratch[1 + i];
+    const int64_t x0 = __builtin_bit_cast(int64_t, q.scratch[1 + 256 + i]);
+    double sib[kWbMaxLevels];
+#pragma unroll
+    for (int l = 0; l < kWbMaxLevels; ++l) sib[l] = q.scratch[kPrioScrSib + l * 256 + i];
+    unsigned char pb[32];
+    {
+      const uint4* pp = reinterpret_cast<const uint4*>(q.scratch + kPrioScrPartner + 4 * i);
+      const uint4 a = pp[0], b = pp[1];
+      const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int l = 0; l < 32; ++l) pb[l] = (unsigned char)(w[l >> 2] >> (8 * (l & 3)));
+    }
+    wb_walk_wave(node, lg, x0, val, active, sib, pb);
+    return;
+  }
+  if (q.phase == 1 && i == 0) q.scratch[0] = 0.0;
+  if (q.abort && *q.abort) return;   // (launch-uniform)
   const int64_t* __restrict__ ids = q.ids;
   const void* __restrict__ prio = q.prio;
-  const int is_f32 = q.is_f32, n = q.n;
+  const int is_f32 = q.is_f32;
   const double exponent = q.exponent;
   double* max_seen = q.max_seen;
   uint32_t* status = q.status;
-  const int i = threadIdx.x;
   const bool active = i < n;
   int64_t leaf = 0;
   double v = 0.0, p64 = 0.0;
@@ -214,6 +283,31 @@ __device__ __forceinline__ void prio_update_body(const PrioUpdateParams& q, int6
                                   (any_bad_i ? DZ_ST_BAD_INDEX : 0u));
     return;
   }
+  if (q.phase == 1) {   // ---- first half: the siblings' trip starts now, next to the maximum's ----
+    const int64_t x0 = active ? cap + leaf : 0;
+    double sib[kWbMaxLevels];
+#pragma unroll
+    for (int l = 0; l < kWbMaxLevels; ++l) {
+      const int64_t xl = x0 >> l;
+      sib[l] = node[(active && xl > 1) ? (xl ^ 1) : 1];
+    }
+    // (the scan too: duplicates resolved and partners found here, under this launch)
+    const double val = wb_scan((uint32_t)x0, v, active, n, *wb);
+    __syncthreads();
+    q.scratch[1 + i] = val;
+    q.scratch[1 + 256 + i] = __builtin_bit_cast(double, x0);
+#pragma unroll
+    for (int l = 0; l < kWbMaxLevels; ++l) q.scratch[kPrioScrSib + l * 256 + i] = sib[l];
+    {
+      unsigned w[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        w[k] = (unsigned)wb->partner[4 * k][i] | ((unsigned)wb->partner[4 * k + 1][i] << 8) |
+               ((unsigned)wb->partner[4 * k + 2][i] << 16) | ((unsigned)wb->partner[4 * k + 3][i] << 24);
+      uint4* pp = reinterpret_cast<uint4*>(q.scratch + kPrioScrPartner + 4 * i);
+      pp[0] = make_uint4(w[0], w[1], w[2], w[3]); pp[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  }
   if (max_seen) {  // rainbow/agent.py:196-197
     double m = active ? p64 : -__builtin_inf();
     for (int off = 32; off >= 1; off >>= 1) {
@@ -228,6 +322,10 @@ __device__ __forceinline__ void prio_update_body(const PrioUpdateParams& q, int6
         mm = s_red[k] > mm ? s_red[k] : mm;
       *max_seen = mm;
     }
+  }
+  if (q.phase == 1) {
+    if (i == 0) q.scratch[0] = 1.0;   // (same block, same launch as the stores above: the NEXT launch reads it)
+    return;
   }
   if (wb && n <= kWbMaxBatch && blockDim.x == 256 && cap <= ((int64_t)1 << 31)) {
     __syncthreads();

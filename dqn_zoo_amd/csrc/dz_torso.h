@@ -224,14 +224,16 @@ struct ConvWgDeferred { bool on3 = false, on2 = false; ConvWgradParams w3, w2; }
 // conv1's weight gradient (register-staged skeleton), conv2's and conv3's (LDS-DMA Ops) in ONE launch
 template <class W1, class W2, class W3, int OCC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
-void dz_conv_wgrad3_kernel(ConvWgradParams p1, dim3 g1, ConvWgradParams p2, dim3 g2, ConvWgradParams p3, dim3 g3) {
+void dz_conv_wgrad3_kernel(ConvWgradParams p1, dim3 g1, ConvWgradParams p2, dim3 g2, ConvWgradParams p3, dim3 g3,
+                           PrioUpdateParams prio) {
   constexpr int A1 = DzGemmSmem<W1>::ELEMS, A2 = DzDmaOpShape<W2>::LDS_FLOATS, A3 = DzDmaOpShape<W3>::LDS_FLOATS;
   constexpr int LDS = A1 > A2 ? (A1 > A3 ? A1 : A3) : (A2 > A3 ? A2 : A3);
   __shared__ __attribute__((aligned(1024))) float lds[LDS];
-  const unsigned n1 = g1.x * g1.y * g1.z, n2 = g2.x * g2.y * g2.z;
+  const unsigned n1 = g1.x * g1.y * g1.z, n2 = g2.x * g2.y * g2.z, n3 = g3.x * g3.y * g3.z;
   if (blockIdx.x < n1) dz_gemm_body<W1>(p1, dz_unflatten(blockIdx.x, g1), lds);
   else if (blockIdx.x < n1 + n2) dz_dmaop_body<W2>(p2, dz_unflatten(blockIdx.x - n1, g2), lds);
-  else dz_dmaop_body<W3>(p3, dz_unflatten(blockIdx.x - n1 - n2, g3), lds);
+  else if (blockIdx.x < n1 + n2 + n3) dz_dmaop_body<W3>(p3, dz_unflatten(blockIdx.x - n1 - n2, g3), lds);
+  else PrioUpdateSideFast::run(prio, 0, lds, (int)sizeof(lds));   // (optional last block: the sum-tree write-back)
 }
 
 // conv3 / conv2 backward: weight (+ bias) gradient slabs fused with the layer's input gradient.
@@ -286,7 +288,8 @@ inline int launch_conv2_bwd(const ConvWgradParams& w, const ConvDgradParams& d, 
                                           dim3(32 / Conv2Dg::BN, Conv2Dg::tiles(B), 4), s);
 }
 
-inline int launch_conv1_wgrad(const ConvWgradParams& p, hipStream_t s, const ConvWgDeferred* defer = nullptr) {
+inline int launch_conv1_wgrad(const ConvWgradParams& p, hipStream_t s, const ConvWgDeferred* defer = nullptr,
+                              const PrioUpdateParams* prio = nullptr) {
 #if DZ_CONV_BWD_SPLIT && DZ_CONV3_BWD_DMA && DZ_CONV2_BWD_DMA
   if (defer && defer->on2) {
     using W3 = ConvWgDmaOp<9, 9, 64, 3, 1, 7, 7, 64, (DZ_CONV3_BWD_DMA / 10) % 10, DZ_CONV3_BWD_DMA % 10>;
@@ -294,8 +297,8 @@ inline int launch_conv1_wgrad(const ConvWgradParams& p, hipStream_t s, const Con
     const dim3 g1(32 / Conv1Wg::BN, Conv1Wg::MT, p.S), g2(1, W2::MT, defer->w2.S),
         g3(1, W3::MT, defer->on3 ? defer->w3.S : 0);
     hipLaunchKernelGGL((dz_conv_wgrad3_kernel<Conv1Wg, W2, W3, DZ_CONV_BWD_OCC>),
-                       dim3(dz_count(g1) + dz_count(g2) + dz_count(g3)), dim3(256), 0, s, p, g1, defer->w2, g2,
-                       defer->on3 ? defer->w3 : defer->w2, g3);
+                       dim3(dz_count(g1) + dz_count(g2) + dz_count(g3) + (prio ? 1 : 0)), dim3(256), 0, s, p, g1,
+                       defer->w2, g2, defer->on3 ? defer->w3 : defer->w2, g3, prio ? *prio : PrioUpdateParams{});
     DZ_LAUNCH_CHECK();
     return DZ_OK;
   }
