@@ -33,9 +33,17 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // AHEAD_: K-stages requested up front; stage s + AHEAD_ is requested behind stage s's barrier.
 // (All four at once queue every co-resident workgroup's 40 KB in front of anyone's SECOND stage:
 // in-kernel stamps showed the launch's first MFMA 1.8 us after the workgroups start.)
-template <int NRB_, int NRG_ = 2, int AHEAD_ = 4>
+// BRING_ = 1 (with AHEAD_ <= 2): only THREE 8 KB filter-bank stages are resident -- stage s + 2 is
+// requested behind stage s's barrier into the buffer stage s - 1 was read from -- i.e. 32 KB of LDS
+// per workgroup at NRB = 1, NRG = 2 instead of 40: FIVE workgroups per CU, so that all 1 200
+// workgroups of the learner's launch are resident at once instead of 1 024 + a second round of 176
+// (in-kernel stamps: the second round starts 5.8 us after the first).  MEASURED SLOWER, kept off:
+// 13.0-13.3 us against 11.5 (bit-identical outputs) -- five workgroups sharing a CU's matrix pipe and
+// memory queue lose more than the second round costs; three per CU (LDS padded): 11.5, two: 13.2.
+template <int NRB_, int NRG_ = 2, int AHEAD_ = 4, int BRING_ = 0>
 struct Conv1DmaCfg {
-  static constexpr int AHEAD = AHEAD_;
+  static constexpr int AHEAD = AHEAD_, BRING = BRING_;
+  static_assert(!BRING_ || AHEAD_ <= 2, "the ring's third buffer is the one stage s - 1 was read from");
   static constexpr int NRB = NRB_, NRG = NRG_, NW = 2 * NRG_, THREADS = 64 * NW, BMW = 16 * NRB_ * NRG_;
   static constexpr int H = 84, W = 84, OH = 20, OW = 20, CO = 32, K = 256, NSTG = 4;
   static constexpr int ROWB = W * 4;                       // bytes per input row
@@ -43,7 +51,7 @@ struct Conv1DmaCfg {
   static constexpr int AI = BMW / 16;                      // A instructions per stage
   static constexpr int BI = 8;                             // B instructions per stage (64 rows x 128 B)
   static constexpr int IPS = AI + BI;
-  static constexpr int B_BYTES = K * CO * 4;
+  static constexpr int B_BYTES = (BRING_ ? 3 : 4) * 64 * CO * 4;
   static constexpr int OUT_PITCH = 36;
   static constexpr int LDS_BYTES = A_BYTES + B_BYTES;
   static_assert(BMW * OUT_PITCH * 4 <= A_BYTES, "the output tile fits in the A region");
@@ -85,7 +93,7 @@ __device__ __forceinline__ void dz_conv1_dma_body(const Conv1DmaParams& p, int m
   const int li = lane & 15, kq = lane >> 4;
   const unsigned lds0 = (unsigned)(uintptr_t)lds;
   unsigned char* As = lds;
-  const float* Bs = (const float*)(lds + C::A_BYTES);
+  const float* Bs0 = (const float*)(lds + C::A_BYTES);
 
   DZ_C1_STAMP(0);
   const int tpg = p.B * C::OH * C::OW / C::BMW;
@@ -130,7 +138,8 @@ __device__ __forceinline__ void dz_conv1_dma_body(const Conv1DmaParams& p, int m
     for (int j = 0; j < NBJ; ++j)
       if (j < nb)
         dz_glds16<0>(bsrc[j] + s * 64 * C::CO,
-                     lds0 + (unsigned)(C::A_BYTES + s * 64 * 128) + (unsigned)((C::NW * j + wave) * 1024));
+                     lds0 + (unsigned)(C::A_BYTES + (C::BRING ? s % 3 : s) * 64 * 128) +
+                         (unsigned)((C::NW * j + wave) * 1024));
   };
 #pragma unroll
   for (int s = 0; s < C::AHEAD && s < C::NSTG; ++s) issue(s);
@@ -150,6 +159,12 @@ __device__ __forceinline__ void dz_conv1_dma_body(const Conv1DmaParams& p, int m
     __syncthreads();
     if (s == 0) DZ_C1_STAMP(2);
     if (s + C::AHEAD < C::NSTG) issue(s + C::AHEAD);
+    // (indexed by the global k below: the ring's buffer of stage s starts 64 s rows earlier)
+    const float* Bs = Bs0 + (C::BRING ? ((s % 3) - s) * 64 * C::CO : 0);
+    // (the ring re-reads LDS addresses an earlier stage read, rewritten in between by DMA
+    // instructions the compiler cannot see through -- it merged stage 3's fragment reads with stage
+    // 0's in this fully unrolled loop, "memory" clobbers notwithstanding: the base goes opaque)
+    if (C::BRING) asm volatile("" : "+v"(Bs));
 #pragma unroll
     for (int c = 0; c < 2; ++c) {   // 32 depth indices: lane (i, q) holds k = 64 s + 32 c + 8 q + t, t < 8
       float bf[8];

@@ -136,7 +136,8 @@ inline int torso_forward_rest(const TorsoBufs& T, int G, int B, const float* con
   return DZ_OK;
 }
 #if DZ_CONV1_DMA
-using Conv1Dma = Conv1DmaCfg<DZ_CONV1_DMA % 10, (DZ_CONV1_DMA / 10) % 10, DZ_CONV1_DMA / 100 ? DZ_CONV1_DMA / 100 : 4>;   // AHEAD * 100 + NRG * 10 + NRB
+using Conv1Dma = Conv1DmaCfg<DZ_CONV1_DMA % 10, (DZ_CONV1_DMA / 10) % 10, (DZ_CONV1_DMA / 100) % 10 ? (DZ_CONV1_DMA / 100) % 10 : 4,
+                             DZ_CONV1_DMA / 1000>;   // BRING * 1000 + AHEAD * 100 + NRG * 10 + NRB
 inline Conv1DmaParams torso_conv1_dma_params(const TorsoBufs& T, int G, int B, const float* const* prm,
                                              const uint8_t* const* in) {
   Conv1DmaParams q;
