@@ -458,8 +458,8 @@ def measure_other_configs(args, device, steps, warmup, prof_steps):
 
 
 def _profile_json(name):
-  """A committed profile table (profiles/r5_<name>.json, else the latest earlier round's)."""
-  for tag in ('r5', 'r4', 'r3', 'r2'):
+  """A committed profile table (profiles/r6_<name>.json, else the latest earlier round's)."""
+  for tag in ('r6', 'r5', 'r4', 'r3', 'r2'):
     try:
       with open(os.path.join(ROOT, 'profiles', '%s_%s.json' % (tag, name))) as f:
         return json.load(f), tag

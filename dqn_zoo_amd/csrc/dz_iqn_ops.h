@@ -205,7 +205,7 @@ struct IqnDgradOp {
       return dz_ld4(p.dy + (long)(t.m0 + row) * p.ldy + (st * CPS + c) * 16 + 4 * q);
     const int m = t.m0 + row, n = (st * CPS + c) * 16 + 4 * q;
     const float* src = p.dy + (long)min(m, p.M - 1) * p.ldy + min(n, p.N - 4);
-    return dz_ld4((m < p.M) & (n < p.N) ? src : dz_page_zero);
+    return dz_ld4(((m < p.M) & (n < p.N)) ? src : dz_page_zero);
   }
   // B tile row = output column k, 4 consecutive reduction indices n
   __device__ static float4 load_b(const Params& p, const Tile& t, int st, int c, int row, int q) {

@@ -22,7 +22,13 @@ constexpr int kMaxS_dfeat = 32;
 constexpr int kMaxS_fc2 = 8;
 // conv weight-gradient split-K counts.  kS_cw3 = 9 makes conv3's backward launch 90 + 162 = 252
 // workgroups: one round on 256 CUs (10 splits = 262 workgroups: 15.6 us; 9: 13.0; 8: 14.3 by events)
-constexpr int kS_cw1 = 50, kS_cw2 = 27, kS_cw3 = 9;   // (re-swept in round 4: 25/34/40/67 x 14/18/22/36 all slower)
+#ifndef DZ_S_CW1
+#define DZ_S_CW1 50
+#endif
+#ifndef DZ_S_CW2
+#define DZ_S_CW2 27
+#endif
+constexpr int kS_cw1 = DZ_S_CW1, kS_cw2 = DZ_S_CW2, kS_cw3 = 9;   // (re-swept in round 4: 25/34/40/67 x 14/18/22/36 all slower)
 constexpr int kNormBlocks = 512;
 constexpr int kNormFinal = 4096;    // fused-norm partials: one per finalize block
 constexpr int kNormSlots = 12288;   // per-wave slots of the weight-gradient kernels
@@ -931,6 +937,7 @@ __device__ __forceinline__ AdamScalars adam_scalars(const float* __restrict__ pa
 // their own streams (adam_fc1_block): `adam_partials_request` issues the loads (at most 16 x 256
 // partials), `adam_scalars_from` is the rest -- identical arithmetic and order.
 constexpr int kAdamPartRounds = 2;   // x 8 loads per thread
+static_assert(kNormFinal <= kAdamPartRounds * 8 * 256, "adam_partials_request covers every fused-norm partial");
 struct AdamPartials { float x[kAdamPartRounds][8]; };
 __device__ __forceinline__ AdamPartials adam_partials_request(const float* __restrict__ part, int nparts) {
   AdamPartials r;
@@ -938,7 +945,7 @@ __device__ __forceinline__ AdamPartials adam_partials_request(const float* __res
   for (int q = 0; q < kAdamPartRounds; ++q)
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      r.x[q][j] = part[min(q * 8 * 256 + j * 256 + (int)threadIdx.x, nparts - 1)];
+      r.x[q][j] = part[max(min(q * 8 * 256 + j * 256 + (int)threadIdx.x, nparts - 1), 0)];   // (nparts == 0: unused)
   return r;
 }
 __device__ __forceinline__ AdamScalars adam_scalars_from(const AdamPartials& r, int nparts,

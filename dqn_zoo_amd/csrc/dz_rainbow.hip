@@ -711,6 +711,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
       rg.lo[1] = (L.fc1_mu_w + mat) >> 2; rg.n[1] = (L.fc1_sig_w - (L.fc1_mu_w + mat)) >> 2;
       rg.lo[2] = (L.fc1_sig_w + mat) >> 2; rg.n[2] = (L.param_count - (L.fc1_sig_w + mat)) >> 2;
       DZ_REQUIRE(!prio_pending);   // (carried by the conv3 backward launch)
+      DZ_REQUIRE(nparts >= 1 && nparts <= kAdamPartRounds * 8 * 256);   // (adam_partials_request's range)
       hipLaunchKernelGGL(adam_onfly_kernel, dim3(adam_onfly_blocks(sgb)), dim3(256), 0, s,
                          a->online, a->grad, a->adam_m, a->adam_v, ws + L.ws_norm_part, nparts,
                          a->adam_count, a->losses, a->weights, B, sc, a->lr, a->b1, a->b2, a->eps,

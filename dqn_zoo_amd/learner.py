@@ -370,6 +370,8 @@ class RainbowLearner:
             enq_stream.synchronize()   # stuck or very slow: the stream the kernel is on decides
             a = words[0, 0]
             break
+          else:
+            time.sleep(0)   # a decision this late (> 2 000 looks) is behind other work: let other threads run
         if a < 0:
           # DZ_ACT_FAILED (a seam of the decision kernel timed out: sticky word set) or the
           # slot was never written: never hand the caller an action
@@ -821,6 +823,8 @@ class DenseLearner:
         elif now > deadline:
           enq_stream.synchronize()   # stuck or very slow: the stream the kernel is on decides
           break
+        elif now > deadline - RainbowLearner.ACT_POLL_SECONDS + 2e-4:
+          time.sleep(0)   # 200 us late: yield the GIL between looks
       if marks.sum() != n_out:
         # a seam of the decision kernel timed out (DZ_ACT_FAILED_MARKER) or outputs never arrived
         owner._reset_act_seams()   # pylint: disable=protected-access
@@ -1004,6 +1008,8 @@ class IqnLearner:
         elif now > deadline:
           enq_stream.synchronize()
           break
+        elif now > deadline - RainbowLearner.ACT_POLL_SECONDS + 2e-4:
+          time.sleep(0)   # 200 us late: yield the GIL between looks
       if not marks.all() or (marks == _lib.ACT_FAILED_MARKER).any():
         owner._reset_act_seams(samples)   # pylint: disable=protected-access
         raise ActDecisionError(

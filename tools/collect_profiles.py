@@ -18,7 +18,7 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r5'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r6'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, 'gpurun_out', tag), os.path.join(root, 'profiles')
 
@@ -26,11 +26,12 @@ src, dst = os.path.join(root, 'gpurun_out', tag), os.path.join(root, 'profiles')
 KERNELS = {
     'adam': 'adam_', 'adam+next_sample': 'adam_',
     'fc1_fwd': 'dz_fc_stream_fwd3', 'fc1_dgrad+wgrad': 'fc1_dgrad_mfma_kernel',
-    'conv1_fwd': 'ConvFwdOp<1, 84', 'conv2_fwd': 'dz_mfma_gemm<ConvFwdOp<0, 20, 20',
-    'conv3_fwd': 'dz_mfma_gemm<ConvFwdOp<0, 9, 9', 'fc2_fwd': 'dz_mfma_gemm<FcFwdOp',
+    # (round 6: the convolutions on the LDS-DMA kernels; conv2's weight gradient rides with conv1's)
+    'conv1_fwd': 'dz_conv1_dma_kernel', 'conv2_fwd': 'dz_conv_dma_fwd_kernel<(anonymous namespace)::ConvDmaCfg<20, 20',
+    'conv3_fwd': 'dz_conv_dma_fwd_kernel<(anonymous namespace)::ConvDmaCfg<9, 9', 'fc2_fwd': 'dz_mfma_gemm<FcFwdOp',
     'fc2_wgrad+dgrad': 'fc2_bwd_rows_kernel', 'head_chain': 'rainbow_head_chain_kernel',
-    'conv3_wgrad+dgrad': 'ConvWgradOp<0, 9, 9', 'conv2_wgrad+dgrad': 'ConvWgradOp<0, 20, 20',
-    'conv1_wgrad': 'dz_mfma_gemm<ConvWgradOp<1, 84', 'head_loss': 'rainbow_head_loss_kernel',
+    'conv3_wgrad+dgrad': 'ConvWgDmaOp<9, 9', 'conv2_dgrad': 'dz_dmaop_kernel<(anonymous namespace)::ConvDgDmaOp<20, 20',
+    'conv_wgrads': 'dz_conv_wgrad3_kernel', 'head_loss': 'rainbow_head_loss_kernel',
     'fc1_epilogue': 'fc_epilogue_kernel',
     'finalize_grads': 'finalize_grads_kernel',
     'sample+gather': 'prioritized_sample_gather_kernel',
@@ -79,7 +80,7 @@ for name in ('kernel_stats_fused.csv', 'kernel_stats_sequential.csv',
              'pmc_double_q_WRITE_SIZE.csv', 'agent_loop_rainbow.json', 'agent_loop_dqn.json',
              'kernel_step_summary_double_q.txt', 'kernel_step_summary_dqn.txt', 'act_decision.txt',
              'head_chain_stamps.txt', 'agent_loop_iqn.json', 'kernel_step_summary_separate_launches.txt',
-             'iqn_step_launches.txt', 'pmc_sq_iqn.txt', 'dense_c51_qr_steps.txt'):
+             'iqn_step_launches.txt', 'pmc_sq_iqn.txt', 'dense_c51_qr_steps.txt', 'kernel_step_summary_a18.txt'):
   p = os.path.join(src, name)
   if os.path.exists(p):
     shutil.copy(p, os.path.join(dst, '%s_%s' % (tag, name)))
@@ -109,7 +110,8 @@ doc = {
     'fetch_calibration': factors, 'kernels': {}}
 pattern_of = {'adam': 'float4_flat', 'fc1_fwd': 'dword_per_lane',
               'fc1_dgrad+wgrad': 'float4_flat'}
-for key in ('adam', 'fc1_fwd', 'fc1_dgrad+wgrad', 'conv1_fwd', 'conv2_fwd', 'conv3_fwd', 'head_chain'):
+for key in ('adam', 'fc1_fwd', 'fc1_dgrad+wgrad', 'conv1_fwd', 'conv2_fwd', 'conv3_fwd', 'head_chain',
+            'conv3_wgrad+dgrad', 'conv2_dgrad', 'conv_wgrads'):
   f, w = find(fetch, KERNELS[key]), find(write, KERNELS[key])
   if f is None or w is None:
     continue

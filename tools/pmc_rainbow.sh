@@ -10,7 +10,7 @@ import csv, sys
 from collections import defaultdict
 d = defaultdict(lambda: defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-  d[r['Kernel_Name'][:70]][r['Counter_Name']].append(float(r['Counter_Value']))
+  d[r['Kernel_Name'][:125]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, c in sorted(d.items()):
   if 'at::' in k or 'rocclr' in k: continue
   print(k.replace('(anonymous namespace)::', ''), {n: int(sorted(v)[len(v) // 2]) for n, v in c.items()})

@@ -7,7 +7,7 @@
 # Outputs under gpurun_out/<tag>/ (python tools/collect_profiles.py <tag> copies the
 # summaries into profiles/).
 ulimit -c 0
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -82,6 +82,12 @@ fi
 # the one-launch decision: parity print-out, back-to-back and per-decision latency, kernel durations
 bash $R/tools/act_prof.sh > $OUT/act_decision.txt 2>&1
 bash $R/tools/dense_trace.sh 200 > $OUT/kernel_step_summary_double_q.txt 2>&1
+# the headline's step with the 18-action head: per-kernel averages of its loop
+rm -rf $OUT/kt
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python $R/tools/run_rainbow_actions.py 18 400 > $OUT/kt_a18.log 2>&1 < /dev/null
+t=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
+[ -n "$t" ] && python $R/tools/step_trace_summary.py "$t" 200 > $OUT/kernel_step_summary_a18.txt 2>&1
+rm -rf $OUT/kt
 bash $R/tools/pmc_rainbow.sh > $OUT/pmc_sq_rainbow.txt 2>&1
 # the IQN learner step: HIP-event duration of every launch, un-profiled step time, SQ counters
 (timeout 150 python $R/tools/iqn_probe.py prof; timeout 150 python $R/tools/iqn_probe.py time) 2>&1 | grep -v amdgpu.ids > $OUT/iqn_step_launches.txt
