@@ -154,16 +154,27 @@ def make_step(replay, learner, batch, fused_write_back=True, fused_next_sample=F
   fused_next_sample: the replay is static between steps, so sample(k+1) + gather(k+1)
   ride in step k's optimiser launch (after write-back(k), which moves into an earlier
   backward launch): same operations, same order, one launch fewer on the chain."""
-  primed = [False]
+  # Host work of the loop, in program order per step: ENQUEUE the step, then make the host RNG draws
+  # and the descriptor of the sample the NEXT step's launch will carry.  (Round 5 prepared the
+  # descriptor in front of the enqueue: the same work per step, but after the mandatory
+  # synchronize() the first timed step then started ~20 us of NumPy later than it had to.)  The
+  # draws are consumed in the reference's order either way: sample k + 1's before sample k + 2's.
+  pend = {}
 
   def step_fused():
-    # (take_prepared() refuses a batch prepared before the replay changed)
-    s = replay.take_prepared() if primed[0] else replay.sample_device(batch)
+    if not pend:
+      s = replay.sample_device(batch)
+      desc, nxt = replay.prepare_next_sample(batch)
+    else:
+      s, desc, nxt = pend['s'], pend['desc'], pend['nxt']
+      if pend['t'] != replay.insertions:   # (what take_prepared() checks)
+        raise RuntimeError('the replay changed between prepare_next_sample and its use')
     t = s.transitions
-    desc, _ = replay.prepare_next_sample(batch)
-    primed[0] = True
     learner.step(t.s_tm1, t.a_tm1, t.r_t, t.discount_t, t.s_t, s.weights32,
                  priority_sink=replay.priority_sink(s.ids), next_sample=desc)
+    # the batch `desc` described exists once this step has run; the one after it is described now
+    d2, n2 = replay.prepare_next_sample(batch)
+    pend.update(s=nxt, desc=d2, nxt=n2, t=replay.insertions)
 
   if fused_next_sample:
     return step_fused

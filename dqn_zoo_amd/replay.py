@@ -351,6 +351,12 @@ class _ReplayBase(Generic[ReplayStructure]):
   def capacity(self) -> int:
     return self._capacity
 
+  @property
+  def insertions(self) -> int:
+    """Total number of items ever added (the reference's `_t`): a prepared sample
+    (`prepare_next_sample`) is valid exactly while this has not moved."""
+    return self._t
+
   def ids(self) -> Iterable[int]:
     """IDs of stored items, oldest first (ref: replay.py:165-167)."""
     return range(self._t - self._size, self._t)
