@@ -229,12 +229,14 @@ def kernel_work(b, a=NUM_ACTIONS, k=NUM_ATOMS):
   w['conv2_wgrad+dgrad'] = (f(512, 64, b * 81) + f(b * 400, 32, 256),
                             2 * b * (12800 + 5184) * 4)
   w['conv1_wgrad'] = (f(256, 32, b * 400), b * 28224 + b * 12800 * 4)
-  # round 6: the conv3 / conv2 launches carry the input gradient only; the three weight gradients
-  # share the chain's last launch
+  # round 6: the conv3 / conv2 launches carry the input gradient only; conv1's and conv2's weight
+  # gradients share the chain's last launch (conv3's stays with its input gradient)
   w['conv3_dgrad'] = (f(b * 81, 64, 576), b * (5184 + 3136) * 4)
   w['conv2_dgrad'] = (f(b * 400, 32, 256), b * (12800 + 5184) * 4)
-  w['conv_wgrads'] = (f(576, 64, b * 49) + f(512, 64, b * 81) + f(256, 32, b * 400),
-                      b * (5184 + 3136) * 4 + b * (12800 + 5184) * 4 + b * 28224 + b * 12800 * 4)
+  w['conv_wgrads'] = (f(512, 64, b * 81) + f(256, 32, b * 400),       # conv2's + conv1's (the shipped cut)
+                      b * (12800 + 5184) * 4 + b * 28224 + b * 12800 * 4)
+  w['conv_wgrads3'] = (f(576, 64, b * 49) + w['conv_wgrads'][0],       # ... + conv3's (DZ_CONV_BWD_SPLIT 1)
+                       b * (5184 + 3136) * 4 + w['conv_wgrads'][1])
   # SURVEY.md 8d's figure: read g,p,m,v; write p,m,v.  (The launch itself moves less: it
   # forms fc1's 2 x 3.2 M gradient entries from L2-resident factors instead of reading
   # them -- ADAM_BYTES_MOVED, reported next to `achieved` as `achieved_moved`.)
@@ -274,8 +276,10 @@ def dense_kernel_work(b, g, a=NUM_ACTIONS):
   w['conv1_wgrad'] = (f(256, 32, b * 400), b * 28224 + b * 12800 * 4)
   w['conv3_dgrad'] = (f(b * 81, 64, 576), b * (5184 + 3136) * 4)
   w['conv2_dgrad'] = (f(b * 400, 32, 256), b * (12800 + 5184) * 4)
-  w['conv_wgrads'] = (f(576, 64, b * 49) + f(512, 64, b * 81) + f(256, 32, b * 400),
-                      b * (5184 + 3136) * 4 + b * (12800 + 5184) * 4 + b * 28224 + b * 12800 * 4)
+  w['conv_wgrads'] = (f(512, 64, b * 81) + f(256, 32, b * 400),       # conv2's + conv1's (the shipped cut)
+                      b * (12800 + 5184) * 4 + b * 28224 + b * 12800 * 4)
+  w['conv_wgrads3'] = (f(576, 64, b * 49) + w['conv_wgrads'][0],       # ... + conv3's (DZ_CONV_BWD_SPLIT 1)
+                       b * (5184 + 3136) * 4 + w['conv_wgrads'][1])
   w['rmsprop'] = (0.0, 7.0 * p_ref * 4)  # read g,p,mu,nu; write p,mu,nu
   w['finalize+rmsprop'] = w['rmsprop']   # RMSProp rides in the finalize launch (+ the next sample in fused mode)
   return w

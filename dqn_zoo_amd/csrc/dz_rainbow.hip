@@ -639,7 +639,7 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
         rc = launch_conv1_wgrad(p, s, &wg_defer);
       }
       if (rc) return rc;
-      DZ_PROF(s, wg_defer.on2 ? "conv_wgrads" : "conv1_wgrad");
+      DZ_PROF(s, wg_defer.on3 ? "conv_wgrads3" : wg_defer.on2 ? "conv_wgrads" : "conv1_wgrad");
     }
     {  // reduce the three conv partial slabs; linear-layer bias gradients
       FinalizeJobs J;

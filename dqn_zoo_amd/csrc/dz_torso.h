@@ -355,7 +355,7 @@ inline int torso_backward(const TorsoBufs& T, int B, const float* online,
     p.in = s_tm1; p.dy = dact1; p.part = part1; p.B = B; p.S = kS_cw1;
     rc = launch_conv1_wgrad(p, s, &defer);
     if (rc) return rc;
-    DZ_PROF(s, defer.on2 ? "conv_wgrads" : "conv1_wgrad");
+    DZ_PROF(s, defer.on3 ? "conv_wgrads3" : defer.on2 ? "conv_wgrads" : "conv1_wgrad");
   }
   jobs[0] = {part1, kS_cw1, (long)Conv1Wg::KROWS * 32, grad + T.conv_w[0]};
   jobs[1] = {part2, kS_cw2, (long)Conv2Wg::KROWS * 64, grad + T.conv_w[1]};
