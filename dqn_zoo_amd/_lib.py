@@ -177,9 +177,25 @@ SC_CHAIN_FAIL = 6
 PHASE_FORWARD, PHASE_BACKWARD, PHASE_OPTIMIZER, PHASE_ALL = 1, 2, 4, 7
 PHASE_FWD_NETS, PHASE_FWD_LOSS = 8, 16   # the two halves of PHASE_FORWARD
 
+class ReplayInsertArgs(ctypes.Structure):
+  """dz_replay_insert_args_t."""
+  _fields_ = [('fields', ctypes.POINTER(InsertField)), ('num_fields', c_i32), ('reserved', c_i32),
+              ('t', c_i64), ('capacity', c_i64), ('node', c_vp), ('cap_pow2', c_i64),
+              ('priority_h', c_f64), ('priority_d', c_vp), ('exponent', c_f64), ('status', c_vp)]
+
+
+class RainbowActArgs(ctypes.Structure):
+  """dz_rainbow_act_args_t."""
+  _fields_ = [('num_actions', c_i32), ('num_atoms', c_i32), ('batch', c_i32), ('reserved', c_i32),
+              ('params', c_vp), ('states', c_vp), ('noise', c_vp),
+              ('noise_seed', ctypes.c_uint64), ('noise_counter', ctypes.c_uint64),
+              ('step_counter', c_vp), ('support', c_vp), ('ws', c_vp), ('q_values_out', c_vp),
+              ('greedy_out', c_vp), ('vmax_out', c_vp)]
+
+
 STRUCT_IDS = {0: FieldDesc, 1: PrioSampleArgs, 2: RainbowLayout, 3: RainbowArgs,
               4: DenseLayout, 5: DenseArgs, 6: IqnLayout, 7: IqnArgs,
-              8: InsertField, 9: NextSample}
+              8: InsertField, 9: NextSample, 10: ReplayInsertArgs, 11: RainbowActArgs}
 
 # name -> (restype, argtypes).  tests/test_abi.py checks this table against
 # the prototypes in include/dqnzoo_hip.h and against the built library.
@@ -232,6 +248,9 @@ SIGNATURES = {
                                          c_i64, c_i64, c_i64, c_vp, c_vp]),
     'dz_replay_insert': (c_int, [ctypes.POINTER(InsertField), c_int, c_i64, c_i64,
                                  c_vp, c_i64, c_f64, c_vp, c_f64, c_vp, c_vp]),
+    'dz_replay_insert_v': (c_int, [ctypes.POINTER(ReplayInsertArgs), c_vp]),
+    'dz_sample_gather_desc': (c_int, [ctypes.POINTER(NextSample), c_vp]),
+    'dz_rainbow_act_v': (c_int, [ctypes.POINTER(RainbowActArgs), c_vp]),
     'dz_uniform_pos_to_id': (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp,
                                      c_vp]),
     'dz_sumtree_set': (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_vp,

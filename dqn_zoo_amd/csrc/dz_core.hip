@@ -28,12 +28,15 @@ extern "C" int dz_struct_size(int which) {
     case 7: return (int)sizeof(dz_iqn_args_t);
     case 8: return (int)sizeof(dz_insert_field_t);
     case 9: return (int)sizeof(dz_next_sample_t);
+    case 10: return (int)sizeof(dz_replay_insert_args_t);
+    case 11: return (int)sizeof(dz_rainbow_act_args_t);
     default: return -1;
   }
 }
 
 // ---- event profiler ----------------------------------------------------------
 #include <string.h>
+#include <time.h>
 bool g_dz_prof_on = false;
 namespace {
 constexpr int kMaxMarks = 96;
@@ -41,16 +44,27 @@ hipEvent_t g_ev[kMaxMarks + 1];
 const char* g_names[kMaxMarks];
 int g_nmarks = 0;
 bool g_ev_created = false;
+// dz_prof_enable(2): the marks take the HOST's clock instead of recording events -- what the
+// enqueue of each launch costs the calling thread (tools/window_events.py)
+bool g_host_clock = false;
+long long g_host_ns[kMaxMarks + 1];
+long long host_ns() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
 }  // namespace
 
 void dz_prof_begin(hipStream_t s) {
   g_nmarks = 0;
+  if (g_host_clock) { g_host_ns[0] = host_ns(); return; }
   (void)hipEventRecord(g_ev[0], s);
 }
 void dz_prof_mark(hipStream_t s, const char* name) {
   if (g_nmarks >= kMaxMarks) return;
   g_names[g_nmarks] = name;
-  (void)hipEventRecord(g_ev[g_nmarks + 1], s);
+  if (g_host_clock) g_host_ns[g_nmarks + 1] = host_ns();
+  else (void)hipEventRecord(g_ev[g_nmarks + 1], s);
   ++g_nmarks;
 }
 // Replay entry points (0 sample, 1 gather, 2 priority update): an event pair
@@ -79,6 +93,7 @@ extern "C" int dz_prof_enable(int on) {
     g_ev_created = true;
   }
   g_dz_prof_on = on != 0;
+  g_host_clock = on == 2;
   g_nmarks = 0;
   return DZ_OK;
 }
@@ -87,7 +102,8 @@ extern "C" int dz_prof_read(int max_marks, float* ms_out, char* names_out) {
   const int n = g_nmarks < max_marks ? g_nmarks : max_marks;
   for (int i = 0; i < n; ++i) {
     float ms = 0.f;
-    DZ_HIP_CHECK(hipEventElapsedTime(&ms, g_ev[i], g_ev[i + 1]));
+    if (g_host_clock) ms = (float)(g_host_ns[i + 1] - g_host_ns[i]) * 1e-6f;
+    else DZ_HIP_CHECK(hipEventElapsedTime(&ms, g_ev[i], g_ev[i + 1]));
     ms_out[i] = ms;
     strncpy(names_out + 32 * i, g_names[i], 31);
     names_out[32 * i + 31] = 0;

@@ -838,6 +838,18 @@ extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const f
                               uint64_t noise_counter, int32_t* step_counter,
                               const float* support, float* ws,
                               float* q_values_out, int32_t* greedy_out, float* vmax_out,
+                              dz_stream_t stream);
+extern "C" int dz_rainbow_act_v(const dz_rainbow_act_args_t* a, dz_stream_t stream) {
+  DZ_REQUIRE(a);
+  return dz_rainbow_act(a->num_actions, a->num_atoms, a->batch, a->params, a->states, a->noise,
+                        a->noise_seed, a->noise_counter, a->step_counter, a->support, a->ws,
+                        a->q_values_out, a->greedy_out, a->vmax_out, stream);
+}
+extern "C" int dz_rainbow_act(int num_actions, int num_atoms, int batch, const float* params,
+                              const uint8_t* states, float* noise, uint64_t noise_seed,
+                              uint64_t noise_counter, int32_t* step_counter,
+                              const float* support, float* ws,
+                              float* q_values_out, int32_t* greedy_out, float* vmax_out,
                               dz_stream_t stream) {
   DZ_REQUIRE(params && states && noise && support && ws && q_values_out);
   dz_rainbow_layout_t L;

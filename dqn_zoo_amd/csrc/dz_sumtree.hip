@@ -304,6 +304,12 @@ extern "C" int dz_prioritized_sample_gather(
   return DZ_OK;
 }
 
+extern "C" int dz_sample_gather_desc(const dz_next_sample_t* d, dz_stream_t stream) {
+  DZ_REQUIRE(d);
+  return dz_prioritized_sample_gather(&d->args, d->n, d->pos_h, d->u_target_h, d->u_mix_h, d->fields,
+                                      d->num_fields, d->ids_out, d->probs_out, d->weights_out,
+                                      d->weights32_out, d->status, stream);
+}
 extern "C" int dz_prioritized_update(double* node, int64_t cap_pow2,
                                      int64_t capacity, int64_t size, int64_t t,
                                      const int64_t* ids, const void* priorities,
@@ -344,6 +350,15 @@ extern "C" int dz_prioritized_add(double* node, int64_t cap_pow2,
   return DZ_OK;
 }
 
+extern "C" int dz_replay_insert(const dz_insert_field_t* fields, int num_fields, int64_t t,
+                                int64_t capacity, double* node, int64_t cap_pow2,
+                                double priority_h, const double* priority_d,
+                                double exponent, uint32_t* status, dz_stream_t stream);
+extern "C" int dz_replay_insert_v(const dz_replay_insert_args_t* a, dz_stream_t stream) {
+  DZ_REQUIRE(a);
+  return dz_replay_insert(a->fields, a->num_fields, a->t, a->capacity, a->node, a->cap_pow2,
+                          a->priority_h, a->priority_d, a->exponent, a->status, stream);
+}
 extern "C" int dz_replay_insert(const dz_insert_field_t* fields, int num_fields, int64_t t,
                                 int64_t capacity, double* node, int64_t cap_pow2,
                                 double priority_h, const double* priority_d,

@@ -68,6 +68,11 @@ class DenseAgent(parts.Agent):
         network, self.LOSS, optimizer, batch_size,
         grad_error_bound=grad_error_bound, huber_param=huber_param,
         seed=int(rng_key), device=replay._device)  # pylint: disable=protected-access
+    # The learner step is enqueued eagerly: a frame that learns is GPU-bound (the decision kernel
+    # covers the host's enqueue time) and a hipGraph replay of the same launches runs 3-6 % slower
+    # on the device -- measured on the drop-in loop: Rainbow +3 %, DQN +4.5 %, IQN +2.5 % agent
+    # steps/s against graph replay (EXPERIMENTS.md R6-15).  `learner.use_graphs = True` replays.
+    self._learner.use_graphs = False
     self._device = self._learner.device
     self._policy_rng = np.random.RandomState(int(rng_key) % (2 ** 32))
     self._action = None

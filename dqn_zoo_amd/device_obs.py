@@ -48,6 +48,7 @@ def depth_for(accumulator, floor: int = 8) -> int:
 
 
 UNKNOWN_WINDOW_DEPTH = 64
+_TRANSITION_FIELDS = ('s_tm1', 'a_tm1', 'r_t', 'discount_t', 's_t')
 
 
 class ObservationCache:
@@ -57,8 +58,11 @@ class ObservationCache:
     self._pin = torch.empty((depth,) + tuple(shape), dtype=torch.uint8,
                             pin_memory=True)
     self._pin_np = self._pin.numpy()
+    self._pin_rows = [self._pin[k] for k in range(depth)]   # (the same tensor objects every frame)
+    self._pin_batches = [self._pin[k:k + 1] for k in range(depth)]
     self._host = [None] * depth
     self._ext = [None] * depth   # device tensors handed in as observations
+    self._slot_of = {}           # id(observation) -> slot (checked with `is`: ids are recycled)
     self._pos = 0
 
   def upload(self, observation) -> torch.Tensor:
@@ -69,6 +73,10 @@ class ObservationCache:
     behind them reads slots at most n + 1 frames old (`depth_for`)."""
     k = self._pos % self._depth
     self._pos += 1
+    old = self._host[k]
+    if old is not None and self._slot_of.get(id(old)) == k:
+      del self._slot_of[id(old)]
+    self._slot_of[id(observation)] = k
     if isinstance(observation, torch.Tensor):
       # already in HBM (processors.atari(device_observations=True)): no copy at
       # all; remembered by identity so that the replay insert finds it too
@@ -85,18 +93,23 @@ class ObservationCache:
     # pinned copy plus an async H2D memcpy launch (~12 us of host time per frame
     # during which the GPU had nothing to do)
     np.copyto(self._pin_np[k], observation, casting='same_kind')
-    return self._pin[k:k + 1]
+    return self._pin_batches[k]
 
   def lookup(self, observation):
-    for k in range(self._depth):
-      if self._host[k] is observation:
-        return self._pin[k] if self._ext[k] is None else self._ext[k]
-    return None
+    k = self._slot_of.get(id(observation))
+    if k is None or self._host[k] is not observation:
+      return None
+    e = self._ext[k]
+    return self._pin_rows[k] if e is None else e
 
   def on_device(self, transition):
     """The transition with `s_tm1` / `s_t` replaced by their device copies
     where the cache holds them."""
     a, b = self.lookup(transition.s_tm1), self.lookup(transition.s_t)
+    if transition._fields == _TRANSITION_FIELDS:   # one construction instead of two `_replace`s
+      return type(transition)(transition.s_tm1 if a is None else a, np.int64(transition.a_tm1),
+                              np.float64(transition.r_t), np.float64(transition.discount_t),
+                              transition.s_t if b is None else b)
     return canonical_scalars(transition)._replace(
         s_tm1=transition.s_tm1 if a is None else a,
         s_t=transition.s_t if b is None else b)
@@ -104,3 +117,4 @@ class ObservationCache:
   def clear(self) -> None:
     self._host = [None] * self._depth
     self._ext = [None] * self._depth
+    self._slot_of = {}

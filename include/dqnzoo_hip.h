@@ -55,7 +55,8 @@ const char* dz_built_arch(void);
 /* sizeof() of the ABI structs as the library was compiled, so that a binding
  * can verify its mirror: 0 dz_field_t, 1 dz_prio_sample_args_t,
  * 2 dz_rainbow_layout_t, 3 dz_rainbow_args_t, 4 dz_dense_layout_t, 9 dz_next_sample_t,
- * 5 dz_dense_args_t, 6 dz_iqn_layout_t, 7 dz_iqn_args_t, 8 dz_insert_field_t.
+ * 5 dz_dense_args_t, 6 dz_iqn_layout_t, 7 dz_iqn_args_t, 8 dz_insert_field_t,
+ * 10 dz_replay_insert_args_t, 11 dz_rainbow_act_args_t.
  * -1 for an unknown id.                                                      */
 int dz_struct_size(int which);
 
@@ -107,6 +108,24 @@ int dz_replay_insert(const dz_insert_field_t* fields, int num_fields, int64_t t,
                      int64_t capacity, double* node, int64_t cap_pow2,
                      double priority_h, const double* priority_d, double exponent,
                      uint32_t* status, dz_stream_t stream);
+
+/* dz_replay_insert with its arguments in a struct the caller keeps and patches (`t`, the
+ * fields' src_row / imm): for bindings that pay per marshalled argument (ctypes: ~0.15 us
+ * each -- the agents' loop inserts once per frame).  Same launch, same checks.            */
+typedef struct {
+  const dz_insert_field_t* fields;
+  int32_t num_fields;
+  int32_t reserved;
+  int64_t t;
+  int64_t capacity;
+  double* node;
+  int64_t cap_pow2;
+  double priority_h;
+  const double* priority_d;
+  double exponent;
+  uint32_t* status;
+} dz_replay_insert_args_t;
+int dz_replay_insert_v(const dz_replay_insert_args_t* args, dz_stream_t stream);
 
 /* Position -> id map of the reference's swap-remove id list under its only
  * usage pattern (one add at a time, evict oldest): closed form verified against
@@ -207,6 +226,12 @@ int dz_prioritized_sample_gather(
     int num_fields, int64_t* ids_out, double* probs_out, double* weights_out,
     float* weights32_out, uint32_t* status, dz_stream_t stream);
 
+/* dz_prioritized_sample_gather with its arguments in the descriptor a learner step can also
+ * carry (dz_next_sample_t, declared with dz_rainbow_args_t below): a binding keeps one per
+ * output slot and patches `args` per call.                                               */
+struct dz_next_sample;
+int dz_sample_gather_desc(const struct dz_next_sample* desc, dz_stream_t stream);
+
 /* leaf(id) = power_zero_safe(priority, exponent) for each id, then SumTree.set.
  * `prio_is_f32`: priorities are float32 and -- as NumPy does for an f32 array
  * raised to a Python-float exponent -- the power is evaluated in float32.
@@ -284,7 +309,7 @@ int dz_rainbow_layout(int num_actions, int num_atoms, int batch,
 /* The NEXT step's replay sample, carried by a learner step (dz_rainbow_args_t::
  * next_sample): exactly the arguments of dz_prioritized_sample_gather.  The draws
  * are HOST arrays (n each), copied into the kernel arguments at enqueue time.     */
-typedef struct {
+typedef struct dz_next_sample {
   dz_prio_sample_args_t args;
   const int64_t* pos_h;
   const double* u_target_h;
@@ -427,6 +452,23 @@ int dz_rainbow_act(int num_actions, int num_atoms, int batch, const float* param
                    const float* support, float* ws,
                    float* q_values_out, int32_t* greedy_out, float* vmax_out,
                    dz_stream_t stream);
+
+/* dz_rainbow_act with its arguments in a struct the caller fills once per (observation slot,
+ * result slot): the agent's per-frame decision is then a two-argument call.                */
+typedef struct {
+  int32_t num_actions, num_atoms, batch, reserved;
+  const float* params;
+  const uint8_t* states;
+  float* noise;
+  uint64_t noise_seed, noise_counter;
+  int32_t* step_counter;
+  const float* support;
+  float* ws;
+  float* q_values_out;
+  int32_t* greedy_out;
+  float* vmax_out;
+} dz_rainbow_act_args_t;
+int dz_rainbow_act_v(const dz_rainbow_act_args_t* args, dz_stream_t stream);
 
 /* Test hook of the one-launch decision kernels (dz_rainbow_act batch 1, dz_dense_act):
  * sets the number of polling rounds a workgroup spends on an empty seam before it gives up
@@ -656,7 +698,10 @@ int dz_uniform_fill(float* out, int64_t n, uint64_t seed, uint64_t counter,
  * dz_prof_read (call after synchronising the stream) returns the number of
  * marks of the LAST learn call and writes, per mark, the elapsed milliseconds
  * since the previous event and a NUL-terminated name of at most 31 chars
- * (names_out: max_marks * 32 bytes).  Used by bench.py for `roofline`.       */
+ * (names_out: max_marks * 32 bytes).  Used by bench.py for `roofline`.
+ * dz_prof_enable(2): the marks take the calling thread's monotonic clock instead of
+ * recording events -- dz_prof_read then returns what the ENQUEUE of each launch cost
+ * the host (no synchronisation needed; tools/window_events.py).               */
 int dz_prof_enable(int on);
 int dz_prof_read(int max_marks, float* ms_out, char* names_out);
 /* With timing enabled, dz_prioritized_sample (0), dz_replay_gather (1) and

@@ -185,3 +185,15 @@ def test_observation_cache_depth_follows_the_n_step_window():
 
   assert device_obs.depth_for(Wrapper(replay_lib.NStepTransitionAccumulator(9))) == \
       device_obs.UNKNOWN_WINDOW_DEPTH
+
+
+def test_random_sample_is_uniform_bit_for_bit():
+  """`sample_device` / `prepare_next_sample` draw their float64 uniforms with
+  `RandomState.random_sample(n)`; the reference calls `uniform(size=n)` (replay.py:551-566).
+  The two are the same doubles (0.0 + 1.0 * x) from the same stream positions."""
+  a, b = np.random.RandomState(11), np.random.RandomState(11)
+  for n in (1, 7, 32, 64, 257):
+    assert a.randint(1000, size=n).tobytes() == b.randint(1000, size=n).tobytes()
+    assert a.uniform(size=n).tobytes() == b.random_sample(n).tobytes()
+    assert a.uniform(size=n).tobytes() == b.random_sample(n).tobytes()
+  assert a.randint(10 ** 9) == b.randint(10 ** 9)

@@ -28,8 +28,8 @@ def main():
 
 def instrument(ag, rep, which, acc):
   add_name = 'add_with_device_priority' if which == 'rainbow' else 'add'
-  if 'eager-learn' in sys.argv[3:]:
-    ag._learner.use_graphs = False   # learner launches eager, acting applies still from graphs  # pylint: disable=protected-access
+  if 'graph-learn' in sys.argv[3:]:
+    ag._learner.use_graphs = True   # learner step replayed from a hipGraph (the agents' default is eager)  # pylint: disable=protected-access
   def wrap(obj, name, key):
     f = getattr(obj, name)
     def g(*a, **k):
