@@ -98,6 +98,41 @@ def test_iqn_step(b, samples):
   assert int(ln.opt_count.item()) == 1
 
 
+@pytest.mark.parametrize('feat_scale', [1e-12, 1e-25])
+def test_iqn_mix_backward_with_tiny_features(feat_scale):
+  """The learner does not store the tau embedding's activation: the backward of the mix
+  `head_in = temb * feat` recovers `temb` from `head_in / feat` and takes its ReLU mask from
+  `head_in > 0` (numerics note).  With the torso's output scaled down
+  to ~1e-12 / ~1e-25 (and fc1 scaled up by as much, so that everything downstream stays O(1)) the
+  products `temb * feat` are still normal float32 numbers and the recovered gradients -- the
+  embedding's weight and bias gradient and, through dfeat, every torso gradient -- agree with
+  the float64 truth computed the reference's way (sum dhin * temb) as they do at ordinary
+  magnitudes."""
+  from dqn_zoo_amd import _lib
+  b, samples = 8, (16, 8, 24)
+  rs, online, target, ln, taus = _make(b, samples, 77)
+  for p in (online, target):
+    p['conv3/w'] = (p['conv3/w'] * feat_scale).astype(np.float32)
+    p['conv3/b'] = (np.abs(p['conv3/b']) * feat_scale + feat_scale).astype(np.float32)   # (keeps most features alive)
+    p['fc1/w'] = (p['fc1/w'] / feat_scale).astype(np.float32)
+  ln.set_params(online, 'online')
+  ln.set_params(target, 'target')
+  batch = _batch(rs, b, scale_r=2.0)
+  ln.step(*_dev(batch), taus=_dev(taus), phases=_lib.PHASE_FORWARD | _lib.PHASE_BACKWARD)
+  torch.cuda.synchronize()
+  _, losses, g32, aux = qo.iqn_loss_and_grads(online, target, batch, taus, 1.0)
+  np.testing.assert_allclose(ln.losses.cpu().numpy(), losses, rtol=2e-5, atol=1e-7)
+  _, _, g64, _ = qo.iqn_loss_and_grads(_f64(online), _f64(target), batch,
+                                       [t.astype(np.float64) for t in taus], 1.0, np.float64)
+  g_dev = ln.layout.unpack(ln.grad.cpu().numpy())
+  for k in sorted(g64):
+    scale = np.abs(g64[k]).max()
+    assert scale > 0, k
+    e_dev = np.abs(g_dev[k].astype(np.float64) - g64[k]).max() / scale
+    e_orc = np.abs(g32[k].astype(np.float64) - g64[k]).max() / scale
+    assert e_dev < max(2e-4, 4 * e_orc), (k, feat_scale, e_dev, e_orc)
+
+
 def test_iqn_apply_and_tau_draws():
   from dqn_zoo_amd import _lib
   rs, online, target, ln, _ = _make(4, (8, 8, 8), 77)
