@@ -74,29 +74,54 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
   // streams' first tiles arrive, instead of behind them (vector loads return in order; same
   // box 6 603-6 625 -> 6 645-6 665 steps/s)
   const AdamPartials parts = adam_partials_request(part, nparts);
-  {  // LDS fill first (its staging registers die before the streams are requested):
-     // dh1 strip [32][C], X tile [R][32 (+4)], the strip's eps_out and the rows' eps_in
+#ifndef DZ_OF_EARLY
+#define DZ_OF_EARLY 0
+#endif
+#ifndef DZ_OF_AHEAD   // the next rows of the six streams are requested BEFORE this iteration's arithmetic (round 6)
+#define DZ_OF_AHEAD 1
+#endif
+  unsigned om = q.mu_b + ((unsigned)(k0 + rl) * (unsigned)q.ld + (unsigned)col) * 4u;
+  unsigned os = q.sig_b + ((unsigned)(k0 + rl) * (unsigned)q.ld + (unsigned)col) * 4u;
+  float4 pm, mm, vm, ps, ms, vs;
+  {  // LDS fill: dh1 strip [32][C], X tile [R][32 (+4)], the strip's eps_out and the rows' eps_in.
+     // DZ_OF_EARLY: the factors are REQUESTED, then the six streams' first rows, and only then are
+     // the factors written to LDS (vmcnt counts in order: that wait leaves the streams in flight) --
+     // otherwise the streams start one cold round trip late.
+    float4 dreg[C / 32];
+    float freg[(32 * T::R + 255) / 256];
 #pragma unroll
     for (int i = 0; i < C / 32; ++i) {
       const int e = tid + 256 * i, b = e / T::TPR, cc = e % T::TPR;
-      const float4 d = *(const float4*)(q.dh1 + (unsigned)(min(b, q.B - 1) * 1024 + c0 + 4 * cc));
-      *(float4*)(s_dh1 + b * C + 4 * cc) = b < q.B ? d : dz_f4zero();
+      dreg[i] = *(const float4*)(q.dh1 + (unsigned)(min(b, q.B - 1) * 1024 + c0 + 4 * cc));
+    }
+#pragma unroll
+    for (int i = 0; i < (32 * T::R + 255) / 256; ++i) {
+      const int e = min(tid + 256 * i, 32 * T::R - 1), b = e / T::R, r = e % T::R;
+      freg[i] = q.feat[(unsigned)(min(b, q.B - 1) * kFlat + k0 + r)];
+    }
+    const float ereg = tid < C ? q.eps_out[c0 + tid] : ein[k0 + min(tid - C, T::R - 1)];
+#if DZ_OF_EARLY
+    __builtin_amdgcn_sched_barrier(0);
+    pm = ld_off(p, om); mm = ld_off(m, om); vm = ld_off(v, om);
+    ps = ld_off(p, os); ms = ld_off(m, os); vs = ld_off(v, os);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int i = 0; i < C / 32; ++i) {
+      const int e = tid + 256 * i, b = e / T::TPR, cc = e % T::TPR;
+      *(float4*)(s_dh1 + b * C + 4 * cc) = b < q.B ? dreg[i] : dz_f4zero();
     }
 #pragma unroll
     for (int i = 0; i < (32 * T::R + 255) / 256; ++i) {
       const int e = tid + 256 * i, b = e / T::R, r = e % T::R;
-      if (e < 32 * T::R) {
-        const float f = q.feat[(unsigned)(min(b, q.B - 1) * kFlat + k0 + r)];
-        s_ft[r * T::FS + b] = b < q.B ? f : 0.f;
-      }
+      if (e < 32 * T::R) s_ft[r * T::FS + b] = b < q.B ? freg[i] : 0.f;
     }
-    if (tid < C) s_eo[tid] = q.eps_out[c0 + tid];
-    else if (tid < C + T::R) s_eo[tid] = ein[k0 + tid - C];
+    if (tid < C + T::R) s_eo[tid] = ereg;
   }
-  unsigned om = q.mu_b + ((unsigned)(k0 + rl) * (unsigned)q.ld + (unsigned)col) * 4u;
-  unsigned os = q.sig_b + ((unsigned)(k0 + rl) * (unsigned)q.ld + (unsigned)col) * 4u;
-  float4 pm = ld_off(p, om), mm = ld_off(m, om), vm = ld_off(v, om);
-  float4 ps = ld_off(p, os), ms = ld_off(m, os), vs = ld_off(v, os);
+#if !DZ_OF_EARLY
+  pm = ld_off(p, om); mm = ld_off(m, om); vm = ld_off(v, om);
+  ps = ld_off(p, os); ms = ld_off(m, os); vs = ld_off(v, os);
+#endif
   const AdamScalars sc0 = adam_scalars_from(parts, nparts, count, b1, b2, max_norm, red);  // (syncs)
   const float gn = dz_sgpr(sc0.gn), bc1 = dz_sgpr(sc0.bc1), bc2 = dz_sgpr(sc0.bc2);
   const bool pass = __builtin_amdgcn_readfirstlane((int)sc0.pass) != 0;
@@ -142,6 +167,66 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
   // an approximate-arithmetic build 30.3; skipping the divisions that are exact no-ops
   // (unused clip scaling, x / bc1 once bc1 == 1.0f): no change.
   {
+#if DZ_OF_AHEAD
+    // Two register sets: the NEXT rows of the six streams are requested before this iteration's
+    // arithmetic (fully unrolled: static set indices, no loop-carried copies of loaded registers --
+    // a copy would wait for its load).  At 1.75 tile workgroups per CU a wave that computes with
+    // nothing in flight leaves the memory pipe idle for the length of its arithmetic (~0.8 us per
+    // iteration).  Same box, rocprofv3: 31.9-32.0 -> 30.3-31.0 us in the step, 30.9 -> 28.5 back to
+    // back without the sample blocks (tools/adam_repeat_probe.sh); bit-identical.  Two rows ahead
+    // (142 VGPRs, three waves per SIMD): 32.3; the streams' first rows requested before the LDS
+    // fill's wait (DZ_OF_EARLY): 28.9 back to back -- no gain; tile blocks dispatched before the
+    // sample blocks (DZ_OF_TILES_FIRST): 31.3.
+    float4 S[2][6] = {{pm, mm, vm, ps, ms, vs}, {}};
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      float4& pm = S[it & 1][0]; float4& mm = S[it & 1][1]; float4& vm = S[it & 1][2];
+      float4& ps = S[it & 1][3]; float4& ms = S[it & 1][4]; float4& vs = S[it & 1][5];
+      if (it + 1 < IT) {
+        const unsigned nm = om + rstep, ns = os + rstep;
+        S[(it + 1) & 1][0] = ld_off(p, nm); S[(it + 1) & 1][1] = ld_off(m, nm); S[(it + 1) & 1][2] = ld_off(v, nm);
+        S[(it + 1) & 1][3] = ld_off(p, ns); S[(it + 1) & 1][4] = ld_off(m, ns); S[(it + 1) & 1][5] = ld_off(v, ns);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#if DZ_ADAM_MFMA
+      const float4 g4 = *(const float4*)(lds + (it * T::RP + rl) * T::GP + 4 * c4);
+      float a0 = g4.x, a1 = g4.y, a2 = g4.z, a3 = g4.w;
+#else
+      const float* ft = s_ft + (it * T::RP + rl) * T::FS;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 1
+      for (int bq = 0; bq < 8; ++bq) {       // G[k][n] = sum_b x[b][k] dh1[b][n], b ascending
+        const float4 f = *(const float4*)(ft + 4 * bq);
+        const float fx[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 d = *(const float4*)(s_dh1 + (4 * bq + j) * C + 4 * c4);
+          a0 = __builtin_fmaf(fx[j], d.x, a0); a1 = __builtin_fmaf(fx[j], d.y, a1);
+          a2 = __builtin_fmaf(fx[j], d.z, a2); a3 = __builtin_fmaf(fx[j], d.w, a3);
+        }
+      }
+#endif
+      const float G[4] = {a0, a1, a2, a3};
+      const float4 eo = *(const float4*)(s_eo + 4 * c4);
+      const float ei = s_eo[C + it * T::RP + rl];
+      const float EO[4] = {eo.x, eo.y, eo.z, eo.w};
+      float* PM = (float*)&pm; float* MM = (float*)&mm; float* VM = (float*)&vm;
+      float* PS = (float*)&ps; float* MS = (float*)&ms; float* VS = (float*)&vs;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gm = G[j];
+        asm volatile("" : "+v"(gm));
+        adam_elem(PM[j], gm, MM[j], VM[j], pass, gn, bc1, bc2, lr, b1, b2, eps, max_norm);
+        // sigma: the rounded product the stored-gradient path applies (adam_body)
+        float gs = G[j] * (ei * EO[j]);
+        asm volatile("" : "+v"(gs));
+        adam_elem(PS[j], gs, MS[j], VS[j], pass, gn, bc1, bc2, lr, b1, b2, eps, max_norm);
+      }
+      st_off(m, om, mm); st_off(v, om, vm); st_off(p, om, pm);
+      st_off(m, os, ms); st_off(v, os, vs); st_off(p, os, ps);
+      om += rstep; os += rstep;
+    }
+#else
 #pragma unroll 1
     for (int it = 0; it < IT; ++it) {
 #if DZ_ADAM_MFMA
@@ -186,6 +271,7 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
         ps = ld_off(p, os); ms = ld_off(m, os); vs = ld_off(v, os);
       }
     }
+#endif
   }
 }
 
@@ -287,10 +373,14 @@ __device__ __forceinline__ void adam_flat_ranges(unsigned bid, unsigned nblk, co
 // streams requested before the current arithmetic 33.8 (no gain: the arithmetic is the
 // exposed part, see adam_fc1_block).
 constexpr int kOfC = 64, kOfIT = 7, kOfFlatBlocks = 64;
-// (compiled for SIX waves per SIMD -- the occupancy the allocation reaches anyway: the target of
-// eight of rounds 3-4 was never met (77 VGPRs) and cost 0.3-0.5 us of squeezing; targets 5 / 4:
-// the same; 3: 38 us -- the launch's ~1 060 workgroups no longer fit)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))
+// (compiled for FOUR waves per SIMD since round 6: the second register set of the look-ahead needs 118
+// VGPRs, and the launch's 801 workgroups -- 289 sample + gather, 448 tiles, 64 flat -- still fit at four
+// per CU.  Rounds 3-5: six, the occupancy the 77-register form reached; 5 with the look-ahead spills
+// (39 us), 3: the workgroups no longer fit at once (32.4 tiles first, 34.7 sample blocks first).)
+#ifndef DZ_OF_OCC
+#define DZ_OF_OCC 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DZ_OF_OCC, DZ_OF_OCC)))
 void adam_onfly_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
     float* __restrict__ v, const float* __restrict__ part, int nparts,
@@ -302,9 +392,19 @@ void adam_onfly_kernel(
   __shared__ float red[4];
   constexpr unsigned fc1_blocks = OfTile<kOfC, kOfIT>::kBlocks;
   unsigned bid = blockIdx.x;
+#ifndef DZ_OF_TILES_FIRST
+#define DZ_OF_TILES_FIRST 0
+#endif
+#if DZ_OF_TILES_FIRST
+  // block ids: [fc1 tiles | flat ranges | next sample + gather]: the streams' workgroups get their
+  // slots first, the short side blocks fill what is left of every CU
+  if (bid >= fc1_blocks + kOfFlatBlocks) { SampleGatherSide::run(sg, bid - (fc1_blocks + kOfFlatBlocks)); return; }
+  if (abort && *abort) return;
+#else
   if (bid < sg_blocks) { SampleGatherSide::run(sg, bid); return; }
   if (abort && *abort) return;   // the step is void (adam_kernel); the next step's sample is still good
   bid -= sg_blocks;
+#endif
   if (bid < fc1_blocks) {
     adam_fc1_block<kOfC, kOfIT>(bid, q, p, m, v, part, nparts, count, lr, b1, b2, eps, max_norm,
                                 red, lds);

@@ -718,6 +718,14 @@ extern "C" int dz_rainbow_learn(const dz_rainbow_args_t* a, int phases,
                          a->max_norm, of, rg, q, sgb, chain_abort);
       DZ_LAUNCH_CHECK();
       DZ_PROF(s, a->next_sample ? "adam+next_sample" : "adam");
+#ifdef DZ_ADAM_REPEAT   // (timing probe, variant builds only: the same launch again, back to back,
+                        //  without the next sample's blocks -- wrong parameters, right durations)
+      for (int rep = 0; rep < DZ_ADAM_REPEAT; ++rep)
+        hipLaunchKernelGGL(adam_onfly_kernel, dim3(adam_onfly_blocks(0)), dim3(256), 0, s,
+                           a->online, a->grad, a->adam_m, a->adam_v, ws + L.ws_norm_part, nparts,
+                           a->adam_count, a->losses, a->weights, B, sc, a->lr, a->b1, a->b2, a->eps,
+                           a->max_norm, of, rg, SampleGatherParams{}, 0u, chain_abort);
+#endif
     } else if (a->next_sample) {
       hipLaunchKernelGGL(adam_sg_kernel, dim3(sgb + (unsigned)kAdamBlocksSG), dim3(256), 0, s,
                          a->online, a->grad, a->adam_m, a->adam_v, (long)(L.param_count >> 2),
