@@ -11,8 +11,8 @@
 //     row-owning stream, dz_row_dgrad.h) and the layer's contribution to the global
 //     gradient norm  <X X^T, D D^T>  (both parameter matrices, per head), one non-negative
 //     float per block into the fused-norm slots;
-//   * adam_onfly_kernel (here): the optimiser; a workgroup owns a 112 x 64 tile of the mu
-//     AND sigma matrices, keeps the 32 x 64 strip of dh1 and the 112 x 32 tile of X in
+//   * adam_onfly_kernel (here): the optimiser; a workgroup owns a 56 x 128 tile (rounds 3-5: 112 x 64)
+//     of the mu AND sigma matrices, keeps the 32 x 128 strip of dh1 and the 56 x 32 tile of X in
 //     LDS, and forms every gradient element (32 FMAs) right before its update.  The rest
 //     of the parameter vector (convs, biases, fc2: 4 % of it) is streamed from the stored
 //     gradient by 64 more blocks of the same launch.
@@ -55,6 +55,7 @@ struct OfTile {
   static constexpr int kFill = 32 * C + R * FS;           // dh1 strip + X tile (dead once the tile exists)
   static constexpr int kLds = (kFill > R * GP ? kFill : R * GP) + C + R;   // floats
   static_assert(kFlat % R == 0, "rows");
+  static_assert(C + R <= 256, "one thread per eps_out column and eps_in row of the tile");
 };
 template <int C, int IT>
 __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
@@ -372,7 +373,14 @@ __device__ __forceinline__ void adam_flat_ranges(unsigned bid, unsigned nblk, co
 // 36.6 us, 16 x 128 34.3, 32 x 128 34.6, 56 x 128 33.2, 112 x 64 33.0; the next rows'
 // streams requested before the current arithmetic 33.8 (no gain: the arithmetic is the
 // exposed part, see adam_fc1_block).
-constexpr int kOfC = 64, kOfIT = 7, kOfFlatBlocks = 64;
+#ifndef DZ_OF_C   // columns of a tile: 128 since round 6 (56 rows x 128 columns: 512 contiguous bytes per row and
+                  // stream; same box, six bench lines each: 7 079 -> 7 104 steps/s against 112 x 64, bit-identical)
+#define DZ_OF_C 128
+#endif
+#ifndef DZ_OF_IT
+#define DZ_OF_IT 7
+#endif
+constexpr int kOfC = DZ_OF_C, kOfIT = DZ_OF_IT, kOfFlatBlocks = 64;
 // (compiled for FOUR waves per SIMD since round 6: the second register set of the look-ahead needs 118
 // VGPRs, and the launch's 801 workgroups -- 289 sample + gather, 448 tiles, 64 flat -- still fit at four
 // per CU.  Rounds 3-5: six, the occupancy the 77-register form reached; 5 with the look-ahead spills
