@@ -178,6 +178,27 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
     // (142 VGPRs, three waves per SIMD): 32.3; the streams' first rows requested before the LDS
     // fill's wait (DZ_OF_EARLY): 28.9 back to back -- no gain; tile blocks dispatched before the
     // sample blocks (DZ_OF_TILES_FIRST): 31.3.
+#if DZ_OF_AHEAD >= 2   // (experiment: D rows ahead, D + 1 register sets)
+    constexpr int D = DZ_OF_AHEAD, NS = D + 1;
+    float4 S[NS][6];
+    S[0][0] = pm; S[0][1] = mm; S[0][2] = vm; S[0][3] = ps; S[0][4] = ms; S[0][5] = vs;
+#pragma unroll
+    for (int d = 1; d < D; ++d) {
+      const unsigned nm = om + d * rstep, ns = os + d * rstep;
+      S[d][0] = ld_off(p, nm); S[d][1] = ld_off(m, nm); S[d][2] = ld_off(v, nm);
+      S[d][3] = ld_off(p, ns); S[d][4] = ld_off(m, ns); S[d][5] = ld_off(v, ns);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      float4& pm = S[it % NS][0]; float4& mm = S[it % NS][1]; float4& vm = S[it % NS][2];
+      float4& ps = S[it % NS][3]; float4& ms = S[it % NS][4]; float4& vs = S[it % NS][5];
+      if (it + D < IT) {
+        const unsigned nm = om + D * rstep, ns = os + D * rstep;
+        S[(it + D) % NS][0] = ld_off(p, nm); S[(it + D) % NS][1] = ld_off(m, nm); S[(it + D) % NS][2] = ld_off(v, nm);
+        S[(it + D) % NS][3] = ld_off(p, ns); S[(it + D) % NS][4] = ld_off(m, ns); S[(it + D) % NS][5] = ld_off(v, ns);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
     float4 S[2][6] = {{pm, mm, vm, ps, ms, vs}, {}};
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -189,14 +210,20 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
         S[(it + 1) & 1][3] = ld_off(p, ns); S[(it + 1) & 1][4] = ld_off(m, ns); S[(it + 1) & 1][5] = ld_off(v, ns);
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
 #if DZ_ADAM_MFMA
       const float4 g4 = *(const float4*)(lds + (it * T::RP + rl) * T::GP + 4 * c4);
       float a0 = g4.x, a1 = g4.y, a2 = g4.z, a3 = g4.w;
 #else
       const float* ft = s_ft + (it * T::RP + rl) * T::FS;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#ifdef DZ_ADAM_NOG   // (timing probe, variant builds only: wrong numbers)
+#define DZ_NOG_TRIPS 1
+#else
+#define DZ_NOG_TRIPS 8
+#endif
 #pragma unroll 1
-      for (int bq = 0; bq < 8; ++bq) {       // G[k][n] = sum_b x[b][k] dh1[b][n], b ascending
+      for (int bq = 0; bq < DZ_NOG_TRIPS; ++bq) {       // G[k][n] = sum_b x[b][k] dh1[b][n], b ascending
         const float4 f = *(const float4*)(ft + 4 * bq);
         const float fx[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
@@ -236,8 +263,13 @@ __device__ __forceinline__ void adam_fc1_block(unsigned blk, const Fc1OnFly& q,
 #else
       const float* ft = s_ft + (it * T::RP + rl) * T::FS;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#ifdef DZ_ADAM_NOG   // (timing probe, variant builds only: wrong numbers)
+#define DZ_NOG_TRIPS 1
+#else
+#define DZ_NOG_TRIPS 8
+#endif
 #pragma unroll 1
-      for (int bq = 0; bq < 8; ++bq) {       // G[k][n] = sum_b x[b][k] dh1[b][n], b ascending
+      for (int bq = 0; bq < DZ_NOG_TRIPS; ++bq) {       // G[k][n] = sum_b x[b][k] dh1[b][n], b ascending
         const float4 f = *(const float4*)(ft + 4 * bq);
         const float fx[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll

@@ -1,4 +1,9 @@
 #!/bin/bash
+# The shipped optimiser kernel back to back (cache-warm, without the next sample's blocks) against its duration
+# in the step: a variant build with -DDZ_ADAM_REPEAT=3 (tools/build_variants.sh dz_rainbow adam_rep:"-DDZ_ADAM_REPEAT=3 ...")
+# enqueues it three more times behind itself -- wrong parameters, right durations -- and this script reads the four
+# launches of every step off a rocprofv3 kernel trace of the bench loop.  Further timing-only switches of the same
+# build: -DDZ_ADAM_CHEAP (the per-element update as three additions), -DDZ_ADAM_NOG (one eighth of the tile's FMA chains).
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/q; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 cp $R/dqn_zoo_amd/libdqnzoo_hip.so /tmp/keep.so; cp $R/tools/ab/adam_rep.so $R/dqn_zoo_amd/libdqnzoo_hip.so
 rm -rf $OUT/kt
