@@ -111,7 +111,8 @@ int dz_replay_insert(const dz_insert_field_t* fields, int num_fields, int64_t t,
 
 /* dz_replay_insert with its arguments in a struct the caller keeps and patches (`t`, the
  * fields' src_row / imm): for bindings that pay per marshalled argument (ctypes: ~0.15 us
- * each -- the agents' loop inserts once per frame).  Same launch, same checks.            */
+ * each -- the agents' loop inserts once per frame).  Same launch, same checks.
+ * ref: replay.py:141-150 (TransitionReplay.add), 690-699 (PrioritizedTransitionReplay.add).  */
 typedef struct {
   const dz_insert_field_t* fields;
   int32_t num_fields;
@@ -228,7 +229,8 @@ int dz_prioritized_sample_gather(
 
 /* dz_prioritized_sample_gather with its arguments in the descriptor a learner step can also
  * carry (dz_next_sample_t, declared with dz_rainbow_args_t below): a binding keeps one per
- * output slot and patches `args` per call.                                               */
+ * output slot and patches `args` per call.
+ * ref: replay.py:706-723 (PrioritizedTransitionReplay.sample).                           */
 struct dz_next_sample;
 int dz_sample_gather_desc(const struct dz_next_sample* desc, dz_stream_t stream);
 
@@ -454,7 +456,8 @@ int dz_rainbow_act(int num_actions, int num_atoms, int batch, const float* param
                    dz_stream_t stream);
 
 /* dz_rainbow_act with its arguments in a struct the caller fills once per (observation slot,
- * result slot): the agent's per-frame decision is then a two-argument call.                */
+ * result slot): the agent's per-frame decision is then a two-argument call.
+ * ref: rainbow/agent.py:125-131, 171-179 (select_action with a fresh key).                 */
 typedef struct {
   int32_t num_actions, num_atoms, batch, reserved;
   const float* params;
